@@ -1,0 +1,215 @@
+/*
+ * lesseq_hip.h -- C ABI of the MI355X-native count + solve path of LESSeq.
+ *
+ * The reference (gersteinlab/LESSeq) has no plugin / FFI seam: its `count` and `solve`
+ * programs are monolithic main() bodies (count/count.cpp:88-501, solve/solve.cpp:102-856).
+ * This header is the seam a maintainer would cut: each entry point replaces a contiguous
+ * stretch of those main() bodies, cited per function.  INTEGRATION.md shows the call sites.
+ *
+ * Conventions: plain C, caller-owned buffers, no exceptions across the boundary.  Every
+ * function returns LSQ_OK (0) or a negative lsq_status; lsq_last_error() gives the text for
+ * the calling thread.  Coordinates are 0-based half-open, as the reference holds them after
+ * `start - 1` (count/count.cpp:319,323).  One lsq_ctx per GPU, used from one host thread.
+ *
+ * Two groups:
+ *   host-only  (no GPU touched): annotation loading, event compilation, MRF parsing,
+ *              text formatting, the synthetic workload generator;
+ *   device     (HIP, gfx950):    context, uploads, the count and EM kernels, result fetch.
+ * There is no CPU implementation of the device group: without a usable GPU these calls
+ * fail with LSQ_E_DEVICE.
+ */
+#ifndef LESSEQ_HIP_H
+#define LESSEQ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSQ_ABI_VERSION 1
+
+typedef enum {
+	LSQ_OK = 0,
+	LSQ_E_ARG = -1,          /* bad argument / malformed table */
+	LSQ_E_IO = -2,           /* file cannot be opened / read */
+	LSQ_E_FORMAT = -3,       /* unknown file format / read type literal (reference: exit 1) */
+	LSQ_E_PARSE = -4,        /* lexical_cast failure (reference: exit 1) */
+	LSQ_E_RANGE = -5,        /* coordinate or size outside what the device tables hold */
+	LSQ_E_UNSUPPORTED = -6,  /* event shape outside the device kernels' limits */
+	LSQ_E_DEVICE = -7,       /* HIP error, or no gfx950 device */
+	LSQ_E_STATE = -8         /* call order violated (e.g. count before uploads) */
+} lsq_status;
+
+/* device kernel limits (events beyond them are refused by lsq_events_upload) */
+#define LSQ_MAX_SEGMENTS 32   /* atomic exon segments per event (LESSeq local events: <= 4) */
+#define LSQ_MAX_ISOFORMS 6    /* isoforms per event (LESSeq local events: 2) */
+#define LSQ_MAX_METHODS 8     /* read files ("sampling methods") per run */
+
+const char *lsq_last_error(void);
+int lsq_abi_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * Host-only group
+ * ------------------------------------------------------------------------------------ */
+
+typedef struct lsq_annotation lsq_annotation;   /* selected genes + their isoform records */
+typedef struct lsq_events lsq_events;           /* compiled event tables (host copy) */
+typedef struct lsq_reads lsq_reads;             /* parsed reads of one MRF file, file order */
+
+/* Replaces count/count.cpp:135-216 (== solve/solve.cpp:152-234 for these two formats):
+ * loads LH_GENE_TXT + UCSC_GENE2ISOFORM, selects genes whose index in the bytewise-sorted
+ * gene-name set lies in [gene_begin_idx, gene_end_idx).  Format literals other than
+ * "LH_GENE_TXT" / "UCSC_GENE2ISOFORM" give LSQ_E_FORMAT. */
+int lsq_annotation_load(const char *isoform_format, const char *isoforms_path,
+                        const char *g2i_format, const char *g2i_path,
+                        uint64_t gene_begin_idx, uint64_t gene_end_idx,
+                        lsq_annotation **out);
+void lsq_annotation_free(lsq_annotation *a);
+int64_t lsq_annotation_num_genes(const lsq_annotation *a);      /* selected genes */
+int64_t lsq_annotation_num_isoforms_loaded(const lsq_annotation *a);
+int64_t lsq_annotation_num_genes_loaded(const lsq_annotation *a);
+
+/* Replaces count/count.cpp:231-258 + the per-gene ARS construction at :394-416
+ * (common/splicing_graph.h:88-169,235-252,318-361; common/accessible_read_starts.h:48-89,
+ * 221-274; jsc/util/interval_list.hpp:462-503): atomic segments, isoform masks, event
+ * spans, per-chromosome covered regions, and for each of the n_methods read files the
+ * per-isoform ARS total.  read_types[m] is "SHORT_READ" or "MEDIUM_READ" (LSQ_E_FORMAT
+ * otherwise, the reference's unknown_readtype_err). */
+int lsq_events_compile(const lsq_annotation *a, int n_methods, const char *const *read_types,
+                       const uint64_t *expected_read_lengths, lsq_events **out);
+void lsq_events_free(lsq_events *e);
+
+/* read-only views into compiled events, in output order (bytewise-sorted gene names) */
+int64_t lsq_events_count(const lsq_events *e);
+int64_t lsq_events_total_isoforms(const lsq_events *e);
+const char *lsq_events_gene_name(const lsq_events *e, int64_t ev);
+const char *lsq_events_chrom(const lsq_events *e, int64_t ev);
+const char *lsq_events_strand(const lsq_events *e, int64_t ev);
+int lsq_events_num_isoforms(const lsq_events *e, int64_t ev);
+int lsq_events_num_segments(const lsq_events *e, int64_t ev);
+const char *lsq_events_isoform_name(const lsq_events *e, int64_t ev, int iso);
+/* segment n of the event as [start,end); isoform mask bit n set iff the isoform holds it */
+int lsq_events_segment(const lsq_events *e, int64_t ev, int n, int64_t *start, int64_t *end);
+uint64_t lsq_events_isoform_mask(const lsq_events *e, int64_t ev, int iso);
+uint64_t lsq_events_isoform_length(const lsq_events *e, int64_t ev, int iso);
+uint64_t lsq_events_ars(const lsq_events *e, int method, int64_t ev, int iso);
+int lsq_events_span(const lsq_events *e, int64_t ev, int64_t *gene_start, int64_t *gene_end);
+int64_t lsq_events_num_buckets(const lsq_events *e);
+
+/* Replaces count/count.cpp:279-336 (== solve/solve.cpp:429-486) minus the containment
+ * filter: parses an MRF_SINGLE file into blocks in file order.  A lexical_cast failure
+ * gives LSQ_E_PARSE; a format literal other than "MRF_SINGLE" LSQ_E_FORMAT.  Chromosome and
+ * strand strings are interned against the events' dictionaries (unknown chromosomes get an
+ * id that matches no covered region). n_threads <= 0 picks the host's core count. */
+int lsq_mrf_parse(const char *read_format, const char *path, lsq_events *e,
+                  int n_threads, lsq_reads **out);
+/* Wraps caller-made arrays as a read set without copying (the arrays must outlive it).
+ * blk_off has n_reads+1 entries; blocks are 0-based half-open; chrom_id / strand_id index
+ * lsq_events_chrom_id() / lsq_events_strand_id() dictionaries; line_no is the 1-based line
+ * number after the header (read name "read-<line_no>", count/count.cpp:293-295). */
+int lsq_reads_wrap(uint64_t n_reads, const uint64_t *blk_off, const uint32_t *line_no,
+                   const int32_t *blk_start, const int32_t *blk_end,
+                   const uint16_t *blk_chrom_id, const uint8_t *blk_strand_id, lsq_reads **out);
+void lsq_reads_free(lsq_reads *r);
+uint64_t lsq_reads_count(const lsq_reads *r);
+uint64_t lsq_reads_num_blocks(const lsq_reads *r);
+int lsq_events_chrom_id(lsq_events *e, const char *chrom);     /* interns; >= 0 */
+int lsq_events_strand_id(lsq_events *e, const char *strand);   /* interns; >= 0 */
+
+/* ------------------------------------------------------------------------------------
+ * Device group
+ * ------------------------------------------------------------------------------------ */
+
+typedef struct lsq_ctx lsq_ctx;
+
+int lsq_ctx_create(int device_id, lsq_ctx **out);
+void lsq_ctx_destroy(lsq_ctx *c);
+/* HIP stream the context launches on (hipStream_t as void*), for callers timing with events */
+void *lsq_ctx_stream(lsq_ctx *c);
+int lsq_ctx_synchronize(lsq_ctx *c);
+
+/* Uploads the compiled tables: per-bucket LDS images (bin directory, event records,
+ * segments, isoform masks), tie-break records and G = 1/ARS. */
+int lsq_events_upload(lsq_ctx *c, const lsq_events *e);
+
+/* Replaces the retained-read state the reference builds at count/count.cpp:319-324 and
+ * :348-364: applies the per-block containment filter against the covered regions, merges
+ * kept blocks with interval_list::add_interval semantics, and stores each retained read in
+ * the bucket of its first kept base, split into 1-block / 2-block / n-block pools
+ * (structure-of-arrays in HBM).  method in [0, n_methods). */
+int lsq_reads_upload(lsq_ctx *c, int method, const lsq_reads *r);
+uint64_t lsq_reads_retained(const lsq_ctx *c, int method);      /* "loaded N reads" log line */
+uint64_t lsq_reads_retained_blocks(const lsq_ctx *c, int method);
+
+/* Replaces the per-gene candidate scan + Read::build + compatibility + validity + counting
+ * (count/count.cpp:420-482 == solve/solve.cpp:719-793; common/read.h:44-79,198-274): one
+ * pass over every uploaded method's reads; fills per-(method, event, compatibility class)
+ * read counts and matched-base sums on the device.  Asynchronous on the context stream. */
+int lsq_count(lsq_ctx *c);
+
+/* Replaces solve/solve.cpp:796-806,823-826 (common/read.h:592-660): batched EM over the
+ * class counts, one event per lane, fp64.  Needs lsq_count first.  Asynchronous. */
+int lsq_solve(lsq_ctx *c);
+
+/* Result fetch (synchronises the stream).  Arrays are in output order; class c (1 <= c <
+ * 2^K) of an event is the set of isoforms j with bit j set, and its slot is
+ * class_off[ev] + c - 1 where class_off is the exclusive prefix sum of (2^K - 1).
+ *   class_count[m * n_classes + slot], class_bases[...]: uint64
+ *   theta[iso_off[ev] + j], logll[ev], em_iters[ev], em_flags[ev]
+ * em_flags bit 0: the stop criterion |1 - old_ll/ll| came within 1e-9 (relative 1e-3) of
+ * the 1e-6 threshold at some iteration, so a different summation order could stop one
+ * iteration earlier or later. */
+int64_t lsq_results_num_classes(const lsq_ctx *c);
+int lsq_results_class_offsets(const lsq_ctx *c, uint64_t *class_off /* n_events+1 */);
+int lsq_results_counts(lsq_ctx *c, uint64_t *class_count, uint64_t *class_bases);
+int lsq_results_solve(lsq_ctx *c, double *theta, double *logll, uint32_t *em_iters, uint8_t *em_flags);
+
+/* Device timing of the last lsq_count / lsq_solve (ms, from HIP events on the context
+ * stream) and the count kernel's launch geometry; for bench.py. */
+int lsq_last_timing(lsq_ctx *c, float *count_ms, float *solve_ms);
+
+/* ------------------------------------------------------------------------------------
+ * Output rows (host): replaces count/count.cpp:486-492 and solve/solve.cpp:808-847
+ * ------------------------------------------------------------------------------------ */
+
+/* Formats the count table from fetched class counts into a malloc'd NUL-terminated buffer
+ * (free with lsq_free). */
+int lsq_format_count(const lsq_events *e, int n_methods, const uint64_t *class_count, char **out_text);
+int lsq_format_solve(const lsq_events *e, int n_methods, const uint64_t *class_count,
+                     const uint64_t *class_bases, const double *theta, const double *logll,
+                     const double *total_read_bases, char **out_text);
+void lsq_free(void *p);
+
+/* Whole executables in-process: argv as the reference's (argv[0] ignored).  tool is
+ * "count", "solve" or "classify".  stdout text is returned in *out_text (malloc'd), the
+ * return value is the process exit status the reference would give (0, 1). */
+int lsq_cli_run(const char *tool, int argc, const char *const *argv, char **out_text);
+
+/* ------------------------------------------------------------------------------------
+ * Synthetic workload; deterministic in (seed, sizes).  Host-only.
+ * ------------------------------------------------------------------------------------ */
+typedef struct {
+	uint64_t seed;
+	uint64_t n_events;
+	uint64_t n_reads;
+	uint32_t read_length;
+	uint32_t n_chrom;          /* chr1..chrN */
+	uint32_t event_types;      /* bit t set: type t allowed (SE RI A5SS A3SS MXE AFE ALE T3) */
+	uint32_t zipf;             /* 0: uniform depth; 1: Zipf(1.1) depth over events */
+	double overlap_frac;       /* fraction of events that overlap their left neighbour */
+	uint64_t first_read;       /* reads are numbered first_read .. first_read+n_reads-1 in the spec's
+	                              read stream (counter-based), so chunks of one stream can be made */
+} lsq_synth_spec;
+
+/* Writes <stem>.interval, <stem>.map and (if write_mrf) <stem>.mrf under dir. */
+int lsq_synth_write(const lsq_synth_spec *s, const char *dir, const char *stem, int write_mrf);
+/* Generates the reads directly as a read set against already compiled events made from
+ * lsq_synth_write's annotation with the same spec (no text round trip). */
+int lsq_synth_reads(const lsq_synth_spec *s, lsq_events *e, int n_threads, lsq_reads **out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

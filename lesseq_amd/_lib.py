@@ -1,0 +1,94 @@
+"""ctypes loader for liblesseq_hip.so (built in-tree by lesseq_amd/csrc/Makefile)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_build", "liblesseq_hip.so")
+
+
+class LsqError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("lsq status %d: %s" % (status, msg))
+        self.status = status
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError("%s is missing: build it with `make -C lesseq_amd/csrc` (or __graft_entry__.build()); "
+                      "there is no fallback implementation" % LIB_PATH)
+
+lib = C.CDLL(LIB_PATH)
+
+u64, i64, u32, i32, u16, u8 = C.c_uint64, C.c_int64, C.c_uint32, C.c_int32, C.c_uint16, C.c_uint8
+P = C.POINTER
+vp = C.c_void_p
+cs = C.c_char_p
+
+
+class SynthSpecStruct(C.Structure):
+    _fields_ = [("seed", u64), ("n_events", u64), ("n_reads", u64), ("read_length", u32), ("n_chrom", u32),
+                ("event_types", u32), ("zipf", u32), ("overlap_frac", C.c_double), ("first_read", u64)]
+
+
+def _sig(name, res, *args):
+    f = getattr(lib, name)
+    f.restype = res
+    f.argtypes = list(args)
+    return f
+
+
+_sig("lsq_last_error", cs)
+_sig("lsq_abi_version", C.c_int)
+_sig("lsq_free", None, vp)
+_sig("lsq_annotation_load", C.c_int, cs, cs, cs, cs, u64, u64, P(vp))
+_sig("lsq_annotation_free", None, vp)
+_sig("lsq_annotation_num_genes", i64, vp)
+_sig("lsq_annotation_num_isoforms_loaded", i64, vp)
+_sig("lsq_annotation_num_genes_loaded", i64, vp)
+_sig("lsq_events_compile", C.c_int, vp, C.c_int, P(cs), P(u64), P(vp))
+_sig("lsq_events_free", None, vp)
+_sig("lsq_events_count", i64, vp)
+_sig("lsq_events_total_isoforms", i64, vp)
+_sig("lsq_events_gene_name", cs, vp, i64)
+_sig("lsq_events_chrom", cs, vp, i64)
+_sig("lsq_events_strand", cs, vp, i64)
+_sig("lsq_events_num_isoforms", C.c_int, vp, i64)
+_sig("lsq_events_num_segments", C.c_int, vp, i64)
+_sig("lsq_events_isoform_name", cs, vp, i64, C.c_int)
+_sig("lsq_events_segment", C.c_int, vp, i64, C.c_int, P(i64), P(i64))
+_sig("lsq_events_isoform_mask", u64, vp, i64, C.c_int)
+_sig("lsq_events_isoform_length", u64, vp, i64, C.c_int)
+_sig("lsq_events_ars", u64, vp, C.c_int, i64, C.c_int)
+_sig("lsq_events_span", C.c_int, vp, i64, P(i64), P(i64))
+_sig("lsq_events_num_buckets", i64, vp)
+_sig("lsq_mrf_parse", C.c_int, cs, cs, vp, C.c_int, P(vp))
+_sig("lsq_reads_wrap", C.c_int, u64, P(u64), P(u32), P(i32), P(i32), P(u16), P(u8), P(vp))
+_sig("lsq_reads_free", None, vp)
+_sig("lsq_reads_count", u64, vp)
+_sig("lsq_reads_num_blocks", u64, vp)
+_sig("lsq_events_chrom_id", C.c_int, vp, cs)
+_sig("lsq_events_strand_id", C.c_int, vp, cs)
+_sig("lsq_ctx_create", C.c_int, C.c_int, P(vp))
+_sig("lsq_ctx_destroy", None, vp)
+_sig("lsq_ctx_stream", vp, vp)
+_sig("lsq_ctx_synchronize", C.c_int, vp)
+_sig("lsq_events_upload", C.c_int, vp, vp)
+_sig("lsq_reads_upload", C.c_int, vp, C.c_int, vp)
+_sig("lsq_reads_retained", u64, vp, C.c_int)
+_sig("lsq_reads_retained_blocks", u64, vp, C.c_int)
+_sig("lsq_count", C.c_int, vp)
+_sig("lsq_solve", C.c_int, vp)
+_sig("lsq_results_num_classes", i64, vp)
+_sig("lsq_results_class_offsets", C.c_int, vp, P(u64))
+_sig("lsq_results_counts", C.c_int, vp, P(u64), P(u64))
+_sig("lsq_results_solve", C.c_int, vp, P(C.c_double), P(C.c_double), P(u32), P(u8))
+_sig("lsq_last_timing", C.c_int, vp, P(C.c_float), P(C.c_float))
+_sig("lsq_format_count", C.c_int, vp, C.c_int, P(u64), P(vp))
+_sig("lsq_format_solve", C.c_int, vp, C.c_int, P(u64), P(u64), P(C.c_double), P(C.c_double), P(C.c_double), P(vp))
+_sig("lsq_cli_run", C.c_int, cs, C.c_int, P(cs), P(vp))
+_sig("lsq_synth_write", C.c_int, P(SynthSpecStruct), cs, cs, C.c_int)
+_sig("lsq_synth_reads", C.c_int, P(SynthSpecStruct), vp, C.c_int, P(vp))
+
+
+def check(status):
+    if status != 0:
+        raise LsqError(status, lib.lsq_last_error().decode("utf-8", "replace"))

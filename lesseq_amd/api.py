@@ -1,0 +1,274 @@
+"""Thin object wrappers over the C ABI (include/lesseq_hip.h).  No compute lives here."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import lib, check, SynthSpecStruct, u64, u32, i32, u16, u8, i64, vp, cs, P
+
+EVENT_TYPES = ("SE", "RI", "A5SS", "A3SS", "MXE", "AFE", "ALE", "T3")
+
+
+def _b(s):
+    return s.encode() if isinstance(s, str) else s
+
+
+def _take_text(ptr):
+    if not ptr:
+        return ""
+    s = C.string_at(ptr).decode()
+    lib.lsq_free(ptr)
+    return s
+
+
+def _ptr(a, ct):
+    return a.ctypes.data_as(P(ct))
+
+
+class Annotation:
+    """lsq_annotation_load: LH_GENE_TXT + UCSC_GENE2ISOFORM, genes [begin, end) of the sorted name set"""
+
+    def __init__(self, isoforms_path, g2i_path, begin=0, end=2 ** 62, isoform_format="LH_GENE_TXT", g2i_format="UCSC_GENE2ISOFORM"):
+        h = vp()
+        check(lib.lsq_annotation_load(_b(isoform_format), _b(isoforms_path), _b(g2i_format), _b(g2i_path), begin, end, C.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib.lsq_annotation_free(self.h)
+            self.h = None
+
+    @property
+    def num_genes(self):
+        return lib.lsq_annotation_num_genes(self.h)
+
+
+class Events:
+    """lsq_events_compile: segments, isoform masks, ARS per read file, covered regions, device plan"""
+
+    def __init__(self, annotation, read_types=("SHORT_READ",), read_lengths=(100,)):
+        M = len(read_types)
+        rt = (cs * max(M, 1))(*[_b(t) for t in read_types])
+        rl = (u64 * max(M, 1))(*read_lengths)
+        h = vp()
+        check(lib.lsq_events_compile(annotation.h, M, rt, rl, C.byref(h)))
+        self.h = h
+        self.n_methods = M
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib.lsq_events_free(self.h)
+            self.h = None
+
+    def __len__(self):
+        return lib.lsq_events_count(self.h)
+
+    @property
+    def total_isoforms(self):
+        return lib.lsq_events_total_isoforms(self.h)
+
+    @property
+    def num_buckets(self):
+        return lib.lsq_events_num_buckets(self.h)
+
+    def gene_name(self, ev):
+        return lib.lsq_events_gene_name(self.h, ev).decode()
+
+    def chrom(self, ev):
+        return lib.lsq_events_chrom(self.h, ev).decode()
+
+    def strand(self, ev):
+        return lib.lsq_events_strand(self.h, ev).decode()
+
+    def K(self, ev):
+        return lib.lsq_events_num_isoforms(self.h, ev)
+
+    def N(self, ev):
+        return lib.lsq_events_num_segments(self.h, ev)
+
+    def isoform_name(self, ev, j):
+        return lib.lsq_events_isoform_name(self.h, ev, j).decode()
+
+    def segments(self, ev):
+        out = []
+        s, e = i64(), i64()
+        for n in range(self.N(ev)):
+            check(lib.lsq_events_segment(self.h, ev, n, C.byref(s), C.byref(e)))
+            out.append((s.value, e.value))
+        return out
+
+    def isoform_mask(self, ev, j):
+        return lib.lsq_events_isoform_mask(self.h, ev, j)
+
+    def isoform_length(self, ev, j):
+        return lib.lsq_events_isoform_length(self.h, ev, j)
+
+    def ars(self, method, ev, j):
+        return lib.lsq_events_ars(self.h, method, ev, j)
+
+    def span(self, ev):
+        s, e = i64(), i64()
+        check(lib.lsq_events_span(self.h, ev, C.byref(s), C.byref(e)))
+        return s.value, e.value
+
+    def chrom_id(self, name):
+        return lib.lsq_events_chrom_id(self.h, _b(name))
+
+    def strand_id(self, name):
+        return lib.lsq_events_strand_id(self.h, _b(name))
+
+    def class_offsets(self):
+        off = [0]
+        for ev in range(len(self)):
+            off.append(off[-1] + (1 << self.K(ev)) - 1)
+        return off
+
+
+class Reads:
+    """A parsed read set in file order: from an MRF file, caller arrays, or the synthetic generator"""
+
+    def __init__(self, handle, keep=None):
+        self.h = handle
+        self._keep = keep
+
+    @classmethod
+    def from_mrf(cls, path, events, n_threads=0, read_format="MRF_SINGLE"):
+        h = vp()
+        check(lib.lsq_mrf_parse(_b(read_format), _b(path), events.h, n_threads, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_arrays(cls, blk_off, line_no, blk_start, blk_end, blk_chrom, blk_strand):
+        arrs = (np.ascontiguousarray(blk_off, np.uint64), np.ascontiguousarray(line_no, np.uint32),
+                np.ascontiguousarray(blk_start, np.int32), np.ascontiguousarray(blk_end, np.int32),
+                np.ascontiguousarray(blk_chrom, np.uint16), np.ascontiguousarray(blk_strand, np.uint8))
+        h = vp()
+        check(lib.lsq_reads_wrap(len(arrs[1]), _ptr(arrs[0], u64), _ptr(arrs[1], u32), _ptr(arrs[2], i32),
+                                 _ptr(arrs[3], i32), _ptr(arrs[4], u16), _ptr(arrs[5], u8), C.byref(h)))
+        return cls(h, keep=arrs)
+
+    @classmethod
+    def synthetic(cls, spec, events, n_threads=0):
+        h = vp()
+        check(lib.lsq_synth_reads(C.byref(spec.c), events.h, n_threads, C.byref(h)))
+        return cls(h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib.lsq_reads_free(self.h)
+            self.h = None
+
+    def __len__(self):
+        return lib.lsq_reads_count(self.h)
+
+    @property
+    def num_blocks(self):
+        return lib.lsq_reads_num_blocks(self.h)
+
+
+class Context:
+    """One GPU: uploads, the count kernel, the EM kernel, result fetch"""
+
+    def __init__(self, device=0):
+        h = vp()
+        check(lib.lsq_ctx_create(device, C.byref(h)))
+        self.h = h
+        self.events = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.lsq_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def upload_events(self, events):
+        check(lib.lsq_events_upload(self.h, events.h))
+        self.events = events
+
+    def upload_reads(self, method, reads):
+        check(lib.lsq_reads_upload(self.h, method, reads.h))
+
+    def retained(self, method):
+        return lib.lsq_reads_retained(self.h, method)
+
+    def retained_blocks(self, method):
+        return lib.lsq_reads_retained_blocks(self.h, method)
+
+    def count(self):
+        check(lib.lsq_count(self.h))
+
+    def solve(self):
+        check(lib.lsq_solve(self.h))
+
+    def synchronize(self):
+        check(lib.lsq_ctx_synchronize(self.h))
+
+    @property
+    def stream(self):
+        return lib.lsq_ctx_stream(self.h)
+
+    def timing(self):
+        a, b = C.c_float(), C.c_float()
+        check(lib.lsq_last_timing(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def counts(self):
+        """(class_count, class_bases) as uint64 arrays of shape [n_methods, n_classes], output order"""
+        n = lib.lsq_results_num_classes(self.h)
+        M = self.events.n_methods
+        cnt = np.zeros((max(M, 1), max(n, 1)), np.uint64)
+        bases = np.zeros((max(M, 1), max(n, 1)), np.uint64)
+        check(lib.lsq_results_counts(self.h, _ptr(cnt, u64), _ptr(bases, u64)))
+        return cnt[:M, :n], bases[:M, :n]
+
+    def solution(self):
+        """(theta[n_isoforms], logll[n_events], iters, flags), output order"""
+        ne, ni = len(self.events), self.events.total_isoforms
+        theta = np.zeros(max(ni, 1), np.float64)
+        ll = np.zeros(max(ne, 1), np.float64)
+        it = np.zeros(max(ne, 1), np.uint32)
+        fl = np.zeros(max(ne, 1), np.uint8)
+        check(lib.lsq_results_solve(self.h, _ptr(theta, C.c_double), _ptr(ll, C.c_double), _ptr(it, u32), _ptr(fl, u8)))
+        return theta[:ni], ll[:ne], it[:ne], fl[:ne]
+
+
+class SynthSpec:
+    def __init__(self, seed, n_events, n_reads, read_length=100, n_chrom=1, event_types=EVENT_TYPES, zipf=False, overlap_frac=0.10, first_read=0):
+        mask = 0
+        for t in event_types:
+            mask |= 1 << EVENT_TYPES.index(t)
+        self.c = SynthSpecStruct(seed, n_events, n_reads, read_length, n_chrom, mask, 1 if zipf else 0, overlap_frac, first_read)
+
+
+def synth_write(spec, directory, stem, write_mrf=True):
+    check(lib.lsq_synth_write(C.byref(spec.c), _b(directory), _b(stem), 1 if write_mrf else 0))
+
+
+def format_count(events, cnt):
+    out = vp()
+    a = np.ascontiguousarray(cnt, np.uint64)
+    check(lib.lsq_format_count(events.h, events.n_methods, _ptr(a, u64), C.byref(out)))
+    return _take_text(out)
+
+
+def format_solve(events, cnt, bases, theta, logll, total_read_bases):
+    out = vp()
+    a = np.ascontiguousarray(cnt, np.uint64)
+    b = np.ascontiguousarray(bases, np.uint64)
+    t = np.ascontiguousarray(theta, np.float64)
+    l = np.ascontiguousarray(logll, np.float64)
+    r = np.ascontiguousarray(total_read_bases, np.float64)
+    check(lib.lsq_format_solve(events.h, events.n_methods, _ptr(a, u64), _ptr(b, u64), _ptr(t, C.c_double),
+                               _ptr(l, C.c_double), _ptr(r, C.c_double), C.byref(out)))
+    return _take_text(out)
+
+
+def cli_run(tool, argv):
+    """Runs count / solve / classify in-process with the reference's argv (without argv[0]).
+    Returns (exit_status, stdout_text).  The log goes to this process's stderr."""
+    full = [b"lsq"] + [_b(a) for a in argv]
+    arr = (cs * len(full))(*full)
+    out = vp()
+    rc = lib.lsq_cli_run(_b(tool), len(full), arr, C.byref(out))
+    return rc, _take_text(out)

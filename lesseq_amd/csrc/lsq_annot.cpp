@@ -1,0 +1,557 @@
+// Host side of the path, part 1: annotation loading, event compilation and the device plan
+// (buckets + LDS images).  Semantics restated from the reference lines cited at each step.
+#include <algorithm>
+#include <cerrno>
+#include <cstdarg>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <thread>
+
+#include "lsq_internal.hpp"
+
+namespace lsq {
+
+static thread_local std::string g_err;
+
+int fail(int status, const char *fmt, ...) {
+	char buf[1024];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof buf, fmt, ap);
+	va_end(ap);
+	g_err = buf;
+	return status;
+}
+
+int host_threads(int requested) {
+	if (requested > 0) return requested;
+	if (const char *e = getenv("LSQ_THREADS")) { int v = atoi(e); if (v > 0) return v; }
+	unsigned hc = std::thread::hardware_concurrency();
+	return hc ? (int)std::min(hc, 32u) : 4;
+}
+
+int Dict::intern(const std::string &s) {
+	std::lock_guard<std::mutex> g(mu);
+	auto it = ids.find(s);
+	if (it != ids.end()) return it->second;
+	int id = (int)names.size();
+	names.push_back(s);
+	ids.emplace(s, id);
+	return id;
+}
+int Dict::find(const std::string &s) const {
+	auto it = ids.find(s);
+	return it == ids.end() ? -1 : it->second;
+}
+
+// ---- interval_list::add_interval (interval_list.hpp:462-503) -------------------------------
+// The reference edits its `starts` and `ends` vectors independently, driven by four
+// lower_bound positions.  Consequence worth knowing: an interval that ends exactly where the
+// new one starts is merged with it, one that starts exactly where the new one ends is not.
+void IntervalList::add(int64_t start, int64_t end) {
+	if (!(start < end)) return;
+	auto ss = std::lower_bound(s.begin(), s.end(), start) - s.begin();
+	auto se = std::lower_bound(e.begin(), e.end(), start) - e.begin();
+	auto es = std::lower_bound(s.begin(), s.end(), end) - s.begin();
+	auto ee = std::lower_bound(e.begin(), e.end(), end) - e.begin();
+	bool start_inside = (ss - se == 1), end_inside = (es - ee == 1);
+	auto sit = s.erase(s.begin() + ss, s.begin() + es);
+	auto eit = e.erase(e.begin() + se, e.begin() + ee);
+	if (!start_inside) s.insert(sit, start);
+	if (!end_inside) e.insert(eit, end);
+}
+// interval_list::contains_interval (interval_list.hpp:396-422): inside ONE stored interval
+bool IntervalList::contains(int64_t start, int64_t end) const {
+	if (!(start < end)) return true;
+	size_t i = std::lower_bound(s.begin(), s.end(), start) - s.begin();
+	if (i < s.size() && s[i] <= start && end <= e[i]) return true;
+	if (i >= 1 && i - 1 < s.size() && s[i - 1] <= start && end <= e[i - 1]) return true;
+	return false;
+}
+
+// ---- ExonSet::insert (splicing_graph.h:88-169) ----------------------------------------------
+// Segments are kept ordered by start with unique starts (the reference's std::set compares
+// starts only, so inserting a piece whose start is already present is a no-op).
+namespace {
+struct Seg { int64_t start, end; };
+
+void put_unique(std::vector<Seg> &v, Seg x) {
+	if (!(x.start < x.end)) return;
+	auto it = std::lower_bound(v.begin(), v.end(), x.start, [](const Seg &a, int64_t s) { return a.start < s; });
+	if (it != v.end() && it->start == x.start) return;
+	v.insert(it, x);
+}
+
+void exon_insert(std::vector<Seg> &v, int64_t start, int64_t end) {
+	Seg nw{start, end};
+	std::vector<Seg> pieces;
+	size_t i = std::lower_bound(v.begin(), v.end(), nw.start, [](const Seg &a, int64_t s) { return a.start < s; }) - v.begin();
+	if (!v.empty() && i != 0) --i;
+	for (; i < v.size() && v[i].start < nw.end; ++i) {
+		Seg &old = v[i];
+		if (old.start == nw.start) {
+			if (old.end > nw.end) { pieces.push_back({nw.end, old.end}); old.end = nw.end; nw.start = nw.end; }
+			else nw.start = old.end;
+		} else if (old.start < nw.start) {
+			if (old.end > nw.start) {
+				if (old.end > nw.end) {          // new exon strictly inside the old one
+					pieces.push_back({nw.start, nw.end});
+					pieces.push_back({nw.end, old.end});
+					old.end = nw.start;
+					nw.start = nw.end;
+				} else {                          // overlap on the old exon's right side
+					pieces.push_back({nw.start, old.end});
+					int64_t old_end = old.end;
+					old.end = nw.start;
+					nw.start = old_end;
+				}
+			}
+		} else {
+			if (old.end > nw.end) {               // overlap on the old exon's left side
+				pieces.push_back({nw.end, old.end});
+				old.end = nw.end;
+				nw.end = old.start;
+			} else {                              // old exon inside the new one
+				pieces.push_back({nw.start, old.start});
+				nw.start = old.end;
+			}
+		}
+	}
+	put_unique(v, nw);
+	for (const Seg &p : pieces) put_unique(v, p);
+}
+
+// boost::lexical_cast-like strict integer (whole token, optional sign, digits)
+bool strict_long(const std::string &t, int64_t &out) {
+	if (t.empty() || t.size() > 40) return false;
+	size_t i = (t[0] == '+' || t[0] == '-') ? 1 : 0;
+	if (i == t.size()) return false;
+	for (size_t j = i; j < t.size(); ++j) if (t[j] < '0' || t[j] > '9') return false;
+	errno = 0;
+	char *endp;
+	long v = strtol(t.c_str(), &endp, 10);
+	if (errno == ERANGE || *endp) return false;
+	out = v;
+	return true;
+}
+
+// tokenizer(",") + atol per token (count/count.cpp:154-168)
+void split_atol(const std::string &s, std::vector<int64_t> &out) {
+	size_t i = 0;
+	while (i < s.size()) {
+		while (i < s.size() && s[i] == ',') ++i;
+		if (i >= s.size()) break;
+		size_t j = s.find(',', i);
+		if (j == std::string::npos) j = s.size();
+		out.push_back(atol(s.substr(i, j - i).c_str()));
+		i = j;
+	}
+}
+
+// `while (getline(ifs, line) && !ifs.eof())`: only newline-terminated lines are seen
+bool read_lines(const char *path, std::vector<std::string> &lines) {
+	FILE *f = fopen(path, "rb");
+	if (!f) return false;
+	std::string data;
+	char buf[1 << 16];
+	size_t n;
+	while ((n = fread(buf, 1, sizeof buf, f)) > 0) data.append(buf, n);
+	fclose(f);
+	size_t pos = 0;
+	while (pos < data.size()) {
+		size_t nl = data.find('\n', pos);
+		if (nl == std::string::npos) break;
+		lines.emplace_back(data, pos, nl - pos);
+		pos = nl + 1;
+	}
+	return true;
+}
+} // namespace
+
+} // namespace lsq
+
+using namespace lsq;
+
+extern "C" {
+
+const char *lsq_last_error(void) { return lsq::g_err.c_str(); }
+int lsq_abi_version(void) { return LSQ_ABI_VERSION; }
+void lsq_free(void *p) { free(p); }
+
+// count/count.cpp:135-216
+int lsq_annotation_load(const char *isoform_format, const char *isoforms_path,
+                        const char *g2i_format, const char *g2i_path,
+                        uint64_t gene_begin_idx, uint64_t gene_end_idx, lsq_annotation **out) {
+	if (!isoform_format || !isoforms_path || !g2i_format || !g2i_path || !out) return fail(LSQ_E_ARG, "null argument");
+	std::vector<std::string> lines;
+	if (!read_lines(isoforms_path, lines)) return fail(LSQ_E_IO, "cannot open isoforms file %s", isoforms_path);
+	if (strcmp(isoform_format, "LH_GENE_TXT") != 0) return fail(LSQ_E_FORMAT, "Unknown file format error: %s", isoform_format);
+	std::unique_ptr<lsq_annotation> a(new lsq_annotation);
+	for (const std::string &line : lines) {
+		std::istringstream iss(line);
+		std::unique_ptr<IsoRec> r(new IsoRec);
+		std::string t_s, t_e, t_n, starts, ends;
+		iss >> r->name >> r->chrom >> r->strand >> t_s >> t_e >> t_n >> starts >> ends;
+		int64_t cnt = 0;
+		if (strict_long(t_s, r->txStart) && strict_long(t_e, r->txEnd) && strict_long(t_n, cnt) && cnt >= 0) {
+			r->exonCount = (uint64_t)cnt;
+			split_atol(starts, r->exonStarts);
+			split_atol(ends, r->exonEnds);
+		}
+		a->recs.push_back(std::move(r));
+	}
+	// iname2gap: the last record of a name wins (count/count.cpp:176-179)
+	std::unordered_map<std::string, const IsoRec *> by_name;
+	for (auto &r : a->recs) by_name[r->name] = r.get();
+
+	lines.clear();
+	if (!read_lines(g2i_path, lines)) return fail(LSQ_E_IO, "cannot open gene->isoform file %s", g2i_path);
+	if (strcmp(g2i_format, "UCSC_GENE2ISOFORM") != 0) return fail(LSQ_E_FORMAT, "Unknown file format error: %s", g2i_format);
+	std::map<std::string, std::vector<const IsoRec *>> genes;   // std::map: bytewise key order == std::set<string>
+	for (const std::string &line : lines) {
+		std::istringstream iss(line);
+		std::string g, i;
+		iss >> g >> i;
+		auto it = by_name.find(i);
+		if (it == by_name.end())
+			return fail(LSQ_E_ARG, "gene %s names isoform '%s' that is not in %s (the reference dereferences a null record here)", g.c_str(), i.c_str(), isoforms_path);
+		genes[g].push_back(it->second);
+	}
+	a->n_genes_loaded = (int64_t)genes.size();
+	uint64_t idx = 0;
+	for (auto &kv : genes) {
+		if (idx >= gene_begin_idx && idx < gene_end_idx) {
+			Gene g;
+			g.name = kv.first;
+			g.isos = kv.second;
+			a->selected.push_back(std::move(g));
+		}
+		++idx;
+	}
+	*out = a.release();
+	return LSQ_OK;
+}
+void lsq_annotation_free(lsq_annotation *a) { delete a; }
+int64_t lsq_annotation_num_genes(const lsq_annotation *a) { return a ? (int64_t)a->selected.size() : 0; }
+int64_t lsq_annotation_num_isoforms_loaded(const lsq_annotation *a) { return a ? (int64_t)a->recs.size() : 0; }
+int64_t lsq_annotation_num_genes_loaded(const lsq_annotation *a) { return a ? a->n_genes_loaded : 0; }
+
+} // extern "C"
+
+namespace lsq {
+
+// accessible_read_starts.h:48-89 (MEDIUM) and :221-274 (SHORT, min_partial_exon_size = 0):
+// walking the isoform's segments, every segment before the one where the remaining
+// transcript gets shorter than a read contributes l (MEDIUM) or l + 1 (SHORT: the union
+// [0, max(l-R+1,0)) U [max(l-R,0), l+1) is [0, l+1)); that segment contributes
+// max(l + 1 - (c + R - L), 0); later segments nothing.
+static uint64_t ars_total(const std::vector<uint64_t> &seg_len, uint64_t R, bool short_read) {
+	uint64_t L = 0;
+	for (uint64_t l : seg_len) L += l;
+	uint64_t total = 0, c = 0;
+	for (uint64_t l : seg_len) {
+		c += l;
+		if (c + R > L) {
+			int64_t v = (int64_t)l + 1 - (int64_t)(c + R - L);
+			total += (uint64_t)std::max<int64_t>(v, 0);
+			break;
+		}
+		total += short_read ? (l > 0 ? l + 1 : 0) : l;
+	}
+	return total;
+}
+
+static const int64_t COORD_LIMIT = (int64_t)1 << 30;
+
+static uint32_t lds_budget_bytes() {
+	if (const char *e = getenv("LSQ_LDS_BUDGET")) { long v = atol(e); if (v >= 4096 && v <= 160 * 1024) return (uint32_t)v; }
+	return 64 * 1024;
+}
+
+// Builds buckets + LDS images from the compiled events.
+static int plan_device(lsq_events &E) {
+	const size_t n = E.ev.size();
+	E.lds_budget = lds_budget_bytes();
+	E.buckets.clear(); E.images.clear(); E.dev2out.clear(); E.ties.clear();
+	E.dev_cls_base.clear(); E.dev_iso_base.clear(); E.dev_K.clear();
+	E.cut_lo.assign(E.chroms.names.size(), {});
+	E.chrom_first_bucket.assign(E.chroms.names.size(), -1);
+	E.n_cls_total = E.n_iso_total = 0;
+	E.max_lds_bytes = 0;
+
+	// events per chromosome, ordered by span start
+	std::vector<std::vector<int32_t>> per_chrom(E.chroms.names.size());
+	for (size_t i = 0; i < n; ++i) per_chrom[E.ev[i].chrom_id].push_back((int32_t)i);
+	auto ev_bytes = [&](const Event &e) -> uint32_t {
+		return 16u + 8u * (uint32_t)e.N + 4u * (uint32_t)e.K + 8u * ((1u << e.K) - 1u);
+	};
+	for (size_t c = 0; c < per_chrom.size(); ++c) {
+		auto &lst = per_chrom[c];
+		if (lst.empty()) continue;
+		std::sort(lst.begin(), lst.end(), [&](int32_t a, int32_t b) {
+			const Event &x = E.ev[a], &y = E.ev[b];
+			if (x.gene_start != y.gene_start) return x.gene_start < y.gene_start;
+			if (x.gene_end != y.gene_end) return x.gene_end < y.gene_end;
+			return a < b;
+		});
+		// clusters of transitively overlapping spans (a read start p is a candidate of an event
+		// iff gene_start <= p <= gene_end), packed greedily into buckets
+		size_t i = 0;
+		while (i < lst.size()) {
+			size_t b_begin = i;
+			uint32_t bytes = 0;
+			size_t n_ev = 0;
+			while (i < lst.size()) {
+				size_t j = i;
+				int64_t max_end = E.ev[lst[j]].gene_end;
+				uint32_t cb = 0;
+				size_t cn = 0;
+				while (j < lst.size() && (j == i || E.ev[lst[j]].gene_start <= max_end)) {
+					max_end = std::max(max_end, E.ev[lst[j]].gene_end);
+					cb += ev_bytes(E.ev[lst[j]]);
+					++cn; ++j;
+				}
+				// bins: at most 2 B per event pair, bounded; keep 8 KiB aside for them
+				uint32_t cap = E.lds_budget - 8192 - 64;
+				if (n_ev > 0 && (bytes + cb > cap || n_ev + cn > 60000)) break;
+				if (n_ev == 0 && (cb > cap || cn > 60000))
+					return fail(LSQ_E_UNSUPPORTED, "%zu mutually overlapping events on %s need %u bytes of LDS tables (budget %u): not supported by the device path yet",
+					            cn, E.chroms.names[c].c_str(), cb, E.lds_budget);
+				bytes += cb; n_ev += cn; i = j;
+			}
+			// ---- emit bucket [b_begin, i)
+			BucketDesc d;
+			memset(&d, 0, sizeof d);
+			d.chrom_id = (int32_t)c;
+			d.n_events = (uint32_t)(i - b_begin);
+			int64_t lo = E.ev[lst[b_begin]].gene_start, hi = lo;
+			uint32_t nseg = 0, niso = 0, ncls = 0;
+			for (size_t k = b_begin; k < i; ++k) {
+				const Event &e = E.ev[lst[k]];
+				hi = std::max(hi, e.gene_end);
+				nseg += (uint32_t)e.N; niso += (uint32_t)e.K; ncls += (1u << e.K) - 1u;
+			}
+			if (nseg > 65535 || niso > 65535 || ncls > 65535) return fail(LSQ_E_UNSUPPORTED, "bucket tables exceed 16-bit offsets");
+			uint32_t want = 16;
+			while (want < 2 * d.n_events && want < 4096) want <<= 1;
+			uint32_t shift = 0;
+			while ((((uint64_t)(hi - lo)) >> shift) >= want) ++shift;
+			d.n_bins = want; d.shift = shift; d.lo = (int32_t)lo;
+			auto align16 = [](uint32_t x) { return (x + 15u) & ~15u; };
+			uint32_t off = 0;
+			uint32_t bins_off = off; off = align16(off + 2 * d.n_bins);
+			d.ev_off = off; off = align16(off + 16 * d.n_events);
+			d.seg_off = off; off = align16(off + 8 * nseg);
+			d.iso_off = off; off = align16(off + 4 * niso);
+			d.img_bytes = off;
+			d.hist_off = off; off += 8 * ncls;
+			d.n_cls = ncls;
+			if (off > E.lds_budget) return fail(LSQ_E_UNSUPPORTED, "internal: bucket of %u events needs %u bytes of LDS", d.n_events, off);
+			E.max_lds_bytes = std::max(E.max_lds_bytes, off);
+			d.img_off = (uint32_t)E.images.size();
+			d.cls_base = E.n_cls_total;
+			d.ev_base = (uint32_t)E.dev2out.size();
+			E.images.resize(E.images.size() + d.img_bytes, 0);
+			uint8_t *img = E.images.data() + d.img_off;
+			uint16_t *bins = reinterpret_cast<uint16_t *>(img + bins_off);
+			EventRec *recs = reinterpret_cast<EventRec *>(img + d.ev_off);
+			int32_t *segs = reinterpret_cast<int32_t *>(img + d.seg_off);
+			uint32_t *isos = reinterpret_cast<uint32_t *>(img + d.iso_off);
+			uint32_t so = 0, io = 0, co = 0;
+			for (size_t k = b_begin; k < i; ++k) {
+				const Event &e = E.ev[lst[k]];
+				EventRec &r = recs[k - b_begin];
+				r.gs = (int32_t)e.gene_start; r.ge = (int32_t)e.gene_end;
+				r.seg_off = (uint16_t)so; r.iso_off = (uint16_t)io; r.cls_off = (uint16_t)co;
+				r.nseg = (uint8_t)e.N; r.K = (uint8_t)e.K;
+				for (int s = 0; s < e.N; ++s) { segs[2 * (so + s)] = (int32_t)e.seg_s[s]; segs[2 * (so + s) + 1] = (int32_t)e.seg_e[s]; }
+				for (int q = 0; q < e.K; ++q) isos[io + q] = (uint32_t)e.iso_mask[q];
+				E.dev2out.push_back(lst[k]);
+				E.dev_cls_base.push_back(E.n_cls_total + co);
+				E.dev_iso_base.push_back(E.n_iso_total + io);
+				E.dev_K.push_back((uint8_t)e.K);
+				TieRec t;
+				memset(&t, 0, sizeof t);
+				t.strand_id = (uint8_t)e.strand_id;
+				t.tie_mode = (uint8_t)e.tie_mode;
+				t.tail_len = (uint8_t)std::min<size_t>(e.tie_tail.size(), sizeof t.tail);
+				memcpy(t.tail, e.tie_tail.data(), t.tail_len);
+				E.ties.push_back(t);
+				so += (uint32_t)e.N; io += (uint32_t)e.K; co += (1u << e.K) - 1u;
+			}
+			E.n_cls_total += ncls; E.n_iso_total += niso;
+			// bin k -> first event (span-start order) whose span reaches bin k or beyond
+			uint32_t first = 0;
+			for (uint32_t k = 0; k < d.n_bins; ++k) {
+				int64_t bin_lo = lo + ((int64_t)k << shift);
+				// an event is passed over only once its end lies left of a bin start, so it can
+				// never reach a later bin: `first` is min{i : ge_i >= bin_lo} for every k
+				while (first < d.n_events && recs[first].ge < bin_lo) ++first;
+				bins[k] = (uint16_t)first;
+			}
+			if (E.chrom_first_bucket[c] < 0) E.chrom_first_bucket[c] = (int32_t)E.buckets.size();
+			E.cut_lo[c].push_back((int32_t)lo);
+			E.buckets.push_back(d);
+		}
+	}
+	return LSQ_OK;
+}
+
+} // namespace lsq
+
+namespace lsq {
+
+// count/count.cpp:231-258 and :394-416.  device_plan = false (classify) skips the device
+// limits and the bucket/LDS-image plan.
+int compile_events(const lsq_annotation *a, int n_methods, const char *const *read_types,
+                   const uint64_t *expected_read_lengths, bool device_plan, lsq_events **out) {
+	if (!a || !out || n_methods < 0 || n_methods > LSQ_MAX_METHODS) return fail(LSQ_E_ARG, "bad argument (1..%d methods)", LSQ_MAX_METHODS);
+	std::unique_ptr<lsq_events> E(new lsq_events);
+	E->n_methods = n_methods;
+	std::vector<bool> is_short(n_methods);
+	for (int m = 0; m < n_methods; ++m) {
+		E->read_types.push_back(read_types[m]);
+		E->read_lengths.push_back(expected_read_lengths[m]);
+		if (E->read_types[m] == "SHORT_READ") is_short[m] = true;
+		else if (E->read_types[m] == "MEDIUM_READ") is_short[m] = false;
+		else return fail(LSQ_E_FORMAT, "Unknown read type error: %s", read_types[m]);
+	}
+	E->ev.reserve(a->selected.size());
+	for (const Gene &g : a->selected) {
+		Event e;
+		e.gname = g.name;
+		std::vector<Seg> segs;
+		IntervalList span;
+		if (!g.isos.empty()) { e.chrom = g.isos[0]->chrom; e.strand = g.isos[0]->strand; }   // splicing_graph.h:239-242
+		e.chrom_id = E->chroms.intern(e.chrom);
+		e.strand_id = E->strands.intern(e.strand);
+		for (const IsoRec *r : g.isos) {
+			if (r->exonStarts.size() < r->exonCount || r->exonEnds.size() < r->exonCount)
+				return fail(LSQ_E_ARG, "isoform %s: exonCount %llu exceeds the listed exons (the reference reads past its vectors here)", r->name.c_str(), (unsigned long long)r->exonCount);
+			int cid = E->chroms.intern(r->chrom);
+			if ((size_t)cid >= E->covered.size()) E->covered.resize(cid + 1);
+			for (uint64_t i = 0; i < r->exonCount; ++i) {
+				int64_t s = r->exonStarts[i], t = r->exonEnds[i];
+				if (s <= -COORD_LIMIT || s >= COORD_LIMIT || t <= -COORD_LIMIT || t >= COORD_LIMIT)
+					return fail(LSQ_E_RANGE, "isoform %s: exon coordinate outside +-2^30", r->name.c_str());
+				if (s > t) return fail(LSQ_E_ARG, "isoform %s: exon start > end (the reference asserts)", r->name.c_str());
+				exon_insert(segs, s, t);
+				E->covered[cid].add(s, t);
+				span.add(s, t);
+			}
+		}
+		if (span.size() == 0) return fail(LSQ_E_ARG, "gene %s has no exon (the reference reads an empty vector here)", g.name.c_str());
+		e.gene_start = span.s.front();
+		e.gene_end = span.e.back();
+		e.N = (int)segs.size();
+		e.K = (int)g.isos.size();
+		if (e.N > 64 && !device_plan) return fail(LSQ_E_UNSUPPORTED, "gene %s has %d segments (limit 64)", g.name.c_str(), e.N);
+		if (!device_plan) { /* no device limits */ }
+		else if (e.N > LSQ_MAX_SEGMENTS) return fail(LSQ_E_UNSUPPORTED, "gene %s has %d segments (device limit %d)", g.name.c_str(), e.N, LSQ_MAX_SEGMENTS);
+		if (device_plan && e.K > LSQ_MAX_ISOFORMS) return fail(LSQ_E_UNSUPPORTED, "gene %s has %d isoforms (device limit %d)", g.name.c_str(), e.K, LSQ_MAX_ISOFORMS);
+		for (const Seg &s : segs) { e.seg_s.push_back(s.start); e.seg_e.push_back(s.end); }
+		// build_isoform_array (splicing_graph.h:318-361): per isoform walk the segments in order;
+		// the exon search resumes at the exon that held the previous segment
+		e.ars.assign(n_methods, {});
+		for (const IsoRec *r : g.isos) {
+			uint64_t mask = 0, len = 0;
+			uint64_t from = 0;
+			std::vector<uint64_t> seg_len;
+			for (int n = 0; n < e.N; ++n) {
+				for (uint64_t i = from; i < r->exonCount; ++i) {
+					if (r->exonStarts[i] <= e.seg_s[n] && e.seg_e[n] <= r->exonEnds[i]) {
+						mask |= 1ull << n;
+						uint64_t l = (uint64_t)(e.seg_e[n] - e.seg_s[n]);
+						len += l;
+						seg_len.push_back(l);
+						from = i;
+						break;
+					}
+				}
+			}
+			if (seg_len.empty()) return fail(LSQ_E_ARG, "isoform %s holds no segment (the reference asserts)", r->name.c_str());
+			e.iso_names.push_back(r->name);
+			e.iso_mask.push_back(mask);
+			e.iso_len.push_back(len);
+			for (int m = 0; m < n_methods; ++m) e.ars[m].push_back(ars_total(seg_len, E->read_lengths[m], is_short[m]));
+		}
+		// "read-<n>" < gname ? (count/count.cpp:71, std::string operator<)
+		static const char pfx[] = "read-";
+		size_t p = 0;
+		while (p < 5 && p < e.gname.size() && e.gname[p] == pfx[p]) ++p;
+		if (p == 5) { e.tie_mode = 2; e.tie_tail = e.gname.substr(5); }
+		else if (p == e.gname.size()) e.tie_mode = 0;                    // gname is a proper prefix of "read-"
+		else e.tie_mode = ((unsigned char)pfx[p] < (unsigned char)e.gname[p]) ? 1 : 0;
+		E->ev.push_back(std::move(e));
+	}
+	if (E->covered.size() < E->chroms.names.size()) E->covered.resize(E->chroms.names.size());
+	if (E->chroms.names.size() > 65000) return fail(LSQ_E_RANGE, "too many chromosomes");
+	if (E->strands.names.size() > 255) return fail(LSQ_E_RANGE, "more than 255 distinct strand strings");
+	if (!device_plan) { *out = E.release(); return LSQ_OK; }
+	E->class_off.assign(E->ev.size() + 1, 0);
+	E->iso_off.assign(E->ev.size() + 1, 0);
+	for (size_t i = 0; i < E->ev.size(); ++i) {
+		E->class_off[i + 1] = E->class_off[i] + (E->ev[i].K < 32 ? ((1ull << E->ev[i].K) - 1) : 0);
+		E->iso_off[i + 1] = E->iso_off[i] + (uint64_t)E->ev[i].K;
+	}
+	int rc = plan_device(*E);
+	if (rc) return rc;
+	*out = E.release();
+	return LSQ_OK;
+}
+
+} // namespace lsq
+
+extern "C" {
+
+int lsq_events_compile(const lsq_annotation *a, int n_methods, const char *const *read_types,
+                       const uint64_t *expected_read_lengths, lsq_events **out) {
+	return lsq::compile_events(a, n_methods, read_types, expected_read_lengths, true, out);
+}
+void lsq_events_free(lsq_events *e) { delete e; }
+
+int64_t lsq_events_count(const lsq_events *e) { return e ? (int64_t)e->ev.size() : 0; }
+int64_t lsq_events_total_isoforms(const lsq_events *e) { return e ? (int64_t)e->iso_off.back() : 0; }
+#define EV_OR(ret) if (!e || ev < 0 || (size_t)ev >= e->ev.size()) return ret
+const char *lsq_events_gene_name(const lsq_events *e, int64_t ev) { EV_OR(nullptr); return e->ev[ev].gname.c_str(); }
+const char *lsq_events_chrom(const lsq_events *e, int64_t ev) { EV_OR(nullptr); return e->ev[ev].chrom.c_str(); }
+const char *lsq_events_strand(const lsq_events *e, int64_t ev) { EV_OR(nullptr); return e->ev[ev].strand.c_str(); }
+int lsq_events_num_isoforms(const lsq_events *e, int64_t ev) { EV_OR(-1); return e->ev[ev].K; }
+int lsq_events_num_segments(const lsq_events *e, int64_t ev) { EV_OR(-1); return e->ev[ev].N; }
+const char *lsq_events_isoform_name(const lsq_events *e, int64_t ev, int iso) {
+	EV_OR(nullptr);
+	if (iso < 0 || iso >= e->ev[ev].K) return nullptr;
+	return e->ev[ev].iso_names[iso].c_str();
+}
+int lsq_events_segment(const lsq_events *e, int64_t ev, int n, int64_t *start, int64_t *end) {
+	EV_OR(LSQ_E_ARG);
+	if (n < 0 || n >= e->ev[ev].N) return LSQ_E_ARG;
+	*start = e->ev[ev].seg_s[n]; *end = e->ev[ev].seg_e[n];
+	return LSQ_OK;
+}
+uint64_t lsq_events_isoform_mask(const lsq_events *e, int64_t ev, int iso) { EV_OR(0); return (iso < 0 || iso >= e->ev[ev].K) ? 0 : e->ev[ev].iso_mask[iso]; }
+uint64_t lsq_events_isoform_length(const lsq_events *e, int64_t ev, int iso) { EV_OR(0); return (iso < 0 || iso >= e->ev[ev].K) ? 0 : e->ev[ev].iso_len[iso]; }
+uint64_t lsq_events_ars(const lsq_events *e, int method, int64_t ev, int iso) {
+	EV_OR(0);
+	if (method < 0 || method >= e->n_methods || iso < 0 || iso >= e->ev[ev].K) return 0;
+	return e->ev[ev].ars[method][iso];
+}
+int lsq_events_span(const lsq_events *e, int64_t ev, int64_t *gs, int64_t *ge) { EV_OR(LSQ_E_ARG); *gs = e->ev[ev].gene_start; *ge = e->ev[ev].gene_end; return LSQ_OK; }
+int64_t lsq_events_num_buckets(const lsq_events *e) { return e ? (int64_t)e->buckets.size() : 0; }
+
+int lsq_events_chrom_id(lsq_events *e, const char *chrom) {
+	if (!e || !chrom) return LSQ_E_ARG;
+	int id = e->chroms.intern(chrom);
+	if (id > 65000) return fail(LSQ_E_RANGE, "too many chromosome names");
+	return id;
+}
+int lsq_events_strand_id(lsq_events *e, const char *strand) {
+	if (!e || !strand) return LSQ_E_ARG;
+	int id = e->strands.intern(strand);
+	if (id > 255) return fail(LSQ_E_RANGE, "more than 256 distinct strand strings");
+	return id;
+}
+
+} // extern "C"

@@ -1,0 +1,307 @@
+// Host side of the path, part 3: output rows (count/count.cpp:486-492, solve/solve.cpp:808-847)
+// and the three executables' argv handling, exit codes and stderr log.
+#include <algorithm>
+#include <cctype>
+#include <cerrno>
+#include <cstdarg>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <string>
+#include <vector>
+
+#include "lsq_internal.hpp"
+
+using namespace lsq;
+
+namespace lsq { int compile_events(const lsq_annotation *a, int n_methods, const char *const *read_types,
+                                   const uint64_t *lens, bool device_plan, lsq_events **out); }
+
+namespace {
+
+// C++ `ostream << double` with default flags prints like printf("%g")
+void put_g(std::string &o, double v) {
+	char t[64];
+	int n = snprintf(t, sizeof t, "%g", v);
+	o.append(t, (size_t)n);
+}
+
+char *dup_text(const std::string &s) {
+	char *p = (char *)malloc(s.size() + 1);
+	if (p) { memcpy(p, s.data(), s.size()); p[s.size()] = 0; }
+	return p;
+}
+
+// jsc/util/log.hpp:22-79: "[LOG YYYY-MM-DD hh:mm:ss LEVEL] text" on stderr when level <= reporting level
+int g_log_level = 2;
+void logf(int level, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+void logf(int level, const char *fmt, ...) {
+	if (level > g_log_level) return;
+	static const char *names[] = {"ERROR", "WARNING", "INFO", "DEBUG"};
+	time_t raw; time(&raw);
+	struct tm tmv; localtime_r(&raw, &tmv);
+	char msg[2048];
+	va_list ap; va_start(ap, fmt); vsnprintf(msg, sizeof msg, fmt, ap); va_end(ap);
+	fprintf(stderr, "[LOG %d-%02d-%02d %02d:%02d:%02d %s] %s\n", tmv.tm_year + 1900, tmv.tm_mon + 1, tmv.tm_mday,
+	        tmv.tm_hour, tmv.tm_min, tmv.tm_sec, names[level < 3 ? level : 3], msg);
+	fflush(stderr);
+}
+
+bool cast_long(const char *s, long &out) {
+	if (!*s) return false;
+	size_t i = (s[0] == '+' || s[0] == '-') ? 1 : 0;
+	if (!s[i]) return false;
+	for (size_t j = i; s[j]; ++j) if (s[j] < '0' || s[j] > '9') return false;
+	errno = 0; char *e; long v = strtol(s, &e, 10);
+	if (errno == ERANGE || *e) return false;
+	out = v; return true;
+}
+bool cast_ulong(const char *s, unsigned long &out) {
+	if (!*s) return false;
+	size_t i = (s[0] == '+' || s[0] == '-') ? 1 : 0;
+	if (!s[i]) return false;
+	for (size_t j = i; s[j]; ++j) if (s[j] < '0' || s[j] > '9') return false;
+	errno = 0; char *e; unsigned long v = strtoul(s, &e, 10);
+	if (errno == ERANGE || *e) return false;
+	out = v; return true;
+}
+bool cast_double(const char *s, double &out) {
+	if (!*s || isspace((unsigned char)*s)) return false;
+	char *e; double v = strtod(s, &e);
+	if (e == s || *e) return false;
+	out = v; return true;
+}
+
+const int EXIT_ABORT = 134;   // the reference dies on assert / an uncaught exception
+
+int status_to_exit(int st) {
+	switch (st) {
+	case LSQ_OK: return 0;
+	case LSQ_E_IO: return EXIT_ABORT;          // assert(ifs.is_open()) (count/count.cpp:139,185,278)
+	case LSQ_E_FORMAT: case LSQ_E_PARSE: return 1;
+	default: return 2;                         // conditions the reference has no defined behaviour for
+	}
+}
+
+struct Freer {
+	lsq_annotation *a = nullptr; lsq_events *e = nullptr; lsq_ctx *c = nullptr;
+	std::vector<lsq_reads *> r;
+	~Freer() { for (auto *x : r) lsq_reads_free(x); if (c) lsq_ctx_destroy(c); lsq_events_free(e); lsq_annotation_free(a); }
+};
+
+int run_classify(int argc, const char *const *argv) {
+	if (argc < 10) { logf(0, "Usage:\nclassify\n\tlog_level(0,1,2,...) proj_name out_prefix\n\tisoform_format isoforms_path g2i_format g2i_path gene_begin_idx gene_end_idx"); return 1; }
+	long lvl;
+	if (!cast_long(argv[1], lvl)) return EXIT_ABORT;
+	g_log_level = (int)lvl;
+	std::string out_prefix = argv[3];
+	unsigned long gb, ge;
+	if (!cast_ulong(argv[8], gb) || !cast_ulong(argv[9], ge)) { logf(0, "Lexical_cast error when converting arguments to numeric values"); return 1; }
+	Freer F;
+	int st = lsq_annotation_load(argv[4], argv[5], argv[6], argv[7], gb, ge, &F.a);
+	if (st) { logf(0, "%s", lsq_last_error()); return status_to_exit(st); }
+	logf(2, "Loaded %lld isoforms", (long long)lsq_annotation_num_isoforms_loaded(F.a));
+	logf(2, "Loaded %lld genes", (long long)lsq_annotation_num_genes_loaded(F.a));
+	st = compile_events(F.a, 0, nullptr, nullptr, false, &F.e);
+	if (st) { logf(0, "%s", lsq_last_error()); return status_to_exit(st); }
+	size_t written = 0;
+	for (const Event &e : F.e->ev) {
+		if (e.K < 2) continue;                                       // classify/classify.cpp:159
+		std::string path = out_prefix + e.gname + ".matrix";
+		FILE *f = fopen(path.c_str(), "w");
+		if (!f) { logf(0, "cannot write %s", path.c_str()); return EXIT_ABORT; }
+		fprintf(f, "%s\t%s\t", e.chrom.c_str(), e.strand.c_str());
+		for (int n = 0; n < e.N; ++n) fprintf(f, "[%lld,%lld)-", (long long)e.seg_s[n], (long long)e.seg_e[n]);
+		fputc('\n', f);
+		for (int k = 0; k < e.K; ++k) {
+			for (int n = 0; n < e.N; ++n) fprintf(f, "%d\t", (int)(e.iso_mask[k] >> n & 1));
+			fputc('\n', f);
+		}
+		fclose(f);
+		++written;
+	}
+	logf(2, "Built isoform structures for the %zu selected gene(s)", written);
+	return 0;
+}
+
+int run_count_solve(bool solve, int argc, const char *const *argv, std::string &out) {
+	const int per = solve ? 5 : 4;
+	auto usage = [&] {
+		logf(0, "Usage:\n%s\n\tlog_level(0,1,2,...) proj_name out_prefix\n\tisoform_format isoforms_path g2i_format g2i_path gene_begin_idx gene_end_idx\n  (read_format read_type expected_read_length reads_path%s)+",
+		     solve ? "solve" : "count", solve ? " total_read_bases" : "");
+		return 1;
+	};
+	if (argc < (solve ? 15 : 14)) return usage();
+	long lvl;
+	if (!cast_long(argv[1], lvl)) return EXIT_ABORT;      // lexical_cast outside the try block (count/count.cpp:99)
+	g_log_level = (int)lvl;
+	unsigned long gb, ge;
+	if (!cast_ulong(argv[8], gb) || !cast_ulong(argv[9], ge)) { logf(0, "Lexical_cast error when converting arguments to numeric values"); return 1; }
+	std::vector<const char *> fmts, types, paths;
+	std::vector<uint64_t> lens;
+	std::vector<double> trb;
+	for (int i = 10; i < argc;) {
+		if (argc - i < per) return usage();
+		fmts.push_back(argv[i++]);
+		types.push_back(argv[i++]);
+		unsigned long L;
+		if (!cast_ulong(argv[i++], L)) { logf(0, "Lexical_cast error when converting arguments to numeric values"); return 1; }
+		lens.push_back(L);
+		paths.push_back(argv[i++]);
+		if (solve) { double v; if (!cast_double(argv[i++], v)) { logf(0, "Lexical_cast error when converting arguments to numeric values"); return 1; } trb.push_back(v); }
+	}
+	const int M = (int)paths.size();
+	if (M > LSQ_MAX_METHODS) { logf(0, "more than %d read files", LSQ_MAX_METHODS); return 2; }
+	Freer F;
+	logf(2, "Loading isoforms...");
+	int st = lsq_annotation_load(argv[4], argv[5], argv[6], argv[7], gb, ge, &F.a);
+	if (st) { logf(0, "%s", lsq_last_error()); return status_to_exit(st); }
+	logf(2, "Loaded %lld isoforms", (long long)lsq_annotation_num_isoforms_loaded(F.a));
+	logf(2, "Loaded %lld genes", (long long)lsq_annotation_num_genes_loaded(F.a));
+	logf(2, "Selected %lld gene(s)", (long long)lsq_annotation_num_genes(F.a));
+	// An unknown read type is only noticed inside the per-gene loop of the reference
+	// (count/count.cpp:417-419), i.e. after every read file was loaded and only when at least one
+	// gene is selected; keep that precedence.
+	bool bad_type = false;
+	std::string bad_type_name;
+	std::vector<const char *> use_types(types);
+	for (int m = 0; m < M; ++m)
+		if (strcmp(types[m], "SHORT_READ") != 0 && strcmp(types[m], "MEDIUM_READ") != 0) {
+			if (!bad_type) bad_type_name = types[m];
+			bad_type = true; use_types[m] = "SHORT_READ";
+		}
+	st = lsq_events_compile(F.a, M, use_types.data(), lens.data(), &F.e);
+	if (st) { logf(0, "%s", lsq_last_error()); return status_to_exit(st); }
+	const int64_t n_ev = lsq_events_count(F.e);
+	logf(2, "Built isoform structures for the %lld selected gene(s)", (long long)n_ev);
+	logf(2, "Loading the reads from %d sampling method(s)", M);
+	for (int m = 0; m < M; ++m) {
+		lsq_reads *r = nullptr;
+		st = lsq_mrf_parse(fmts[m], paths[m], F.e, 0, &r);
+		if (st) {
+			if (st == LSQ_E_PARSE) { logf(0, "%s", lsq_last_error()); logf(0, "Lexical_cast error when converting arguments to numeric values"); }
+			else logf(0, "%s", lsq_last_error());
+			return status_to_exit(st);
+		}
+		F.r.push_back(r);
+		if (!F.c) {
+			// the GPU is first touched here, after the first read file parsed cleanly
+			int dev = 0;
+			if (const char *e = getenv("LSQ_DEVICE")) dev = atoi(e);
+			st = lsq_ctx_create(dev, &F.c);
+			if (!st) st = lsq_events_upload(F.c, F.e);
+			if (st) { logf(0, "%s", lsq_last_error()); return 3; }
+		}
+		st = lsq_reads_upload(F.c, m, r);
+		if (st) { logf(0, "%s", lsq_last_error()); return st == LSQ_E_DEVICE ? 3 : 2; }
+		logf(2, "Sampling method #%d: loaded %llu reads associated with the selected gene regions", m, (unsigned long long)lsq_reads_retained(F.c, m));
+		lsq_reads_free(r); F.r.back() = nullptr;
+	}
+	if (bad_type && n_ev > 0) { logf(0, "Unknown read type error: %s", bad_type_name.c_str()); return 1; }
+	logf(2, "Processing reads info for genes");
+	st = lsq_count(F.c);
+	if (!st && solve) st = lsq_solve(F.c);
+	if (st) { logf(0, "%s", lsq_last_error()); return 3; }
+	const size_t n_cls = (size_t)lsq_results_num_classes(F.c);
+	std::vector<uint64_t> cnt(std::max<size_t>((size_t)M * n_cls, 1)), bases(std::max<size_t>((size_t)M * n_cls, 1));
+	st = lsq_results_counts(F.c, cnt.data(), bases.data());
+	if (st) { logf(0, "%s", lsq_last_error()); return 3; }
+	char *text = nullptr;
+	if (!solve) {
+		st = lsq_format_count(F.e, M, cnt.data(), &text);
+	} else {
+		std::vector<double> theta(std::max<size_t>((size_t)lsq_events_total_isoforms(F.e), 1)), ll(std::max<size_t>((size_t)n_ev, 1));
+		std::vector<uint8_t> flags(std::max<size_t>((size_t)n_ev, 1));
+		st = lsq_results_solve(F.c, theta.data(), ll.data(), nullptr, flags.data());
+		if (st) { logf(0, "%s", lsq_last_error()); return 3; }
+		for (int64_t i = 0; i < n_ev; ++i)
+			if (flags[i] & 1) logf(1, "gene %s: EM stop criterion within 1e-9 of its threshold; a per-read summation order could stop one iteration apart", lsq_events_gene_name(F.e, i));
+		st = lsq_format_solve(F.e, M, cnt.data(), bases.data(), theta.data(), ll.data(), trb.data(), &text);
+	}
+	if (st || !text) { logf(0, "%s", lsq_last_error()); return 2; }
+	out.assign(text);
+	free(text);
+	logf(2, "Processed %lld genes... Done", (long long)n_ev);
+	return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int lsq_format_count(const lsq_events *E, int M, const uint64_t *cnt, char **out_text) {
+	if (!E || !cnt || !out_text || M != E->n_methods) return fail(LSQ_E_ARG, "bad argument");
+	const size_t n_cls = E->class_off.back();
+	std::string o;
+	for (size_t i = 0; i < E->ev.size(); ++i) {
+		const Event &e = E->ev[i];
+		const size_t nc = (1u << e.K) - 1u;
+		std::vector<double> supports(M, 0.0), iso_count(e.K, 0.0);
+		for (int m = 0; m < M; ++m)
+			for (size_t c = 1; c <= nc; ++c) {
+				double v = (double)cnt[(size_t)m * n_cls + E->class_off[i] + c - 1];
+				supports[m] += v;
+				for (int j = 0; j < e.K; ++j) if (c >> j & 1) iso_count[j] += v;
+			}
+		for (int j = 0; j < e.K; ++j) {
+			o += e.gname; o += '\t';
+			for (int m = 0; m < M; ++m) { put_g(o, supports[m]); o += '\t'; }
+			o += e.iso_names[j]; o += '\t'; put_g(o, iso_count[j]); o += '\n';
+		}
+	}
+	*out_text = dup_text(o);
+	return *out_text ? LSQ_OK : fail(LSQ_E_ARG, "out of memory");
+}
+
+int lsq_format_solve(const lsq_events *E, int M, const uint64_t *cnt, const uint64_t *bases,
+                     const double *theta, const double *logll, const double *total_read_bases, char **out_text) {
+	if (!E || !cnt || !bases || !theta || !logll || !total_read_bases || !out_text || M != E->n_methods) return fail(LSQ_E_ARG, "bad argument");
+	const size_t n_cls = E->class_off.back();
+	std::string o;
+	for (size_t i = 0; i < E->ev.size(); ++i) {
+		const Event &e = E->ev[i];
+		const size_t nc = (1u << e.K) - 1u;
+		std::vector<double> supports(M, 0.0), support_bases(M, 0.0);
+		for (int m = 0; m < M; ++m) {
+			uint64_t s = 0, b = 0;
+			for (size_t c = 0; c < nc; ++c) { s += cnt[(size_t)m * n_cls + E->class_off[i] + c]; b += bases[(size_t)m * n_cls + E->class_off[i] + c]; }
+			supports[m] = (double)s; support_bases[m] = (double)b;
+		}
+		const double *th = theta + E->iso_off[i];
+		// solve/solve.cpp:808-821, same operation order
+		std::vector<double> rpkm(e.K, 0.0);
+		double total_read_mbases = 0.0;
+		for (int m = 0; m < M; ++m) {
+			total_read_mbases += total_read_bases[m] / 1.0E6;
+			for (int j = 0; j < e.K; ++j) rpkm[j] += support_bases[m] * th[j];
+		}
+		for (int j = 0; j < e.K; ++j) {
+			rpkm[j] /= ((double)e.iso_len[j] / 1.0E3);
+			rpkm[j] /= total_read_mbases;
+		}
+		double sum_supports = 0.0;
+		for (int m = 0; m < M; ++m) sum_supports += supports[m];
+		for (int j = 0; j < e.K; ++j) {
+			o += e.gname; o += '\t';
+			for (int m = 0; m < M; ++m) { put_g(o, supports[m]); o += '\t'; }
+			o += e.iso_names[j]; o += '\t'; put_g(o, th[j]); o += '\t'; put_g(o, rpkm[j]);
+			if (sum_supports > 1E-5) { o += '\t'; put_g(o, logll[i] / sum_supports); o += '\n'; }
+			else o += "\t0\n";
+		}
+	}
+	*out_text = dup_text(o);
+	return *out_text ? LSQ_OK : fail(LSQ_E_ARG, "out of memory");
+}
+
+int lsq_cli_run(const char *tool, int argc, const char *const *argv, char **out_text) {
+	std::string out;
+	int rc;
+	if (tool && strcmp(tool, "count") == 0) rc = run_count_solve(false, argc, argv, out);
+	else if (tool && strcmp(tool, "solve") == 0) rc = run_count_solve(true, argc, argv, out);
+	else if (tool && strcmp(tool, "classify") == 0) rc = run_classify(argc, argv);
+	else { fail(LSQ_E_ARG, "unknown tool"); return 2; }
+	if (out_text) *out_text = dup_text(out);
+	return rc;
+}
+
+} // extern "C"

@@ -1,0 +1,637 @@
+// Device group of the C ABI: context, uploads, the count kernel and the EM kernel (gfx950).
+//
+// Data layout in HBM (one set per read file / "sampling method"):
+//   pool 1  int2  (start,end)            one merged block   -- 8 B per read, the common case
+//   pool 2  int4  (s0,e0,s1,e1)          two merged blocks  -- 16 B per read
+//   pool n  u32 block offsets + int2     three or more
+//   side arrays strand id (u8) and line number (u32): touched only on span-start ties
+// every pool is ordered by bucket; a bucket is a coordinate range of one chromosome whose
+// event tables (bin directory, 16-byte event records, segments, isoform masks) plus its
+// class histogram fit one workgroup's LDS.
+//
+// count kernel: each workgroup owns a contiguous range of read slots (bucket-major), stages
+// the bucket image into LDS, and for each read: bin lookup -> candidate events by span ->
+// span-start tie rule (count/count.cpp:64-85,429-432) -> segment walk (common/read.h:204-274)
+// -> contiguous-run compatibility per isoform (read.h:44-79) -> 0.98 validity (count.cpp:441)
+// -> one LDS atomic on (event, class) carrying count and matched bases.  Per bucket the
+// histogram is flushed with global atomics; integer sums make the result order-independent.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "lsq_internal.hpp"
+
+using namespace lsq;
+
+#define HIP_TRY(expr)                                                                          \
+	do {                                                                                       \
+		hipError_t _e = (expr);                                                                \
+		if (_e != hipSuccess) return fail(LSQ_E_DEVICE, "%s: %s", #expr, hipGetErrorString(_e)); \
+	} while (0)
+
+namespace {
+
+constexpr int COUNT_BLOCK = 512;
+constexpr unsigned long long BASES_MASK = (1ull << 40) - 1;
+
+struct CountArgs {
+	const BucketDesc *buckets;
+	const unsigned char *images;
+	const TieRec *ties;
+	const unsigned char *strand_rank;
+	unsigned n_buckets;
+	const int2 *p1; const unsigned char *p1_strand; const unsigned *p1_line;
+	const int4 *p2; const unsigned char *p2_strand; const unsigned *p2_line;
+	const unsigned *pn_blk_off; const int2 *pn_se; const unsigned char *pn_strand; const unsigned *pn_line;
+	const unsigned long long *p1_off, *p2_off, *pn_off, *slot_off;    // n_buckets + 1 each
+	unsigned long long total_slots;
+	unsigned long long *cnt, *bases;
+};
+
+struct LdsView {
+	const unsigned short *bins;
+	const EventRec *ev;
+	const int2 *segs;
+	const unsigned *iso;
+	unsigned long long *hist;
+};
+
+// "read-<line>" < gene name ?  (std::string operator< on the reference's read names)
+__device__ inline bool name_less(unsigned line, const TieRec &t) {
+	if (t.tie_mode != 2) return t.tie_mode == 1;
+	char dg[10];
+	int nd = 0;
+	unsigned v = line;
+	do { dg[nd++] = (char)('0' + v % 10); v /= 10; } while (v);
+	// dg holds the digits least-significant first
+	int n = nd < (int)t.tail_len ? nd : (int)t.tail_len;
+	for (int i = 0; i < n; ++i) {
+		unsigned char a = (unsigned char)dg[nd - 1 - i], b = (unsigned char)t.tail[i];
+		if (a != b) return a < b;
+	}
+	return nd < (int)t.tail_len;
+}
+
+// Segment walk of one read against one event's ascending segments.  `pos` is the furthest
+// matched coordinate (or the current segment's start), `it` the segment cursor, which never
+// moves back.  The first block may start anywhere inside a segment; once something has
+// matched, every continuation must start exactly at `pos`.
+template <class GetBlock>
+__device__ inline void walk_segments(const int2 *segs, int nseg, int nblk, GetBlock get, unsigned &mask, int &matched) {
+	int pos = 0, it = 0;
+	bool found = false;
+	mask = 0; matched = 0;
+	for (int bi = 0; bi < nblk; ++bi) {
+		int a, b;
+		get(bi, a, b);
+		while (it < nseg) {
+			const int2 sg = segs[it];
+			if (!(sg.x < b)) break;
+			pos = max(pos, sg.x);
+			if (a >= pos && a < sg.y) {
+				if (found && a > pos) break;
+				found = true;
+				mask |= 1u << it;
+				pos = min(sg.y, b);
+				matched += pos - a;
+				if (b < sg.y) { a = b; break; }
+				a = (b == sg.y) ? b : sg.y;
+			} else if (pos > sg.x && pos < sg.y) {
+				break;
+			}
+			++it;
+		}
+		if (a != b) break;
+	}
+}
+
+// One read against the staged bucket.  p = first merged start, q = last merged end.
+template <class GetBlock>
+__device__ inline void process_read(const LdsView &L, const BucketDesc &d, const CountArgs &A,
+                                    int p, int q, int total, int nblk, GetBlock get,
+                                    const unsigned char *strand_arr, const unsigned *line_arr, unsigned long long slot) {
+	long long rel = (long long)p - (long long)d.lo;
+	unsigned bin = rel <= 0 ? 0u : (unsigned)(rel >> d.shift);
+	if (bin >= d.n_bins) bin = d.n_bins - 1;
+	for (unsigned i = L.bins[bin]; i < d.n_events; ++i) {
+		const EventRec e = L.ev[i];
+		if (e.gs > p) break;
+		if (p > e.ge) continue;
+		if (p == e.gs) {
+			// reads ordered before the key (chrom, gene_start, gene_end, strand, name) are skipped
+			if (q < e.ge) continue;
+			if (q == e.ge) {
+				const TieRec t = A.ties[d.ev_base + i];
+				unsigned rs = A.strand_rank[strand_arr[slot]], gsr = A.strand_rank[t.strand_id];
+				if (rs < gsr) continue;
+				if (rs == gsr && name_less(line_arr[slot], t)) continue;
+			}
+		}
+		unsigned mask; int matched;
+		walk_segments(L.segs + e.seg_off, e.nseg, nblk, get, mask, matched);
+		if (!mask) continue;
+		// (double)matched / total > 0.98  <=>  50*matched > 49*total for these magnitudes
+		if (!(50ll * matched > 49ll * total)) continue;
+		unsigned hi = 31u - (unsigned)__clz((int)mask), lo = (unsigned)__ffs((int)mask) - 1u;
+		unsigned span = ((2u << hi) - 1u) & ~((1u << lo) - 1u);
+		unsigned cls = 0;
+		for (unsigned j = 0; j < e.K; ++j) {
+			unsigned iso = L.iso[e.iso_off + j];
+			if ((mask & ~iso) == 0 && (iso & span) == mask) cls |= 1u << j;
+		}
+		if (cls) atomicAdd(&L.hist[e.cls_off + cls - 1], (1ull << 40) | (unsigned long long)(unsigned)matched);
+	}
+}
+
+__global__ void __launch_bounds__(COUNT_BLOCK) lsq_count_kernel(CountArgs A) {
+	extern __shared__ __align__(16) unsigned char lds[];
+	const unsigned tid = threadIdx.x;
+	const unsigned long long s_begin = A.total_slots * blockIdx.x / gridDim.x;
+	const unsigned long long s_end = A.total_slots * (blockIdx.x + 1ull) / gridDim.x;
+	if (s_begin >= s_end) return;
+	// last bucket whose first slot is <= s_begin
+	unsigned lo_b = 0, hi_b = A.n_buckets;
+	while (hi_b - lo_b > 1) {
+		unsigned mid = (lo_b + hi_b) >> 1;
+		if (A.slot_off[mid] <= s_begin) lo_b = mid; else hi_b = mid;
+	}
+	for (unsigned b = lo_b; b < A.n_buckets && A.slot_off[b] < s_end; ++b) {
+		const unsigned long long bs = A.slot_off[b], be = A.slot_off[b + 1];
+		if (be <= s_begin || be == bs) continue;
+		const BucketDesc d = A.buckets[b];
+		// ---- stage the image, clear the histogram
+		{
+			const uint4 *src = reinterpret_cast<const uint4 *>(A.images + d.img_off);
+			uint4 *dst = reinterpret_cast<uint4 *>(lds);
+			for (unsigned i = tid; i < d.img_bytes / 16; i += COUNT_BLOCK) dst[i] = src[i];
+			unsigned long long *h = reinterpret_cast<unsigned long long *>(lds + d.hist_off);
+			for (unsigned i = tid; i < d.n_cls; i += COUNT_BLOCK) h[i] = 0;
+		}
+		__syncthreads();
+		LdsView L;
+		L.bins = reinterpret_cast<const unsigned short *>(lds);
+		L.ev = reinterpret_cast<const EventRec *>(lds + d.ev_off);
+		L.segs = reinterpret_cast<const int2 *>(lds + d.seg_off);
+		L.iso = reinterpret_cast<const unsigned *>(lds + d.iso_off);
+		L.hist = reinterpret_cast<unsigned long long *>(lds + d.hist_off);
+		const unsigned long long l0 = (s_begin > bs ? s_begin : bs) - bs;
+		const unsigned long long l1 = (s_end < be ? s_end : be) - bs;
+		const unsigned long long n1 = A.p1_off[b + 1] - A.p1_off[b];
+		const unsigned long long n2 = A.p2_off[b + 1] - A.p2_off[b];
+		// ---- pool 1
+		{
+			unsigned long long a = l0, z = l1 < n1 ? l1 : n1;
+			const unsigned long long base = A.p1_off[b];
+			for (unsigned long long i = a + tid; i < z; i += COUNT_BLOCK) {
+				const int2 r = A.p1[base + i];
+				process_read(L, d, A, r.x, r.y, r.y - r.x, 1,
+				             [&](int, int &s, int &e) { s = r.x; e = r.y; }, A.p1_strand, A.p1_line, base + i);
+			}
+		}
+		// ---- pool 2
+		if (l1 > n1 && n2) {
+			unsigned long long a = (l0 > n1 ? l0 : n1) - n1, z = (l1 < n1 + n2 ? l1 : n1 + n2) - n1;
+			const unsigned long long base = A.p2_off[b];
+			for (unsigned long long i = a + tid; i < z; i += COUNT_BLOCK) {
+				const int4 r = A.p2[base + i];
+				process_read(L, d, A, r.x, r.w, (r.y - r.x) + (r.w - r.z), 2,
+				             [&](int k, int &s, int &e) { if (k == 0) { s = r.x; e = r.y; } else { s = r.z; e = r.w; } },
+				             A.p2_strand, A.p2_line, base + i);
+			}
+		}
+		// ---- pool n
+		if (l1 > n1 + n2) {
+			unsigned long long a = (l0 > n1 + n2 ? l0 : n1 + n2) - (n1 + n2), z = l1 - (n1 + n2);
+			const unsigned long long base = A.pn_off[b];
+			for (unsigned long long i = a + tid; i < z; i += COUNT_BLOCK) {
+				const unsigned o0 = A.pn_blk_off[base + i], o1 = A.pn_blk_off[base + i + 1];
+				const int2 *blk = A.pn_se + o0;
+				int total = 0;
+				for (unsigned k = o0; k < o1; ++k) { int2 v = A.pn_se[k]; total += v.y - v.x; }
+				process_read(L, d, A, blk[0].x, A.pn_se[o1 - 1].y, total, (int)(o1 - o0),
+				             [&](int k, int &s, int &e) { int2 v = blk[k]; s = v.x; e = v.y; },
+				             A.pn_strand, A.pn_line, base + i);
+			}
+		}
+		__syncthreads();
+		// ---- flush
+		for (unsigned i = tid; i < d.n_cls; i += COUNT_BLOCK) {
+			unsigned long long v = L.hist[i];
+			if (v) {
+				atomicAdd(&A.cnt[d.cls_base + i], v >> 40);
+				atomicAdd(&A.bases[d.cls_base + i], v & BASES_MASK);
+			}
+		}
+		__syncthreads();
+	}
+}
+
+// ---- EM: one event per lane (common/read.h:592-660 on compatibility classes) ----------------
+struct EmArgs {
+	unsigned n_events, n_methods, n_cls, n_iso;
+	const unsigned char *K;
+	const unsigned *cls_base, *iso_base;
+	const unsigned long long *cnt;     // [method][n_cls]
+	const double *G;                   // [method][n_iso]
+	double *theta, *logll;
+	unsigned *iters;
+	unsigned char *flags;
+};
+
+__device__ inline double em_loglik(const EmArgs &A, unsigned cb, unsigned ib, int K, const double *th) {
+	double ll = 0;
+	const int nc = (1 << K) - 1;
+	for (unsigned m = 0; m < A.n_methods; ++m) {
+		const unsigned long long *n = A.cnt + (size_t)m * A.n_cls + cb;
+		const double *g = A.G + (size_t)m * A.n_iso + ib;
+		for (int c = 1; c <= nc; ++c) {
+			unsigned long long k = n[c - 1];
+			if (!k) continue;
+			double s = 0;
+			for (int j = 0; j < K; ++j) if (c >> j & 1) s += th[j] * g[j];
+			ll += (double)k * log(s);
+		}
+	}
+	return ll;
+}
+
+__global__ void __launch_bounds__(256) lsq_em_kernel(EmArgs A) {
+	unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= A.n_events) return;
+	const int K = A.K[e];
+	const unsigned cb = A.cls_base[e], ib = A.iso_base[e];
+	const int nc = (1 << K) - 1;
+	double th[LSQ_MAX_ISOFORMS], nw[LSQ_MAX_ISOFORMS];
+	unsigned long long total = 0;
+	for (unsigned m = 0; m < A.n_methods; ++m)
+		for (int c = 0; c < nc; ++c) total += A.cnt[(size_t)m * A.n_cls + cb + c];
+	unsigned iters = 0;
+	unsigned char flag = 0;
+	double ll = 0;
+	if (total == 0) {
+		for (int j = 0; j < K; ++j) th[j] = 1.0 / (double)K;         // solve/solve.cpp:798-800
+	} else if (K == 1) {
+		th[0] = 1;                                                    // solve/solve.cpp:801-802
+		ll = em_loglik(A, cb, ib, K, th);
+	} else {
+		for (int j = 0; j < K; ++j) th[j] = 1.0 / (double)K;
+		ll = em_loglik(A, cb, ib, K, th);
+		const double n_total = (double)total;
+		while (true) {
+			const double old_ll = ll;
+			for (int j = 0; j < K; ++j) nw[j] = 0;
+			for (unsigned m = 0; m < A.n_methods; ++m) {
+				const unsigned long long *n = A.cnt + (size_t)m * A.n_cls + cb;
+				const double *g = A.G + (size_t)m * A.n_iso + ib;
+				for (int c = 1; c <= nc; ++c) {
+					unsigned long long k = n[c - 1];
+					if (!k) continue;
+					double s = 0;
+					for (int j = 0; j < K; ++j) if (c >> j & 1) s += th[j] * g[j];
+					if (s > 0)
+						for (int j = 0; j < K; ++j) if (c >> j & 1) {
+							double local = th[j] * g[j];
+							if (local > 0) nw[j] += (double)k * (local / s);
+						}
+				}
+			}
+			for (int j = 0; j < K; ++j) th[j] = nw[j] / n_total;
+			ll = em_loglik(A, cb, ib, K, th);
+			++iters;
+			const double crit = fabs(1.0 - old_ll / ll);
+			if (fabs(crit - 1E-6) < 1E-9) flag |= 1;
+			if (!(crit > 1E-6)) break;
+			if (iters >= 1000000u) { flag |= 2; break; }
+		}
+	}
+	for (int j = 0; j < K; ++j) A.theta[ib + j] = th[j];
+	A.logll[e] = ll;
+	A.iters[e] = iters;
+	A.flags[e] = flag;
+}
+
+template <class T>
+struct DevBuf {
+	T *p = nullptr;
+	size_t n = 0;
+	~DevBuf() { if (p) (void)hipFree(p); }
+	int alloc(size_t count) {
+		if (p) { (void)hipFree(p); p = nullptr; }
+		n = count;
+		HIP_TRY(hipMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T)));
+		return LSQ_OK;
+	}
+	int upload(const T *src, size_t count, hipStream_t st) {
+		int rc = alloc(count);
+		if (rc) return rc;
+		if (count) HIP_TRY(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, st));
+		return LSQ_OK;
+	}
+};
+
+struct MethodReads {
+	bool present = false;
+	uint64_t n_retained = 0, n_retained_blocks = 0, total_slots = 0;
+	DevBuf<int32_t> p1, p2, pn_se;
+	DevBuf<uint8_t> p1_strand, p2_strand, pn_strand;
+	DevBuf<uint32_t> p1_line, p2_line, pn_line, pn_blk_off;
+	DevBuf<unsigned long long> p1_off, p2_off, pn_off, slot_off;
+};
+
+} // namespace
+
+struct lsq_ctx {
+	int device = 0;
+	int n_cu = 256;
+	hipStream_t stream = nullptr;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+	const lsq_events *E = nullptr;          // must outlive the uploads made from it
+	DevBuf<BucketDesc> buckets;
+	DevBuf<uint8_t> images, strand_rank, dK;
+	DevBuf<TieRec> ties;
+	DevBuf<uint32_t> cls_base, iso_base, iters;
+	DevBuf<double> G, theta, logll;
+	DevBuf<uint8_t> flags;
+	DevBuf<unsigned long long> cnt, bases;
+	MethodReads reads[LSQ_MAX_METHODS];
+	bool counted = false, solved = false;
+	float count_ms = 0, solve_ms = 0;
+};
+
+static int upload_strand_ranks(lsq_ctx *c) {
+	const auto &names = c->E->strands.names;
+	if (names.size() > 256) return fail(LSQ_E_RANGE, "more than 256 distinct strand strings");
+	std::vector<int> order(names.size());
+	std::iota(order.begin(), order.end(), 0);
+	std::sort(order.begin(), order.end(), [&](int a, int b) { return names[a] < names[b]; });
+	std::vector<uint8_t> rank(256, 0);
+	for (size_t r = 0; r < order.size(); ++r) rank[order[r]] = (uint8_t)r;
+	int rc = c->strand_rank.upload(rank.data(), 256, c->stream);
+	if (rc) return rc;
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	return LSQ_OK;
+}
+
+extern "C" {
+
+int lsq_ctx_create(int device_id, lsq_ctx **out) {
+	if (!out) return fail(LSQ_E_ARG, "null argument");
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess || n <= 0) return fail(LSQ_E_DEVICE, "no HIP device available (%s)", e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+	if (device_id < 0 || device_id >= n) return fail(LSQ_E_ARG, "device %d out of range (%d devices)", device_id, n);
+	HIP_TRY(hipSetDevice(device_id));
+	hipDeviceProp_t prop;
+	HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+	if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+		return fail(LSQ_E_DEVICE, "device %d is %s; this library carries gfx950 code only", device_id, prop.gcnArchName);
+	std::unique_ptr<lsq_ctx> c(new lsq_ctx);
+	c->device = device_id;
+	c->n_cu = prop.multiProcessorCount;
+	HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+	HIP_TRY(hipEventCreate(&c->ev0)); HIP_TRY(hipEventCreate(&c->ev1));
+	HIP_TRY(hipEventCreate(&c->ev2)); HIP_TRY(hipEventCreate(&c->ev3));
+	*out = c.release();
+	return LSQ_OK;
+}
+
+void lsq_ctx_destroy(lsq_ctx *c) {
+	if (!c) return;
+	(void)hipSetDevice(c->device);
+	if (c->stream) (void)hipStreamSynchronize(c->stream);
+	if (c->ev0) (void)hipEventDestroy(c->ev0);
+	if (c->ev1) (void)hipEventDestroy(c->ev1);
+	if (c->ev2) (void)hipEventDestroy(c->ev2);
+	if (c->ev3) (void)hipEventDestroy(c->ev3);
+	if (c->stream) (void)hipStreamDestroy(c->stream);
+	delete c;
+}
+
+void *lsq_ctx_stream(lsq_ctx *c) { return c ? (void *)c->stream : nullptr; }
+int lsq_ctx_synchronize(lsq_ctx *c) {
+	if (!c) return fail(LSQ_E_ARG, "null context");
+	HIP_TRY(hipSetDevice(c->device));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	return LSQ_OK;
+}
+
+int lsq_events_upload(lsq_ctx *c, const lsq_events *E) {
+	if (!c || !E) return fail(LSQ_E_ARG, "null argument");
+	HIP_TRY(hipSetDevice(c->device));
+	if (E->max_lds_bytes > 160 * 1024) return fail(LSQ_E_UNSUPPORTED, "bucket tables exceed the CU's LDS");
+	c->E = E;
+	c->counted = c->solved = false;
+	for (auto &r : c->reads) r.present = false;
+	int rc;
+	if ((rc = c->buckets.upload(E->buckets.data(), E->buckets.size(), c->stream))) return rc;
+	if ((rc = c->images.upload(E->images.data(), E->images.size(), c->stream))) return rc;
+	if ((rc = c->ties.upload(E->ties.data(), E->ties.size(), c->stream))) return rc;
+	if ((rc = c->dK.upload(E->dev_K.data(), E->dev_K.size(), c->stream))) return rc;
+	if ((rc = c->cls_base.upload(E->dev_cls_base.data(), E->dev_cls_base.size(), c->stream))) return rc;
+	if ((rc = c->iso_base.upload(E->dev_iso_base.data(), E->dev_iso_base.size(), c->stream))) return rc;
+	// G = 1/ARS (common/read.h:331-340), device isoform order, per method
+	const size_t n_iso = E->n_iso_total, M = (size_t)E->n_methods;
+	std::vector<double> G(std::max<size_t>(M * n_iso, 1), 0.0);
+	for (size_t d = 0; d < E->dev2out.size(); ++d) {
+		const Event &ev = E->ev[E->dev2out[d]];
+		for (size_t m = 0; m < M; ++m)
+			for (int j = 0; j < ev.K; ++j) {
+				double nd = (double)ev.ars[m][j];
+				G[m * n_iso + E->dev_iso_base[d] + j] = nd <= 0 ? 0.0 : (double)1.0 / nd;
+			}
+	}
+	if ((rc = c->G.upload(G.data(), M * n_iso, c->stream))) return rc;
+	const size_t n_cls = E->n_cls_total, n_ev = E->dev2out.size();
+	if ((rc = c->cnt.alloc(std::max<size_t>(M, 1) * n_cls))) return rc;
+	if ((rc = c->bases.alloc(std::max<size_t>(M, 1) * n_cls))) return rc;
+	if ((rc = c->theta.alloc(n_iso))) return rc;
+	if ((rc = c->logll.alloc(n_ev))) return rc;
+	if ((rc = c->iters.alloc(n_ev))) return rc;
+	if ((rc = c->flags.alloc(n_ev))) return rc;
+	if ((rc = upload_strand_ranks(c))) return rc;
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	return LSQ_OK;
+}
+
+int lsq_reads_upload(lsq_ctx *c, int method, const lsq_reads *R) {
+	if (!c || !R) return fail(LSQ_E_ARG, "null argument");
+	if (!c->E) return fail(LSQ_E_STATE, "lsq_events_upload must come first");
+	if (method < 0 || method >= c->E->n_methods) return fail(LSQ_E_ARG, "method %d out of range", method);
+	HIP_TRY(hipSetDevice(c->device));
+	PooledReads P;
+	int rc = ingest_reads(*c->E, *R, 0, P);
+	if (rc) return rc;
+	MethodReads &mr = c->reads[method];
+	mr.present = false;
+	const size_t B = c->E->buckets.size();
+	std::vector<unsigned long long> slot(B + 1, 0), o1(B + 1), o2(B + 1), on(B + 1);
+	for (size_t b = 0; b <= B; ++b) { o1[b] = P.p1_off[b]; o2[b] = P.p2_off[b]; on[b] = P.pn_off[b]; slot[b] = o1[b] + o2[b] + on[b]; }
+	hipStream_t st = c->stream;
+	if ((rc = mr.p1.upload(P.p1_se.data(), P.p1_se.size(), st))) return rc;
+	if ((rc = mr.p1_strand.upload(P.p1_strand.data(), P.p1_strand.size(), st))) return rc;
+	if ((rc = mr.p1_line.upload(P.p1_line.data(), P.p1_line.size(), st))) return rc;
+	if ((rc = mr.p2.upload(P.p2_se.data(), P.p2_se.size(), st))) return rc;
+	if ((rc = mr.p2_strand.upload(P.p2_strand.data(), P.p2_strand.size(), st))) return rc;
+	if ((rc = mr.p2_line.upload(P.p2_line.data(), P.p2_line.size(), st))) return rc;
+	if ((rc = mr.pn_se.upload(P.pn_se.data(), P.pn_se.size(), st))) return rc;
+	if ((rc = mr.pn_blk_off.upload(P.pn_blk_off.data(), P.pn_blk_off.size(), st))) return rc;
+	if ((rc = mr.pn_strand.upload(P.pn_strand.data(), P.pn_strand.size(), st))) return rc;
+	if ((rc = mr.pn_line.upload(P.pn_line.data(), P.pn_line.size(), st))) return rc;
+	if ((rc = mr.p1_off.upload(o1.data(), B + 1, st))) return rc;
+	if ((rc = mr.p2_off.upload(o2.data(), B + 1, st))) return rc;
+	if ((rc = mr.pn_off.upload(on.data(), B + 1, st))) return rc;
+	if ((rc = mr.slot_off.upload(slot.data(), B + 1, st))) return rc;
+	if ((rc = upload_strand_ranks(c))) return rc;      // the reads may have introduced new strand strings
+	HIP_TRY(hipStreamSynchronize(st));
+	mr.n_retained = P.n_retained;
+	mr.n_retained_blocks = P.n_retained_blocks;
+	mr.total_slots = slot[B];
+	mr.present = true;
+	c->counted = c->solved = false;
+	return LSQ_OK;
+}
+
+uint64_t lsq_reads_retained(const lsq_ctx *c, int method) { return (c && method >= 0 && method < LSQ_MAX_METHODS) ? c->reads[method].n_retained : 0; }
+uint64_t lsq_reads_retained_blocks(const lsq_ctx *c, int method) { return (c && method >= 0 && method < LSQ_MAX_METHODS) ? c->reads[method].n_retained_blocks : 0; }
+
+int lsq_count(lsq_ctx *c) {
+	if (!c) return fail(LSQ_E_ARG, "null context");
+	if (!c->E) return fail(LSQ_E_STATE, "lsq_events_upload must come first");
+	HIP_TRY(hipSetDevice(c->device));
+	const lsq_events &E = *c->E;
+	const size_t n_cls = E.n_cls_total;
+	const int M = E.n_methods;
+	for (int m = 0; m < M; ++m) if (!c->reads[m].present) return fail(LSQ_E_STATE, "reads of method %d were not uploaded", m);
+	hipStream_t st = c->stream;
+	HIP_TRY(hipEventRecord(c->ev0, st));
+	if (M * n_cls) {
+		HIP_TRY(hipMemsetAsync(c->cnt.p, 0, (size_t)M * n_cls * sizeof(unsigned long long), st));
+		HIP_TRY(hipMemsetAsync(c->bases.p, 0, (size_t)M * n_cls * sizeof(unsigned long long), st));
+	}
+	const unsigned lds_bytes = std::max<unsigned>(E.max_lds_bytes, 16);
+	if (lds_bytes > 64 * 1024)
+		HIP_TRY(hipFuncSetAttribute((const void *)lsq_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+	unsigned per_cu = std::max(1u, std::min(2048u / COUNT_BLOCK, (160u * 1024u) / lds_bytes));
+	unsigned mult = 2;
+	if (const char *e = getenv("LSQ_GRID_MULT")) { int v = atoi(e); if (v >= 1 && v <= 64) mult = (unsigned)v; }
+	for (int m = 0; m < M; ++m) {
+		MethodReads &mr = c->reads[m];
+		if (mr.total_slots == 0 || E.buckets.empty()) continue;
+		unsigned long long grid = (unsigned long long)c->n_cu * per_cu * mult;
+		// one workgroup's share must keep the packed LDS counters (24-bit count, 40-bit bases) exact
+		grid = std::max(grid, mr.total_slots / (1ull << 21) + 1);
+		grid = std::min<unsigned long long>(grid, std::max<unsigned long long>(mr.total_slots / 64, 1));
+		CountArgs A;
+		A.buckets = c->buckets.p; A.images = c->images.p; A.ties = c->ties.p; A.strand_rank = c->strand_rank.p;
+		A.n_buckets = (unsigned)E.buckets.size();
+		A.p1 = reinterpret_cast<const int2 *>(mr.p1.p); A.p1_strand = mr.p1_strand.p; A.p1_line = mr.p1_line.p;
+		A.p2 = reinterpret_cast<const int4 *>(mr.p2.p); A.p2_strand = mr.p2_strand.p; A.p2_line = mr.p2_line.p;
+		A.pn_blk_off = mr.pn_blk_off.p; A.pn_se = reinterpret_cast<const int2 *>(mr.pn_se.p);
+		A.pn_strand = mr.pn_strand.p; A.pn_line = mr.pn_line.p;
+		A.p1_off = mr.p1_off.p; A.p2_off = mr.p2_off.p; A.pn_off = mr.pn_off.p; A.slot_off = mr.slot_off.p;
+		A.total_slots = mr.total_slots;
+		A.cnt = c->cnt.p + (size_t)m * n_cls; A.bases = c->bases.p + (size_t)m * n_cls;
+		hipLaunchKernelGGL(lsq_count_kernel, dim3((unsigned)grid), dim3(COUNT_BLOCK), lds_bytes, st, A);
+		HIP_TRY(hipGetLastError());
+	}
+	HIP_TRY(hipEventRecord(c->ev1, st));
+	c->counted = true;
+	c->solved = false;
+	return LSQ_OK;
+}
+
+int lsq_solve(lsq_ctx *c) {
+	if (!c) return fail(LSQ_E_ARG, "null context");
+	if (!c->counted) return fail(LSQ_E_STATE, "lsq_count must come first");
+	HIP_TRY(hipSetDevice(c->device));
+	const lsq_events &E = *c->E;
+	hipStream_t st = c->stream;
+	HIP_TRY(hipEventRecord(c->ev2, st));
+	const unsigned n_ev = (unsigned)E.dev2out.size();
+	if (n_ev) {
+		EmArgs A;
+		A.n_events = n_ev; A.n_methods = (unsigned)E.n_methods; A.n_cls = E.n_cls_total; A.n_iso = E.n_iso_total;
+		A.K = c->dK.p; A.cls_base = c->cls_base.p; A.iso_base = c->iso_base.p;
+		A.cnt = c->cnt.p; A.G = c->G.p; A.theta = c->theta.p; A.logll = c->logll.p; A.iters = c->iters.p; A.flags = c->flags.p;
+		hipLaunchKernelGGL(lsq_em_kernel, dim3((n_ev + 255) / 256), dim3(256), 0, st, A);
+		HIP_TRY(hipGetLastError());
+	}
+	HIP_TRY(hipEventRecord(c->ev3, st));
+	c->solved = true;
+	return LSQ_OK;
+}
+
+int64_t lsq_results_num_classes(const lsq_ctx *c) { return (c && c->E) ? (int64_t)c->E->n_cls_total : 0; }
+
+int lsq_results_class_offsets(const lsq_ctx *c, uint64_t *class_off) {
+	if (!c || !c->E || !class_off) return fail(LSQ_E_ARG, "null argument");
+	memcpy(class_off, c->E->class_off.data(), c->E->class_off.size() * sizeof(uint64_t));
+	return LSQ_OK;
+}
+
+int lsq_results_counts(lsq_ctx *c, uint64_t *class_count, uint64_t *class_bases) {
+	if (!c || !class_count) return fail(LSQ_E_ARG, "null argument");
+	if (!c->counted) return fail(LSQ_E_STATE, "lsq_count must come first");
+	HIP_TRY(hipSetDevice(c->device));
+	const lsq_events &E = *c->E;
+	const size_t n_cls = E.n_cls_total, M = (size_t)E.n_methods;
+	std::vector<unsigned long long> hc(std::max<size_t>(M * n_cls, 1)), hb(std::max<size_t>(M * n_cls, 1));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	if (M * n_cls) {
+		HIP_TRY(hipMemcpy(hc.data(), c->cnt.p, M * n_cls * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(hb.data(), c->bases.p, M * n_cls * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	}
+	for (size_t d = 0; d < E.dev2out.size(); ++d) {
+		const size_t o = (size_t)E.dev2out[d];
+		const size_t nc = (1u << E.ev[o].K) - 1u;
+		for (size_t m = 0; m < M; ++m)
+			for (size_t k = 0; k < nc; ++k) {
+				class_count[m * n_cls + E.class_off[o] + k] = hc[m * n_cls + E.dev_cls_base[d] + k];
+				if (class_bases) class_bases[m * n_cls + E.class_off[o] + k] = hb[m * n_cls + E.dev_cls_base[d] + k];
+			}
+	}
+	return LSQ_OK;
+}
+
+int lsq_results_solve(lsq_ctx *c, double *theta, double *logll, uint32_t *em_iters, uint8_t *em_flags) {
+	if (!c || !theta || !logll) return fail(LSQ_E_ARG, "null argument");
+	if (!c->solved) return fail(LSQ_E_STATE, "lsq_solve must come first");
+	HIP_TRY(hipSetDevice(c->device));
+	const lsq_events &E = *c->E;
+	const size_t n_ev = E.dev2out.size(), n_iso = E.n_iso_total;
+	std::vector<double> ht(std::max<size_t>(n_iso, 1)), hl(std::max<size_t>(n_ev, 1));
+	std::vector<uint32_t> hi(std::max<size_t>(n_ev, 1));
+	std::vector<uint8_t> hf(std::max<size_t>(n_ev, 1));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	if (n_ev) {
+		HIP_TRY(hipMemcpy(ht.data(), c->theta.p, n_iso * sizeof(double), hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(hl.data(), c->logll.p, n_ev * sizeof(double), hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(hi.data(), c->iters.p, n_ev * sizeof(uint32_t), hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(hf.data(), c->flags.p, n_ev * sizeof(uint8_t), hipMemcpyDeviceToHost));
+	}
+	for (size_t d = 0; d < n_ev; ++d) {
+		const size_t o = (size_t)E.dev2out[d];
+		for (int j = 0; j < E.ev[o].K; ++j) theta[E.iso_off[o] + j] = ht[E.dev_iso_base[d] + j];
+		logll[o] = hl[d];
+		if (em_iters) em_iters[o] = hi[d];
+		if (em_flags) em_flags[o] = hf[d];
+	}
+	return LSQ_OK;
+}
+
+int lsq_last_timing(lsq_ctx *c, float *count_ms, float *solve_ms) {
+	if (!c) return fail(LSQ_E_ARG, "null context");
+	HIP_TRY(hipSetDevice(c->device));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	if (count_ms) { *count_ms = 0; if (c->counted) HIP_TRY(hipEventElapsedTime(count_ms, c->ev0, c->ev1)); }
+	if (solve_ms) { *solve_ms = 0; if (c->solved) HIP_TRY(hipEventElapsedTime(solve_ms, c->ev2, c->ev3)); }
+	return LSQ_OK;
+}
+
+} // extern "C"

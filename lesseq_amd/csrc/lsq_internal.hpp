@@ -1,0 +1,178 @@
+// Internal structures shared by the host-side translation units and the HIP layer.
+// Nothing here is part of the ABI (include/lesseq_hip.h is).
+#pragma once
+
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/lesseq_hip.h"
+
+namespace lsq {
+
+// ---- error text for the calling thread -------------------------------------------------
+int fail(int status, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+// ---- interval_list<long> semantics (jsc/util/interval_list.hpp:396-422,462-503) -----------
+struct IntervalList {
+	std::vector<int64_t> s, e;
+	void add(int64_t start, int64_t end);
+	bool contains(int64_t start, int64_t end) const;
+	size_t size() const { return s.size(); }
+};
+
+// ---- annotation ---------------------------------------------------------------------------
+struct IsoRec {                    // one LH_GENE_TXT line (count/count.cpp:142-171)
+	std::string name, chrom, strand;
+	int64_t txStart = 0, txEnd = 0;
+	uint64_t exonCount = 0;
+	std::vector<int64_t> exonStarts, exonEnds;
+};
+struct Gene {
+	std::string name;
+	std::vector<const IsoRec *> isos;      // order of lines in the g2i file
+};
+
+// ---- compiled event ---------------------------------------------------------------------------
+struct Event {
+	std::string gname, chrom, strand;
+	int chrom_id = -1, strand_id = -1;
+	int K = 0, N = 0;
+	std::vector<int64_t> seg_s, seg_e;             // atomic segments, ascending
+	std::vector<std::string> iso_names;
+	std::vector<uint64_t> iso_mask;                // bit n: isoform holds segment n (N <= 64)
+	std::vector<uint64_t> iso_len;                 // total segment length per isoform
+	int64_t gene_start = 0, gene_end = 0;          // first start / last end of the merged exon list
+	std::vector<std::vector<uint64_t>> ars;        // [method][iso]
+	// name tie-break against "read-<n>" (count/count.cpp:71): 0 never less, 1 always less,
+	// 2 compare the decimal digits of n with `tail`
+	int tie_mode = 0;
+	std::string tie_tail;
+};
+
+// One LDS image per bucket: a contiguous coordinate range of one chromosome whose event
+// tables fit the kernel's LDS budget.  Layout of the image (all offsets in bytes from the
+// image start, 16-byte aligned):  bins u16[n_bins] | event records 16 B | segments int2 |
+// isoform masks u32 | (histogram u64[n_cls], not part of the image, zeroed by the kernel)
+struct BucketDesc {
+	uint32_t img_off;      // byte offset of the image in the images blob
+	uint32_t img_bytes;    // bytes to stage
+	uint32_t n_events;
+	uint32_t n_bins;
+	int32_t lo;            // coordinate of bin 0
+	uint32_t shift;        // bin = (p - lo) >> shift
+	uint32_t ev_off, seg_off, iso_off, hist_off;   // LDS byte offsets
+	uint32_t n_cls;        // histogram slots
+	uint32_t cls_base;     // first class slot of the bucket in device class order
+	uint32_t ev_base;      // first event of the bucket in device event order
+	int32_t chrom_id;
+	uint32_t pad[2];
+};
+static_assert(sizeof(BucketDesc) == 64, "BucketDesc is copied to the device verbatim");
+
+struct EventRec {          // 16-byte LDS record
+	int32_t gs, ge;
+	uint16_t seg_off, iso_off, cls_off;   // element indices inside the bucket
+	uint8_t nseg, K;
+};
+static_assert(sizeof(EventRec) == 16, "EventRec layout");
+
+struct TieRec {            // global memory, device event order; read only on start ties
+	uint8_t strand_id;
+	uint8_t tie_mode;
+	uint8_t tail_len;      // capped at 21: a decimal read number has at most 20 digits
+	char tail[21];
+};
+static_assert(sizeof(TieRec) == 24, "TieRec layout");
+
+struct Dict {              // string interning (chromosomes, strands)
+	std::vector<std::string> names;
+	std::unordered_map<std::string, int> ids;
+	std::mutex mu;
+	int intern(const std::string &s);
+	int find(const std::string &s) const;
+};
+
+} // namespace lsq
+
+struct lsq_annotation {
+	std::vector<std::unique_ptr<lsq::IsoRec>> recs;
+	std::vector<lsq::Gene> selected;
+	int64_t n_genes_loaded = 0;
+};
+
+struct lsq_events {
+	std::vector<lsq::Event> ev;                    // output order
+	int n_methods = 0;
+	std::vector<std::string> read_types;
+	std::vector<uint64_t> read_lengths;
+	lsq::Dict chroms, strands;
+	std::vector<lsq::IntervalList> covered;        // by chrom id (events' chromosomes)
+	// ---- device plan
+	uint32_t lds_budget = 0;
+	std::vector<lsq::BucketDesc> buckets;          // sorted by (chrom_id, lo)
+	std::vector<uint8_t> images;                   // all bucket images
+	std::vector<int32_t> dev2out;                  // device event index -> output index
+	std::vector<uint32_t> dev_cls_base;            // per device event
+	std::vector<uint32_t> dev_iso_base;            // per device event
+	std::vector<lsq::TieRec> ties;                 // device order
+	std::vector<uint8_t> dev_K;                    // device order
+	uint32_t n_cls_total = 0, n_iso_total = 0;
+	uint32_t max_lds_bytes = 0;                    // image + histogram, max over buckets
+	// bucket lookup: per chrom id, ascending cut coordinates and the bucket of each range
+	std::vector<std::vector<int32_t>> cut_lo;      // cut_lo[chrom][i] = buckets[first+i].lo
+	std::vector<int32_t> chrom_first_bucket;       // -1 when the chromosome has no bucket
+	std::vector<uint64_t> class_off;               // output order, n_events+1
+	std::vector<uint64_t> iso_off;                 // output order, n_events+1
+};
+
+struct lsq_reads {
+	uint64_t n_reads = 0, n_blocks = 0;
+	const uint64_t *blk_off = nullptr;
+	const uint32_t *line_no = nullptr;
+	const int32_t *blk_start = nullptr, *blk_end = nullptr;
+	const uint16_t *blk_chrom = nullptr;
+	const uint8_t *blk_strand = nullptr;
+	// owned storage (empty when wrapping caller arrays)
+	std::vector<uint64_t> o_blk_off;
+	std::vector<uint32_t> o_line_no;
+	std::vector<int32_t> o_start, o_end;
+	std::vector<uint16_t> o_chrom;
+	std::vector<uint8_t> o_strand;
+	void adopt();
+};
+
+namespace lsq {
+
+// Retained reads of one method, bucketed and pooled: what is copied to HBM.
+struct PooledReads {
+	uint64_t n_retained = 0, n_retained_blocks = 0;
+	// pool 1: one merged block
+	std::vector<int32_t> p1_se;        // 2 per read
+	std::vector<uint8_t> p1_strand;
+	std::vector<uint32_t> p1_line;
+	std::vector<uint64_t> p1_off;      // per bucket, n_buckets+1
+	// pool 2: two merged blocks
+	std::vector<int32_t> p2_se;        // 4 per read
+	std::vector<uint8_t> p2_strand;
+	std::vector<uint32_t> p2_line;
+	std::vector<uint64_t> p2_off;
+	// pool n: three or more
+	std::vector<uint32_t> pn_blk_off;  // nN+1, into pn_se pairs
+	std::vector<int32_t> pn_se;
+	std::vector<uint8_t> pn_strand;
+	std::vector<uint32_t> pn_line;
+	std::vector<uint64_t> pn_off;
+};
+
+// host ingest: containment filter + add_interval merge + bucket/pool scatter
+int ingest_reads(const lsq_events &ev, const lsq_reads &rd, int n_threads, PooledReads &out);
+
+int host_threads(int requested);
+
+} // namespace lsq

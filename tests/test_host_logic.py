@@ -1,0 +1,155 @@
+"""Host-side logic of the product library on CPU: the C ABI loads and exports what the header
+declares; annotation loading, event compilation (segments, masks, ARS), MRF parsing, classify
+and the exit statuses that are decided before a GPU is touched.  No device calls here."""
+import json
+import os
+import re
+
+import pytest
+
+import lesseq_amd as L
+import oracle_binding as ob
+from test_oracle_golden import GOLD, CASES, load_case
+
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "lesseq_hip.h")).read()
+    names = set(re.findall(r"\b(lsq_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) > 40
+    for n in sorted(names):
+        assert hasattr(L.lib, n), "missing export " + n
+    assert L.lib.lsq_abi_version() == 1
+
+
+def test_device_calls_fail_loudly_without_a_gpu():
+    from conftest import has_gpu
+    if has_gpu():
+        pytest.skip("a GPU is present")
+    with pytest.raises(L.LsqError) as ei:
+        L.Context(0)
+    assert ei.value.status == -7
+
+
+def parse_interval(path):
+    iso = {}
+    for line in open(path).read().split("\n")[:-1]:
+        t = line.split()
+        n = int(t[5])
+        s = [int(x) for x in t[6].split(",") if x][:n]
+        e = [int(x) for x in t[7].split(",") if x][:n]
+        iso[t[0]] = list(zip(s, e))      # last duplicate wins
+    return iso
+
+
+def parse_map(path):
+    genes = {}
+    for line in open(path).read().split("\n")[:-1]:
+        g, i = line.split()
+        genes.setdefault(g, []).append(i)
+    return genes
+
+
+@pytest.mark.parametrize("name", [c for c in CASES if c not in ("errors", "fmt1m")])
+def test_event_compilation_matches_oracle(name, tmp_path):
+    c, d = load_case(name, tmp_path)
+    argv = c["count"][0]["argv"]
+    iv, mp = os.path.join(d, argv[4]), os.path.join(d, argv[6])
+    R = int(argv[11])
+    rtype = argv[10]
+    a = L.Annotation(iv, mp, int(argv[7]), int(argv[8]))
+    ev = L.Events(a, (rtype,), (R,))
+    iso, genes = parse_interval(iv), parse_map(mp)
+    gsel = sorted(genes, key=lambda s: s.encode())[int(argv[7]):int(argv[8])]
+    assert [ev.gene_name(i) for i in range(len(ev))] == gsel
+    for i, g in enumerate(gsel):
+        exons = [x for nm in genes[g] for x in iso[nm]]
+        segs = ob.segments(exons)
+        assert ev.segments(i) == segs, (name, g)
+        merged = ob.merge_intervals(exons)
+        assert ev.span(i) == (merged[0][0], merged[-1][1])
+        seg_len = [e - s for s, e in segs]
+        for j, nm in enumerate(genes[g]):
+            assert ev.isoform_name(i, j) == nm
+            mask = ev.isoform_mask(i, j)
+            idx = [n for n in range(len(segs)) if mask >> n & 1]
+            assert ev.ars(0, i, j) == ob.ars_total(seg_len, idx, R, rtype == "SHORT_READ"), (name, g, nm)
+            assert ev.isoform_length(i, j) == sum(seg_len[n] for n in idx)
+
+
+def test_interval_merge_is_order_dependent():
+    # the reference's add_interval merges a touching interval only when it is already stored
+    # to the LEFT of the new one
+    assert ob.merge_intervals([(10, 20), (20, 30)]) == [(10, 30)]
+    assert ob.merge_intervals([(20, 30), (10, 20)]) == [(10, 20), (20, 30)]
+    assert ob.merge_intervals([(10, 20), (15, 40), (50, 60), (5, 55)]) == [(5, 60)]
+
+
+def test_mrf_parse_counts(tmp_path):
+    c, d = load_case("edge", tmp_path)
+    a = L.Annotation(os.path.join(d, "e.interval"), os.path.join(d, "e.map"))
+    ev = L.Events(a, ("SHORT_READ",), (100,))
+    r = L.Reads.from_mrf(os.path.join(d, "e.mrf"), ev)
+    # 15 lines after the header, one comment, the unterminated last line is never seen
+    assert len(r) == 13
+    assert r.num_blocks == 16
+    with pytest.raises(L.LsqError) as ei:
+        L.Reads.from_mrf(os.path.join(d, "e.mrf"), ev, read_format="MRF_PAIRED")
+    assert ei.value.status == -3
+    with pytest.raises(L.LsqError) as ei:
+        L.Reads.from_mrf(os.path.join(GOLD, "errors", "bad_number.mrf"), ev)
+    assert ei.value.status == -4
+
+
+def test_mrf_parse_threads_agree(tmp_path):
+    spec = L.SynthSpec(seed=5, n_events=50, n_reads=120000, read_length=75, n_chrom=3)
+    L.synth_write(spec, str(tmp_path), "t", write_mrf=True)
+    a = L.Annotation(str(tmp_path / "t.interval"), str(tmp_path / "t.map"))
+    ev = L.Events(a, ("SHORT_READ",), (75,))
+    r1 = L.Reads.from_mrf(str(tmp_path / "t.mrf"), ev, n_threads=1)
+    r4 = L.Reads.from_mrf(str(tmp_path / "t.mrf"), ev, n_threads=4)
+    rs = L.Reads.synthetic(spec, ev)
+    assert len(r1) == len(r4) == len(rs) == 120000
+    assert r1.num_blocks == r4.num_blocks == rs.num_blocks
+
+
+def test_classify_matches_reference(tmp_path, monkeypatch):
+    c, d = load_case("toy", tmp_path)
+    out = tmp_path / "classify"
+    out.mkdir()
+    monkeypatch.chdir(d)
+    argv = list(c["classify"]["argv"])
+    argv[2] = str(out) + "/"
+    rc, _ = L.cli_run("classify", argv)
+    assert rc == c["classify"]["exit"] == 0
+    assert sorted(os.listdir(out)) == c["classify"]["files"]
+    for fn in c["classify"]["files"]:
+        assert open(out / fn).read() == open(os.path.join(d, "classify", fn)).read()
+
+
+def test_exit_statuses_decided_before_the_gpu(tmp_path, monkeypatch):
+    c, d = load_case("errors", tmp_path)
+    monkeypatch.chdir(d)
+    # count #1 (unknown read type) is only detected after the reads were uploaded: GPU test
+    for idx in (0, 2, 3, 4, 5, 6):
+        r = c["count"][idx]
+        rc, text = L.cli_run("count", r["argv"])
+        assert rc == r["exit"] == 1, r["argv"]
+        assert text == ""
+    r = c["solve"][0]
+    rc, text = L.cli_run("solve", r["argv"])
+    assert rc == r["exit"] == 1 and text == ""
+    # unopenable file: the reference asserts (SIGABRT); here exit status 134
+    rc, _ = L.cli_run("count", ["0", "x", "./", "LH_GENE_TXT", "nope.interval", "UCSC_GENE2ISOFORM", "toy.map", "0", "10", "MRF_SINGLE", "SHORT_READ", "50", "toy.mrf"])
+    assert rc == 134
+
+
+def test_synthetic_generator_is_deterministic(tmp_path):
+    spec = L.SynthSpec(seed=3, n_events=30, n_reads=2000, read_length=100, n_chrom=2)
+    (tmp_path / "a").mkdir()
+    (tmp_path / "b").mkdir()
+    L.synth_write(spec, str(tmp_path / "a"), "s")
+    L.synth_write(spec, str(tmp_path / "b"), "s")
+    for ext in ("interval", "map", "mrf"):
+        assert open(tmp_path / "a" / ("s." + ext)).read() == open(tmp_path / "b" / ("s." + ext)).read()
+    assert len(open(tmp_path / "a" / "s.mrf").read().splitlines()) == 2001
