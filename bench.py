@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py -- count+solve hot path on synthetic MRF reads, one process per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c1]
+
+A step = one pass of the hot path over the reads resident in HBM: the count kernel over every
+retained read, the batched EM kernel over every event, and the hand-off of the per-event
+outputs (device copy; for N > 1 an RCCL all-gather of the fixed-stride per-event records).
+Parsing, the containment filter and the bucket/pool layout are ingest: done once before the
+timed region (their wall time is reported under config.ingest_s, never in `value`).
+
+Weak scaling: every rank holds its own shard -- `n_events` events and the reads over them
+(the reference shards by gene index range the same way, count/count.cpp:204-215); rank 0
+receives all per-event outputs.
+
+The JSON line carries `roofline` for the count kernel (algorithmic bytes = 8 B per retained
+read block + the event tables read once + the class tables written once, SURVEY.md 8(d);
+duration from HIP events recorded on the library's stream around the kernel launches) and
+`cpu_baseline`: the oracle (a port; never part of the product path) timed single-threaded on
+a bounded prefix of the same read stream over the same events.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # BASELINE.json configs[2]/[3]: 100 M reads over 50 k mixed events, 24 chromosomes
+    "c3": dict(n_events=50_000, n_reads=100_000_000, R=100, n_chrom=24, types=None, seed=3,
+               desc="BASELINE configs[2]: 100M synthetic 100bp reads over 50k mixed events (SE/RI/A5SS/A3SS/MXE/AFE/ALE/T3), 24 chromosomes"),
+    # configs[1]: 10 M reads over 5 k two-isoform SE/RI events, one chromosome
+    "c2": dict(n_events=5_000, n_reads=10_000_000, R=100, n_chrom=1, types=("SE", "RI"), seed=2,
+               desc="BASELINE configs[1]: 10M synthetic 100bp reads over 5k SE/RI events, one chromosome"),
+    "c1": dict(n_events=100, n_reads=10_000, R=100, n_chrom=1, types=("SE",), seed=1,
+               desc="BASELINE configs[0]: 10k reads over 100 SE events (plumbing)"),
+}
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 measured copy rate
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-sample", type=int, default=5_000_000, help="reads in the cpu_baseline sample (0 = skip)")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        a.gpus = world
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import lesseq_amd as L
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the hot path has no CPU implementation")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    W = WORKLOADS[a.workload]
+    types = W["types"] or L.EVENT_TYPES
+    spec = L.SynthSpec(W["seed"] + 1000 * rank, W["n_events"], W["n_reads"], W["R"], W["n_chrom"], types)
+    tmp = tempfile.mkdtemp(prefix="lsq_bench_r%d_" % rank)
+
+    # ---- ingest (untimed): annotation -> compiled events -> reads -> bucketed pools in HBM
+    t0 = time.time()
+    L.synth_write(spec, tmp, "w", write_mrf=False)
+    ann = L.Annotation(os.path.join(tmp, "w.interval"), os.path.join(tmp, "w.map"))
+    ev = L.Events(ann, ("SHORT_READ",), (W["R"],))
+    reads = L.Reads.synthetic(spec, ev)
+    n_mrf_reads = len(reads)
+    t_gen = time.time() - t0
+    ctx = L.Context(local_rank)
+    ctx.upload_events(ev)
+    t0 = time.time()
+    ctx.upload_reads(0, reads)
+    t_ingest = time.time() - t0
+    del reads
+    retained, retained_blocks = ctx.retained(0), ctx.retained_blocks(0)
+    n_ev = len(ev)
+    n_cls = int(L.lib.lsq_results_num_classes(ctx.h))
+    n_iso = ev.total_isoforms
+
+    # per-event outputs as torch tensors so that RCCL can move them
+    t_cnt = torch.zeros(max(n_cls, 1), dtype=torch.int64, device=dev)
+    t_theta = torch.zeros(max(n_iso, 1), dtype=torch.float64, device=dev)
+    t_ll = torch.zeros(max(n_ev, 1), dtype=torch.float64, device=dev)
+    if world > 1:
+        g_cnt = torch.zeros(world * t_cnt.numel(), dtype=torch.int64, device=dev)
+        g_theta = torch.zeros(world * t_theta.numel(), dtype=torch.float64, device=dev)
+        g_ll = torch.zeros(world * t_ll.numel(), dtype=torch.float64, device=dev)
+
+    count_ms, solve_ms = [], []
+
+    def step(record):
+        ctx.count()
+        ctx.solve()
+        ctx.copy_results_device(t_cnt.data_ptr(), t_theta.data_ptr(), t_ll.data_ptr())
+        if world > 1:
+            ctx.synchronize()          # the library's stream -> visible to torch's stream
+            dist.all_gather_into_tensor(g_cnt, t_cnt)
+            dist.all_gather_into_tensor(g_theta, t_theta)
+            dist.all_gather_into_tensor(g_ll, t_ll)
+        if record:
+            c, s = ctx.timing()        # HIP events on the library's stream (synchronises it)
+            count_ms.append(c)
+            solve_ms.append(s)
+
+    def fence():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        ctx.synchronize()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step(False)
+    fence()
+    elapsed = time.perf_counter() - t0
+    # kernel durations: a separate short loop, so that reading the events does not sit in the timed one
+    for _ in range(min(a.steps, 10)):
+        step(True)
+    fence()
+
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    tot = torch.tensor([float(retained), float(retained_blocks), float(n_mrf_reads)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    elapsed = float(tmax.item())
+    total_retained, total_blocks, total_mrf = [float(x) for x in tot.tolist()]
+
+    # sanity of the resident result (every step recomputes it from zeroed tables)
+    cnt, bases = ctx.counts()
+    theta, ll, iters, flags = ctx.solution()
+    assert int(cnt.sum()) == int(t_cnt.sum().item()), "device copy and fetched counts disagree"
+    assert 0 < int(cnt.sum()) <= retained
+    assert np.isfinite(theta).all() and abs(float(theta.sum()) - n_ev) < 1e-6 * n_ev
+
+    if rank == 0:
+        ck = float(np.mean(count_ms))
+        off = ev.class_offsets()
+        ev_bytes = 0
+        for i in range(0, n_ev):
+            K, N = ev.K(i), ev.N(i)
+            ev_bytes += 8 * N + 8 * K + 16 + 8 * ((1 << K) - 1) + 8
+        alg_bytes = 8.0 * retained_blocks + ev_bytes
+        achieved = alg_bytes / (ck * 1e-3) / 1e9
+        out = {
+            "metric": "MRF reads/sec through count+solve",
+            "value": total_retained * a.steps / elapsed,
+            "unit": "reads/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": 1e3 * elapsed / a.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int32 coordinates / u64 counters (count), f64 (EM)",
+            "data": "synthetic",
+            "config": {
+                "workload": W["desc"],
+                "events_per_gpu": n_ev, "mrf_reads_per_gpu": n_mrf_reads, "retained_reads_per_gpu": retained,
+                "retained_blocks_per_gpu": retained_blocks, "buckets": ev.num_buckets,
+                "reads_counted": "retained reads (those that pass the load-time containment filter, count/count.cpp:319); off-target reads are dropped at ingest",
+                "count_kernel_ms": ck, "em_kernel_ms": float(np.mean(solve_ms)),
+                "valid_read_assignments": int(cnt.sum()), "em_flagged_events": int((flags & 1).sum()),
+                "em_max_iters": int(iters.max()) if n_ev else 0,
+                "generate_s": t_gen, "ingest_s": t_ingest,
+                "parallelism": "events sharded by rank; RCCL all-gather of per-event outputs" if world > 1 else "single GPU",
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "lsq_count_kernel",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": alg_bytes,
+            },
+        }
+        # ---- cpu_baseline: the oracle on a bounded prefix of the same stream (rank 0, N = 1 only)
+        if world == 1 and a.cpu_sample > 0:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_binding as ob
+            ns = min(a.cpu_sample, W["n_reads"])
+            sspec = L.SynthSpec(W["seed"], W["n_events"], ns, W["R"], W["n_chrom"], types)
+            L.synth_write(sspec, tmp, "s", write_mrf=True)
+            argv = ["0", "s", "./", "LH_GENE_TXT", os.path.join(tmp, "w.interval"), "UCSC_GENE2ISOFORM", os.path.join(tmp, "w.map"),
+                    "0", "1000000000", "MRF_SINGLE", "SHORT_READ", str(W["R"]), os.path.join(tmp, "s.mrf"), str(ns * W["R"])]
+            t0 = time.perf_counter()
+            rc, _, exact = ob.run("solve", argv)
+            dt = time.perf_counter() - t0
+            assert rc == 0
+            out["cpu_baseline"] = {
+                "value": ob.last_n_loaded[0] / dt, "unit": "reads/s",
+                "cores": 1, "kind": "port",
+                "sample": "first %d MRF reads of the same stream (%d retained) over the same %d events; oracle count+solve "
+                          "from MRF text incl. parse, filter and index, single thread, %.1f s" % (ns, ob.last_n_loaded[0], W["n_events"], dt),
+            }
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -166,6 +166,14 @@ int lsq_results_class_offsets(const lsq_ctx *c, uint64_t *class_off /* n_events+
 int lsq_results_counts(lsq_ctx *c, uint64_t *class_count, uint64_t *class_bases);
 int lsq_results_solve(lsq_ctx *c, double *theta, double *logll, uint32_t *em_iters, uint8_t *em_flags);
 
+/* Copies the raw device-order results into caller-provided DEVICE buffers (e.g. tensors of a
+ * framework that will run a collective on them), asynchronously on the context stream:
+ * d_class_count [n_methods * n_classes] uint64, d_theta [n_isoforms] f64, d_logll [n_events]
+ * f64; any may be NULL.  lsq_results_device_order() gives, per device-order event, its output
+ * index, so a gathered buffer can be put in output order on the receiving side. */
+int lsq_results_copy_device(lsq_ctx *c, void *d_class_count, void *d_theta, void *d_logll);
+int lsq_results_device_order(const lsq_ctx *c, int32_t *dev2out /* n_events */);
+
 /* Device timing of the last lsq_count / lsq_solve (ms, from HIP events on the context
  * stream) and the count kernel's launch geometry; for bench.py. */
 int lsq_last_timing(lsq_ctx *c, float *count_ms, float *solve_ms);

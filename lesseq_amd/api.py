@@ -213,6 +213,15 @@ class Context:
         check(lib.lsq_last_timing(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def copy_results_device(self, d_class_count=None, d_theta=None, d_logll=None):
+        """raw device-order results into caller device buffers (integer addresses), async"""
+        check(lib.lsq_results_copy_device(self.h, vp(d_class_count), vp(d_theta), vp(d_logll)))
+
+    def device_order(self):
+        o = np.zeros(max(len(self.events), 1), np.int32)
+        check(lib.lsq_results_device_order(self.h, _ptr(o, i32)))
+        return o[:len(self.events)]
+
     def counts(self):
         """(class_count, class_bases) as uint64 arrays of shape [n_methods, n_classes], output order"""
         n = lib.lsq_results_num_classes(self.h)

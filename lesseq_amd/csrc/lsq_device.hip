@@ -509,11 +509,11 @@ int lsq_count(lsq_ctx *c) {
 	const int M = E.n_methods;
 	for (int m = 0; m < M; ++m) if (!c->reads[m].present) return fail(LSQ_E_STATE, "reads of method %d were not uploaded", m);
 	hipStream_t st = c->stream;
-	HIP_TRY(hipEventRecord(c->ev0, st));
 	if (M * n_cls) {
 		HIP_TRY(hipMemsetAsync(c->cnt.p, 0, (size_t)M * n_cls * sizeof(unsigned long long), st));
 		HIP_TRY(hipMemsetAsync(c->bases.p, 0, (size_t)M * n_cls * sizeof(unsigned long long), st));
 	}
+	HIP_TRY(hipEventRecord(c->ev0, st));      // ev0..ev1 brackets the count kernel launches only
 	const unsigned lds_bytes = std::max<unsigned>(E.max_lds_bytes, 16);
 	if (lds_bytes > 64 * 1024)
 		HIP_TRY(hipFuncSetAttribute((const void *)lsq_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -622,6 +622,25 @@ int lsq_results_solve(lsq_ctx *c, double *theta, double *logll, uint32_t *em_ite
 		if (em_iters) em_iters[o] = hi[d];
 		if (em_flags) em_flags[o] = hf[d];
 	}
+	return LSQ_OK;
+}
+
+int lsq_results_copy_device(lsq_ctx *c, void *d_class_count, void *d_theta, void *d_logll) {
+	if (!c) return fail(LSQ_E_ARG, "null context");
+	if (!c->counted) return fail(LSQ_E_STATE, "lsq_count must come first");
+	if ((d_theta || d_logll) && !c->solved) return fail(LSQ_E_STATE, "lsq_solve must come first");
+	HIP_TRY(hipSetDevice(c->device));
+	const lsq_events &E = *c->E;
+	const size_t n_cls = E.n_cls_total, M = (size_t)E.n_methods;
+	if (d_class_count && M * n_cls) HIP_TRY(hipMemcpyAsync(d_class_count, c->cnt.p, M * n_cls * sizeof(unsigned long long), hipMemcpyDeviceToDevice, c->stream));
+	if (d_theta && E.n_iso_total) HIP_TRY(hipMemcpyAsync(d_theta, c->theta.p, (size_t)E.n_iso_total * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+	if (d_logll && !E.dev2out.empty()) HIP_TRY(hipMemcpyAsync(d_logll, c->logll.p, E.dev2out.size() * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+	return LSQ_OK;
+}
+
+int lsq_results_device_order(const lsq_ctx *c, int32_t *dev2out) {
+	if (!c || !c->E || !dev2out) return fail(LSQ_E_ARG, "null argument");
+	memcpy(dev2out, c->E->dev2out.data(), c->E->dev2out.size() * sizeof(int32_t));
 	return LSQ_OK;
 }
 

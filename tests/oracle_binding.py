@@ -34,6 +34,9 @@ _o.lsqo_em_rows.restype = C.c_ulong
 _o.lsqo_connected_compat.restype = C.c_long
 
 
+last_n_loaded = []      # retained reads per read file of the most recent run()
+
+
 def run(tool, argv, n_methods=None):
     """Runs the oracle's count/solve with the reference's argv (without argv[0]).
     Returns (exit_status, stdout_text, exact) where exact is a list of per-gene dicts."""
@@ -48,7 +51,9 @@ def run(tool, argv, n_methods=None):
     per = 5 if is_solve else 4
     M = n_methods if n_methods is not None else max((len(argv) - 9) // per, 0)
     exact = []
+    del last_n_loaded[:]
     if rc == 0 and ex:
+        last_n_loaded.extend(_o.lsqo_exact_n_loaded(ex, m) for m in range(M))
         for g in range(_o.lsqo_exact_n_genes(ex)):
             K = _o.lsqo_exact_K(ex, g)
             exact.append({

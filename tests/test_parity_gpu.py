@@ -65,6 +65,13 @@ def gpu_exact(argv, tool="solve"):
     return out
 
 
+def close(a, b):
+    """equal (also both -inf / both nan, the ARS = 0 corner) or within REL_TOL relative"""
+    if a == b or (a != a and b != b):
+        return True
+    return abs(a - b) <= REL_TOL * max(abs(a), abs(b))
+
+
 def compare_exact(got, exp, what):
     assert len(got) == len(exp), what
     n_flag = 0
@@ -79,8 +86,8 @@ def compare_exact(got, exp, what):
                 continue
             assert g["iters"] == e["iters"], (what, g["gname"], g["iters"], e["iters"])
             for a, b in zip(g["theta"], e["theta"]):
-                assert abs(a - b) <= REL_TOL * max(abs(a), abs(b)) or (a != a and b != b), (what, g["gname"], a, b)
-            assert abs(g["logll"] - e["logll"]) <= REL_TOL * max(abs(e["logll"]), 1e-300) or (g["logll"] != g["logll"]), (what, g["gname"])
+                assert close(a, b), (what, g["gname"], a, b)
+            assert close(g["logll"], e["logll"]), (what, g["gname"], g["logll"], e["logll"])
     return n_flag
 
 
