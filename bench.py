@@ -151,7 +151,7 @@ def main():
     cnt, bases = ctx.counts()
     theta, ll, iters, flags = ctx.solution()
     assert int(cnt.sum()) == int(t_cnt.sum().item()), "device copy and fetched counts disagree"
-    assert 0 < int(cnt.sum()) <= retained
+    assert 0 < int(cnt.sum()) <= 4 * retained
     assert np.isfinite(theta).all() and abs(float(theta.sum()) - n_ev) < 1e-6 * n_ev
 
     if rank == 0:

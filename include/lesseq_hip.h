@@ -158,7 +158,7 @@ int lsq_solve(lsq_ctx *c);
  * class_off[ev] + c - 1 where class_off is the exclusive prefix sum of (2^K - 1).
  *   class_count[m * n_classes + slot], class_bases[...]: uint64
  *   theta[iso_off[ev] + j], logll[ev], em_iters[ev], em_flags[ev]
- * em_flags bit 0: the stop criterion |1 - old_ll/ll| came within 1e-9 (relative 1e-3) of
+ * em_flags bit 0: the stop criterion |1 - old_ll/ll| came within 1e-11 (relative 1e-5) of
  * the 1e-6 threshold at some iteration, so a different summation order could stop one
  * iteration earlier or later. */
 int64_t lsq_results_num_classes(const lsq_ctx *c);

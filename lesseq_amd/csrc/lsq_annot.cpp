@@ -2,6 +2,7 @@
 // (buckets + LDS images).  Semantics restated from the reference lines cited at each step.
 #include <algorithm>
 #include <cerrno>
+#include <climits>
 #include <cstdarg>
 #include <cstdlib>
 #include <cstring>
@@ -265,9 +266,13 @@ static uint64_t ars_total(const std::vector<uint64_t> &seg_len, uint64_t R, bool
 
 static const int64_t COORD_LIMIT = (int64_t)1 << 30;
 
+// Budget for one bucket's event tables in LDS (records + segments + isoform masks + class
+// histogram; the bin directory comes on top, at most 8 KiB).  Small buckets keep the per-
+// workgroup staging and flush cost low and the occupancy high; the price is a longer cut list
+// for the ingest-time bucket lookup.  LSQ_LDS_BUDGET overrides (tests use it to vary the split).
 static uint32_t lds_budget_bytes() {
-	if (const char *e = getenv("LSQ_LDS_BUDGET")) { long v = atol(e); if (v >= 4096 && v <= 160 * 1024) return (uint32_t)v; }
-	return 64 * 1024;
+	if (const char *e = getenv("LSQ_LDS_BUDGET")) { long v = atol(e); if (v >= 512 && v <= 144 * 1024) return (uint32_t)v; }
+	return 4096;
 }
 
 // Builds buckets + LDS images from the compiled events.
@@ -285,7 +290,7 @@ static int plan_device(lsq_events &E) {
 	std::vector<std::vector<int32_t>> per_chrom(E.chroms.names.size());
 	for (size_t i = 0; i < n; ++i) per_chrom[E.ev[i].chrom_id].push_back((int32_t)i);
 	auto ev_bytes = [&](const Event &e) -> uint32_t {
-		return 16u + 8u * (uint32_t)e.N + 4u * (uint32_t)e.K + 8u * ((1u << e.K) - 1u);
+		return std::max(48u, 16u + 8u * (uint32_t)e.N + 4u * (uint32_t)e.K) + 8u * ((1u << e.K) - 1u);
 	};
 	for (size_t c = 0; c < per_chrom.size(); ++c) {
 		auto &lst = per_chrom[c];
@@ -296,6 +301,9 @@ static int plan_device(lsq_events &E) {
 			if (x.gene_end != y.gene_end) return x.gene_end < y.gene_end;
 			return a < b;
 		});
+		// the branch-free walk assumes non-negative coordinates (the reference's cursor starts at 0,
+		// common/read.h:217); covered regions of a chromosome are unions of its exons
+		const bool chrom_nonneg = c >= E.covered.size() || E.covered[c].s.empty() || E.covered[c].s.front() >= 0;
 		// clusters of transitively overlapping spans (a read start p is a candidate of an event
 		// iff gene_start <= p <= gene_end), packed greedily into buckets
 		size_t i = 0;
@@ -313,10 +321,10 @@ static int plan_device(lsq_events &E) {
 					cb += ev_bytes(E.ev[lst[j]]);
 					++cn; ++j;
 				}
-				// bins: at most 2 B per event pair, bounded; keep 8 KiB aside for them
-				uint32_t cap = E.lds_budget - 8192 - 64;
+				uint32_t cap = E.lds_budget;
 				if (n_ev > 0 && (bytes + cb > cap || n_ev + cn > 60000)) break;
-				if (n_ev == 0 && (cb > cap || cn > 60000))
+				// a single cluster may exceed the budget as long as it fits the CU's LDS
+				if (n_ev == 0 && (cb > 150u * 1024u || cn > 60000))
 					return fail(LSQ_E_UNSUPPORTED, "%zu mutually overlapping events on %s need %u bytes of LDS tables (budget %u): not supported by the device path yet",
 					            cn, E.chroms.names[c].c_str(), cb, E.lds_budget);
 				bytes += cb; n_ev += cn; i = j;
@@ -328,27 +336,36 @@ static int plan_device(lsq_events &E) {
 			d.n_events = (uint32_t)(i - b_begin);
 			int64_t lo = E.ev[lst[b_begin]].gene_start, hi = lo;
 			uint32_t nseg = 0, niso = 0, ncls = 0;
+			bool fast = chrom_nonneg;
 			for (size_t k = b_begin; k < i; ++k) {
 				const Event &e = E.ev[lst[k]];
 				hi = std::max(hi, e.gene_end);
 				nseg += (uint32_t)e.N; niso += (uint32_t)e.K; ncls += (1u << e.K) - 1u;
+				if (e.N > 4 || e.K > 4 || e.seg_s.front() < 0) fast = false;
 			}
+			if (getenv("LSQ_FORCE_GENERIC")) fast = false;
 			if (nseg > 65535 || niso > 65535 || ncls > 65535) return fail(LSQ_E_UNSUPPORTED, "bucket tables exceed 16-bit offsets");
 			uint32_t want = 16;
-			while (want < 2 * d.n_events && want < 4096) want <<= 1;
+			while (want < 4 * d.n_events && want < 4096) want <<= 1;
 			uint32_t shift = 0;
 			while ((((uint64_t)(hi - lo)) >> shift) >= want) ++shift;
 			d.n_bins = want; d.shift = shift; d.lo = (int32_t)lo;
+			d.kind = fast ? 1u : 0u;
 			auto align16 = [](uint32_t x) { return (x + 15u) & ~15u; };
 			uint32_t off = 0;
 			uint32_t bins_off = off; off = align16(off + 2 * d.n_bins);
-			d.ev_off = off; off = align16(off + 16 * d.n_events);
-			d.seg_off = off; off = align16(off + 8 * nseg);
-			d.iso_off = off; off = align16(off + 4 * niso);
+			if (fast) {
+				d.ev_off = off; off = align16(off + (uint32_t)sizeof(FastRec) * d.n_events);
+				d.seg_off = d.iso_off = off;
+			} else {
+				d.ev_off = off; off = align16(off + 16 * d.n_events);
+				d.seg_off = off; off = align16(off + 8 * nseg);
+				d.iso_off = off; off = align16(off + 4 * niso);
+			}
 			d.img_bytes = off;
 			d.hist_off = off; off += 8 * ncls;
 			d.n_cls = ncls;
-			if (off > E.lds_budget) return fail(LSQ_E_UNSUPPORTED, "internal: bucket of %u events needs %u bytes of LDS", d.n_events, off);
+			if (off > 160u * 1024u) return fail(LSQ_E_UNSUPPORTED, "internal: bucket of %u events needs %u bytes of LDS", d.n_events, off);
 			E.max_lds_bytes = std::max(E.max_lds_bytes, off);
 			d.img_off = (uint32_t)E.images.size();
 			d.cls_base = E.n_cls_total;
@@ -357,17 +374,33 @@ static int plan_device(lsq_events &E) {
 			uint8_t *img = E.images.data() + d.img_off;
 			uint16_t *bins = reinterpret_cast<uint16_t *>(img + bins_off);
 			EventRec *recs = reinterpret_cast<EventRec *>(img + d.ev_off);
+			FastRec *frecs = reinterpret_cast<FastRec *>(img + d.ev_off);
 			int32_t *segs = reinterpret_cast<int32_t *>(img + d.seg_off);
 			uint32_t *isos = reinterpret_cast<uint32_t *>(img + d.iso_off);
 			uint32_t so = 0, io = 0, co = 0;
+			std::vector<int32_t> ends(d.n_events);
 			for (size_t k = b_begin; k < i; ++k) {
 				const Event &e = E.ev[lst[k]];
-				EventRec &r = recs[k - b_begin];
-				r.gs = (int32_t)e.gene_start; r.ge = (int32_t)e.gene_end;
-				r.seg_off = (uint16_t)so; r.iso_off = (uint16_t)io; r.cls_off = (uint16_t)co;
-				r.nseg = (uint8_t)e.N; r.K = (uint8_t)e.K;
-				for (int s = 0; s < e.N; ++s) { segs[2 * (so + s)] = (int32_t)e.seg_s[s]; segs[2 * (so + s) + 1] = (int32_t)e.seg_e[s]; }
-				for (int q = 0; q < e.K; ++q) isos[io + q] = (uint32_t)e.iso_mask[q];
+				ends[k - b_begin] = (int32_t)e.gene_end;
+				if (fast) {
+					FastRec &r = frecs[k - b_begin];
+					r.gs = (int32_t)e.gene_start; r.ge = (int32_t)e.gene_end;
+					r.meta = co | ((uint32_t)e.K << 16) | ((uint32_t)e.N << 24);
+					r.iso = 0;
+					for (int q = 0; q < e.K; ++q) r.iso |= ((uint32_t)e.iso_mask[q] & 0xFu) << (4 * q);
+					if (k + 1 < i && E.ev[lst[k + 1]].gene_start <= e.gene_end) r.iso |= FAST_FLAG_OVERLAPS_NEXT;
+					for (int sgi = 0; sgi < 4; ++sgi) {
+						r.seg[2 * sgi] = sgi < e.N ? (int32_t)e.seg_s[sgi] : INT32_MAX;
+						r.seg[2 * sgi + 1] = sgi < e.N ? (int32_t)e.seg_e[sgi] : INT32_MAX;
+					}
+				} else {
+					EventRec &r = recs[k - b_begin];
+					r.gs = (int32_t)e.gene_start; r.ge = (int32_t)e.gene_end;
+					r.seg_off = (uint16_t)so; r.iso_off = (uint16_t)io; r.cls_off = (uint16_t)co;
+					r.nseg = (uint8_t)e.N; r.K = (uint8_t)e.K;
+					for (int sgi = 0; sgi < e.N; ++sgi) { segs[2 * (so + sgi)] = (int32_t)e.seg_s[sgi]; segs[2 * (so + sgi) + 1] = (int32_t)e.seg_e[sgi]; }
+					for (int q = 0; q < e.K; ++q) isos[io + q] = (uint32_t)e.iso_mask[q];
+				}
 				E.dev2out.push_back(lst[k]);
 				E.dev_cls_base.push_back(E.n_cls_total + co);
 				E.dev_iso_base.push_back(E.n_iso_total + io);
@@ -388,7 +421,7 @@ static int plan_device(lsq_events &E) {
 				int64_t bin_lo = lo + ((int64_t)k << shift);
 				// an event is passed over only once its end lies left of a bin start, so it can
 				// never reach a later bin: `first` is min{i : ge_i >= bin_lo} for every k
-				while (first < d.n_events && recs[first].ge < bin_lo) ++first;
+				while (first < d.n_events && ends[first] < bin_lo) ++first;
 				bins[k] = (uint16_t)first;
 			}
 			if (E.chrom_first_bucket[c] < 0) E.chrom_first_bucket[c] = (int32_t)E.buckets.size();

@@ -37,7 +37,8 @@ using namespace lsq;
 
 namespace {
 
-constexpr int COUNT_BLOCK = 512;
+constexpr int COUNT_BLOCK = 256;
+constexpr int TILE_WORDS = COUNT_BLOCK * 4;      // 16-byte words per read tile (16 KiB): 2048 one-block reads or 1024 two-block reads
 constexpr unsigned long long BASES_MASK = (1ull << 40) - 1;
 
 struct CountArgs {
@@ -46,6 +47,7 @@ struct CountArgs {
 	const TieRec *ties;
 	const unsigned char *strand_rank;
 	unsigned n_buckets;
+	unsigned tables_lds_bytes;         // LDS bytes reserved for the bucket image + histogram (16-byte multiple)
 	const int2 *p1; const unsigned char *p1_strand; const unsigned *p1_line;
 	const int4 *p2; const unsigned char *p2_strand; const unsigned *p2_line;
 	const unsigned *pn_blk_off; const int2 *pn_se; const unsigned char *pn_strand; const unsigned *pn_line;
@@ -62,34 +64,40 @@ struct LdsView {
 	unsigned long long *hist;
 };
 
-// "read-<line>" < gene name ?  (std::string operator< on the reference's read names)
-__device__ inline bool name_less(unsigned line, const TieRec &t) {
-	if (t.tie_mode != 2) return t.tie_mode == 1;
-	char dg[10];
-	int nd = 0;
+// Span-start tie (count/count.cpp:64-85): the read starts exactly at the event's first base and
+// ends exactly at its last; it is a candidate unless (strand, name) orders it before the event.
+// "read-<line>" < gene name is std::string operator< on the reference's read names.
+__device__ __noinline__ bool tie_orders_read_first(const TieRec *ties, const unsigned char *strand_rank,
+                                                   unsigned ev_index, unsigned read_strand, unsigned line) {
+	const TieRec *t = ties + ev_index;
+	const unsigned rs = strand_rank[read_strand], gs = strand_rank[t->strand_id];
+	if (rs != gs) return rs < gs;
+	const unsigned mode = t->tie_mode;
+	if (mode != 2) return mode == 1;
+	// compare the decimal digits of `line`, most significant first, with the name's tail
+	unsigned pow10 = 1, nd = 1;
+	while (nd < 10 && line / pow10 >= 10) { pow10 *= 10; ++nd; }
+	const unsigned tl = t->tail_len;
 	unsigned v = line;
-	do { dg[nd++] = (char)('0' + v % 10); v /= 10; } while (v);
-	// dg holds the digits least-significant first
-	int n = nd < (int)t.tail_len ? nd : (int)t.tail_len;
-	for (int i = 0; i < n; ++i) {
-		unsigned char a = (unsigned char)dg[nd - 1 - i], b = (unsigned char)t.tail[i];
+	for (unsigned i = 0; i < nd && i < tl; ++i) {
+		const unsigned char a = (unsigned char)('0' + v / pow10), b = (unsigned char)t->tail[i];
 		if (a != b) return a < b;
+		v %= pow10; pow10 /= 10;
 	}
-	return nd < (int)t.tail_len;
+	return nd < tl;
 }
 
-// Segment walk of one read against one event's ascending segments.  `pos` is the furthest
-// matched coordinate (or the current segment's start), `it` the segment cursor, which never
-// moves back.  The first block may start anywhere inside a segment; once something has
-// matched, every continuation must start exactly at `pos`.
-template <class GetBlock>
-__device__ inline void walk_segments(const int2 *segs, int nseg, int nblk, GetBlock get, unsigned &mask, int &matched) {
+// Segment walk of one read against one event's ascending segments (common/read.h:204-274).
+// `pos` is the furthest matched coordinate (or the current segment's start), `it` the segment
+// cursor, which never moves back.  The first block may start anywhere inside a segment; once
+// something has matched, every continuation must start exactly at `pos`.
+struct Walk {
 	int pos = 0, it = 0;
 	bool found = false;
-	mask = 0; matched = 0;
-	for (int bi = 0; bi < nblk; ++bi) {
-		int a, b;
-		get(bi, a, b);
+	unsigned mask = 0;
+	int matched = 0;
+	// returns false when the walk must stop (block not fully consumed)
+	__device__ inline bool block(const int2 *segs, int nseg, int a, int b) {
 		while (it < nseg) {
 			const int2 sg = segs[it];
 			if (!(sg.x < b)) break;
@@ -107,50 +115,236 @@ __device__ inline void walk_segments(const int2 *segs, int nseg, int nblk, GetBl
 			}
 			++it;
 		}
-		if (a != b) break;
+		return a == b;
 	}
-}
+};
 
-// One read against the staged bucket.  p = first merged start, q = last merged end.
-template <class GetBlock>
-__device__ inline void process_read(const LdsView &L, const BucketDesc &d, const CountArgs &A,
-                                    int p, int q, int total, int nblk, GetBlock get,
+// One read against the staged bucket.  NB = 1 / 2: blocks in registers (v.x,v.y[,v.z,v.w]);
+// NB = 0: nblk blocks at blk[].  p = first merged start, q = last merged end.
+template <int NB>
+__device__ inline void process_read(const LdsView &L, const BucketDesc &d, const CountArgs &A, const int4 v,
+                                    const int2 *blk, int nblk, int total,
                                     const unsigned char *strand_arr, const unsigned *line_arr, unsigned long long slot) {
-	long long rel = (long long)p - (long long)d.lo;
-	unsigned bin = rel <= 0 ? 0u : (unsigned)(rel >> d.shift);
-	if (bin >= d.n_bins) bin = d.n_bins - 1;
+	const int p = v.x, q = (NB == 1) ? v.y : v.w;
+	const int rel = p - d.lo;       // both within +-2^30
+	unsigned bin = rel <= 0 ? 0u : ((unsigned)rel >> d.shift);
+	bin = min(bin, d.n_bins - 1u);
 	for (unsigned i = L.bins[bin]; i < d.n_events; ++i) {
 		const EventRec e = L.ev[i];
 		if (e.gs > p) break;
 		if (p > e.ge) continue;
 		if (p == e.gs) {
-			// reads ordered before the key (chrom, gene_start, gene_end, strand, name) are skipped
+			// reads ordered before the key (chrom, gene_start, gene_end, strand, name) are not candidates
 			if (q < e.ge) continue;
-			if (q == e.ge) {
-				const TieRec t = A.ties[d.ev_base + i];
-				unsigned rs = A.strand_rank[strand_arr[slot]], gsr = A.strand_rank[t.strand_id];
-				if (rs < gsr) continue;
-				if (rs == gsr && name_less(line_arr[slot], t)) continue;
-			}
+			if (q == e.ge && tie_orders_read_first(A.ties, A.strand_rank, d.ev_base + i, strand_arr[slot], line_arr[slot])) continue;
 		}
-		unsigned mask; int matched;
-		walk_segments(L.segs + e.seg_off, e.nseg, nblk, get, mask, matched);
+		Walk w;
+		const int2 *segs = L.segs + e.seg_off;
+		if (NB == 1) {
+			w.block(segs, e.nseg, v.x, v.y);
+		} else if (NB == 2) {
+			if (w.block(segs, e.nseg, v.x, v.y)) w.block(segs, e.nseg, v.z, v.w);
+		} else {
+			for (int k = 0; k < nblk; ++k) { const int2 bk = blk[k]; if (!w.block(segs, e.nseg, bk.x, bk.y)) break; }
+		}
+		const unsigned mask = w.mask;
 		if (!mask) continue;
 		// (double)matched / total > 0.98  <=>  50*matched > 49*total for these magnitudes
-		if (!(50ll * matched > 49ll * total)) continue;
-		unsigned hi = 31u - (unsigned)__clz((int)mask), lo = (unsigned)__ffs((int)mask) - 1u;
-		unsigned span = ((2u << hi) - 1u) & ~((1u << lo) - 1u);
+		if (!(50ll * w.matched > 49ll * total)) continue;
+		const unsigned hi = 31u - (unsigned)__clz((int)mask), lo = (unsigned)__ffs((int)mask) - 1u;
+		const unsigned span = ((2u << hi) - 1u) & ~((1u << lo) - 1u);
 		unsigned cls = 0;
 		for (unsigned j = 0; j < e.K; ++j) {
-			unsigned iso = L.iso[e.iso_off + j];
+			const unsigned iso = L.iso[e.iso_off + j];
 			if ((mask & ~iso) == 0 && (iso & span) == mask) cls |= 1u << j;
 		}
-		if (cls) atomicAdd(&L.hist[e.cls_off + cls - 1], (1ull << 40) | (unsigned long long)(unsigned)matched);
+		if (cls) atomicAdd(&L.hist[e.cls_off + cls - 1], (1ull << 40) | (unsigned long long)(unsigned)w.matched);
+	}
+}
+
+// ---- branch-free path for buckets of packed FastRec events ------------------------------------
+// The same state machine as Walk::block, with every decision turned into a predicate so that
+// the 64 lanes of a wave (each on its own read, usually on different events) run one
+// instruction stream: four segment steps per block, no data-dependent branches.  Unused
+// segments are INT32_MAX sentinels, which stop the walk exactly like the end of the list.
+struct FastWalk {
+	int pos = 0, it = 0;
+	bool found = false;
+	unsigned mask = 0;
+	int matched = 0;
+	// one block; returns true when the block was fully consumed
+	__device__ inline bool block(const int (&sx)[4], const int (&sy)[4], int a, const int b, bool enable) {
+		bool done = !enable;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const bool live = !done && k >= it;
+			const bool in_reach = sx[k] < b;                       // else: the list is exhausted for this block
+			const int npos = max(pos, sx[k]);
+			const bool hit = a >= npos && a < sy[k];
+			const bool off_path = hit && found && a > npos;        // continuation must start exactly at pos
+			const bool blocked = !hit && npos > sx[k] && npos < sy[k];
+			const bool take = live && in_reach && hit && !off_path;
+			const bool stop = live && (!in_reach || off_path || blocked);
+			pos = (live && in_reach) ? npos : pos;
+			const int e2 = min(sy[k], b);
+			matched += take ? e2 - a : 0;
+			mask |= take ? (1u << k) : 0u;
+			found = found || take;
+			pos = take ? e2 : pos;
+			const bool inside = b < sy[k];                          // block ends inside this segment: cursor stays
+			a = take ? (b <= sy[k] ? b : sy[k]) : a;
+			it += (live && !stop && !(take && inside)) ? 1 : 0;
+			done = done || stop || (take && a == b);
+		}
+		return enable && a == b;
+	}
+};
+
+template <int NB>
+__device__ inline void process_read_fast(const unsigned short *bins, const uint4 *recs, unsigned long long *hist,
+                                         const BucketDesc &d, const CountArgs &A, const int4 v, const int total,
+                                         const unsigned char *strand_arr, const unsigned *line_arr, unsigned long long slot, const bool valid_lane) {
+	const int p = v.x, q = (NB == 1) ? v.y : v.w;
+	const int rel = p - d.lo;
+	unsigned bin = rel <= 0 ? 0u : ((unsigned)rel >> d.shift);
+	bin = min(bin, d.n_bins - 1u);
+	unsigned i = valid_lane ? bins[bin] : d.n_events;
+	bool act = valid_lane;
+	// wave-uniform loop: one trip aligns most lanes with the event that covers their read; lanes
+	// whose bin starts with an event that ends before p, or whose event overlaps the next one,
+	// ask for further trips
+	do {
+		const bool inb = act && i < d.n_events;
+		const uint4 w0 = recs[3u * (inb ? i : 0u)];
+		const int gs = (int)w0.x, ge = (int)w0.y;
+		const bool started = inb && gs <= p;
+		bool covers = started && p <= ge;
+		if (__any(covers)) {
+			// span-start tie rule: reads that sort before (gene_start, gene_end, strand, name) are not candidates
+			if (covers && p == gs) {
+				if (q < ge) covers = false;
+				else if (q == ge && tie_orders_read_first(A.ties, A.strand_rank, d.ev_base + i, strand_arr[slot], line_arr[slot])) covers = false;
+			}
+			const uint4 w1 = recs[3u * (inb ? i : 0u) + 1], w2 = recs[3u * (inb ? i : 0u) + 2];
+			const int sx[4] = {(int)w1.x, (int)w1.z, (int)w2.x, (int)w2.z};
+			const int sy[4] = {(int)w1.y, (int)w1.w, (int)w2.y, (int)w2.w};
+			FastWalk w;
+			bool c1 = w.block(sx, sy, v.x, v.y, covers);
+			if (NB == 2) w.block(sx, sy, v.z, v.w, c1);
+			const unsigned mask = w.mask;
+			const bool ok = covers && mask != 0 && (50ll * w.matched > 49ll * total);
+			const unsigned m1 = mask | (mask == 0);             // keep clz/ffs defined
+			const unsigned hi = 31u - (unsigned)__clz((int)m1), lo = (unsigned)__ffs((int)m1) - 1u;
+			const unsigned span = ((2u << hi) - 1u) & ~((1u << lo) - 1u);
+			unsigned cls = 0;
+#pragma unroll
+			for (unsigned j = 0; j < 4; ++j) {
+				const unsigned iso = (w0.w >> (4 * j)) & 0xFu;      // absent isoforms are 0 and never contain the mask
+				cls |= ((mask & ~iso) == 0 && (iso & span) == mask) ? (1u << j) : 0u;
+			}
+			if (ok && cls) atomicAdd(&hist[(w0.z & 0xFFFFu) + cls - 1], (1ull << 40) | (unsigned long long)(unsigned)w.matched);
+		}
+		act = started && (!(p <= ge) || (w0.w & FAST_FLAG_OVERLAPS_NEXT));
+		++i;
+	} while (__any(act));
+}
+
+// Reads with three or more blocks in a FastRec bucket (rare): the branching walk over the
+// record's segments.
+__device__ __noinline__ void process_read_n_on_fast(const unsigned short *bins, const uint4 *recs, unsigned long long *hist,
+                                                    const BucketDesc &d, const CountArgs &A, const int2 *blk, int nblk, int total,
+                                                    unsigned long long slot) {
+	const int p = blk[0].x, q = blk[nblk - 1].y;
+	const int rel = p - d.lo;
+	unsigned bin = rel <= 0 ? 0u : ((unsigned)rel >> d.shift);
+	bin = min(bin, d.n_bins - 1u);
+	for (unsigned i = bins[bin]; i < d.n_events; ++i) {
+		const uint4 w0 = recs[3u * i];
+		const int gs = (int)w0.x, ge = (int)w0.y;
+		if (gs > p) break;
+		if (p > ge) continue;
+		if (p == gs) {
+			if (q < ge) continue;
+			if (q == ge && tie_orders_read_first(A.ties, A.strand_rank, d.ev_base + i, A.pn_strand[slot], A.pn_line[slot])) continue;
+		}
+		const uint4 w1 = recs[3u * i + 1], w2 = recs[3u * i + 2];
+		int2 segs[4] = {make_int2((int)w1.x, (int)w1.y), make_int2((int)w1.z, (int)w1.w), make_int2((int)w2.x, (int)w2.y), make_int2((int)w2.z, (int)w2.w)};
+		const int nseg = (int)(w0.z >> 24);
+		Walk w;
+		for (int k = 0; k < nblk; ++k) { const int2 bk = blk[k]; if (!w.block(segs, nseg, bk.x, bk.y)) break; }
+		const unsigned mask = w.mask;
+		if (!mask) continue;
+		if (!(50ll * w.matched > 49ll * total)) continue;
+		const unsigned hi = 31u - (unsigned)__clz((int)mask), lo = (unsigned)__ffs((int)mask) - 1u;
+		const unsigned span = ((2u << hi) - 1u) & ~((1u << lo) - 1u);
+		unsigned cls = 0;
+		for (unsigned j = 0; j < 4; ++j) {
+			const unsigned iso = (w0.w >> (4 * j)) & 0xFu;
+			if ((mask & ~iso) == 0 && (iso & span) == mask) cls |= 1u << j;
+		}
+		if (cls) atomicAdd(&hist[(w0.z & 0xFFFFu) + cls - 1], (1ull << 40) | (unsigned long long)(unsigned)w.matched);
+	}
+}
+
+// Streams the 16-byte words [w0, w1) of `src` through an LDS tile: wide coalesced loads by the
+// whole workgroup (next tile's loads are issued before the current tile is processed), then
+// each lane walks its reads out of LDS in a compact loop.  READS_PER_WORD = 2 (pool 1) or 1.
+template <int RPW, bool FAST>
+__device__ inline void stream_pool(const LdsView &L, const BucketDesc &d, const CountArgs &A, uint4 *tile,
+                                   const uint4 *src, unsigned long long g0, unsigned long long g1,
+                                   const unsigned char *strand_arr, const unsigned *line_arr) {
+	// reads [g0, g1) in the pool's global numbering; words [w0, w1)
+	const unsigned tid = threadIdx.x;
+	const unsigned long long w0 = g0 / RPW, w1 = (g1 + RPW - 1) / RPW;
+	uint4 nxt[4];
+	auto fetch = [&](unsigned long long wt) {
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const unsigned long long w = wt + (unsigned)k * COUNT_BLOCK + tid;
+			nxt[k] = w < w1 ? src[w] : make_uint4(0, 0, 0, 0);
+		}
+	};
+	fetch(w0);
+	for (unsigned long long wt = w0; wt < w1; wt += TILE_WORDS) {
+#pragma unroll
+		for (int k = 0; k < 4; ++k) tile[k * COUNT_BLOCK + tid] = nxt[k];
+		__syncthreads();
+		if (wt + TILE_WORDS < w1) fetch(wt + TILE_WORDS);
+		const unsigned long long r_base = wt * RPW;
+#pragma unroll 1
+		for (int k = 0; k < 4 * RPW; ++k) {
+			const unsigned r = (unsigned)k * COUNT_BLOCK + tid;
+			const unsigned long long g = r_base + r;
+			const bool in = g >= g0 && g < g1;
+			if (FAST) {
+				// every lane runs the predicated body (wave-uniform control flow inside)
+				const uint4 *recs = reinterpret_cast<const uint4 *>(L.ev);
+				if (RPW == 2) {
+					const int2 rd = reinterpret_cast<const int2 *>(tile)[r];
+					process_read_fast<1>(L.bins, recs, L.hist, d, A, make_int4(rd.x, rd.y, 0, 0), rd.y - rd.x, strand_arr, line_arr, g, in);
+				} else {
+					const uint4 u = tile[r];
+					const int4 rd = make_int4((int)u.x, (int)u.y, (int)u.z, (int)u.w);
+					process_read_fast<2>(L.bins, recs, L.hist, d, A, rd, (rd.y - rd.x) + (rd.w - rd.z), strand_arr, line_arr, g, in);
+				}
+			} else if (in) {
+				if (RPW == 2) {
+					const int2 rd = reinterpret_cast<const int2 *>(tile)[r];
+					process_read<1>(L, d, A, make_int4(rd.x, rd.y, 0, 0), nullptr, 1, rd.y - rd.x, strand_arr, line_arr, g);
+				} else {
+					const uint4 u = tile[r];
+					const int4 rd = make_int4((int)u.x, (int)u.y, (int)u.z, (int)u.w);
+					process_read<2>(L, d, A, rd, nullptr, 2, (rd.y - rd.x) + (rd.w - rd.z), strand_arr, line_arr, g);
+				}
+			}
+		}
+		__syncthreads();
 	}
 }
 
 __global__ void __launch_bounds__(COUNT_BLOCK) lsq_count_kernel(CountArgs A) {
 	extern __shared__ __align__(16) unsigned char lds[];
+	uint4 *tile = reinterpret_cast<uint4 *>(lds + A.tables_lds_bytes);
 	const unsigned tid = threadIdx.x;
 	const unsigned long long s_begin = A.total_slots * blockIdx.x / gridDim.x;
 	const unsigned long long s_end = A.total_slots * (blockIdx.x + 1ull) / gridDim.x;
@@ -185,25 +379,17 @@ __global__ void __launch_bounds__(COUNT_BLOCK) lsq_count_kernel(CountArgs A) {
 		const unsigned long long n1 = A.p1_off[b + 1] - A.p1_off[b];
 		const unsigned long long n2 = A.p2_off[b + 1] - A.p2_off[b];
 		// ---- pool 1
-		{
-			unsigned long long a = l0, z = l1 < n1 ? l1 : n1;
+		if (l0 < n1) {
 			const unsigned long long base = A.p1_off[b];
-			for (unsigned long long i = a + tid; i < z; i += COUNT_BLOCK) {
-				const int2 r = A.p1[base + i];
-				process_read(L, d, A, r.x, r.y, r.y - r.x, 1,
-				             [&](int, int &s, int &e) { s = r.x; e = r.y; }, A.p1_strand, A.p1_line, base + i);
-			}
+			if (d.kind == 1) stream_pool<2, true>(L, d, A, tile, reinterpret_cast<const uint4 *>(A.p1), base + l0, base + (l1 < n1 ? l1 : n1), A.p1_strand, A.p1_line);
+			else stream_pool<2, false>(L, d, A, tile, reinterpret_cast<const uint4 *>(A.p1), base + l0, base + (l1 < n1 ? l1 : n1), A.p1_strand, A.p1_line);
 		}
 		// ---- pool 2
-		if (l1 > n1 && n2) {
-			unsigned long long a = (l0 > n1 ? l0 : n1) - n1, z = (l1 < n1 + n2 ? l1 : n1 + n2) - n1;
+		if (l1 > n1 && l0 < n1 + n2) {
 			const unsigned long long base = A.p2_off[b];
-			for (unsigned long long i = a + tid; i < z; i += COUNT_BLOCK) {
-				const int4 r = A.p2[base + i];
-				process_read(L, d, A, r.x, r.w, (r.y - r.x) + (r.w - r.z), 2,
-				             [&](int k, int &s, int &e) { if (k == 0) { s = r.x; e = r.y; } else { s = r.z; e = r.w; } },
-				             A.p2_strand, A.p2_line, base + i);
-			}
+			const unsigned long long g0 = base + ((l0 > n1 ? l0 : n1) - n1), g1 = base + ((l1 < n1 + n2 ? l1 : n1 + n2) - n1);
+			if (d.kind == 1) stream_pool<1, true>(L, d, A, tile, reinterpret_cast<const uint4 *>(A.p2), g0, g1, A.p2_strand, A.p2_line);
+			else stream_pool<1, false>(L, d, A, tile, reinterpret_cast<const uint4 *>(A.p2), g0, g1, A.p2_strand, A.p2_line);
 		}
 		// ---- pool n
 		if (l1 > n1 + n2) {
@@ -214,9 +400,11 @@ __global__ void __launch_bounds__(COUNT_BLOCK) lsq_count_kernel(CountArgs A) {
 				const int2 *blk = A.pn_se + o0;
 				int total = 0;
 				for (unsigned k = o0; k < o1; ++k) { int2 v = A.pn_se[k]; total += v.y - v.x; }
-				process_read(L, d, A, blk[0].x, A.pn_se[o1 - 1].y, total, (int)(o1 - o0),
-				             [&](int k, int &s, int &e) { int2 v = blk[k]; s = v.x; e = v.y; },
-				             A.pn_strand, A.pn_line, base + i);
+				if (d.kind == 1)
+					process_read_n_on_fast(L.bins, reinterpret_cast<const uint4 *>(L.ev), L.hist, d, A, blk, (int)(o1 - o0), total, base + i);
+				else
+					process_read<0>(L, d, A, make_int4(blk[0].x, 0, 0, A.pn_se[o1 - 1].y), blk, (int)(o1 - o0), total,
+					                A.pn_strand, A.pn_line, base + i);
 			}
 		}
 		__syncthreads();
@@ -305,7 +493,7 @@ __global__ void __launch_bounds__(256) lsq_em_kernel(EmArgs A) {
 			ll = em_loglik(A, cb, ib, K, th);
 			++iters;
 			const double crit = fabs(1.0 - old_ll / ll);
-			if (fabs(crit - 1E-6) < 1E-9) flag |= 1;
+			if (fabs(crit - 1E-6) < 1E-11) flag |= 1;
 			if (!(crit > 1E-6)) break;
 			if (iters >= 1000000u) { flag |= 2; break; }
 		}
@@ -514,11 +702,13 @@ int lsq_count(lsq_ctx *c) {
 		HIP_TRY(hipMemsetAsync(c->bases.p, 0, (size_t)M * n_cls * sizeof(unsigned long long), st));
 	}
 	HIP_TRY(hipEventRecord(c->ev0, st));      // ev0..ev1 brackets the count kernel launches only
-	const unsigned lds_bytes = std::max<unsigned>(E.max_lds_bytes, 16);
+	const unsigned tables_bytes = (std::max<unsigned>(E.max_lds_bytes, 16) + 15u) & ~15u;
+	const unsigned lds_bytes = tables_bytes + TILE_WORDS * 16;
+	if (lds_bytes > 160 * 1024) return fail(LSQ_E_UNSUPPORTED, "bucket tables + read tile exceed the CU's LDS");
 	if (lds_bytes > 64 * 1024)
 		HIP_TRY(hipFuncSetAttribute((const void *)lsq_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
 	unsigned per_cu = std::max(1u, std::min(2048u / COUNT_BLOCK, (160u * 1024u) / lds_bytes));
-	unsigned mult = 2;
+	unsigned mult = 1;
 	if (const char *e = getenv("LSQ_GRID_MULT")) { int v = atoi(e); if (v >= 1 && v <= 64) mult = (unsigned)v; }
 	for (int m = 0; m < M; ++m) {
 		MethodReads &mr = c->reads[m];
@@ -530,6 +720,7 @@ int lsq_count(lsq_ctx *c) {
 		CountArgs A;
 		A.buckets = c->buckets.p; A.images = c->images.p; A.ties = c->ties.p; A.strand_rank = c->strand_rank.p;
 		A.n_buckets = (unsigned)E.buckets.size();
+		A.tables_lds_bytes = tables_bytes;
 		A.p1 = reinterpret_cast<const int2 *>(mr.p1.p); A.p1_strand = mr.p1_strand.p; A.p1_line = mr.p1_line.p;
 		A.p2 = reinterpret_cast<const int4 *>(mr.p2.p); A.p2_strand = mr.p2_strand.p; A.p2_line = mr.p2_line.p;
 		A.pn_blk_off = mr.pn_blk_off.p; A.pn_se = reinterpret_cast<const int2 *>(mr.pn_se.p);

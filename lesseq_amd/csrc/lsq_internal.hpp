@@ -71,7 +71,8 @@ struct BucketDesc {
 	uint32_t cls_base;     // first class slot of the bucket in device class order
 	uint32_t ev_base;      // first event of the bucket in device event order
 	int32_t chrom_id;
-	uint32_t pad[2];
+	uint32_t kind;         // 0: generic records (EventRec + segments + masks); 1: packed 48-byte FastRec
+	uint32_t pad;
 };
 static_assert(sizeof(BucketDesc) == 64, "BucketDesc is copied to the device verbatim");
 
@@ -81,6 +82,19 @@ struct EventRec {          // 16-byte LDS record
 	uint8_t nseg, K;
 };
 static_assert(sizeof(EventRec) == 16, "EventRec layout");
+
+// Packed record of a "small" event (<= 4 segments, <= 4 isoforms, non-negative coordinates):
+// three 16-byte words, read with three wide LDS loads and walked without branches.
+//   w0: gs, ge, cls_off | K << 16 | nseg << 24, iso nibbles (4 bits per isoform) | flags << 16
+//   w1: seg0.start seg0.end seg1.start seg1.end     w2: seg2 / seg3 likewise
+// unused segments hold INT32_MAX (they end the walk like running off the segment list)
+struct FastRec {
+	int32_t gs, ge;
+	uint32_t meta, iso;
+	int32_t seg[8];
+};
+static_assert(sizeof(FastRec) == 48, "FastRec layout");
+constexpr uint32_t FAST_FLAG_OVERLAPS_NEXT = 1u << 16;   // the next event (span-start order) starts inside this span
 
 struct TieRec {            // global memory, device event order; read only on start ties
 	uint8_t strand_id;

@@ -151,7 +151,7 @@ def test_results_do_not_depend_on_launch_geometry(tmp_path, monkeypatch):
     a_dir = str(tmp_path)
     L.synth_write(spec, a_dir, "g", write_mrf=False)
     results = []
-    for budget, mult in (("65536", "2"), ("16384", "1"), ("163840", "7"), ("32768", "16")):
+    for budget, mult in (("4096", "1"), ("1024", "2"), ("65536", "7"), ("140000", "16")):
         monkeypatch.setenv("LSQ_LDS_BUDGET", budget)
         monkeypatch.setenv("LSQ_GRID_MULT", mult)
         a = L.Annotation(os.path.join(a_dir, "g.interval"), os.path.join(a_dir, "g.map"))
@@ -184,7 +184,7 @@ def test_full_size_config2_linearity_and_sample(tmp_path):
     ctx.count()
     cnt_all, bases_all = [x.copy() for x in ctx.counts()]
     retained_all = ctx.retained(0)
-    assert int(cnt_all.sum()) > n_reads // 2 and retained_all >= int(cnt_all.sum())
+    assert int(cnt_all.sum()) > n_reads // 2      # a read may be valid for two overlapping events
     cs_sum, bs_sum, retained = np.zeros_like(cnt_all), np.zeros_like(bases_all), 0
     per = n_reads // chunks
     for k in range(chunks):

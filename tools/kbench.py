@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Developer sweep: count-kernel time over LDS budgets / grid multipliers (not part of the product).
+usage: python tools/kbench.py c2|c3 [budgets csv] [mults csv]"""
+import os, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import lesseq_amd as L
+from bench import WORKLOADS
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "c2"
+budgets = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "4096").split(",")]
+mults = [int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "1").split(",")]
+W = WORKLOADS[wl]
+types = W["types"] or L.EVENT_TYPES
+spec = L.SynthSpec(W["seed"], W["n_events"], W["n_reads"], W["R"], W["n_chrom"], types)
+tmp = tempfile.mkdtemp()
+L.synth_write(spec, tmp, "w", write_mrf=False)
+ann = L.Annotation(tmp + "/w.interval", tmp + "/w.map")
+ref = None
+for bud in budgets:
+    os.environ["LSQ_LDS_BUDGET"] = str(bud)
+    ev = L.Events(ann, ("SHORT_READ",), (W["R"],))
+    reads = L.Reads.synthetic(spec, ev)
+    ctx = L.Context(0)
+    ctx.upload_events(ev)
+    t0 = time.time(); ctx.upload_reads(0, reads); ti = time.time() - t0
+    del reads
+    nb = ctx.retained_blocks(0)
+    for m in mults:
+        os.environ["LSQ_GRID_MULT"] = str(m)
+        ts, es = [], []
+        for it in range(12):
+            ctx.count(); ctx.solve()
+            c, s = ctx.timing()
+            ts.append(c); es.append(s)
+        cnt, bases = ctx.counts()
+        chk = (int(cnt.sum()), int(bases.sum()))
+        if ref is None: ref = chk
+        t = float(np.median(ts[2:]))
+        print("%s budget=%6d buckets=%5d mult=%2d count_ms med=%.4f min=%.4f  %.0f GB/s (%.1f%% of 8TB/s)  em_ms=%.4f ingest_s=%.2f check=%s" % (
+            wl, bud, ev.num_buckets, m, t, min(ts), 8.0 * nb / t / 1e6, 100 * 8.0 * nb / t / 1e6 / 8000, float(np.median(es)), ti, "ok" if chk == ref else "MISMATCH"), flush=True)
+    ctx.close()
