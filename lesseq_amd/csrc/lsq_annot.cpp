@@ -341,12 +341,12 @@ static int plan_device(lsq_events &E) {
 				const Event &e = E.ev[lst[k]];
 				hi = std::max(hi, e.gene_end);
 				nseg += (uint32_t)e.N; niso += (uint32_t)e.K; ncls += (1u << e.K) - 1u;
-				if (e.N > 4 || e.K > 4 || e.seg_s.front() < 0) fast = false;
+				if (e.N > 4 || e.K > 4 || e.seg_s.front() < 0 || e.gene_start != e.seg_s.front()) fast = false;
 			}
 			if (getenv("LSQ_FORCE_GENERIC")) fast = false;
 			if (nseg > 65535 || niso > 65535 || ncls > 65535) return fail(LSQ_E_UNSUPPORTED, "bucket tables exceed 16-bit offsets");
 			uint32_t want = 16;
-			while (want < 4 * d.n_events && want < 4096) want <<= 1;
+			while (want < 8 * d.n_events && want < 4096) want <<= 1;
 			uint32_t shift = 0;
 			while ((((uint64_t)(hi - lo)) >> shift) >= want) ++shift;
 			d.n_bins = want; d.shift = shift; d.lo = (int32_t)lo;
@@ -384,11 +384,24 @@ static int plan_device(lsq_events &E) {
 				ends[k - b_begin] = (int32_t)e.gene_end;
 				if (fast) {
 					FastRec &r = frecs[k - b_begin];
-					r.gs = (int32_t)e.gene_start; r.ge = (int32_t)e.gene_end;
-					r.meta = co | ((uint32_t)e.K << 16) | ((uint32_t)e.N << 24);
-					r.iso = 0;
-					for (int q = 0; q < e.K; ++q) r.iso |= ((uint32_t)e.iso_mask[q] & 0xFu) << (4 * q);
-					if (k + 1 < i && E.ev[lst[k + 1]].gene_start <= e.gene_end) r.iso |= FAST_FLAG_OVERLAPS_NEXT;
+					r.ge = (int32_t)e.gene_end;
+					r.meta = co | ((uint32_t)e.N << FAST_NSEG_SHIFT);
+					for (int sgi = 0; sgi + 1 < e.N; ++sgi) if (e.seg_s[sgi + 1] == e.seg_e[sgi]) r.meta |= 1u << (FAST_ABUT_SHIFT + sgi);
+					if (k + 1 < i && E.ev[lst[k + 1]].gene_start <= e.gene_end) r.meta |= FAST_FLAG_OVERLAPS_NEXT;
+					// class of every segment mask: isoform j is compatible iff the mask is a contiguous run
+					// of its segment list (common/read.h:44-79)
+					uint64_t tbl = 0;
+					for (uint32_t m = 1; m < 16; ++m) {
+						uint32_t hi_b = 31u - (uint32_t)__builtin_clz(m), lo_b = (uint32_t)__builtin_ctz(m);
+						uint32_t span = ((2u << hi_b) - 1u) & ~((1u << lo_b) - 1u);
+						uint64_t cls = 0;
+						for (int q = 0; q < e.K; ++q) {
+							uint32_t iso = (uint32_t)e.iso_mask[q] & 0xFu;
+							if ((m & ~iso) == 0 && (iso & span) == m) cls |= 1ull << q;
+						}
+						tbl |= cls << (4 * m);
+					}
+					r.tbl_lo = (uint32_t)tbl; r.tbl_hi = (uint32_t)(tbl >> 32);
 					for (int sgi = 0; sgi < 4; ++sgi) {
 						r.seg[2 * sgi] = sgi < e.N ? (int32_t)e.seg_s[sgi] : INT32_MAX;
 						r.seg[2 * sgi + 1] = sgi < e.N ? (int32_t)e.seg_e[sgi] : INT32_MAX;

@@ -200,6 +200,23 @@ struct FastWalk {
 	}
 };
 
+// 0/1 integer predicates kept in vector registers: combining them with & and | costs VALU ops,
+// where bool && / || on 64-lane masks would go through the CU's single scalar unit.
+__device__ inline int nonneg(int x) { return (int)(~(unsigned)x >> 31); }
+__device__ inline int inside01(int a, int sx, int sy) { return nonneg((a - sx) | (sy - 1 - a)); }   // sx <= a < sy
+__device__ inline int gt01(int b, int sy) { return (int)((unsigned)(sy - b) >> 31); }                  // b > sy
+
+// One block [a,b) that may START a match (fresh state) or, with `starts` given, continue one:
+// r_k says segment k is matched.  A run extends from segment k to k+1 only when k+1 starts where k
+// ends and the block goes past k's end.  Returns the run bits; end_run = end of the last one.
+__device__ inline unsigned run_bits(const int (&sy)[4], unsigned abut, int r0, int r1, int r2, int r3, int b, int &end_run) {
+	r1 |= r0 & (int)(abut & 1u) & gt01(b, sy[0]);
+	r2 |= r1 & (int)((abut >> 1) & 1u) & gt01(b, sy[1]);
+	r3 |= r2 & (int)((abut >> 2) & 1u) & gt01(b, sy[2]);
+	end_run = max(max(r0 ? sy[0] : 0, r1 ? sy[1] : 0), max(r2 ? sy[2] : 0, r3 ? sy[3] : 0));
+	return (unsigned)(r0 | (r1 << 1) | (r2 << 2) | (r3 << 3));
+}
+
 template <int NB>
 __device__ inline void process_read_fast(const unsigned short *bins, const uint4 *recs, unsigned long long *hist,
                                          const BucketDesc &d, const CountArgs &A, const int4 v, const int total,
@@ -215,36 +232,56 @@ __device__ inline void process_read_fast(const unsigned short *bins, const uint4
 	// ask for further trips
 	do {
 		const bool inb = act && i < d.n_events;
-		const uint4 w0 = recs[3u * (inb ? i : 0u)];
-		const int gs = (int)w0.x, ge = (int)w0.y;
+		const unsigned ri = 3u * (inb ? i : 0u);
+		const uint4 w0 = recs[ri], w1 = recs[ri + 1], w2 = recs[ri + 2];
+		const int gs = (int)w1.x, ge = (int)w0.x;
 		const bool started = inb && gs <= p;
 		bool covers = started && p <= ge;
-		if (__any(covers)) {
-			// span-start tie rule: reads that sort before (gene_start, gene_end, strand, name) are not candidates
+		// span-start tie rule: reads that sort before (gene_start, gene_end, strand, name) are not candidates
+		if (__any(covers && p == gs)) {
 			if (covers && p == gs) {
 				if (q < ge) covers = false;
 				else if (q == ge && tie_orders_read_first(A.ties, A.strand_rank, d.ev_base + i, strand_arr[slot], line_arr[slot])) covers = false;
 			}
-			const uint4 w1 = recs[3u * (inb ? i : 0u) + 1], w2 = recs[3u * (inb ? i : 0u) + 2];
-			const int sx[4] = {(int)w1.x, (int)w1.z, (int)w2.x, (int)w2.z};
-			const int sy[4] = {(int)w1.y, (int)w1.w, (int)w2.y, (int)w2.w};
-			FastWalk w;
-			bool c1 = w.block(sx, sy, v.x, v.y, covers);
-			if (NB == 2) w.block(sx, sy, v.z, v.w, c1);
-			const unsigned mask = w.mask;
-			const bool ok = covers && mask != 0 && (50ll * w.matched > 49ll * total);
-			const unsigned m1 = mask | (mask == 0);             // keep clz/ffs defined
-			const unsigned hi = 31u - (unsigned)__clz((int)m1), lo = (unsigned)__ffs((int)m1) - 1u;
-			const unsigned span = ((2u << hi) - 1u) & ~((1u << lo) - 1u);
-			unsigned cls = 0;
-#pragma unroll
-			for (unsigned j = 0; j < 4; ++j) {
-				const unsigned iso = (w0.w >> (4 * j)) & 0xFu;      // absent isoforms are 0 and never contain the mask
-				cls |= ((mask & ~iso) == 0 && (iso & span) == mask) ? (1u << j) : 0u;
-			}
-			if (ok && cls) atomicAdd(&hist[(w0.z & 0xFFFFu) + cls - 1], (1ull << 40) | (unsigned long long)(unsigned)w.matched);
 		}
-		act = started && (!(p <= ge) || (w0.w & FAST_FLAG_OVERLAPS_NEXT));
+		const int sx[4] = {(int)w1.x, (int)w1.z, (int)w2.x, (int)w2.z};
+		const int sy[4] = {(int)w1.y, (int)w1.w, (int)w2.y, (int)w2.w};
+		const unsigned abut = (w0.y >> FAST_ABUT_SHIFT) & 7u;
+		unsigned mask;
+		int matched;
+		// block 1 starts the match: the segment that holds its first base
+		int end1;
+		const unsigned m1 = run_bits(sy, abut, inside01(v.x, sx[0], sy[0]), inside01(v.x, sx[1], sy[1]),
+		                             inside01(v.x, sx[2], sy[2]), inside01(v.x, sx[3], sy[3]), v.y, end1);
+		matched = m1 ? min(v.y, end1) - v.x : 0;
+		mask = m1;
+		if (NB == 2) {
+			// block 2 continues only if block 1 ended exactly on a segment end, and must then start
+			// exactly on the start of a later segment
+			const int exact1 = (m1 != 0 && v.y == end1) ? 1 : 0;
+			const int l3 = (int)(~m1 >> 3) & 1, l2 = l3 & (int)(~m1 >> 2) & 1, l1 = l2 & (int)(~m1 >> 1) & 1;   // no matched segment at index >= k
+			int end2;
+			const unsigned m2 = run_bits(sy, abut, 0, exact1 & l1 & (int)(sx[1] == v.z), exact1 & l2 & (int)(sx[2] == v.z),
+			                             exact1 & l3 & (int)(sx[3] == v.z), v.w, end2);
+			matched += m2 ? min(v.w, end2) - v.z : 0;
+			mask |= m2;
+			// two blocks that touch (kept apart only by the reference's insertion-order rule) walk like
+			// one block; they take the stepwise path
+			if (__any(covers && v.z == v.y)) {
+				if (covers && v.z == v.y) {
+					FastWalk w;
+					const bool c1 = w.block(sx, sy, v.x, v.y, true);
+					w.block(sx, sy, v.z, v.w, c1);
+					mask = w.mask; matched = w.matched;
+				}
+			}
+		}
+		// (double)matched / total > 0.98  <=>  50*matched > 49*total (both below 2^18 here)
+		const unsigned long long tbl = ((unsigned long long)w0.w << 32) | w0.z;
+		const unsigned cls = (unsigned)(tbl >> (4u * mask)) & 0xFu;
+		if (covers && cls != 0 && 50 * matched > 49 * total)
+			atomicAdd(&hist[(w0.y & 0xFFFFu) + cls - 1], (1ull << 40) | (unsigned long long)(unsigned)matched);
+		act = started && (!(p <= ge) || (w0.y & FAST_FLAG_OVERLAPS_NEXT));
 		++i;
 	} while (__any(act));
 }
@@ -259,30 +296,24 @@ __device__ __noinline__ void process_read_n_on_fast(const unsigned short *bins, 
 	unsigned bin = rel <= 0 ? 0u : ((unsigned)rel >> d.shift);
 	bin = min(bin, d.n_bins - 1u);
 	for (unsigned i = bins[bin]; i < d.n_events; ++i) {
-		const uint4 w0 = recs[3u * i];
-		const int gs = (int)w0.x, ge = (int)w0.y;
+		const uint4 w0 = recs[3u * i], w1 = recs[3u * i + 1], w2 = recs[3u * i + 2];
+		const int gs = (int)w1.x, ge = (int)w0.x;
 		if (gs > p) break;
 		if (p > ge) continue;
 		if (p == gs) {
 			if (q < ge) continue;
 			if (q == ge && tie_orders_read_first(A.ties, A.strand_rank, d.ev_base + i, A.pn_strand[slot], A.pn_line[slot])) continue;
 		}
-		const uint4 w1 = recs[3u * i + 1], w2 = recs[3u * i + 2];
 		int2 segs[4] = {make_int2((int)w1.x, (int)w1.y), make_int2((int)w1.z, (int)w1.w), make_int2((int)w2.x, (int)w2.y), make_int2((int)w2.z, (int)w2.w)};
-		const int nseg = (int)(w0.z >> 24);
+		const int nseg = (int)((w0.y >> FAST_NSEG_SHIFT) & 7u);
 		Walk w;
 		for (int k = 0; k < nblk; ++k) { const int2 bk = blk[k]; if (!w.block(segs, nseg, bk.x, bk.y)) break; }
 		const unsigned mask = w.mask;
 		if (!mask) continue;
 		if (!(50ll * w.matched > 49ll * total)) continue;
-		const unsigned hi = 31u - (unsigned)__clz((int)mask), lo = (unsigned)__ffs((int)mask) - 1u;
-		const unsigned span = ((2u << hi) - 1u) & ~((1u << lo) - 1u);
-		unsigned cls = 0;
-		for (unsigned j = 0; j < 4; ++j) {
-			const unsigned iso = (w0.w >> (4 * j)) & 0xFu;
-			if ((mask & ~iso) == 0 && (iso & span) == mask) cls |= 1u << j;
-		}
-		if (cls) atomicAdd(&hist[(w0.z & 0xFFFFu) + cls - 1], (1ull << 40) | (unsigned long long)(unsigned)w.matched);
+		const unsigned long long tbl = ((unsigned long long)w0.w << 32) | w0.z;
+		const unsigned cls = (unsigned)(tbl >> (4u * mask)) & 0xFu;
+		if (cls) atomicAdd(&hist[(w0.y & 0xFFFFu) + cls - 1], (1ull << 40) | (unsigned long long)(unsigned)w.matched);
 	}
 }
 

@@ -83,18 +83,22 @@ struct EventRec {          // 16-byte LDS record
 };
 static_assert(sizeof(EventRec) == 16, "EventRec layout");
 
-// Packed record of a "small" event (<= 4 segments, <= 4 isoforms, non-negative coordinates):
-// three 16-byte words, read with three wide LDS loads and walked without branches.
-//   w0: gs, ge, cls_off | K << 16 | nseg << 24, iso nibbles (4 bits per isoform) | flags << 16
+// Packed record of a "small" event (<= 4 segments, <= 4 isoforms, non-negative coordinates,
+// span start == first segment start): three 16-byte words, read with three wide LDS loads.
+//   w0: ge, meta, class table (64 bits: 4-bit compatibility class per 4-bit segment mask)
 //   w1: seg0.start seg0.end seg1.start seg1.end     w2: seg2 / seg3 likewise
-// unused segments hold INT32_MAX (they end the walk like running off the segment list)
+//   meta: bits 0-15 first class slot in the bucket; 16-18 "segment k+1 starts where k ends";
+//         19 the next event (span-start order) starts inside this span; 24-26 segment count
+// unused segments hold INT32_MAX (they end a walk like running off the segment list)
 struct FastRec {
-	int32_t gs, ge;
-	uint32_t meta, iso;
+	int32_t ge;
+	uint32_t meta, tbl_lo, tbl_hi;
 	int32_t seg[8];
 };
 static_assert(sizeof(FastRec) == 48, "FastRec layout");
-constexpr uint32_t FAST_FLAG_OVERLAPS_NEXT = 1u << 16;   // the next event (span-start order) starts inside this span
+constexpr uint32_t FAST_ABUT_SHIFT = 16;
+constexpr uint32_t FAST_FLAG_OVERLAPS_NEXT = 1u << 19;
+constexpr uint32_t FAST_NSEG_SHIFT = 24;
 
 struct TieRec {            // global memory, device event order; read only on start ties
 	uint8_t strand_id;
