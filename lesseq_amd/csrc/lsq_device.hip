@@ -47,6 +47,7 @@ struct CountArgs {
 	const TieRec *ties;
 	const unsigned char *strand_rank;
 	unsigned n_buckets;
+	unsigned ablate;                   // developer switch (LSQ_ABLATE): 1 skip per-read work, 2 skip LDS atomics, 4 skip flush, 8 skip record look
 	unsigned tables_lds_bytes;         // LDS bytes reserved for the bucket image + histogram (16-byte multiple)
 	const int2 *p1; const unsigned char *p1_strand; const unsigned *p1_line;
 	const int4 *p2; const unsigned char *p2_strand; const unsigned *p2_line;
@@ -217,73 +218,88 @@ __device__ inline unsigned run_bits(const int (&sy)[4], unsigned abut, int r0, i
 	return (unsigned)(r0 | (r1 << 1) | (r2 << 2) | (r3 << 3));
 }
 
+// One read against ONE packed event record (index i in the staged bucket).  Returns true when
+// a further event has to be examined for this read: the bin's first event ended left of the
+// read, or this event's span is overlapped by the next one.
 template <int NB>
-__device__ inline void process_read_fast(const unsigned short *bins, const uint4 *recs, unsigned long long *hist,
-                                         const BucketDesc &d, const CountArgs &A, const int4 v, const int total,
-                                         const unsigned char *strand_arr, const unsigned *line_arr, unsigned long long slot, const bool valid_lane) {
+__device__ inline bool fast_trip(const uint4 *recs, unsigned long long *hist, const BucketDesc &d, const CountArgs &A,
+                                 const int4 v, const int total, const unsigned char *strand_arr, const unsigned *line_arr,
+                                 const unsigned long long slot_base, const unsigned r, const unsigned i, const bool valid) {
 	const int p = v.x, q = (NB == 1) ? v.y : v.w;
-	const int rel = p - d.lo;
-	unsigned bin = rel <= 0 ? 0u : ((unsigned)rel >> d.shift);
-	bin = min(bin, d.n_bins - 1u);
-	unsigned i = valid_lane ? bins[bin] : d.n_events;
-	bool act = valid_lane;
-	// wave-uniform loop: one trip aligns most lanes with the event that covers their read; lanes
-	// whose bin starts with an event that ends before p, or whose event overlaps the next one,
-	// ask for further trips
-	do {
-		const bool inb = act && i < d.n_events;
-		const unsigned ri = 3u * (inb ? i : 0u);
-		const uint4 w0 = recs[ri], w1 = recs[ri + 1], w2 = recs[ri + 2];
-		const int gs = (int)w1.x, ge = (int)w0.x;
-		const bool started = inb && gs <= p;
-		bool covers = started && p <= ge;
-		// span-start tie rule: reads that sort before (gene_start, gene_end, strand, name) are not candidates
-		if (__any(covers && p == gs)) {
-			if (covers && p == gs) {
-				if (q < ge) covers = false;
-				else if (q == ge && tie_orders_read_first(A.ties, A.strand_rank, d.ev_base + i, strand_arr[slot], line_arr[slot])) covers = false;
-			}
+	const bool inb = valid && i < d.n_events;
+	const unsigned ri = 3u * (inb ? i : 0u);
+	const uint4 w0 = recs[ri], w1 = recs[ri + 1], w2 = recs[ri + 2];
+	const int gs = (int)w1.x, ge = (int)w0.x;
+	const bool started = inb && gs <= p;
+	bool covers = started && p <= ge;
+	// span-start tie rule: reads that sort before (gene_start, gene_end, strand, name) are not candidates
+	if (covers && p == gs) {
+		if (q < ge) covers = false;
+		else if (q == ge && tie_orders_read_first(A.ties, A.strand_rank, d.ev_base + i, strand_arr[slot_base + r], line_arr[slot_base + r])) covers = false;
+	}
+	const int sx[4] = {(int)w1.x, (int)w1.z, (int)w2.x, (int)w2.z};
+	const int sy[4] = {(int)w1.y, (int)w1.w, (int)w2.y, (int)w2.w};
+	const unsigned abut = (w0.y >> FAST_ABUT_SHIFT) & 7u;
+	// block 1 starts the match: the segment that holds its first base
+	int end1;
+	const unsigned m1 = run_bits(sy, abut, inside01(v.x, sx[0], sy[0]), inside01(v.x, sx[1], sy[1]),
+	                             inside01(v.x, sx[2], sy[2]), inside01(v.x, sx[3], sy[3]), v.y, end1);
+	int matched = m1 ? min(v.y, end1) - v.x : 0;
+	unsigned mask = m1;
+	if (NB == 2) {
+		// block 2 continues only if block 1 ended exactly on a segment end, and must then start
+		// exactly on the start of a later segment
+		const int exact1 = (m1 != 0 && v.y == end1) ? 1 : 0;
+		const int l3 = (int)(~m1 >> 3) & 1, l2 = l3 & (int)(~m1 >> 2) & 1, l1 = l2 & (int)(~m1 >> 1) & 1;   // no matched segment at index >= k
+		int end2;
+		const unsigned m2 = run_bits(sy, abut, 0, exact1 & l1 & (int)(sx[1] == v.z), exact1 & l2 & (int)(sx[2] == v.z),
+		                             exact1 & l3 & (int)(sx[3] == v.z), v.w, end2);
+		matched += m2 ? min(v.w, end2) - v.z : 0;
+		mask |= m2;
+		// two blocks that touch (kept apart only by the reference's insertion-order rule) walk like
+		// one block; they take the stepwise path
+		if (covers && v.z == v.y) {
+			FastWalk w;
+			const bool c1 = w.block(sx, sy, v.x, v.y, true);
+			w.block(sx, sy, v.z, v.w, c1);
+			mask = w.mask; matched = w.matched;
 		}
-		const int sx[4] = {(int)w1.x, (int)w1.z, (int)w2.x, (int)w2.z};
-		const int sy[4] = {(int)w1.y, (int)w1.w, (int)w2.y, (int)w2.w};
-		const unsigned abut = (w0.y >> FAST_ABUT_SHIFT) & 7u;
-		unsigned mask;
-		int matched;
-		// block 1 starts the match: the segment that holds its first base
-		int end1;
-		const unsigned m1 = run_bits(sy, abut, inside01(v.x, sx[0], sy[0]), inside01(v.x, sx[1], sy[1]),
-		                             inside01(v.x, sx[2], sy[2]), inside01(v.x, sx[3], sy[3]), v.y, end1);
-		matched = m1 ? min(v.y, end1) - v.x : 0;
-		mask = m1;
-		if (NB == 2) {
-			// block 2 continues only if block 1 ended exactly on a segment end, and must then start
-			// exactly on the start of a later segment
-			const int exact1 = (m1 != 0 && v.y == end1) ? 1 : 0;
-			const int l3 = (int)(~m1 >> 3) & 1, l2 = l3 & (int)(~m1 >> 2) & 1, l1 = l2 & (int)(~m1 >> 1) & 1;   // no matched segment at index >= k
-			int end2;
-			const unsigned m2 = run_bits(sy, abut, 0, exact1 & l1 & (int)(sx[1] == v.z), exact1 & l2 & (int)(sx[2] == v.z),
-			                             exact1 & l3 & (int)(sx[3] == v.z), v.w, end2);
-			matched += m2 ? min(v.w, end2) - v.z : 0;
-			mask |= m2;
-			// two blocks that touch (kept apart only by the reference's insertion-order rule) walk like
-			// one block; they take the stepwise path
-			if (__any(covers && v.z == v.y)) {
-				if (covers && v.z == v.y) {
-					FastWalk w;
-					const bool c1 = w.block(sx, sy, v.x, v.y, true);
-					w.block(sx, sy, v.z, v.w, c1);
-					mask = w.mask; matched = w.matched;
-				}
-			}
+	}
+	// (double)matched / total > 0.98  <=>  50*matched > 49*total (both below 2^18 here)
+	const unsigned long long tbl = ((unsigned long long)w0.w << 32) | w0.z;
+	const unsigned cls = (unsigned)(tbl >> (4u * mask)) & 0xFu;
+	if (covers && cls != 0 && 50 * matched > 49 * total) {
+		if (!(A.ablate & 2u)) atomicAdd(&hist[(w0.y & 0xFFFFu) + cls - 1], (1ull << 40) | (unsigned long long)(unsigned)matched);
+		else asm volatile("" ::"v"(matched), "v"(cls));
+	}
+	return started && (!(p <= ge) || (w0.y & FAST_FLAG_OVERLAPS_NEXT)) && i + 1 < d.n_events;
+}
+
+// Pending second looks: (tile-local read index | event index << 16).  Most reads are settled by
+// one record; the few that need another (overlapping events, a bin that begins with an event
+// that ends left of the read) are parked here and worked off densely after the tile, instead
+// of making their whole wave loop.
+constexpr unsigned QUEUE_CAP = 1024;
+struct PendingQueues {
+	unsigned *buf[2];
+	unsigned *cnt;      // cnt[0], cnt[1]
+};
+
+template <int NB>
+__device__ inline void fast_read(const unsigned short *bins, const uint4 *recs, unsigned long long *hist, const BucketDesc &d,
+                                 const CountArgs &A, const int4 v, const int total, const unsigned char *strand_arr,
+                                 const unsigned *line_arr, const unsigned long long slot_base, const unsigned r, unsigned i,
+                                 const bool valid, const PendingQueues &Q, const unsigned qsel) {
+	bool more = fast_trip<NB>(recs, hist, d, A, v, total, strand_arr, line_arr, slot_base, r, i, valid);
+	if (more) {
+		const unsigned slot = atomicAdd(&Q.cnt[qsel], 1u);
+		if (slot < QUEUE_CAP) {
+			Q.buf[qsel][slot] = r | ((i + 1u) << 16);
+		} else {
+			// queue full: finish this read here
+			while (more) { ++i; more = fast_trip<NB>(recs, hist, d, A, v, total, strand_arr, line_arr, slot_base, r, i, true); }
 		}
-		// (double)matched / total > 0.98  <=>  50*matched > 49*total (both below 2^18 here)
-		const unsigned long long tbl = ((unsigned long long)w0.w << 32) | w0.z;
-		const unsigned cls = (unsigned)(tbl >> (4u * mask)) & 0xFu;
-		if (covers && cls != 0 && 50 * matched > 49 * total)
-			atomicAdd(&hist[(w0.y & 0xFFFFu) + cls - 1], (1ull << 40) | (unsigned long long)(unsigned)matched);
-		act = started && (!(p <= ge) || (w0.y & FAST_FLAG_OVERLAPS_NEXT));
-		++i;
-	} while (__any(act));
+	}
 }
 
 // Reads with three or more blocks in a FastRec bucket (rare): the branching walk over the
@@ -317,22 +333,29 @@ __device__ __noinline__ void process_read_n_on_fast(const unsigned short *bins, 
 	}
 }
 
-// Streams the 16-byte words [w0, w1) of `src` through an LDS tile: wide coalesced loads by the
-// whole workgroup (next tile's loads are issued before the current tile is processed), then
-// each lane walks its reads out of LDS in a compact loop.  READS_PER_WORD = 2 (pool 1) or 1.
+// Streams the 16-byte words of a pool through an LDS tile: wide coalesced loads by the whole
+// workgroup (the next tile's loads are issued before the current tile is processed), then each
+// lane walks its reads out of LDS in a compact loop.  RPW = reads per word: 2 (pool 1) or 1.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef const u32x4 __attribute__((address_space(1))) *global_words;
+
 template <int RPW, bool FAST>
-__device__ inline void stream_pool(const LdsView &L, const BucketDesc &d, const CountArgs &A, uint4 *tile,
-                                   const uint4 *src, unsigned long long g0, unsigned long long g1,
+__device__ inline void stream_pool(const LdsView &L, const BucketDesc &d, const CountArgs &A, uint4 *tile, const PendingQueues &Q,
+                                   const uint4 *src_generic, unsigned long long g0, unsigned long long g1,
                                    const unsigned char *strand_arr, const unsigned *line_arr) {
 	// reads [g0, g1) in the pool's global numbering; words [w0, w1)
+	global_words src = (global_words)src_generic;       // kernel-argument memory: global address space
 	const unsigned tid = threadIdx.x;
 	const unsigned long long w0 = g0 / RPW, w1 = (g1 + RPW - 1) / RPW;
 	uint4 nxt[4];
 	auto fetch = [&](unsigned long long wt) {
+		const unsigned n = (unsigned)min((unsigned long long)TILE_WORDS, w1 - wt);
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
-			const unsigned long long w = wt + (unsigned)k * COUNT_BLOCK + tid;
-			nxt[k] = w < w1 ? src[w] : make_uint4(0, 0, 0, 0);
+			const unsigned w = (unsigned)k * COUNT_BLOCK + tid;
+			u32x4 t = {0u, 0u, 0u, 0u};
+			if (w < n) t = src[wt + w];
+			nxt[k] = make_uint4(t.x, t.y, t.z, t.w);
 		}
 	};
 	fetch(w0);
@@ -342,30 +365,65 @@ __device__ inline void stream_pool(const LdsView &L, const BucketDesc &d, const 
 		__syncthreads();
 		if (wt + TILE_WORDS < w1) fetch(wt + TILE_WORDS);
 		const unsigned long long r_base = wt * RPW;
+		// tile-relative bounds of the reads that belong to this workgroup's range
+		const unsigned lo_r = g0 > r_base ? (unsigned)(g0 - r_base) : 0u;
+		const unsigned hi_r = (unsigned)min((unsigned long long)(TILE_WORDS * RPW), g1 - r_base);
+		if (FAST) {
+			const uint4 *recs = reinterpret_cast<const uint4 *>(L.ev);
 #pragma unroll 1
-		for (int k = 0; k < 4 * RPW; ++k) {
-			const unsigned r = (unsigned)k * COUNT_BLOCK + tid;
-			const unsigned long long g = r_base + r;
-			const bool in = g >= g0 && g < g1;
-			if (FAST) {
-				// every lane runs the predicated body (wave-uniform control flow inside)
-				const uint4 *recs = reinterpret_cast<const uint4 *>(L.ev);
-				if (RPW == 2) {
-					const int2 rd = reinterpret_cast<const int2 *>(tile)[r];
-					process_read_fast<1>(L.bins, recs, L.hist, d, A, make_int4(rd.x, rd.y, 0, 0), rd.y - rd.x, strand_arr, line_arr, g, in);
-				} else {
-					const uint4 u = tile[r];
-					const int4 rd = make_int4((int)u.x, (int)u.y, (int)u.z, (int)u.w);
-					process_read_fast<2>(L.bins, recs, L.hist, d, A, rd, (rd.y - rd.x) + (rd.w - rd.z), strand_arr, line_arr, g, in);
+			for (int k = 0; k < 4 * RPW; ++k) {
+				const unsigned r = (unsigned)k * COUNT_BLOCK + tid;
+				const bool in = r >= lo_r && r < hi_r;
+				int4 rd;
+				if (RPW == 2) { const int2 t = reinterpret_cast<const int2 *>(tile)[r]; rd = make_int4(t.x, t.y, t.x, t.y); }
+				else { const uint4 u = tile[r]; rd = make_int4((int)u.x, (int)u.y, (int)u.z, (int)u.w); }
+				const int total = RPW == 2 ? rd.y - rd.x : (rd.y - rd.x) + (rd.w - rd.z);
+				const int rel = rd.x - d.lo;
+				unsigned bin = rel <= 0 ? 0u : ((unsigned)rel >> d.shift);
+				bin = min(bin, d.n_bins - 1u);
+				const unsigned i0 = L.bins[bin];
+				if (A.ablate & 1u) { asm volatile("" ::"v"(i0), "v"(rd.x), "v"(rd.y), "v"(rd.z), "v"(rd.w)); continue; }
+				fast_read<(RPW == 2 ? 1 : 2)>(L.bins, recs, L.hist, d, A, rd, total, strand_arr, line_arr, r_base, r, i0, in, Q, 0);
+			}
+			// work off the parked second looks, round by round (a round may park third looks)
+			unsigned cur = 0;
+			for (;;) {
+				__syncthreads();
+				const unsigned n = min(Q.cnt[cur], QUEUE_CAP);
+				if (n == 0) break;
+				__syncthreads();
+				if (tid == 0) { Q.cnt[cur ^ 1] = 0; }
+				__syncthreads();
+#pragma unroll 1
+				for (unsigned j0 = 0; j0 < n; j0 += COUNT_BLOCK) {
+					const unsigned j = j0 + tid;
+					const bool in = j < n;
+					const unsigned e = Q.buf[cur][in ? j : 0];
+					const unsigned r = e & 0xFFFFu, i = e >> 16;
+					int4 rd;
+					if (RPW == 2) { const int2 t = reinterpret_cast<const int2 *>(tile)[r]; rd = make_int4(t.x, t.y, t.x, t.y); }
+					else { const uint4 u = tile[r]; rd = make_int4((int)u.x, (int)u.y, (int)u.z, (int)u.w); }
+					const int total = RPW == 2 ? rd.y - rd.x : (rd.y - rd.x) + (rd.w - rd.z);
+					fast_read<(RPW == 2 ? 1 : 2)>(L.bins, recs, L.hist, d, A, rd, total, strand_arr, line_arr, r_base, r, i, in, Q, cur ^ 1);
 				}
-			} else if (in) {
-				if (RPW == 2) {
-					const int2 rd = reinterpret_cast<const int2 *>(tile)[r];
-					process_read<1>(L, d, A, make_int4(rd.x, rd.y, 0, 0), nullptr, 1, rd.y - rd.x, strand_arr, line_arr, g);
-				} else {
-					const uint4 u = tile[r];
-					const int4 rd = make_int4((int)u.x, (int)u.y, (int)u.z, (int)u.w);
-					process_read<2>(L, d, A, rd, nullptr, 2, (rd.y - rd.x) + (rd.w - rd.z), strand_arr, line_arr, g);
+				__syncthreads();
+				if (tid == 0) Q.cnt[cur] = 0;
+				cur ^= 1;
+			}
+			// both counters are zero here; the barrier below orders that before the next tile
+		} else {
+#pragma unroll 1
+			for (int k = 0; k < 4 * RPW; ++k) {
+				const unsigned r = (unsigned)k * COUNT_BLOCK + tid;
+				if (r >= lo_r && r < hi_r) {
+					if (RPW == 2) {
+						const int2 rd = reinterpret_cast<const int2 *>(tile)[r];
+						process_read<1>(L, d, A, make_int4(rd.x, rd.y, 0, 0), nullptr, 1, rd.y - rd.x, strand_arr, line_arr, r_base + r);
+					} else {
+						const uint4 u = tile[r];
+						const int4 rd = make_int4((int)u.x, (int)u.y, (int)u.z, (int)u.w);
+						process_read<2>(L, d, A, rd, nullptr, 2, (rd.y - rd.x) + (rd.w - rd.z), strand_arr, line_arr, r_base + r);
+					}
 				}
 			}
 		}
@@ -376,7 +434,12 @@ __device__ inline void stream_pool(const LdsView &L, const BucketDesc &d, const 
 __global__ void __launch_bounds__(COUNT_BLOCK) lsq_count_kernel(CountArgs A) {
 	extern __shared__ __align__(16) unsigned char lds[];
 	uint4 *tile = reinterpret_cast<uint4 *>(lds + A.tables_lds_bytes);
+	PendingQueues Q;
+	Q.buf[0] = reinterpret_cast<unsigned *>(lds + A.tables_lds_bytes + TILE_WORDS * 16);
+	Q.buf[1] = Q.buf[0] + QUEUE_CAP;
+	Q.cnt = Q.buf[1] + QUEUE_CAP;
 	const unsigned tid = threadIdx.x;
+	if (tid == 0) { Q.cnt[0] = 0; Q.cnt[1] = 0; }
 	const unsigned long long s_begin = A.total_slots * blockIdx.x / gridDim.x;
 	const unsigned long long s_end = A.total_slots * (blockIdx.x + 1ull) / gridDim.x;
 	if (s_begin >= s_end) return;
@@ -392,9 +455,9 @@ __global__ void __launch_bounds__(COUNT_BLOCK) lsq_count_kernel(CountArgs A) {
 		const BucketDesc d = A.buckets[b];
 		// ---- stage the image, clear the histogram
 		{
-			const uint4 *src = reinterpret_cast<const uint4 *>(A.images + d.img_off);
+			global_words src = (global_words)(A.images + d.img_off);
 			uint4 *dst = reinterpret_cast<uint4 *>(lds);
-			for (unsigned i = tid; i < d.img_bytes / 16; i += COUNT_BLOCK) dst[i] = src[i];
+			for (unsigned i = tid; i < d.img_bytes / 16; i += COUNT_BLOCK) { const u32x4 t = src[i]; dst[i] = make_uint4(t.x, t.y, t.z, t.w); }
 			unsigned long long *h = reinterpret_cast<unsigned long long *>(lds + d.hist_off);
 			for (unsigned i = tid; i < d.n_cls; i += COUNT_BLOCK) h[i] = 0;
 		}
@@ -412,15 +475,15 @@ __global__ void __launch_bounds__(COUNT_BLOCK) lsq_count_kernel(CountArgs A) {
 		// ---- pool 1
 		if (l0 < n1) {
 			const unsigned long long base = A.p1_off[b];
-			if (d.kind == 1) stream_pool<2, true>(L, d, A, tile, reinterpret_cast<const uint4 *>(A.p1), base + l0, base + (l1 < n1 ? l1 : n1), A.p1_strand, A.p1_line);
-			else stream_pool<2, false>(L, d, A, tile, reinterpret_cast<const uint4 *>(A.p1), base + l0, base + (l1 < n1 ? l1 : n1), A.p1_strand, A.p1_line);
+			if (d.kind == 1) stream_pool<2, true>(L, d, A, tile, Q, reinterpret_cast<const uint4 *>(A.p1), base + l0, base + (l1 < n1 ? l1 : n1), A.p1_strand, A.p1_line);
+			else stream_pool<2, false>(L, d, A, tile, Q, reinterpret_cast<const uint4 *>(A.p1), base + l0, base + (l1 < n1 ? l1 : n1), A.p1_strand, A.p1_line);
 		}
 		// ---- pool 2
 		if (l1 > n1 && l0 < n1 + n2) {
 			const unsigned long long base = A.p2_off[b];
 			const unsigned long long g0 = base + ((l0 > n1 ? l0 : n1) - n1), g1 = base + ((l1 < n1 + n2 ? l1 : n1 + n2) - n1);
-			if (d.kind == 1) stream_pool<1, true>(L, d, A, tile, reinterpret_cast<const uint4 *>(A.p2), g0, g1, A.p2_strand, A.p2_line);
-			else stream_pool<1, false>(L, d, A, tile, reinterpret_cast<const uint4 *>(A.p2), g0, g1, A.p2_strand, A.p2_line);
+			if (d.kind == 1) stream_pool<1, true>(L, d, A, tile, Q, reinterpret_cast<const uint4 *>(A.p2), g0, g1, A.p2_strand, A.p2_line);
+			else stream_pool<1, false>(L, d, A, tile, Q, reinterpret_cast<const uint4 *>(A.p2), g0, g1, A.p2_strand, A.p2_line);
 		}
 		// ---- pool n
 		if (l1 > n1 + n2) {
@@ -442,7 +505,7 @@ __global__ void __launch_bounds__(COUNT_BLOCK) lsq_count_kernel(CountArgs A) {
 		// ---- flush
 		for (unsigned i = tid; i < d.n_cls; i += COUNT_BLOCK) {
 			unsigned long long v = L.hist[i];
-			if (v) {
+			if (v && !(A.ablate & 4u)) {
 				atomicAdd(&A.cnt[d.cls_base + i], v >> 40);
 				atomicAdd(&A.bases[d.cls_base + i], v & BASES_MASK);
 			}
@@ -734,7 +797,7 @@ int lsq_count(lsq_ctx *c) {
 	}
 	HIP_TRY(hipEventRecord(c->ev0, st));      // ev0..ev1 brackets the count kernel launches only
 	const unsigned tables_bytes = (std::max<unsigned>(E.max_lds_bytes, 16) + 15u) & ~15u;
-	const unsigned lds_bytes = tables_bytes + TILE_WORDS * 16;
+	const unsigned lds_bytes = tables_bytes + TILE_WORDS * 16 + 2 * QUEUE_CAP * 4 + 16;
 	if (lds_bytes > 160 * 1024) return fail(LSQ_E_UNSUPPORTED, "bucket tables + read tile exceed the CU's LDS");
 	if (lds_bytes > 64 * 1024)
 		HIP_TRY(hipFuncSetAttribute((const void *)lsq_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -752,6 +815,8 @@ int lsq_count(lsq_ctx *c) {
 		A.buckets = c->buckets.p; A.images = c->images.p; A.ties = c->ties.p; A.strand_rank = c->strand_rank.p;
 		A.n_buckets = (unsigned)E.buckets.size();
 		A.tables_lds_bytes = tables_bytes;
+		A.ablate = 0;
+		if (const char *e = getenv("LSQ_ABLATE")) A.ablate = (unsigned)atoi(e);
 		A.p1 = reinterpret_cast<const int2 *>(mr.p1.p); A.p1_strand = mr.p1_strand.p; A.p1_line = mr.p1_line.p;
 		A.p2 = reinterpret_cast<const int4 *>(mr.p2.p); A.p2_strand = mr.p2_strand.p; A.p2_line = mr.p2_line.p;
 		A.pn_blk_off = mr.pn_blk_off.p; A.pn_se = reinterpret_cast<const int2 *>(mr.pn_se.p);

@@ -28,6 +28,8 @@ for bud in budgets:
     del reads
     nb = ctx.retained_blocks(0)
     for m in mults:
+      for abl in [int(x) for x in os.environ.get("KB_ABLATE", "0").split(",")]:
+        os.environ["LSQ_ABLATE"] = str(abl)
         os.environ["LSQ_GRID_MULT"] = str(m)
         ts, es = [], []
         for it in range(12):
@@ -38,6 +40,7 @@ for bud in budgets:
         chk = (int(cnt.sum()), int(bases.sum()))
         if ref is None: ref = chk
         t = float(np.median(ts[2:]))
+        print("abl=%d " % abl, end="")
         print("%s budget=%6d buckets=%5d mult=%2d count_ms med=%.4f min=%.4f  %.0f GB/s (%.1f%% of 8TB/s)  em_ms=%.4f ingest_s=%.2f check=%s" % (
             wl, bud, ev.num_buckets, m, t, min(ts), 8.0 * nb / t / 1e6, 100 * 8.0 * nb / t / 1e6 / 8000, float(np.median(es)), ti, "ok" if chk == ref else "MISMATCH"), flush=True)
     ctx.close()
