@@ -41,6 +41,15 @@ constexpr int COUNT_BLOCK = 256;
 constexpr int TILE_WORDS = COUNT_BLOCK * 4;      // 16-byte words per read tile (16 KiB): 2048 one-block reads or 1024 two-block reads
 constexpr unsigned long long BASES_MASK = (1ull << 40) - 1;
 
+// A (read, event) pair the fast kernel does not settle itself: span-start ties that need the
+// strand/name order, two-block reads whose blocks touch, second looks that did not fit the LDS
+// queue.  pool 0 = one-block pool, 1 = two-block pool; scan: continue with the following events.
+struct ExcEntry {
+	unsigned long long slot;       // index into the pool
+	unsigned bucket;
+	unsigned ev_pool_scan;         // event index in the bucket | pool << 30 | scan << 31
+};
+
 struct CountArgs {
 	const BucketDesc *buckets;
 	const unsigned char *images;
@@ -55,6 +64,9 @@ struct CountArgs {
 	const unsigned long long *p1_off, *p2_off, *pn_off, *slot_off;    // n_buckets + 1 each
 	unsigned long long total_slots;
 	unsigned long long *cnt, *bases;
+	struct ExcEntry *exc;              // exception list (rare (read, event) pairs the fast kernel hands to the cleanup kernel)
+	unsigned *exc_count;               // [0] entries appended, [1] set to 1 by the cleanup kernel when [0] > exc_cap
+	unsigned exc_cap;
 };
 
 struct LdsView {
@@ -163,43 +175,78 @@ __device__ inline void process_read(const LdsView &L, const BucketDesc &d, const
 	}
 }
 
-// ---- branch-free path for buckets of packed FastRec events ------------------------------------
-// The same state machine as Walk::block, with every decision turned into a predicate so that
-// the 64 lanes of a wave (each on its own read, usually on different events) run one
-// instruction stream: four segment steps per block, no data-dependent branches.  Unused
-// segments are INT32_MAX sentinels, which stop the walk exactly like the end of the list.
-struct FastWalk {
-	int pos = 0, it = 0;
-	bool found = false;
-	unsigned mask = 0;
-	int matched = 0;
-	// one block; returns true when the block was fully consumed
-	__device__ inline bool block(const int (&sx)[4], const int (&sy)[4], int a, const int b, bool enable) {
-		bool done = !enable;
-#pragma unroll
-		for (int k = 0; k < 4; ++k) {
-			const bool live = !done && k >= it;
-			const bool in_reach = sx[k] < b;                       // else: the list is exhausted for this block
-			const int npos = max(pos, sx[k]);
-			const bool hit = a >= npos && a < sy[k];
-			const bool off_path = hit && found && a > npos;        // continuation must start exactly at pos
-			const bool blocked = !hit && npos > sx[k] && npos < sy[k];
-			const bool take = live && in_reach && hit && !off_path;
-			const bool stop = live && (!in_reach || off_path || blocked);
-			pos = (live && in_reach) ? npos : pos;
-			const int e2 = min(sy[k], b);
-			matched += take ? e2 - a : 0;
-			mask |= take ? (1u << k) : 0u;
-			found = found || take;
-			pos = take ? e2 : pos;
-			const bool inside = b < sy[k];                          // block ends inside this segment: cursor stays
-			a = take ? (b <= sy[k] ? b : sy[k]) : a;
-			it += (live && !stop && !(take && inside)) ? 1 : 0;
-			done = done || stop || (take && a == b);
-		}
-		return enable && a == b;
+// =====================================================================================
+// Generic kernel: buckets whose events do not fit the packed record (more than 4 segments or
+// isoforms, negative coordinates).  One lane per read, branching walk, reads straight from
+// global memory.  Correct for everything; not tuned.
+// =====================================================================================
+__global__ void __launch_bounds__(COUNT_BLOCK) lsq_count_generic_kernel(CountArgs A) {
+	extern __shared__ __align__(16) unsigned char lds[];
+	const unsigned tid = threadIdx.x;
+	const unsigned long long s_begin = A.total_slots * blockIdx.x / gridDim.x;
+	const unsigned long long s_end = A.total_slots * (blockIdx.x + 1ull) / gridDim.x;
+	if (s_begin >= s_end) return;
+	unsigned lo_b = 0, hi_b = A.n_buckets;
+	while (hi_b - lo_b > 1) {
+		unsigned mid = (lo_b + hi_b) >> 1;
+		if (A.slot_off[mid] <= s_begin) lo_b = mid; else hi_b = mid;
 	}
-};
+	for (unsigned b = lo_b; b < A.n_buckets && A.slot_off[b] < s_end; ++b) {
+		const unsigned long long bs = A.slot_off[b], be = A.slot_off[b + 1];
+		if (be <= s_begin || be == bs) continue;
+		const BucketDesc d = A.buckets[b];
+		if (d.kind != 0) continue;
+		{
+			const uint4 *src = reinterpret_cast<const uint4 *>(A.images + d.img_off);
+			uint4 *dst = reinterpret_cast<uint4 *>(lds);
+			for (unsigned i = tid; i < d.img_bytes / 16; i += COUNT_BLOCK) dst[i] = src[i];
+			unsigned long long *h = reinterpret_cast<unsigned long long *>(lds + d.hist_off);
+			for (unsigned i = tid; i < d.n_cls; i += COUNT_BLOCK) h[i] = 0;
+		}
+		__syncthreads();
+		LdsView L;
+		L.bins = reinterpret_cast<const unsigned short *>(lds);
+		L.ev = reinterpret_cast<const EventRec *>(lds + d.ev_off);
+		L.segs = reinterpret_cast<const int2 *>(lds + d.seg_off);
+		L.iso = reinterpret_cast<const unsigned *>(lds + d.iso_off);
+		L.hist = reinterpret_cast<unsigned long long *>(lds + d.hist_off);
+		const unsigned long long l0 = (s_begin > bs ? s_begin : bs) - bs;
+		const unsigned long long l1 = (s_end < be ? s_end : be) - bs;
+		const unsigned long long n1 = A.p1_off[b + 1] - A.p1_off[b];
+		const unsigned long long n2 = A.p2_off[b + 1] - A.p2_off[b];
+		for (unsigned long long i = l0 + tid; i < l1; i += COUNT_BLOCK) {
+			if (i < n1) {
+				const unsigned long long g = A.p1_off[b] + i;
+				const int2 rd = A.p1[g];
+				process_read<1>(L, d, A, make_int4(rd.x, rd.y, 0, 0), nullptr, 1, rd.y - rd.x, A.p1_strand, A.p1_line, g);
+			} else if (i < n1 + n2) {
+				const unsigned long long g = A.p2_off[b] + (i - n1);
+				const int4 rd = A.p2[g];
+				process_read<2>(L, d, A, rd, nullptr, 2, (rd.y - rd.x) + (rd.w - rd.z), A.p2_strand, A.p2_line, g);
+			} else {
+				const unsigned long long g = A.pn_off[b] + (i - n1 - n2);
+				const unsigned o0 = A.pn_blk_off[g], o1 = A.pn_blk_off[g + 1];
+				const int2 *blk = A.pn_se + o0;
+				int total = 0;
+				for (unsigned k = o0; k < o1; ++k) { int2 v = A.pn_se[k]; total += v.y - v.x; }
+				process_read<0>(L, d, A, make_int4(blk[0].x, 0, 0, A.pn_se[o1 - 1].y), blk, (int)(o1 - o0), total, A.pn_strand, A.pn_line, g);
+			}
+		}
+		__syncthreads();
+		for (unsigned i = tid; i < d.n_cls; i += COUNT_BLOCK) {
+			unsigned long long v = L.hist[i];
+			if (v) {
+				atomicAdd(&A.cnt[d.cls_base + i], v >> 40);
+				atomicAdd(&A.bases[d.cls_base + i], v & BASES_MASK);
+			}
+		}
+		__syncthreads();
+	}
+}
+
+// =====================================================================================
+// Fast kernel: buckets of packed 48-byte FastRec events (every LESSeq local-event shape).
+// =====================================================================================
 
 // 0/1 integer predicates kept in vector registers: combining them with & and | costs VALU ops,
 // where bool && / || on 64-lane masks would go through the CU's single scalar unit.
@@ -207,9 +254,9 @@ __device__ inline int nonneg(int x) { return (int)(~(unsigned)x >> 31); }
 __device__ inline int inside01(int a, int sx, int sy) { return nonneg((a - sx) | (sy - 1 - a)); }   // sx <= a < sy
 __device__ inline int gt01(int b, int sy) { return (int)((unsigned)(sy - b) >> 31); }                  // b > sy
 
-// One block [a,b) that may START a match (fresh state) or, with `starts` given, continue one:
-// r_k says segment k is matched.  A run extends from segment k to k+1 only when k+1 starts where k
-// ends and the block goes past k's end.  Returns the run bits; end_run = end of the last one.
+// r_k says segment k is matched by the current block.  A run extends from segment k to k+1 only
+// when k+1 starts where k ends (abut bit k) and the block goes past k's end.  Returns the run
+// bits; end_run = end of the last matched segment.
 __device__ inline unsigned run_bits(const int (&sy)[4], unsigned abut, int r0, int r1, int r2, int r3, int b, int &end_run) {
 	r1 |= r0 & (int)(abut & 1u) & gt01(b, sy[0]);
 	r2 |= r1 & (int)((abut >> 1) & 1u) & gt01(b, sy[1]);
@@ -218,25 +265,52 @@ __device__ inline unsigned run_bits(const int (&sy)[4], unsigned abut, int r0, i
 	return (unsigned)(r0 | (r1 << 1) | (r2 << 2) | (r3 << 3));
 }
 
-// One read against ONE packed event record (index i in the staged bucket).  Returns true when
-// a further event has to be examined for this read: the bin's first event ended left of the
-// read, or this event's span is overlapped by the next one.
+struct FastCtx {                       // wave-uniform state of the bucket being processed
+	const uint4 *recs;
+	unsigned long long *hist;
+	unsigned n_events, bucket;
+	unsigned long long tile_slot;      // pool index of the tile's first read
+	unsigned pool;
+	ExcEntry *exc;
+	unsigned *exc_count;
+	unsigned exc_cap;
+};
+
+__device__ inline void emit_exception(const FastCtx &C, unsigned r, unsigned i, unsigned scan) {
+	const unsigned slot = atomicAdd(C.exc_count, 1u);
+	if (slot < C.exc_cap) {
+		ExcEntry e;
+		e.slot = C.tile_slot + r;
+		e.bucket = C.bucket;
+		e.ev_pool_scan = i | (C.pool << 30) | (scan << 31);
+		C.exc[slot] = e;
+	}
+}
+
+// One read against ONE packed event record (index i).  Returns true when a further event has
+// to be examined for this read: the bin's first event ended left of the read, or this event's
+// span is overlapped by the next one.  No calls, no data-dependent loops: the two cases that
+// need them (a span-start tie that falls through to the strand/name order; two blocks that
+// touch) are written to the exception list instead.
 template <int NB>
-__device__ inline bool fast_trip(const uint4 *recs, unsigned long long *hist, const BucketDesc &d, const CountArgs &A,
-                                 const int4 v, const int total, const unsigned char *strand_arr, const unsigned *line_arr,
-                                 const unsigned long long slot_base, const unsigned r, const unsigned i, const bool valid) {
+__device__ inline bool fast_trip(const FastCtx &C, const int4 v, const int total, const unsigned r, const unsigned i, const bool valid) {
 	const int p = v.x, q = (NB == 1) ? v.y : v.w;
-	const bool inb = valid && i < d.n_events;
+	const bool inb = valid && i < C.n_events;
 	const unsigned ri = 3u * (inb ? i : 0u);
-	const uint4 w0 = recs[ri], w1 = recs[ri + 1], w2 = recs[ri + 2];
+	const uint4 w0 = C.recs[ri], w1 = C.recs[ri + 1], w2 = C.recs[ri + 2];
 	const int gs = (int)w1.x, ge = (int)w0.x;
 	const bool started = inb && gs <= p;
 	bool covers = started && p <= ge;
-	// span-start tie rule: reads that sort before (gene_start, gene_end, strand, name) are not candidates
-	if (covers && p == gs) {
-		if (q < ge) covers = false;
-		else if (q == ge && tie_orders_read_first(A.ties, A.strand_rank, d.ev_base + i, strand_arr[slot_base + r], line_arr[slot_base + r])) covers = false;
+	// span-start tie rule (count/count.cpp:64-85): a read that starts on the event's first base is a
+	// candidate only if it is not ordered before (gene_start, gene_end, strand, name)
+	bool exc = covers && p == gs && q == ge;
+	covers = covers && !(p == gs && q <= ge);
+	if (NB == 2) {
+		const bool touching = covers && v.z == v.y;
+		exc = exc || touching;
+		covers = covers && !touching;
 	}
+	if (exc) emit_exception(C, r, i, 0u);
 	const int sx[4] = {(int)w1.x, (int)w1.z, (int)w2.x, (int)w2.z};
 	const int sy[4] = {(int)w1.y, (int)w1.w, (int)w2.y, (int)w2.w};
 	const unsigned abut = (w0.y >> FAST_ABUT_SHIFT) & 7u;
@@ -256,23 +330,13 @@ __device__ inline bool fast_trip(const uint4 *recs, unsigned long long *hist, co
 		                             exact1 & l3 & (int)(sx[3] == v.z), v.w, end2);
 		matched += m2 ? min(v.w, end2) - v.z : 0;
 		mask |= m2;
-		// two blocks that touch (kept apart only by the reference's insertion-order rule) walk like
-		// one block; they take the stepwise path
-		if (covers && v.z == v.y) {
-			FastWalk w;
-			const bool c1 = w.block(sx, sy, v.x, v.y, true);
-			w.block(sx, sy, v.z, v.w, c1);
-			mask = w.mask; matched = w.matched;
-		}
 	}
 	// (double)matched / total > 0.98  <=>  50*matched > 49*total (both below 2^18 here)
 	const unsigned long long tbl = ((unsigned long long)w0.w << 32) | w0.z;
 	const unsigned cls = (unsigned)(tbl >> (4u * mask)) & 0xFu;
-	if (covers && cls != 0 && 50 * matched > 49 * total) {
-		if (!(A.ablate & 2u)) atomicAdd(&hist[(w0.y & 0xFFFFu) + cls - 1], (1ull << 40) | (unsigned long long)(unsigned)matched);
-		else asm volatile("" ::"v"(matched), "v"(cls));
-	}
-	return started && (!(p <= ge) || (w0.y & FAST_FLAG_OVERLAPS_NEXT)) && i + 1 < d.n_events;
+	if (covers && cls != 0 && 50 * matched > 49 * total)
+		atomicAdd(&C.hist[(w0.y & 0xFFFFu) + cls - 1], (1ull << 40) | (unsigned long long)(unsigned)matched);
+	return started && (!(p <= ge) || (w0.y & FAST_FLAG_OVERLAPS_NEXT)) && i + 1 < C.n_events;
 }
 
 // Pending second looks: (tile-local read index | event index << 16).  Most reads are settled by
@@ -286,64 +350,27 @@ struct PendingQueues {
 };
 
 template <int NB>
-__device__ inline void fast_read(const unsigned short *bins, const uint4 *recs, unsigned long long *hist, const BucketDesc &d,
-                                 const CountArgs &A, const int4 v, const int total, const unsigned char *strand_arr,
-                                 const unsigned *line_arr, const unsigned long long slot_base, const unsigned r, unsigned i,
+__device__ inline void fast_read(const FastCtx &C, const int4 v, const int total, const unsigned r, const unsigned i,
                                  const bool valid, const PendingQueues &Q, const unsigned qsel) {
-	bool more = fast_trip<NB>(recs, hist, d, A, v, total, strand_arr, line_arr, slot_base, r, i, valid);
-	if (more) {
+	if (fast_trip<NB>(C, v, total, r, i, valid)) {
 		const unsigned slot = atomicAdd(&Q.cnt[qsel], 1u);
-		if (slot < QUEUE_CAP) {
-			Q.buf[qsel][slot] = r | ((i + 1u) << 16);
-		} else {
-			// queue full: finish this read here
-			while (more) { ++i; more = fast_trip<NB>(recs, hist, d, A, v, total, strand_arr, line_arr, slot_base, r, i, true); }
-		}
+		if (slot < QUEUE_CAP) Q.buf[qsel][slot] = r | ((i + 1u) << 16);
+		else emit_exception(C, r, i + 1u, 1u);      // queue full: the cleanup kernel finishes this read
 	}
 }
 
-// Reads with three or more blocks in a FastRec bucket (rare): the branching walk over the
-// record's segments.
-__device__ __noinline__ void process_read_n_on_fast(const unsigned short *bins, const uint4 *recs, unsigned long long *hist,
-                                                    const BucketDesc &d, const CountArgs &A, const int2 *blk, int nblk, int total,
-                                                    unsigned long long slot) {
-	const int p = blk[0].x, q = blk[nblk - 1].y;
-	const int rel = p - d.lo;
-	unsigned bin = rel <= 0 ? 0u : ((unsigned)rel >> d.shift);
-	bin = min(bin, d.n_bins - 1u);
-	for (unsigned i = bins[bin]; i < d.n_events; ++i) {
-		const uint4 w0 = recs[3u * i], w1 = recs[3u * i + 1], w2 = recs[3u * i + 2];
-		const int gs = (int)w1.x, ge = (int)w0.x;
-		if (gs > p) break;
-		if (p > ge) continue;
-		if (p == gs) {
-			if (q < ge) continue;
-			if (q == ge && tie_orders_read_first(A.ties, A.strand_rank, d.ev_base + i, A.pn_strand[slot], A.pn_line[slot])) continue;
-		}
-		int2 segs[4] = {make_int2((int)w1.x, (int)w1.y), make_int2((int)w1.z, (int)w1.w), make_int2((int)w2.x, (int)w2.y), make_int2((int)w2.z, (int)w2.w)};
-		const int nseg = (int)((w0.y >> FAST_NSEG_SHIFT) & 7u);
-		Walk w;
-		for (int k = 0; k < nblk; ++k) { const int2 bk = blk[k]; if (!w.block(segs, nseg, bk.x, bk.y)) break; }
-		const unsigned mask = w.mask;
-		if (!mask) continue;
-		if (!(50ll * w.matched > 49ll * total)) continue;
-		const unsigned long long tbl = ((unsigned long long)w0.w << 32) | w0.z;
-		const unsigned cls = (unsigned)(tbl >> (4u * mask)) & 0xFu;
-		if (cls) atomicAdd(&hist[(w0.y & 0xFFFFu) + cls - 1], (1ull << 40) | (unsigned long long)(unsigned)w.matched);
-	}
-}
-
-// Streams the 16-byte words of a pool through an LDS tile: wide coalesced loads by the whole
-// workgroup (the next tile's loads are issued before the current tile is processed), then each
-// lane walks its reads out of LDS in a compact loop.  RPW = reads per word: 2 (pool 1) or 1.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef const u32x4 __attribute__((address_space(1))) *global_words;
 
-template <int RPW, bool FAST>
-__device__ inline void stream_pool(const LdsView &L, const BucketDesc &d, const CountArgs &A, uint4 *tile, const PendingQueues &Q,
-                                   const uint4 *src_generic, unsigned long long g0, unsigned long long g1,
-                                   const unsigned char *strand_arr, const unsigned *line_arr) {
-	// reads [g0, g1) in the pool's global numbering; words [w0, w1)
+// Streams the 16-byte words of a pool through an LDS tile: wide coalesced loads by the whole
+// workgroup (the next tile's loads are issued before the current tile is processed), then each
+// lane takes its reads out of LDS.  RPW = reads per word: 2 (pool 1) or 1 (pool 2).
+template <int RPW>
+__device__ inline void stream_pool_fast(FastCtx &C, const unsigned short *bins, const BucketDesc &d, const CountArgs &A,
+                                        uint4 *tile, const PendingQueues &Q, const uint4 *src_generic,
+                                        const unsigned long long g0, const unsigned long long g1) {
+	constexpr int NB = RPW == 2 ? 1 : 2;
+	C.pool = RPW == 2 ? 0u : 1u;
 	global_words src = (global_words)src_generic;       // kernel-argument memory: global address space
 	const unsigned tid = threadIdx.x;
 	const unsigned long long w0 = g0 / RPW, w1 = (g1 + RPW - 1) / RPW;
@@ -365,73 +392,52 @@ __device__ inline void stream_pool(const LdsView &L, const BucketDesc &d, const 
 		__syncthreads();
 		if (wt + TILE_WORDS < w1) fetch(wt + TILE_WORDS);
 		const unsigned long long r_base = wt * RPW;
+		C.tile_slot = r_base;
 		// tile-relative bounds of the reads that belong to this workgroup's range
 		const unsigned lo_r = g0 > r_base ? (unsigned)(g0 - r_base) : 0u;
 		const unsigned hi_r = (unsigned)min((unsigned long long)(TILE_WORDS * RPW), g1 - r_base);
-		if (FAST) {
-			const uint4 *recs = reinterpret_cast<const uint4 *>(L.ev);
+		auto take = [&](unsigned r, int4 &rd, int &total) {
+			if (RPW == 2) { const int2 t = reinterpret_cast<const int2 *>(tile)[r]; rd = make_int4(t.x, t.y, t.x, t.y); total = t.y - t.x; }
+			else { const uint4 u = tile[r]; rd = make_int4((int)u.x, (int)u.y, (int)u.z, (int)u.w); total = (rd.y - rd.x) + (rd.w - rd.z); }
+		};
 #pragma unroll 1
-			for (int k = 0; k < 4 * RPW; ++k) {
-				const unsigned r = (unsigned)k * COUNT_BLOCK + tid;
-				const bool in = r >= lo_r && r < hi_r;
-				int4 rd;
-				if (RPW == 2) { const int2 t = reinterpret_cast<const int2 *>(tile)[r]; rd = make_int4(t.x, t.y, t.x, t.y); }
-				else { const uint4 u = tile[r]; rd = make_int4((int)u.x, (int)u.y, (int)u.z, (int)u.w); }
-				const int total = RPW == 2 ? rd.y - rd.x : (rd.y - rd.x) + (rd.w - rd.z);
-				const int rel = rd.x - d.lo;
-				unsigned bin = rel <= 0 ? 0u : ((unsigned)rel >> d.shift);
-				bin = min(bin, d.n_bins - 1u);
-				const unsigned i0 = L.bins[bin];
-				if (A.ablate & 1u) { asm volatile("" ::"v"(i0), "v"(rd.x), "v"(rd.y), "v"(rd.z), "v"(rd.w)); continue; }
-				fast_read<(RPW == 2 ? 1 : 2)>(L.bins, recs, L.hist, d, A, rd, total, strand_arr, line_arr, r_base, r, i0, in, Q, 0);
-			}
-			// work off the parked second looks, round by round (a round may park third looks)
-			unsigned cur = 0;
-			for (;;) {
-				__syncthreads();
-				const unsigned n = min(Q.cnt[cur], QUEUE_CAP);
-				if (n == 0) break;
-				__syncthreads();
-				if (tid == 0) { Q.cnt[cur ^ 1] = 0; }
-				__syncthreads();
-#pragma unroll 1
-				for (unsigned j0 = 0; j0 < n; j0 += COUNT_BLOCK) {
-					const unsigned j = j0 + tid;
-					const bool in = j < n;
-					const unsigned e = Q.buf[cur][in ? j : 0];
-					const unsigned r = e & 0xFFFFu, i = e >> 16;
-					int4 rd;
-					if (RPW == 2) { const int2 t = reinterpret_cast<const int2 *>(tile)[r]; rd = make_int4(t.x, t.y, t.x, t.y); }
-					else { const uint4 u = tile[r]; rd = make_int4((int)u.x, (int)u.y, (int)u.z, (int)u.w); }
-					const int total = RPW == 2 ? rd.y - rd.x : (rd.y - rd.x) + (rd.w - rd.z);
-					fast_read<(RPW == 2 ? 1 : 2)>(L.bins, recs, L.hist, d, A, rd, total, strand_arr, line_arr, r_base, r, i, in, Q, cur ^ 1);
-				}
-				__syncthreads();
-				if (tid == 0) Q.cnt[cur] = 0;
-				cur ^= 1;
-			}
-			// both counters are zero here; the barrier below orders that before the next tile
-		} else {
-#pragma unroll 1
-			for (int k = 0; k < 4 * RPW; ++k) {
-				const unsigned r = (unsigned)k * COUNT_BLOCK + tid;
-				if (r >= lo_r && r < hi_r) {
-					if (RPW == 2) {
-						const int2 rd = reinterpret_cast<const int2 *>(tile)[r];
-						process_read<1>(L, d, A, make_int4(rd.x, rd.y, 0, 0), nullptr, 1, rd.y - rd.x, strand_arr, line_arr, r_base + r);
-					} else {
-						const uint4 u = tile[r];
-						const int4 rd = make_int4((int)u.x, (int)u.y, (int)u.z, (int)u.w);
-						process_read<2>(L, d, A, rd, nullptr, 2, (rd.y - rd.x) + (rd.w - rd.z), strand_arr, line_arr, r_base + r);
-					}
-				}
-			}
+		for (int k = 0; k < 4 * RPW; ++k) {
+			const unsigned r = (unsigned)k * COUNT_BLOCK + tid;
+			const bool in = r >= lo_r && r < hi_r;
+			int4 rd; int total;
+			take(r, rd, total);
+			const int rel = rd.x - d.lo;
+			unsigned bin = rel <= 0 ? 0u : ((unsigned)rel >> d.shift);
+			bin = min(bin, d.n_bins - 1u);
+			const unsigned i0 = bins[bin];
+			if (A.ablate & 1u) { asm volatile("" ::"v"(i0), "v"(rd.x), "v"(rd.y), "v"(rd.z), "v"(rd.w)); continue; }
+			fast_read<NB>(C, rd, total, r, i0, in, Q, 0);
 		}
-		__syncthreads();
+		// work off the parked second looks, round by round (a round may park third looks)
+		unsigned cur = 0;
+		for (;;) {
+			__syncthreads();
+			const unsigned n = min(Q.cnt[cur], QUEUE_CAP);
+			if (n == 0) break;
+#pragma unroll 1
+			for (unsigned j0 = 0; j0 < n; j0 += COUNT_BLOCK) {
+				const unsigned j = j0 + tid;
+				const bool in = j < n;
+				const unsigned e = Q.buf[cur][in ? j : 0];
+				const unsigned r = e & 0xFFFFu;
+				int4 rd; int total;
+				take(r, rd, total);
+				fast_read<NB>(C, rd, total, r, e >> 16, in, Q, cur ^ 1);
+			}
+			__syncthreads();
+			if (tid == 0) Q.cnt[cur] = 0;
+			cur ^= 1;
+		}
+		// both counters are zero here; the barrier inside the loop ordered that before the next tile
 	}
 }
 
-__global__ void __launch_bounds__(COUNT_BLOCK) lsq_count_kernel(CountArgs A) {
+__global__ void __launch_bounds__(COUNT_BLOCK) lsq_count_fast_kernel(CountArgs A) {
 	extern __shared__ __align__(16) unsigned char lds[];
 	uint4 *tile = reinterpret_cast<uint4 *>(lds + A.tables_lds_bytes);
 	PendingQueues Q;
@@ -453,6 +459,7 @@ __global__ void __launch_bounds__(COUNT_BLOCK) lsq_count_kernel(CountArgs A) {
 		const unsigned long long bs = A.slot_off[b], be = A.slot_off[b + 1];
 		if (be <= s_begin || be == bs) continue;
 		const BucketDesc d = A.buckets[b];
+		if (d.kind != 1) continue;
 		// ---- stage the image, clear the histogram
 		{
 			global_words src = (global_words)(A.images + d.img_off);
@@ -462,12 +469,13 @@ __global__ void __launch_bounds__(COUNT_BLOCK) lsq_count_kernel(CountArgs A) {
 			for (unsigned i = tid; i < d.n_cls; i += COUNT_BLOCK) h[i] = 0;
 		}
 		__syncthreads();
-		LdsView L;
-		L.bins = reinterpret_cast<const unsigned short *>(lds);
-		L.ev = reinterpret_cast<const EventRec *>(lds + d.ev_off);
-		L.segs = reinterpret_cast<const int2 *>(lds + d.seg_off);
-		L.iso = reinterpret_cast<const unsigned *>(lds + d.iso_off);
-		L.hist = reinterpret_cast<unsigned long long *>(lds + d.hist_off);
+		const unsigned short *bins = reinterpret_cast<const unsigned short *>(lds);
+		FastCtx C;
+		C.recs = reinterpret_cast<const uint4 *>(lds + d.ev_off);
+		C.hist = reinterpret_cast<unsigned long long *>(lds + d.hist_off);
+		C.n_events = d.n_events; C.bucket = b;
+		C.tile_slot = 0; C.pool = 0;
+		C.exc = A.exc; C.exc_count = A.exc_count; C.exc_cap = A.exc_cap;
 		const unsigned long long l0 = (s_begin > bs ? s_begin : bs) - bs;
 		const unsigned long long l1 = (s_end < be ? s_end : be) - bs;
 		const unsigned long long n1 = A.p1_off[b + 1] - A.p1_off[b];
@@ -475,42 +483,139 @@ __global__ void __launch_bounds__(COUNT_BLOCK) lsq_count_kernel(CountArgs A) {
 		// ---- pool 1
 		if (l0 < n1) {
 			const unsigned long long base = A.p1_off[b];
-			if (d.kind == 1) stream_pool<2, true>(L, d, A, tile, Q, reinterpret_cast<const uint4 *>(A.p1), base + l0, base + (l1 < n1 ? l1 : n1), A.p1_strand, A.p1_line);
-			else stream_pool<2, false>(L, d, A, tile, Q, reinterpret_cast<const uint4 *>(A.p1), base + l0, base + (l1 < n1 ? l1 : n1), A.p1_strand, A.p1_line);
+			stream_pool_fast<2>(C, bins, d, A, tile, Q, reinterpret_cast<const uint4 *>(A.p1), base + l0, base + (l1 < n1 ? l1 : n1));
 		}
 		// ---- pool 2
 		if (l1 > n1 && l0 < n1 + n2) {
 			const unsigned long long base = A.p2_off[b];
-			const unsigned long long g0 = base + ((l0 > n1 ? l0 : n1) - n1), g1 = base + ((l1 < n1 + n2 ? l1 : n1 + n2) - n1);
-			if (d.kind == 1) stream_pool<1, true>(L, d, A, tile, Q, reinterpret_cast<const uint4 *>(A.p2), g0, g1, A.p2_strand, A.p2_line);
-			else stream_pool<1, false>(L, d, A, tile, Q, reinterpret_cast<const uint4 *>(A.p2), g0, g1, A.p2_strand, A.p2_line);
+			stream_pool_fast<1>(C, bins, d, A, tile, Q, reinterpret_cast<const uint4 *>(A.p2), base + ((l0 > n1 ? l0 : n1) - n1),
+			                    base + ((l1 < n1 + n2 ? l1 : n1 + n2) - n1));
 		}
-		// ---- pool n
-		if (l1 > n1 + n2) {
-			unsigned long long a = (l0 > n1 + n2 ? l0 : n1 + n2) - (n1 + n2), z = l1 - (n1 + n2);
-			const unsigned long long base = A.pn_off[b];
-			for (unsigned long long i = a + tid; i < z; i += COUNT_BLOCK) {
-				const unsigned o0 = A.pn_blk_off[base + i], o1 = A.pn_blk_off[base + i + 1];
-				const int2 *blk = A.pn_se + o0;
-				int total = 0;
-				for (unsigned k = o0; k < o1; ++k) { int2 v = A.pn_se[k]; total += v.y - v.x; }
-				if (d.kind == 1)
-					process_read_n_on_fast(L.bins, reinterpret_cast<const uint4 *>(L.ev), L.hist, d, A, blk, (int)(o1 - o0), total, base + i);
-				else
-					process_read<0>(L, d, A, make_int4(blk[0].x, 0, 0, A.pn_se[o1 - 1].y), blk, (int)(o1 - o0), total,
-					                A.pn_strand, A.pn_line, base + i);
-			}
-		}
+		// (reads with three or more blocks are left to the cleanup kernel)
 		__syncthreads();
 		// ---- flush
 		for (unsigned i = tid; i < d.n_cls; i += COUNT_BLOCK) {
-			unsigned long long v = L.hist[i];
+			unsigned long long v = C.hist[i];
 			if (v && !(A.ablate & 4u)) {
 				atomicAdd(&A.cnt[d.cls_base + i], v >> 40);
 				atomicAdd(&A.bases[d.cls_base + i], v & BASES_MASK);
 			}
 		}
 		__syncthreads();
+	}
+}
+
+// =====================================================================================
+// Cleanup kernel for FastRec buckets: everything the fast kernel does not settle -- the
+// exception list and the reads with three or more blocks -- one lane per item, tables read
+// from global memory (L2), stepwise walk, global atomics.  Rare work by construction; in
+// `all_reads` mode it redoes pools 1 and 2 completely (used when the exception list overflowed).
+// =====================================================================================
+struct GlobalBucket {
+	const BucketDesc *d;
+	const unsigned short *bins;
+	const uint4 *recs;
+};
+
+__device__ inline GlobalBucket global_bucket(const CountArgs &A, unsigned b) {
+	GlobalBucket G;
+	G.d = A.buckets + b;
+	G.bins = reinterpret_cast<const unsigned short *>(A.images + G.d->img_off);
+	G.recs = reinterpret_cast<const uint4 *>(A.images + G.d->img_off + G.d->ev_off);
+	return G;
+}
+
+// evaluates the read against event i (and, with scan, the following ones as the reference's
+// index scan would); blocks at blk[0..nblk)
+__device__ void eval_read_global(const CountArgs &A, const GlobalBucket &G, const int2 *blk, int nblk, unsigned i, bool scan,
+                                 unsigned strand_id, unsigned line) {
+	const BucketDesc &d = *G.d;
+	const int p = blk[0].x, q = blk[nblk - 1].y;
+	int total = 0;
+	for (int k = 0; k < nblk; ++k) total += blk[k].y - blk[k].x;
+	for (; i < d.n_events; ++i) {
+		const uint4 w0 = G.recs[3u * i], w1 = G.recs[3u * i + 1], w2 = G.recs[3u * i + 2];
+		const int gs = (int)w1.x, ge = (int)w0.x;
+		if (gs > p) break;
+		bool cand = p <= ge;
+		if (cand && p == gs) {
+			if (q < ge) cand = false;
+			else if (q == ge && tie_orders_read_first(A.ties, A.strand_rank, d.ev_base + i, strand_id, line)) cand = false;
+		}
+		if (cand) {
+			int2 segs[4] = {make_int2((int)w1.x, (int)w1.y), make_int2((int)w1.z, (int)w1.w), make_int2((int)w2.x, (int)w2.y), make_int2((int)w2.z, (int)w2.w)};
+			const int nseg = (int)((w0.y >> FAST_NSEG_SHIFT) & 7u);
+			Walk w;
+			for (int k = 0; k < nblk; ++k) { const int2 bk = blk[k]; if (!w.block(segs, nseg, bk.x, bk.y)) break; }
+			const unsigned long long tbl = ((unsigned long long)w0.w << 32) | w0.z;
+			const unsigned cls = w.mask < 16u ? (unsigned)(tbl >> (4u * w.mask)) & 0xFu : 0u;
+			if (cls != 0 && 50ll * w.matched > 49ll * total) {
+				const unsigned slot = d.cls_base + (w0.y & 0xFFFFu) + cls - 1;
+				atomicAdd(&A.cnt[slot], 1ull);
+				atomicAdd(&A.bases[slot], (unsigned long long)(unsigned)w.matched);
+			}
+		}
+		if (!scan) break;
+		if (p <= ge && !(w0.y & FAST_FLAG_OVERLAPS_NEXT)) break;
+	}
+}
+
+__device__ inline unsigned first_event_for(const GlobalBucket &G, int p) {
+	const BucketDesc &d = *G.d;
+	const int rel = p - d.lo;
+	unsigned bin = rel <= 0 ? 0u : ((unsigned)rel >> d.shift);
+	bin = min(bin, d.n_bins - 1u);
+	return G.bins[bin];
+}
+
+__device__ inline unsigned bucket_of_slot(const unsigned long long *off, unsigned n_buckets, unsigned long long g) {
+	unsigned lo = 0, hi = n_buckets;           // last bucket with off[b] <= g
+	while (hi - lo > 1) { unsigned mid = (lo + hi) >> 1; if (off[mid] <= g) lo = mid; else hi = mid; }
+	return lo;
+}
+
+__global__ void __launch_bounds__(256) lsq_count_cleanup_kernel(CountArgs A, unsigned long long n_p1, unsigned long long n_p2,
+                                                                unsigned long long n_pn, int all_reads) {
+	const unsigned long long gtid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+	const unsigned long long gsz = (unsigned long long)gridDim.x * blockDim.x;
+	// ---- exception list
+	if (!all_reads) {
+		const unsigned n_raw = A.exc_count[0];
+		if (n_raw > A.exc_cap && gtid == 0) A.exc_count[1] = 1u;       // overflow: the host redoes the pass in all_reads mode
+		const unsigned n = min(n_raw, A.exc_cap);
+		for (unsigned long long k = gtid; k < n; k += gsz) {
+			const ExcEntry e = A.exc[k];
+			const GlobalBucket G = global_bucket(A, e.bucket);
+			const unsigned i = e.ev_pool_scan & 0x3FFFFFFFu, pool = (e.ev_pool_scan >> 30) & 1u;
+			const bool scan = (e.ev_pool_scan >> 31) != 0;
+			int2 blk[2];
+			if (pool == 0) { blk[0] = A.p1[e.slot]; eval_read_global(A, G, blk, 1, i, scan, A.p1_strand[e.slot], A.p1_line[e.slot]); }
+			else { const int4 v = A.p2[e.slot]; blk[0] = make_int2(v.x, v.y); blk[1] = make_int2(v.z, v.w); eval_read_global(A, G, blk, 2, i, scan, A.p2_strand[e.slot], A.p2_line[e.slot]); }
+		}
+	} else {
+		for (unsigned long long g = gtid; g < n_p1; g += gsz) {
+			const unsigned b = bucket_of_slot(A.p1_off, A.n_buckets, g);
+			if (A.buckets[b].kind != 1) continue;
+			const GlobalBucket G = global_bucket(A, b);
+			int2 blk[1] = {A.p1[g]};
+			eval_read_global(A, G, blk, 1, first_event_for(G, blk[0].x), true, A.p1_strand[g], A.p1_line[g]);
+		}
+		for (unsigned long long g = gtid; g < n_p2; g += gsz) {
+			const unsigned b = bucket_of_slot(A.p2_off, A.n_buckets, g);
+			if (A.buckets[b].kind != 1) continue;
+			const GlobalBucket G = global_bucket(A, b);
+			const int4 v = A.p2[g];
+			int2 blk[2] = {make_int2(v.x, v.y), make_int2(v.z, v.w)};
+			eval_read_global(A, G, blk, 2, first_event_for(G, v.x), true, A.p2_strand[g], A.p2_line[g]);
+		}
+	}
+	// ---- reads with three or more blocks
+	for (unsigned long long g = gtid; g < n_pn; g += gsz) {
+		const unsigned b = bucket_of_slot(A.pn_off, A.n_buckets, g);
+		if (A.buckets[b].kind != 1) continue;
+		const GlobalBucket G = global_bucket(A, b);
+		const unsigned o0 = A.pn_blk_off[g], o1 = A.pn_blk_off[g + 1];
+		eval_read_global(A, G, A.pn_se + o0, (int)(o1 - o0), first_event_for(G, A.pn_se[o0].x), true, A.pn_strand[g], A.pn_line[g]);
 	}
 }
 
@@ -641,8 +746,12 @@ struct lsq_ctx {
 	DevBuf<double> G, theta, logll;
 	DevBuf<uint8_t> flags;
 	DevBuf<unsigned long long> cnt, bases;
+	DevBuf<ExcEntry> exc;                  // shared by the methods (launches are serialised on the stream)
+	DevBuf<unsigned> exc_count;            // per method: [2m] appended, [2m+1] overflow flag
+	bool redo_checked = true;
 	MethodReads reads[LSQ_MAX_METHODS];
 	bool counted = false, solved = false;
+	bool has_fast = false, has_generic = false;
 	float count_ms = 0, solve_ms = 0;
 };
 
@@ -709,6 +818,8 @@ int lsq_events_upload(lsq_ctx *c, const lsq_events *E) {
 	if (E->max_lds_bytes > 160 * 1024) return fail(LSQ_E_UNSUPPORTED, "bucket tables exceed the CU's LDS");
 	c->E = E;
 	c->counted = c->solved = false;
+	c->has_fast = c->has_generic = false;
+	for (const BucketDesc &bd : E->buckets) { if (bd.kind == 1) c->has_fast = true; else c->has_generic = true; }
 	for (auto &r : c->reads) r.present = false;
 	int rc;
 	if ((rc = c->buckets.upload(E->buckets.data(), E->buckets.size(), c->stream))) return rc;
@@ -736,6 +847,7 @@ int lsq_events_upload(lsq_ctx *c, const lsq_events *E) {
 	if ((rc = c->logll.alloc(n_ev))) return rc;
 	if ((rc = c->iters.alloc(n_ev))) return rc;
 	if ((rc = c->flags.alloc(n_ev))) return rc;
+	if ((rc = c->exc_count.alloc(2 * LSQ_MAX_METHODS))) return rc;
 	if ((rc = upload_strand_ranks(c))) return rc;
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	return LSQ_OK;
@@ -769,6 +881,11 @@ int lsq_reads_upload(lsq_ctx *c, int method, const lsq_reads *R) {
 	if ((rc = mr.p2_off.upload(o2.data(), B + 1, st))) return rc;
 	if ((rc = mr.pn_off.upload(on.data(), B + 1, st))) return rc;
 	if ((rc = mr.slot_off.upload(slot.data(), B + 1, st))) return rc;
+	{
+		// exception list: a quarter of the one- and two-block reads, at least 64 Ki entries
+		const size_t want = std::max<size_t>(65536, (P.p1_strand.size() + P.p2_strand.size()) / 4);
+		if (c->exc.n < want && (rc = c->exc.alloc(want))) return rc;
+	}
 	if ((rc = upload_strand_ranks(c))) return rc;      // the reads may have introduced new strand strings
 	HIP_TRY(hipStreamSynchronize(st));
 	mr.n_retained = P.n_retained;
@@ -782,25 +899,24 @@ int lsq_reads_upload(lsq_ctx *c, int method, const lsq_reads *R) {
 uint64_t lsq_reads_retained(const lsq_ctx *c, int method) { return (c && method >= 0 && method < LSQ_MAX_METHODS) ? c->reads[method].n_retained : 0; }
 uint64_t lsq_reads_retained_blocks(const lsq_ctx *c, int method) { return (c && method >= 0 && method < LSQ_MAX_METHODS) ? c->reads[method].n_retained_blocks : 0; }
 
-int lsq_count(lsq_ctx *c) {
-	if (!c) return fail(LSQ_E_ARG, "null context");
-	if (!c->E) return fail(LSQ_E_STATE, "lsq_events_upload must come first");
-	HIP_TRY(hipSetDevice(c->device));
+static int run_count(lsq_ctx *c, bool all_reads) {
 	const lsq_events &E = *c->E;
 	const size_t n_cls = E.n_cls_total;
 	const int M = E.n_methods;
-	for (int m = 0; m < M; ++m) if (!c->reads[m].present) return fail(LSQ_E_STATE, "reads of method %d were not uploaded", m);
 	hipStream_t st = c->stream;
 	if (M * n_cls) {
 		HIP_TRY(hipMemsetAsync(c->cnt.p, 0, (size_t)M * n_cls * sizeof(unsigned long long), st));
 		HIP_TRY(hipMemsetAsync(c->bases.p, 0, (size_t)M * n_cls * sizeof(unsigned long long), st));
 	}
+	HIP_TRY(hipMemsetAsync(c->exc_count.p, 0, c->exc_count.n * sizeof(unsigned), st));
 	HIP_TRY(hipEventRecord(c->ev0, st));      // ev0..ev1 brackets the count kernel launches only
 	const unsigned tables_bytes = (std::max<unsigned>(E.max_lds_bytes, 16) + 15u) & ~15u;
 	const unsigned lds_bytes = tables_bytes + TILE_WORDS * 16 + 2 * QUEUE_CAP * 4 + 16;
 	if (lds_bytes > 160 * 1024) return fail(LSQ_E_UNSUPPORTED, "bucket tables + read tile exceed the CU's LDS");
-	if (lds_bytes > 64 * 1024)
-		HIP_TRY(hipFuncSetAttribute((const void *)lsq_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+	if (lds_bytes > 64 * 1024) {
+		HIP_TRY(hipFuncSetAttribute((const void *)lsq_count_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+		HIP_TRY(hipFuncSetAttribute((const void *)lsq_count_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+	}
 	unsigned per_cu = std::max(1u, std::min(2048u / COUNT_BLOCK, (160u * 1024u) / lds_bytes));
 	unsigned mult = 1;
 	if (const char *e = getenv("LSQ_GRID_MULT")) { int v = atoi(e); if (v >= 1 && v <= 64) mult = (unsigned)v; }
@@ -824,19 +940,62 @@ int lsq_count(lsq_ctx *c) {
 		A.p1_off = mr.p1_off.p; A.p2_off = mr.p2_off.p; A.pn_off = mr.pn_off.p; A.slot_off = mr.slot_off.p;
 		A.total_slots = mr.total_slots;
 		A.cnt = c->cnt.p + (size_t)m * n_cls; A.bases = c->bases.p + (size_t)m * n_cls;
-		hipLaunchKernelGGL(lsq_count_kernel, dim3((unsigned)grid), dim3(COUNT_BLOCK), lds_bytes, st, A);
-		HIP_TRY(hipGetLastError());
+		A.exc = c->exc.p; A.exc_count = c->exc_count.p + 2 * m; A.exc_cap = (unsigned)c->exc.n;
+		const unsigned long long n_p1 = mr.p1.n / 2, n_p2 = mr.p2.n / 4, n_pn = mr.pn_strand.n;
+		if (c->has_fast) {
+			if (!all_reads) {
+				hipLaunchKernelGGL(lsq_count_fast_kernel, dim3((unsigned)grid), dim3(COUNT_BLOCK), lds_bytes, st, A);
+				HIP_TRY(hipGetLastError());
+			}
+			const unsigned long long work = all_reads ? n_p1 + n_p2 + n_pn : std::max<unsigned long long>(n_pn, 65536);
+			const unsigned cgrid = (unsigned)std::min<unsigned long long>((work + 255) / 256, (unsigned long long)c->n_cu * 8);
+			hipLaunchKernelGGL(lsq_count_cleanup_kernel, dim3(std::max(cgrid, 1u)), dim3(256), 0, st, A, n_p1, n_p2, n_pn, all_reads ? 1 : 0);
+			HIP_TRY(hipGetLastError());
+		}
+		if (c->has_generic) {
+			hipLaunchKernelGGL(lsq_count_generic_kernel, dim3((unsigned)grid), dim3(COUNT_BLOCK), tables_bytes, st, A);
+			HIP_TRY(hipGetLastError());
+		}
 	}
 	HIP_TRY(hipEventRecord(c->ev1, st));
-	c->counted = true;
-	c->solved = false;
 	return LSQ_OK;
 }
 
-int lsq_solve(lsq_ctx *c) {
+static int run_solve(lsq_ctx *c);
+
+// After a synchronisation point: did any method's exception list overflow?  Then the counts
+// (and a solve based on them) are redone with the cleanup kernel over every read.
+static int ensure_counts_complete(lsq_ctx *c) {
+	if (c->redo_checked || !c->counted) return LSQ_OK;
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	std::vector<unsigned> h(c->exc_count.n, 0);
+	HIP_TRY(hipMemcpy(h.data(), c->exc_count.p, h.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+	bool overflow = false;
+	for (size_t m = 0; m * 2 + 1 < h.size(); ++m) overflow = overflow || h[2 * m + 1] != 0;
+	c->redo_checked = true;
+	if (overflow || getenv("LSQ_FORCE_REDO")) {
+		int rc = run_count(c, true);
+		if (rc) return rc;
+		if (c->solved) { rc = run_solve(c); if (rc) return rc; }
+		HIP_TRY(hipStreamSynchronize(c->stream));
+	}
+	return LSQ_OK;
+}
+
+int lsq_count(lsq_ctx *c) {
 	if (!c) return fail(LSQ_E_ARG, "null context");
-	if (!c->counted) return fail(LSQ_E_STATE, "lsq_count must come first");
+	if (!c->E) return fail(LSQ_E_STATE, "lsq_events_upload must come first");
 	HIP_TRY(hipSetDevice(c->device));
+	for (int m = 0; m < c->E->n_methods; ++m) if (!c->reads[m].present) return fail(LSQ_E_STATE, "reads of method %d were not uploaded", m);
+	int rc = run_count(c, false);
+	if (rc) return rc;
+	c->counted = true;
+	c->solved = false;
+	c->redo_checked = false;
+	return LSQ_OK;
+}
+
+static int run_solve(lsq_ctx *c) {
 	const lsq_events &E = *c->E;
 	hipStream_t st = c->stream;
 	HIP_TRY(hipEventRecord(c->ev2, st));
@@ -850,6 +1009,15 @@ int lsq_solve(lsq_ctx *c) {
 		HIP_TRY(hipGetLastError());
 	}
 	HIP_TRY(hipEventRecord(c->ev3, st));
+	return LSQ_OK;
+}
+
+int lsq_solve(lsq_ctx *c) {
+	if (!c) return fail(LSQ_E_ARG, "null context");
+	if (!c->counted) return fail(LSQ_E_STATE, "lsq_count must come first");
+	HIP_TRY(hipSetDevice(c->device));
+	int rc = run_solve(c);
+	if (rc) return rc;
 	c->solved = true;
 	return LSQ_OK;
 }
@@ -866,6 +1034,7 @@ int lsq_results_counts(lsq_ctx *c, uint64_t *class_count, uint64_t *class_bases)
 	if (!c || !class_count) return fail(LSQ_E_ARG, "null argument");
 	if (!c->counted) return fail(LSQ_E_STATE, "lsq_count must come first");
 	HIP_TRY(hipSetDevice(c->device));
+	{ int rc = ensure_counts_complete(c); if (rc) return rc; }
 	const lsq_events &E = *c->E;
 	const size_t n_cls = E.n_cls_total, M = (size_t)E.n_methods;
 	std::vector<unsigned long long> hc(std::max<size_t>(M * n_cls, 1)), hb(std::max<size_t>(M * n_cls, 1));
@@ -890,6 +1059,7 @@ int lsq_results_solve(lsq_ctx *c, double *theta, double *logll, uint32_t *em_ite
 	if (!c || !theta || !logll) return fail(LSQ_E_ARG, "null argument");
 	if (!c->solved) return fail(LSQ_E_STATE, "lsq_solve must come first");
 	HIP_TRY(hipSetDevice(c->device));
+	{ int rc = ensure_counts_complete(c); if (rc) return rc; }
 	const lsq_events &E = *c->E;
 	const size_t n_ev = E.dev2out.size(), n_iso = E.n_iso_total;
 	std::vector<double> ht(std::max<size_t>(n_iso, 1)), hl(std::max<size_t>(n_ev, 1));
