@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_build", "liblesseq_hip.so")
+LIB_PATH = os.environ.get("LSQ_LIB") or os.path.join(_HERE, "_build", "liblesseq_hip.so")   # LSQ_LIB: developer override for build variants
 
 
 class LsqError(RuntimeError):

@@ -271,7 +271,7 @@ static const int64_t COORD_LIMIT = (int64_t)1 << 30;
 // workgroup staging and flush cost low and the occupancy high; the price is a longer cut list
 // for the ingest-time bucket lookup.  LSQ_LDS_BUDGET overrides (tests use it to vary the split).
 static uint32_t lds_budget_bytes() {
-	if (const char *e = getenv("LSQ_LDS_BUDGET")) { long v = atol(e); if (v >= 512 && v <= 144 * 1024) return (uint32_t)v; }
+	if (const char *e = getenv("LSQ_LDS_BUDGET")) { long v = atol(e); if (v >= 512 && v <= 120 * 1024) return (uint32_t)v; }
 	return 4096;
 }
 
@@ -290,7 +290,7 @@ static int plan_device(lsq_events &E) {
 	std::vector<std::vector<int32_t>> per_chrom(E.chroms.names.size());
 	for (size_t i = 0; i < n; ++i) per_chrom[E.ev[i].chrom_id].push_back((int32_t)i);
 	auto ev_bytes = [&](const Event &e) -> uint32_t {
-		return std::max(48u, 16u + 8u * (uint32_t)e.N + 4u * (uint32_t)e.K) + 8u * ((1u << e.K) - 1u);
+		return std::max(48u + 16u * (uint32_t)e.N, 16u + 8u * (uint32_t)e.N + 4u * (uint32_t)e.K) + 8u * ((1u << e.K) - 1u);
 	};
 	for (size_t c = 0; c < per_chrom.size(); ++c) {
 		auto &lst = per_chrom[c];
@@ -324,7 +324,7 @@ static int plan_device(lsq_events &E) {
 				uint32_t cap = E.lds_budget;
 				if (n_ev > 0 && (bytes + cb > cap || n_ev + cn > 60000)) break;
 				// a single cluster may exceed the budget as long as it fits the CU's LDS
-				if (n_ev == 0 && (cb > 150u * 1024u || cn > 60000))
+				if (n_ev == 0 && (cb > 120u * 1024u || cn > 60000))
 					return fail(LSQ_E_UNSUPPORTED, "%zu mutually overlapping events on %s need %u bytes of LDS tables (budget %u): not supported by the device path yet",
 					            cn, E.chroms.names[c].c_str(), cb, E.lds_budget);
 				bytes += cb; n_ev += cn; i = j;
@@ -353,10 +353,37 @@ static int plan_device(lsq_events &E) {
 			d.kind = fast ? 1u : 0u;
 			auto align16 = [](uint32_t x) { return (x + 15u) & ~15u; };
 			uint32_t off = 0;
-			uint32_t bins_off = off; off = align16(off + 2 * d.n_bins);
+			uint32_t bins_off = off; off = align16(off + (fast ? 4u : 2u) * d.n_bins);
+			// cells (packed buckets only): segments of events whose span meets no other span
+			std::vector<Cell> cells;
+			if (fast) {
+				uint32_t co2 = 0;
+				for (size_t k = b_begin; k < i; ++k) {
+					const Event &e = E.ev[lst[k]];
+					bool alone = true;
+					for (size_t k2 = b_begin; k2 < i && alone; ++k2)
+						if (k2 != k && E.ev[lst[k2]].gene_start <= e.gene_end && e.gene_start <= E.ev[lst[k2]].gene_end) alone = false;
+					if (alone) {
+						for (int sgi = 0; sgi < e.N; ++sgi) {
+							Cell c;
+							c.lo = (int32_t)e.seg_s[sgi] + (e.seg_s[sgi] == e.gene_start ? 1 : 0);
+							c.hi = (int32_t)e.seg_e[sgi];
+							uint32_t cls = 0;
+							for (int q = 0; q < e.K; ++q) if (e.iso_mask[q] >> sgi & 1) cls |= 1u << q;   // a single segment is a contiguous run of every isoform that holds it
+							c.slot = cls ? co2 + cls - 1 : CELL_NO_CLASS;
+							c.pad = ((uint32_t)(k - b_begin) << 8) | (uint32_t)sgi;
+							if (c.lo < c.hi) cells.push_back(c);
+						}
+					}
+					co2 += (1u << e.K) - 1u;
+				}
+				std::sort(cells.begin(), cells.end(), [](const Cell &x, const Cell &y) { return x.lo < y.lo; });
+				if (cells.size() > 65000) cells.clear();
+			}
 			if (fast) {
 				d.ev_off = off; off = align16(off + (uint32_t)sizeof(FastRec) * d.n_events);
-				d.seg_off = d.iso_off = off;
+				d.seg_off = off; off = align16(off + (uint32_t)sizeof(Cell) * (uint32_t)cells.size());   // cells
+				d.iso_off = (uint32_t)cells.size();                                                       // cell count
 			} else {
 				d.ev_off = off; off = align16(off + 16 * d.n_events);
 				d.seg_off = off; off = align16(off + 8 * nseg);
@@ -373,6 +400,8 @@ static int plan_device(lsq_events &E) {
 			E.images.resize(E.images.size() + d.img_bytes, 0);
 			uint8_t *img = E.images.data() + d.img_off;
 			uint16_t *bins = reinterpret_cast<uint16_t *>(img + bins_off);
+			uint32_t *bins32 = reinterpret_cast<uint32_t *>(img + bins_off);
+			if (fast && !cells.empty()) memcpy(img + d.seg_off, cells.data(), cells.size() * sizeof(Cell));
 			EventRec *recs = reinterpret_cast<EventRec *>(img + d.ev_off);
 			FastRec *frecs = reinterpret_cast<FastRec *>(img + d.ev_off);
 			int32_t *segs = reinterpret_cast<int32_t *>(img + d.seg_off);
@@ -430,12 +459,16 @@ static int plan_device(lsq_events &E) {
 			E.n_cls_total += ncls; E.n_iso_total += niso;
 			// bin k -> first event (span-start order) whose span reaches bin k or beyond
 			uint32_t first = 0;
+			size_t first_cell = 0;
 			for (uint32_t k = 0; k < d.n_bins; ++k) {
 				int64_t bin_lo = lo + ((int64_t)k << shift);
 				// an event is passed over only once its end lies left of a bin start, so it can
 				// never reach a later bin: `first` is min{i : ge_i >= bin_lo} for every k
 				while (first < d.n_events && ends[first] < bin_lo) ++first;
-				bins[k] = (uint16_t)first;
+				if (fast) {
+					while (first_cell < cells.size() && cells[first_cell].hi <= bin_lo) ++first_cell;   // first cell that can hold a base >= bin_lo
+					bins32[k] = first | ((uint32_t)first_cell << 16);
+				} else bins[k] = (uint16_t)first;
 			}
 			if (E.chrom_first_bucket[c] < 0) E.chrom_first_bucket[c] = (int32_t)E.buckets.size();
 			E.cut_lo[c].push_back((int32_t)lo);

@@ -269,7 +269,7 @@ struct FastCtx {                       // wave-uniform state of the bucket being
 	const uint4 *recs;
 	unsigned long long *hist;
 	unsigned n_events, bucket;
-	unsigned long long tile_slot;      // pool index of the tile's first read
+	unsigned long long slot0;          // pool index of the first read of this workgroup's range in the bucket
 	unsigned pool;
 	ExcEntry *exc;
 	unsigned *exc_count;
@@ -280,7 +280,7 @@ __device__ inline void emit_exception(const FastCtx &C, unsigned r, unsigned i, 
 	const unsigned slot = atomicAdd(C.exc_count, 1u);
 	if (slot < C.exc_cap) {
 		ExcEntry e;
-		e.slot = C.tile_slot + r;
+		e.slot = C.slot0 + r;
 		e.bucket = C.bucket;
 		e.ev_pool_scan = i | (C.pool << 30) | (scan << 31);
 		C.exc[slot] = e;
@@ -339,38 +339,48 @@ __device__ inline bool fast_trip(const FastCtx &C, const int4 v, const int total
 	return started && (!(p <= ge) || (w0.y & FAST_FLAG_OVERLAPS_NEXT)) && i + 1 < C.n_events;
 }
 
-// Pending second looks: (tile-local read index | event index << 16).  Most reads are settled by
-// one record; the few that need another (overlapping events, a bin that begins with an event
-// that ends left of the read) are parked here and worked off densely after the tile, instead
-// of making their whole wave loop.
-constexpr unsigned QUEUE_CAP = 1024;
-struct PendingQueues {
-	unsigned *buf[2];
-	unsigned *cnt;      // cnt[0], cnt[1]
+// Parked reads.  The streaming loop settles the commonest shapes with one or two table looks
+// (cells); every other read is parked here -- its blocks, the event to start at, its position in
+// the workgroup's range -- and the general walk runs over the parked reads densely, a few
+// hundred at a time, instead of stalling 64-lane waves on their hardest lane.
+// One-block reads take one 16-byte entry {a, b, event, rel}; two-block reads two.
+constexpr unsigned QUEUE_WORDS = 1024;          // 16-byte words (16 KiB)
+struct Parked {
+	uint4 *buf;
+	unsigned *cnt;
 };
-
-template <int NB>
-__device__ inline void fast_read(const FastCtx &C, const int4 v, const int total, const unsigned r, const unsigned i,
-                                 const bool valid, const PendingQueues &Q, const unsigned qsel) {
-	if (fast_trip<NB>(C, v, total, r, i, valid)) {
-		const unsigned slot = atomicAdd(&Q.cnt[qsel], 1u);
-		if (slot < QUEUE_CAP) Q.buf[qsel][slot] = r | ((i + 1u) << 16);
-		else emit_exception(C, r, i + 1u, 1u);      // queue full: the cleanup kernel finishes this read
-	}
-}
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef const u32x4 __attribute__((address_space(1))) *global_words;
+
+// the general walk over the parked reads [0, n)
+template <int NB>
+__device__ inline void drain_parked(const FastCtx &C, const Parked &Q, const unsigned n) {
+	const unsigned tid = threadIdx.x;
+#pragma unroll 1
+	for (unsigned j0 = 0; j0 < n; j0 += COUNT_BLOCK) {
+		const unsigned j = j0 + tid;
+		bool more = j < n;
+		const unsigned jj = more ? j : 0u;
+		int4 rd; unsigned i, rel;
+		if (NB == 1) { const uint4 e = Q.buf[jj]; rd = make_int4((int)e.x, (int)e.y, (int)e.x, (int)e.y); i = e.z; rel = e.w; }
+		else { const uint4 e0 = Q.buf[2 * jj], e1 = Q.buf[2 * jj + 1]; rd = make_int4((int)e0.x, (int)e0.y, (int)e0.z, (int)e0.w); i = e1.x; rel = e1.y; }
+		const int total = NB == 1 ? rd.y - rd.x : (rd.y - rd.x) + (rd.w - rd.z);
+		while (more) { more = fast_trip<NB>(C, rd, total, rel, i, true); ++i; }
+	}
+}
 
 // Streams the 16-byte words of a pool through an LDS tile: wide coalesced loads by the whole
 // workgroup (the next tile's loads are issued before the current tile is processed), then each
 // lane takes its reads out of LDS.  RPW = reads per word: 2 (pool 1) or 1 (pool 2).
 template <int RPW>
-__device__ inline void stream_pool_fast(FastCtx &C, const unsigned short *bins, const BucketDesc &d, const CountArgs &A,
-                                        uint4 *tile, const PendingQueues &Q, const uint4 *src_generic,
+__device__ inline void stream_pool_fast(FastCtx &C, const unsigned *bins, const uint4 *cells, const unsigned n_cells, const BucketDesc &d,
+                                        const CountArgs &A, uint4 *tile, const Parked &Q, const uint4 *src_generic,
                                         const unsigned long long g0, const unsigned long long g1) {
 	constexpr int NB = RPW == 2 ? 1 : 2;
+	constexpr unsigned CAP = QUEUE_WORDS / NB;          // parked reads that fit
 	C.pool = RPW == 2 ? 0u : 1u;
+	C.slot0 = g0;
 	global_words src = (global_words)src_generic;       // kernel-argument memory: global address space
 	const unsigned tid = threadIdx.x;
 	const unsigned long long w0 = g0 / RPW, w1 = (g1 + RPW - 1) / RPW;
@@ -385,6 +395,11 @@ __device__ inline void stream_pool_fast(FastCtx &C, const unsigned short *bins, 
 			nxt[k] = make_uint4(t.x, t.y, t.z, t.w);
 		}
 	};
+	auto bin_word = [&](int p) {
+		const int rel = p - d.lo;
+		unsigned bin = rel <= 0 ? 0u : ((unsigned)rel >> d.shift);
+		return bins[min(bin, d.n_bins - 1u)];               // first event | first cell << 16
+	};
 	fetch(w0);
 	for (unsigned long long wt = w0; wt < w1; wt += TILE_WORDS) {
 #pragma unroll
@@ -392,60 +407,86 @@ __device__ inline void stream_pool_fast(FastCtx &C, const unsigned short *bins, 
 		__syncthreads();
 		if (wt + TILE_WORDS < w1) fetch(wt + TILE_WORDS);
 		const unsigned long long r_base = wt * RPW;
-		C.tile_slot = r_base;
 		// tile-relative bounds of the reads that belong to this workgroup's range
 		const unsigned lo_r = g0 > r_base ? (unsigned)(g0 - r_base) : 0u;
 		const unsigned hi_r = (unsigned)min((unsigned long long)(TILE_WORDS * RPW), g1 - r_base);
-		auto take = [&](unsigned r, int4 &rd, int &total) {
-			if (RPW == 2) { const int2 t = reinterpret_cast<const int2 *>(tile)[r]; rd = make_int4(t.x, t.y, t.x, t.y); total = t.y - t.x; }
-			else { const uint4 u = tile[r]; rd = make_int4((int)u.x, (int)u.y, (int)u.z, (int)u.w); total = (rd.y - rd.x) + (rd.w - rd.z); }
-		};
+		const unsigned rel0 = (unsigned)(r_base + lo_r - g0) - lo_r;      // rel of tile read r is rel0 + r (wraps to the right value)
 #pragma unroll 1
 		for (int k = 0; k < 4 * RPW; ++k) {
 			const unsigned r = (unsigned)k * COUNT_BLOCK + tid;
 			const bool in = r >= lo_r && r < hi_r;
-			int4 rd; int total;
-			take(r, rd, total);
-			const int rel = rd.x - d.lo;
-			unsigned bin = rel <= 0 ? 0u : ((unsigned)rel >> d.shift);
-			bin = min(bin, d.n_bins - 1u);
-			const unsigned i0 = bins[bin];
-			if (A.ablate & 1u) { asm volatile("" ::"v"(i0), "v"(rd.x), "v"(rd.y), "v"(rd.z), "v"(rd.w)); continue; }
-			fast_read<NB>(C, rd, total, r, i0, in, Q, 0);
-		}
-		// work off the parked second looks, round by round (a round may park third looks)
-		unsigned cur = 0;
-		for (;;) {
-			__syncthreads();
-			const unsigned n = min(Q.cnt[cur], QUEUE_CAP);
-			if (n == 0) break;
-#pragma unroll 1
-			for (unsigned j0 = 0; j0 < n; j0 += COUNT_BLOCK) {
-				const unsigned j = j0 + tid;
-				const bool in = j < n;
-				const unsigned e = Q.buf[cur][in ? j : 0];
-				const unsigned r = e & 0xFFFFu;
-				int4 rd; int total;
-				take(r, rd, total);
-				fast_read<NB>(C, rd, total, r, e >> 16, in, Q, cur ^ 1);
+			if (RPW == 2) {
+				const int2 rd = reinterpret_cast<const int2 *>(tile)[r];
+				const unsigned bw = bin_word(rd.x);
+				if (A.ablate & 1u) { asm volatile("" ::"v"(bw), "v"(rd.x), "v"(rd.y)); continue; }
+				// one block inside one cell: one histogram add, nothing else to decide
+				const unsigned ci = bw >> 16;
+				const uint4 cw = cells[min(ci, n_cells - 1u)];
+				const bool hit = in && ci < n_cells && (int)cw.x <= rd.x && rd.y <= (int)cw.y && !(A.ablate & 8u);
+				if (hit) {
+					if (cw.z != CELL_NO_CLASS) atomicAdd(&C.hist[cw.z], (1ull << 40) | (unsigned long long)(unsigned)(rd.y - rd.x));
+				} else if (in && !(A.ablate & 16u)) {
+					const unsigned slot = atomicAdd(Q.cnt, 1u);
+					if (slot < CAP) Q.buf[slot] = make_uint4((unsigned)rd.x, (unsigned)rd.y, bw & 0xFFFFu, rel0 + r);
+					else emit_exception(C, rel0 + r, bw & 0xFFFFu, 1u);
+				}
+			} else {
+				const uint4 u = tile[r];
+				const int4 rd = make_int4((int)u.x, (int)u.y, (int)u.z, (int)u.w);
+				const unsigned bw1 = bin_word(rd.x), bw2 = bin_word(rd.z);
+				if (A.ablate & 1u) { asm volatile("" ::"v"(bw1), "v"(bw2), "v"(rd.x), "v"(rd.y), "v"(rd.z), "v"(rd.w)); continue; }
+				// the usual junction read: block 1 runs to the end of one segment, block 2 starts on the
+				// first base of a later segment of the same event and ends inside it
+				const unsigned c1 = bw1 >> 16, c2 = bw2 >> 16;
+				const uint4 cw1 = cells[min(c1, n_cells - 1u)], cw2 = cells[min(c2, n_cells - 1u)];
+				const bool hit = in && c1 < n_cells && c2 < n_cells && (int)cw1.x <= rd.x && rd.y == (int)cw1.y &&
+				                 rd.z == (int)cw2.x && rd.w <= (int)cw2.y && (cw1.w >> 8) == (cw2.w >> 8) && (cw2.w & 0xFFu) > (cw1.w & 0xFFu) &&
+				                 !(A.ablate & 8u);
+				if (hit) {
+					const unsigned ev = cw1.w >> 8;
+					const uint4 w0 = C.recs[3u * ev];
+					const unsigned long long tbl = ((unsigned long long)w0.w << 32) | w0.z;
+					const unsigned mask = (1u << (cw1.w & 0xFFu)) | (1u << (cw2.w & 0xFFu));
+					const unsigned cls = (unsigned)(tbl >> (4u * mask)) & 0xFu;
+					if (cls) atomicAdd(&C.hist[(w0.y & 0xFFFFu) + cls - 1], (1ull << 40) | (unsigned long long)(unsigned)((rd.y - rd.x) + (rd.w - rd.z)));
+				} else if (in && !(A.ablate & 16u)) {
+					const unsigned slot = atomicAdd(Q.cnt, 1u);
+					if (slot < CAP) { Q.buf[2 * slot] = u; Q.buf[2 * slot + 1] = make_uint4(bw1 & 0xFFFFu, rel0 + r, 0u, 0u); }
+					else emit_exception(C, rel0 + r, bw1 & 0xFFFFu, 1u);
+				}
 			}
-			__syncthreads();
-			if (tid == 0) Q.cnt[cur] = 0;
-			cur ^= 1;
 		}
-		// both counters are zero here; the barrier inside the loop ordered that before the next tile
+		__syncthreads();
+		// enough parked reads for a dense pass?  (the same value in every lane: read after the barrier)
+		const unsigned n = min(*Q.cnt, CAP);
+		if (n >= CAP / 2) {
+			if (!(A.ablate & 32u)) drain_parked<NB>(C, Q, n);
+			__syncthreads();
+			if (tid == 0) *Q.cnt = 0;
+			__syncthreads();
+		}
 	}
+	__syncthreads();
+	const unsigned n = min(*Q.cnt, CAP);
+	if (n) {
+		if (!(A.ablate & 32u)) drain_parked<NB>(C, Q, n);
+		__syncthreads();
+		if (tid == 0) *Q.cnt = 0;
+	}
+	__syncthreads();
 }
 
-__global__ void __launch_bounds__(COUNT_BLOCK) lsq_count_fast_kernel(CountArgs A) {
+#ifndef LSQ_FAST_WAVES
+#define LSQ_FAST_WAVES 1
+#endif
+__global__ void __launch_bounds__(COUNT_BLOCK, LSQ_FAST_WAVES) lsq_count_fast_kernel(CountArgs A) {
 	extern __shared__ __align__(16) unsigned char lds[];
 	uint4 *tile = reinterpret_cast<uint4 *>(lds + A.tables_lds_bytes);
-	PendingQueues Q;
-	Q.buf[0] = reinterpret_cast<unsigned *>(lds + A.tables_lds_bytes + TILE_WORDS * 16);
-	Q.buf[1] = Q.buf[0] + QUEUE_CAP;
-	Q.cnt = Q.buf[1] + QUEUE_CAP;
+	Parked Q;
+	Q.buf = reinterpret_cast<uint4 *>(lds + A.tables_lds_bytes + TILE_WORDS * 16);
+	Q.cnt = reinterpret_cast<unsigned *>(Q.buf + QUEUE_WORDS);
 	const unsigned tid = threadIdx.x;
-	if (tid == 0) { Q.cnt[0] = 0; Q.cnt[1] = 0; }
+	if (tid == 0) *Q.cnt = 0;
 	const unsigned long long s_begin = A.total_slots * blockIdx.x / gridDim.x;
 	const unsigned long long s_end = A.total_slots * (blockIdx.x + 1ull) / gridDim.x;
 	if (s_begin >= s_end) return;
@@ -469,12 +510,13 @@ __global__ void __launch_bounds__(COUNT_BLOCK) lsq_count_fast_kernel(CountArgs A
 			for (unsigned i = tid; i < d.n_cls; i += COUNT_BLOCK) h[i] = 0;
 		}
 		__syncthreads();
-		const unsigned short *bins = reinterpret_cast<const unsigned short *>(lds);
+		const unsigned *bins = reinterpret_cast<const unsigned *>(lds);
+		const uint4 *cells = reinterpret_cast<const uint4 *>(lds + d.seg_off);
 		FastCtx C;
 		C.recs = reinterpret_cast<const uint4 *>(lds + d.ev_off);
 		C.hist = reinterpret_cast<unsigned long long *>(lds + d.hist_off);
 		C.n_events = d.n_events; C.bucket = b;
-		C.tile_slot = 0; C.pool = 0;
+		C.slot0 = 0; C.pool = 0;
 		C.exc = A.exc; C.exc_count = A.exc_count; C.exc_cap = A.exc_cap;
 		const unsigned long long l0 = (s_begin > bs ? s_begin : bs) - bs;
 		const unsigned long long l1 = (s_end < be ? s_end : be) - bs;
@@ -483,12 +525,12 @@ __global__ void __launch_bounds__(COUNT_BLOCK) lsq_count_fast_kernel(CountArgs A
 		// ---- pool 1
 		if (l0 < n1) {
 			const unsigned long long base = A.p1_off[b];
-			stream_pool_fast<2>(C, bins, d, A, tile, Q, reinterpret_cast<const uint4 *>(A.p1), base + l0, base + (l1 < n1 ? l1 : n1));
+			stream_pool_fast<2>(C, bins, cells, d.iso_off, d, A, tile, Q, reinterpret_cast<const uint4 *>(A.p1), base + l0, base + (l1 < n1 ? l1 : n1));
 		}
 		// ---- pool 2
 		if (l1 > n1 && l0 < n1 + n2) {
 			const unsigned long long base = A.p2_off[b];
-			stream_pool_fast<1>(C, bins, d, A, tile, Q, reinterpret_cast<const uint4 *>(A.p2), base + ((l0 > n1 ? l0 : n1) - n1),
+			stream_pool_fast<1>(C, bins, cells, d.iso_off, d, A, tile, Q, reinterpret_cast<const uint4 *>(A.p2), base + ((l0 > n1 ? l0 : n1) - n1),
 			                    base + ((l1 < n1 + n2 ? l1 : n1 + n2) - n1));
 		}
 		// (reads with three or more blocks are left to the cleanup kernel)
@@ -513,14 +555,14 @@ __global__ void __launch_bounds__(COUNT_BLOCK) lsq_count_fast_kernel(CountArgs A
 // =====================================================================================
 struct GlobalBucket {
 	const BucketDesc *d;
-	const unsigned short *bins;
+	const unsigned *bins;          // packed buckets: first event | first cell << 16
 	const uint4 *recs;
 };
 
 __device__ inline GlobalBucket global_bucket(const CountArgs &A, unsigned b) {
 	GlobalBucket G;
 	G.d = A.buckets + b;
-	G.bins = reinterpret_cast<const unsigned short *>(A.images + G.d->img_off);
+	G.bins = reinterpret_cast<const unsigned *>(A.images + G.d->img_off);
 	G.recs = reinterpret_cast<const uint4 *>(A.images + G.d->img_off + G.d->ev_off);
 	return G;
 }
@@ -565,7 +607,7 @@ __device__ inline unsigned first_event_for(const GlobalBucket &G, int p) {
 	const int rel = p - d.lo;
 	unsigned bin = rel <= 0 ? 0u : ((unsigned)rel >> d.shift);
 	bin = min(bin, d.n_bins - 1u);
-	return G.bins[bin];
+	return G.bins[bin] & 0xFFFFu;
 }
 
 __device__ inline unsigned bucket_of_slot(const unsigned long long *off, unsigned n_buckets, unsigned long long g) {
@@ -911,7 +953,7 @@ static int run_count(lsq_ctx *c, bool all_reads) {
 	HIP_TRY(hipMemsetAsync(c->exc_count.p, 0, c->exc_count.n * sizeof(unsigned), st));
 	HIP_TRY(hipEventRecord(c->ev0, st));      // ev0..ev1 brackets the count kernel launches only
 	const unsigned tables_bytes = (std::max<unsigned>(E.max_lds_bytes, 16) + 15u) & ~15u;
-	const unsigned lds_bytes = tables_bytes + TILE_WORDS * 16 + 2 * QUEUE_CAP * 4 + 16;
+	const unsigned lds_bytes = tables_bytes + TILE_WORDS * 16 + QUEUE_WORDS * 16 + 16;
 	if (lds_bytes > 160 * 1024) return fail(LSQ_E_UNSUPPORTED, "bucket tables + read tile exceed the CU's LDS");
 	if (lds_bytes > 64 * 1024) {
 		HIP_TRY(hipFuncSetAttribute((const void *)lsq_count_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));

@@ -100,6 +100,17 @@ constexpr uint32_t FAST_ABUT_SHIFT = 16;
 constexpr uint32_t FAST_FLAG_OVERLAPS_NEXT = 1u << 19;
 constexpr uint32_t FAST_NSEG_SHIFT = 24;
 
+// Shortcut for the commonest read: one block that lies inside one segment of an event whose span
+// no other event touches, and does not start on the span's first base.  Such a read is valid for
+// exactly that event with matched == its length, and its class is that of the single segment.
+struct Cell {
+	int32_t lo, hi;        // a read [a,b) with lo <= a and b <= hi qualifies
+	uint32_t slot;         // histogram slot inside the bucket, or CELL_NO_CLASS
+	uint32_t pad;          // event index in the bucket << 8 | segment index
+};
+static_assert(sizeof(Cell) == 16, "Cell layout");
+constexpr uint32_t CELL_NO_CLASS = 0xFFFFFFFFu;
+
 struct TieRec {            // global memory, device event order; read only on start ties
 	uint8_t strand_id;
 	uint8_t tie_mode;

@@ -12,8 +12,10 @@ for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
     acc = defaultdict(lambda: [0.0, 0])
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
-            if "lsq_count_kernel" not in row.get("Kernel_Name", ""): continue
-            a = acc[row["Counter_Name"]]; a[0] += float(row["Counter_Value"]); a[1] += 1
-    print("== %s (mean per lsq_count_kernel dispatch)" % os.path.basename(d))
-    for k, (v, n) in sorted(acc.items()):
-        print("   %-28s %18.1f  (n=%d)" % (k, v / max(n, 1), n))
+            kn = row.get("Kernel_Name", "")
+            if "lsq_" not in kn: continue
+            kn = kn.split("lsq_")[1].split("(")[0]
+            a = acc[(kn, row["Counter_Name"])]; a[0] += float(row["Counter_Value"]); a[1] += 1
+    print("== %s (mean per dispatch)" % os.path.basename(d))
+    for (kn, k), (v, n) in sorted(acc.items()):
+        print("   %-22s %-28s %18.1f  (n=%d)" % (kn, k, v / max(n, 1), n))
