@@ -340,33 +340,48 @@ __device__ inline bool fast_trip(const FastCtx &C, const int4 v, const int total
 }
 
 // Parked reads.  The streaming loop settles the commonest shapes with one or two table looks
-// (cells); every other read is parked here -- its blocks, the event to start at, its position in
-// the workgroup's range -- and the general walk runs over the parked reads densely, a few
-// hundred at a time, instead of stalling 64-lane waves on their hardest lane.
-// One-block reads take one 16-byte entry {a, b, event, rel}; two-block reads two.
-constexpr unsigned QUEUE_WORDS = 1024;          // 16-byte words (16 KiB)
+// (cells); every other read of the tile is parked here (tile-local read index | event to start
+// at << 16) and the general walk then runs over the parked reads densely, instead of stalling
+// 64-lane waves on their hardest lane.  One entry per read of a tile at most: never overflows.
+constexpr unsigned QUEUE_ENTRIES = TILE_WORDS * 2;          // 4-byte entries (8 KiB)
 struct Parked {
-	uint4 *buf;
+	unsigned *buf;
 	unsigned *cnt;
 };
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef const u32x4 __attribute__((address_space(1))) *global_words;
 
-// the general walk over the parked reads [0, n)
+// One LDS atomic per wave: the lanes that want a slot are counted by ballot, the first of them
+// reserves the block, every lane takes base + its rank among them.
+__device__ inline unsigned wave_alloc(unsigned *counter, bool want) {
+	const unsigned long long m = __ballot(want);
+	if (m == 0) return 0u;                                   // wave-uniform
+	const unsigned lane = __lane_id();
+	const unsigned rank = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+	const unsigned leader = (unsigned)__ffsll((long long)m) - 1u;
+	unsigned base = 0;
+	if (lane == leader) base = atomicAdd(counter, (unsigned)__popcll(m));
+	base = (unsigned)__shfl((int)base, (int)leader);
+	return base + rank;
+}
+
+// the general walk over the parked reads [0, n) of the current tile
 template <int NB>
-__device__ inline void drain_parked(const FastCtx &C, const Parked &Q, const unsigned n) {
+__device__ inline void drain_parked(const FastCtx &C, const Parked &Q, const uint4 *tile, const unsigned rel0, const unsigned n) {
 	const unsigned tid = threadIdx.x;
 #pragma unroll 1
 	for (unsigned j0 = 0; j0 < n; j0 += COUNT_BLOCK) {
 		const unsigned j = j0 + tid;
 		bool more = j < n;
-		const unsigned jj = more ? j : 0u;
-		int4 rd; unsigned i, rel;
-		if (NB == 1) { const uint4 e = Q.buf[jj]; rd = make_int4((int)e.x, (int)e.y, (int)e.x, (int)e.y); i = e.z; rel = e.w; }
-		else { const uint4 e0 = Q.buf[2 * jj], e1 = Q.buf[2 * jj + 1]; rd = make_int4((int)e0.x, (int)e0.y, (int)e0.z, (int)e0.w); i = e1.x; rel = e1.y; }
+		const unsigned e = Q.buf[more ? j : 0u];
+		const unsigned r = e & 0xFFFFu;
+		unsigned i = e >> 16;
+		int4 rd;
+		if (NB == 1) { const int2 t = reinterpret_cast<const int2 *>(tile)[r]; rd = make_int4(t.x, t.y, t.x, t.y); }
+		else { const uint4 u = tile[r]; rd = make_int4((int)u.x, (int)u.y, (int)u.z, (int)u.w); }
 		const int total = NB == 1 ? rd.y - rd.x : (rd.y - rd.x) + (rd.w - rd.z);
-		while (more) { more = fast_trip<NB>(C, rd, total, rel, i, true); ++i; }
+		while (more) { more = fast_trip<NB>(C, rd, total, rel0 + r, i, true); ++i; }
 	}
 }
 
@@ -378,7 +393,6 @@ __device__ inline void stream_pool_fast(FastCtx &C, const unsigned *bins, const 
                                         const CountArgs &A, uint4 *tile, const Parked &Q, const uint4 *src_generic,
                                         const unsigned long long g0, const unsigned long long g1) {
 	constexpr int NB = RPW == 2 ? 1 : 2;
-	constexpr unsigned CAP = QUEUE_WORDS / NB;          // parked reads that fit
 	C.pool = RPW == 2 ? 0u : 1u;
 	C.slot0 = g0;
 	global_words src = (global_words)src_generic;       // kernel-argument memory: global address space
@@ -423,13 +437,10 @@ __device__ inline void stream_pool_fast(FastCtx &C, const unsigned *bins, const 
 				const unsigned ci = bw >> 16;
 				const uint4 cw = cells[min(ci, n_cells - 1u)];
 				const bool hit = in && ci < n_cells && (int)cw.x <= rd.x && rd.y <= (int)cw.y && !(A.ablate & 8u);
-				if (hit) {
-					if (cw.z != CELL_NO_CLASS) atomicAdd(&C.hist[cw.z], (1ull << 40) | (unsigned long long)(unsigned)(rd.y - rd.x));
-				} else if (in && !(A.ablate & 16u)) {
-					const unsigned slot = atomicAdd(Q.cnt, 1u);
-					if (slot < CAP) Q.buf[slot] = make_uint4((unsigned)rd.x, (unsigned)rd.y, bw & 0xFFFFu, rel0 + r);
-					else emit_exception(C, rel0 + r, bw & 0xFFFFu, 1u);
-				}
+				if (hit && cw.z != CELL_NO_CLASS) atomicAdd(&C.hist[cw.z], (1ull << 40) | (unsigned long long)(unsigned)(rd.y - rd.x));
+				const bool park = in && !hit && !(A.ablate & 16u);
+				const unsigned slot = wave_alloc(Q.cnt, park);
+				if (park) Q.buf[slot] = r | ((bw & 0xFFFFu) << 16);
 			} else {
 				const uint4 u = tile[r];
 				const int4 rd = make_int4((int)u.x, (int)u.y, (int)u.z, (int)u.w);
@@ -449,29 +460,20 @@ __device__ inline void stream_pool_fast(FastCtx &C, const unsigned *bins, const 
 					const unsigned mask = (1u << (cw1.w & 0xFFu)) | (1u << (cw2.w & 0xFFu));
 					const unsigned cls = (unsigned)(tbl >> (4u * mask)) & 0xFu;
 					if (cls) atomicAdd(&C.hist[(w0.y & 0xFFFFu) + cls - 1], (1ull << 40) | (unsigned long long)(unsigned)((rd.y - rd.x) + (rd.w - rd.z)));
-				} else if (in && !(A.ablate & 16u)) {
-					const unsigned slot = atomicAdd(Q.cnt, 1u);
-					if (slot < CAP) { Q.buf[2 * slot] = u; Q.buf[2 * slot + 1] = make_uint4(bw1 & 0xFFFFu, rel0 + r, 0u, 0u); }
-					else emit_exception(C, rel0 + r, bw1 & 0xFFFFu, 1u);
 				}
+				const bool park = in && !hit && !(A.ablate & 16u);
+				const unsigned slot = wave_alloc(Q.cnt, park);
+				if (park) Q.buf[slot] = r | ((bw1 & 0xFFFFu) << 16);
 			}
 		}
 		__syncthreads();
-		// enough parked reads for a dense pass?  (the same value in every lane: read after the barrier)
-		const unsigned n = min(*Q.cnt, CAP);
-		if (n >= CAP / 2) {
-			if (!(A.ablate & 32u)) drain_parked<NB>(C, Q, n);
+		// dense pass over what this tile parked (the same count in every lane: read after the barrier)
+		const unsigned n = *Q.cnt;
+		if (n) {
+			if (!(A.ablate & 32u)) drain_parked<NB>(C, Q, tile, rel0, n);
 			__syncthreads();
-			if (tid == 0) *Q.cnt = 0;
-			__syncthreads();
+			if (tid == 0) *Q.cnt = 0;       // ordered before the next tile's parking by the barrier after its store
 		}
-	}
-	__syncthreads();
-	const unsigned n = min(*Q.cnt, CAP);
-	if (n) {
-		if (!(A.ablate & 32u)) drain_parked<NB>(C, Q, n);
-		__syncthreads();
-		if (tid == 0) *Q.cnt = 0;
 	}
 	__syncthreads();
 }
@@ -483,8 +485,8 @@ __global__ void __launch_bounds__(COUNT_BLOCK, LSQ_FAST_WAVES) lsq_count_fast_ke
 	extern __shared__ __align__(16) unsigned char lds[];
 	uint4 *tile = reinterpret_cast<uint4 *>(lds + A.tables_lds_bytes);
 	Parked Q;
-	Q.buf = reinterpret_cast<uint4 *>(lds + A.tables_lds_bytes + TILE_WORDS * 16);
-	Q.cnt = reinterpret_cast<unsigned *>(Q.buf + QUEUE_WORDS);
+	Q.buf = reinterpret_cast<unsigned *>(lds + A.tables_lds_bytes + TILE_WORDS * 16);
+	Q.cnt = Q.buf + QUEUE_ENTRIES;
 	const unsigned tid = threadIdx.x;
 	if (tid == 0) *Q.cnt = 0;
 	const unsigned long long s_begin = A.total_slots * blockIdx.x / gridDim.x;
@@ -953,7 +955,7 @@ static int run_count(lsq_ctx *c, bool all_reads) {
 	HIP_TRY(hipMemsetAsync(c->exc_count.p, 0, c->exc_count.n * sizeof(unsigned), st));
 	HIP_TRY(hipEventRecord(c->ev0, st));      // ev0..ev1 brackets the count kernel launches only
 	const unsigned tables_bytes = (std::max<unsigned>(E.max_lds_bytes, 16) + 15u) & ~15u;
-	const unsigned lds_bytes = tables_bytes + TILE_WORDS * 16 + QUEUE_WORDS * 16 + 16;
+	const unsigned lds_bytes = tables_bytes + TILE_WORDS * 16 + QUEUE_ENTRIES * 4 + 16;
 	if (lds_bytes > 160 * 1024) return fail(LSQ_E_UNSUPPORTED, "bucket tables + read tile exceed the CU's LDS");
 	if (lds_bytes > 64 * 1024) {
 		HIP_TRY(hipFuncSetAttribute((const void *)lsq_count_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
