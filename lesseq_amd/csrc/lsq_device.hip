@@ -38,7 +38,6 @@ using namespace lsq;
 namespace {
 
 constexpr int COUNT_BLOCK = 256;
-constexpr int TILE_WORDS = COUNT_BLOCK * 4;      // 16-byte words per read tile (16 KiB): 2048 one-block reads or 1024 two-block reads
 constexpr unsigned long long BASES_MASK = (1ull << 40) - 1;
 
 // A (read, event) pair the fast kernel does not settle itself: span-start ties that need the
@@ -340,70 +339,46 @@ __device__ inline bool fast_trip(const FastCtx &C, const int4 v, const int total
 }
 
 // Parked reads.  The streaming loop settles the commonest shapes with one or two table looks
-// (cells); every other read of the tile is parked here (tile-local read index | event to start
-// at << 16) and the general walk then runs over the parked reads densely, instead of stalling
-// 64-lane waves on their hardest lane.  One entry per read of a tile at most: never overflows.
-constexpr unsigned QUEUE_ENTRIES = TILE_WORDS * 2;          // 4-byte entries (8 KiB)
-struct Parked {
-	unsigned *buf;
-	unsigned *cnt;
-};
+// (cells); every other read of the tile is parked (tile-local read index | event to start at
+// << 16) and the general walk then runs over the parked reads densely, instead of stalling a
+// 64-lane wave on its hardest lane.
+//
+// Each wave streams its own part of the workgroup's range through its own LDS tile and its own
+// parking area: no workgroup barrier inside the stream, a slow wave never holds up the others.
+constexpr unsigned WAVE_TILE_WORDS = 256;                     // 16-byte words per wave tile (4 KiB): 512 / 256 reads
+constexpr unsigned WAVE_QUEUE = WAVE_TILE_WORDS * 2;          // 4-byte entries (2 KiB): one per read of a tile at most
+constexpr unsigned WAVES = COUNT_BLOCK / 64;
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef const u32x4 __attribute__((address_space(1))) *global_words;
 
-// One LDS atomic per wave: the lanes that want a slot are counted by ballot, the first of them
-// reserves the block, every lane takes base + its rank among them.
-__device__ inline unsigned wave_alloc(unsigned *counter, bool want) {
-	const unsigned long long m = __ballot(want);
-	if (m == 0) return 0u;                                   // wave-uniform
-	const unsigned lane = __lane_id();
-	const unsigned rank = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-	const unsigned leader = (unsigned)__ffsll((long long)m) - 1u;
-	unsigned base = 0;
-	if (lane == leader) base = atomicAdd(counter, (unsigned)__popcll(m));
-	base = (unsigned)__shfl((int)base, (int)leader);
-	return base + rank;
+__device__ inline void wave_sync_lds() {
+	// LDS operations of one wave complete in order; this only keeps the compiler from moving
+	// accesses of other lanes' data across the point
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
 }
 
-// the general walk over the parked reads [0, n) of the current tile
-template <int NB>
-__device__ inline void drain_parked(const FastCtx &C, const Parked &Q, const uint4 *tile, const unsigned rel0, const unsigned n) {
-	const unsigned tid = threadIdx.x;
-#pragma unroll 1
-	for (unsigned j0 = 0; j0 < n; j0 += COUNT_BLOCK) {
-		const unsigned j = j0 + tid;
-		bool more = j < n;
-		const unsigned e = Q.buf[more ? j : 0u];
-		const unsigned r = e & 0xFFFFu;
-		unsigned i = e >> 16;
-		int4 rd;
-		if (NB == 1) { const int2 t = reinterpret_cast<const int2 *>(tile)[r]; rd = make_int4(t.x, t.y, t.x, t.y); }
-		else { const uint4 u = tile[r]; rd = make_int4((int)u.x, (int)u.y, (int)u.z, (int)u.w); }
-		const int total = NB == 1 ? rd.y - rd.x : (rd.y - rd.x) + (rd.w - rd.z);
-		while (more) { more = fast_trip<NB>(C, rd, total, rel0 + r, i, true); ++i; }
-	}
-}
-
-// Streams the 16-byte words of a pool through an LDS tile: wide coalesced loads by the whole
-// workgroup (the next tile's loads are issued before the current tile is processed), then each
-// lane takes its reads out of LDS.  RPW = reads per word: 2 (pool 1) or 1 (pool 2).
+// RPW = reads per 16-byte word: 2 (pool 1: one block) or 1 (pool 2: two blocks)
 template <int RPW>
 __device__ inline void stream_pool_fast(FastCtx &C, const unsigned *bins, const uint4 *cells, const unsigned n_cells, const BucketDesc &d,
-                                        const CountArgs &A, uint4 *tile, const Parked &Q, const uint4 *src_generic,
+                                        const CountArgs &A, uint4 *wave_tile, unsigned *wave_queue, const uint4 *src_generic,
                                         const unsigned long long g0, const unsigned long long g1) {
 	constexpr int NB = RPW == 2 ? 1 : 2;
 	C.pool = RPW == 2 ? 0u : 1u;
 	C.slot0 = g0;
 	global_words src = (global_words)src_generic;       // kernel-argument memory: global address space
-	const unsigned tid = threadIdx.x;
+	const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	// words [w0, w1) of the workgroup; this wave takes a contiguous quarter, in whole tiles
 	const unsigned long long w0 = g0 / RPW, w1 = (g1 + RPW - 1) / RPW;
+	const unsigned long long per_wave = ((w1 - w0 + WAVES - 1) / WAVES + WAVE_TILE_WORDS - 1) / WAVE_TILE_WORDS * WAVE_TILE_WORDS;
+	const unsigned long long ww0 = min(w0 + wave * per_wave, w1), ww1 = min(ww0 + per_wave, w1);
 	uint4 nxt[4];
 	auto fetch = [&](unsigned long long wt) {
-		const unsigned n = (unsigned)min((unsigned long long)TILE_WORDS, w1 - wt);
+		const unsigned n = (unsigned)min((unsigned long long)WAVE_TILE_WORDS, ww1 - wt);
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
-			const unsigned w = (unsigned)k * COUNT_BLOCK + tid;
+			const unsigned w = (unsigned)k * 64u + lane;
 			u32x4 t = {0u, 0u, 0u, 0u};
 			if (w < n) t = src[wt + w];
 			nxt[k] = make_uint4(t.x, t.y, t.z, t.w);
@@ -414,23 +389,26 @@ __device__ inline void stream_pool_fast(FastCtx &C, const unsigned *bins, const 
 		unsigned bin = rel <= 0 ? 0u : ((unsigned)rel >> d.shift);
 		return bins[min(bin, d.n_bins - 1u)];               // first event | first cell << 16
 	};
-	fetch(w0);
-	for (unsigned long long wt = w0; wt < w1; wt += TILE_WORDS) {
+	if (ww0 < ww1) fetch(ww0);
+	for (unsigned long long wt = ww0; wt < ww1; wt += WAVE_TILE_WORDS) {
 #pragma unroll
-		for (int k = 0; k < 4; ++k) tile[k * COUNT_BLOCK + tid] = nxt[k];
-		__syncthreads();
-		if (wt + TILE_WORDS < w1) fetch(wt + TILE_WORDS);
+		for (int k = 0; k < 4; ++k) wave_tile[k * 64 + lane] = nxt[k];
+		wave_sync_lds();
+		if (wt + WAVE_TILE_WORDS < ww1) fetch(wt + WAVE_TILE_WORDS);
 		const unsigned long long r_base = wt * RPW;
-		// tile-relative bounds of the reads that belong to this workgroup's range
+		// tile-relative bounds of the reads that belong to the workgroup's range
 		const unsigned lo_r = g0 > r_base ? (unsigned)(g0 - r_base) : 0u;
-		const unsigned hi_r = (unsigned)min((unsigned long long)(TILE_WORDS * RPW), g1 - r_base);
-		const unsigned rel0 = (unsigned)(r_base + lo_r - g0) - lo_r;      // rel of tile read r is rel0 + r (wraps to the right value)
+		const unsigned hi_r = (unsigned)min((unsigned long long)(WAVE_TILE_WORDS * RPW), g1 - r_base);
+		const unsigned rel0 = (unsigned)(r_base + lo_r - g0) - lo_r;      // position of tile read r in the range: rel0 + r
+		unsigned qn = 0;                                                   // parked so far (the same in every lane)
 #pragma unroll 1
 		for (int k = 0; k < 4 * RPW; ++k) {
-			const unsigned r = (unsigned)k * COUNT_BLOCK + tid;
+			const unsigned r = (unsigned)k * 64u + lane;
 			const bool in = r >= lo_r && r < hi_r;
+			bool park;
+			unsigned entry;
 			if (RPW == 2) {
-				const int2 rd = reinterpret_cast<const int2 *>(tile)[r];
+				const int2 rd = reinterpret_cast<const int2 *>(wave_tile)[r];
 				const unsigned bw = bin_word(rd.x);
 				if (A.ablate & 1u) { asm volatile("" ::"v"(bw), "v"(rd.x), "v"(rd.y)); continue; }
 				// one block inside one cell: one histogram add, nothing else to decide
@@ -438,11 +416,10 @@ __device__ inline void stream_pool_fast(FastCtx &C, const unsigned *bins, const 
 				const uint4 cw = cells[min(ci, n_cells - 1u)];
 				const bool hit = in && ci < n_cells && (int)cw.x <= rd.x && rd.y <= (int)cw.y && !(A.ablate & 8u);
 				if (hit && cw.z != CELL_NO_CLASS) atomicAdd(&C.hist[cw.z], (1ull << 40) | (unsigned long long)(unsigned)(rd.y - rd.x));
-				const bool park = in && !hit && !(A.ablate & 16u);
-				const unsigned slot = wave_alloc(Q.cnt, park);
-				if (park) Q.buf[slot] = r | ((bw & 0xFFFFu) << 16);
+				park = in && !hit && !(A.ablate & 16u);
+				entry = r | ((bw & 0xFFFFu) << 16);
 			} else {
-				const uint4 u = tile[r];
+				const uint4 u = wave_tile[r];
 				const int4 rd = make_int4((int)u.x, (int)u.y, (int)u.z, (int)u.w);
 				const unsigned bw1 = bin_word(rd.x), bw2 = bin_word(rd.z);
 				if (A.ablate & 1u) { asm volatile("" ::"v"(bw1), "v"(bw2), "v"(rd.x), "v"(rd.y), "v"(rd.z), "v"(rd.w)); continue; }
@@ -455,27 +432,39 @@ __device__ inline void stream_pool_fast(FastCtx &C, const unsigned *bins, const 
 				                 !(A.ablate & 8u);
 				if (hit) {
 					const unsigned ev = cw1.w >> 8;
-					const uint4 w0 = C.recs[3u * ev];
-					const unsigned long long tbl = ((unsigned long long)w0.w << 32) | w0.z;
+					const uint4 w0r = C.recs[3u * ev];
+					const unsigned long long tbl = ((unsigned long long)w0r.w << 32) | w0r.z;
 					const unsigned mask = (1u << (cw1.w & 0xFFu)) | (1u << (cw2.w & 0xFFu));
 					const unsigned cls = (unsigned)(tbl >> (4u * mask)) & 0xFu;
-					if (cls) atomicAdd(&C.hist[(w0.y & 0xFFFFu) + cls - 1], (1ull << 40) | (unsigned long long)(unsigned)((rd.y - rd.x) + (rd.w - rd.z)));
+					if (cls) atomicAdd(&C.hist[(w0r.y & 0xFFFFu) + cls - 1], (1ull << 40) | (unsigned long long)(unsigned)((rd.y - rd.x) + (rd.w - rd.z)));
 				}
-				const bool park = in && !hit && !(A.ablate & 16u);
-				const unsigned slot = wave_alloc(Q.cnt, park);
-				if (park) Q.buf[slot] = r | ((bw1 & 0xFFFFu) << 16);
+				park = in && !hit && !(A.ablate & 16u);
+				entry = r | ((bw1 & 0xFFFFu) << 16);
+			}
+			// park: ranks by ballot, no atomic
+			const unsigned long long m = __ballot(park);
+			if (park) wave_queue[qn + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = entry;
+			qn += (unsigned)__popcll(m);
+		}
+		wave_sync_lds();
+		// dense pass of the general walk over what this tile parked
+		if (!(A.ablate & 32u)) {
+#pragma unroll 1
+			for (unsigned j0 = 0; j0 < qn; j0 += 64u) {
+				const unsigned j = j0 + lane;
+				bool more = j < qn;
+				const unsigned e = wave_queue[more ? j : 0u];
+				const unsigned r = e & 0xFFFFu;
+				unsigned i = e >> 16;
+				int4 rd;
+				if (NB == 1) { const int2 t = reinterpret_cast<const int2 *>(wave_tile)[r]; rd = make_int4(t.x, t.y, t.x, t.y); }
+				else { const uint4 u = wave_tile[r]; rd = make_int4((int)u.x, (int)u.y, (int)u.z, (int)u.w); }
+				const int total = NB == 1 ? rd.y - rd.x : (rd.y - rd.x) + (rd.w - rd.z);
+				while (more) { more = fast_trip<NB>(C, rd, total, rel0 + r, i, true); ++i; }
 			}
 		}
-		__syncthreads();
-		// dense pass over what this tile parked (the same count in every lane: read after the barrier)
-		const unsigned n = *Q.cnt;
-		if (n) {
-			if (!(A.ablate & 32u)) drain_parked<NB>(C, Q, tile, rel0, n);
-			__syncthreads();
-			if (tid == 0) *Q.cnt = 0;       // ordered before the next tile's parking by the barrier after its store
-		}
+		wave_sync_lds();
 	}
-	__syncthreads();
 }
 
 #ifndef LSQ_FAST_WAVES
@@ -483,12 +472,9 @@ __device__ inline void stream_pool_fast(FastCtx &C, const unsigned *bins, const 
 #endif
 __global__ void __launch_bounds__(COUNT_BLOCK, LSQ_FAST_WAVES) lsq_count_fast_kernel(CountArgs A) {
 	extern __shared__ __align__(16) unsigned char lds[];
-	uint4 *tile = reinterpret_cast<uint4 *>(lds + A.tables_lds_bytes);
-	Parked Q;
-	Q.buf = reinterpret_cast<unsigned *>(lds + A.tables_lds_bytes + TILE_WORDS * 16);
-	Q.cnt = Q.buf + QUEUE_ENTRIES;
 	const unsigned tid = threadIdx.x;
-	if (tid == 0) *Q.cnt = 0;
+	uint4 *wave_tile = reinterpret_cast<uint4 *>(lds + A.tables_lds_bytes) + (tid >> 6) * WAVE_TILE_WORDS;
+	unsigned *wave_queue = reinterpret_cast<unsigned *>(lds + A.tables_lds_bytes + WAVES * WAVE_TILE_WORDS * 16) + (tid >> 6) * WAVE_QUEUE;
 	const unsigned long long s_begin = A.total_slots * blockIdx.x / gridDim.x;
 	const unsigned long long s_end = A.total_slots * (blockIdx.x + 1ull) / gridDim.x;
 	if (s_begin >= s_end) return;
@@ -527,12 +513,12 @@ __global__ void __launch_bounds__(COUNT_BLOCK, LSQ_FAST_WAVES) lsq_count_fast_ke
 		// ---- pool 1
 		if (l0 < n1) {
 			const unsigned long long base = A.p1_off[b];
-			stream_pool_fast<2>(C, bins, cells, d.iso_off, d, A, tile, Q, reinterpret_cast<const uint4 *>(A.p1), base + l0, base + (l1 < n1 ? l1 : n1));
+			stream_pool_fast<2>(C, bins, cells, d.iso_off, d, A, wave_tile, wave_queue, reinterpret_cast<const uint4 *>(A.p1), base + l0, base + (l1 < n1 ? l1 : n1));
 		}
 		// ---- pool 2
 		if (l1 > n1 && l0 < n1 + n2) {
 			const unsigned long long base = A.p2_off[b];
-			stream_pool_fast<1>(C, bins, cells, d.iso_off, d, A, tile, Q, reinterpret_cast<const uint4 *>(A.p2), base + ((l0 > n1 ? l0 : n1) - n1),
+			stream_pool_fast<1>(C, bins, cells, d.iso_off, d, A, wave_tile, wave_queue, reinterpret_cast<const uint4 *>(A.p2), base + ((l0 > n1 ? l0 : n1) - n1),
 			                    base + ((l1 < n1 + n2 ? l1 : n1 + n2) - n1));
 		}
 		// (reads with three or more blocks are left to the cleanup kernel)
@@ -955,7 +941,7 @@ static int run_count(lsq_ctx *c, bool all_reads) {
 	HIP_TRY(hipMemsetAsync(c->exc_count.p, 0, c->exc_count.n * sizeof(unsigned), st));
 	HIP_TRY(hipEventRecord(c->ev0, st));      // ev0..ev1 brackets the count kernel launches only
 	const unsigned tables_bytes = (std::max<unsigned>(E.max_lds_bytes, 16) + 15u) & ~15u;
-	const unsigned lds_bytes = tables_bytes + TILE_WORDS * 16 + QUEUE_ENTRIES * 4 + 16;
+	const unsigned lds_bytes = tables_bytes + WAVES * (WAVE_TILE_WORDS * 16 + WAVE_QUEUE * 4);
 	if (lds_bytes > 160 * 1024) return fail(LSQ_E_UNSUPPORTED, "bucket tables + read tile exceed the CU's LDS");
 	if (lds_bytes > 64 * 1024) {
 		HIP_TRY(hipFuncSetAttribute((const void *)lsq_count_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
