@@ -661,76 +661,96 @@ struct EmArgs {
 	unsigned char *flags;
 };
 
-__device__ inline double em_loglik(const EmArgs &A, unsigned cb, unsigned ib, int K, const double *th) {
-	double ll = 0;
-	const int nc = (1 << K) - 1;
-	for (unsigned m = 0; m < A.n_methods; ++m) {
-		const unsigned long long *n = A.cnt + (size_t)m * A.n_cls + cb;
-		const double *g = A.G + (size_t)m * A.n_iso + ib;
-		for (int c = 1; c <= nc; ++c) {
-			unsigned long long k = n[c - 1];
+// Four lanes per event: lane `sub` takes the (method, class) pairs sub, sub+4, ...; the four
+// partial sums meet by two xor-shuffles.  One pass per EM iteration gives, for the current theta,
+// the class mixtures s, the log-likelihood and the numerators of the next theta.  All four
+// lanes of an event hold the same theta and take the same decisions.
+constexpr int EM_LANES = 4;
+
+__device__ inline double group_sum(double x) {
+	x += __shfl_xor(x, 1);
+	x += __shfl_xor(x, 2);
+	return x;
+}
+
+__device__ inline void em_pass(const EmArgs &A, unsigned cb, unsigned ib, int K, int nc, unsigned sub, bool on,
+                               const double *th, double &ll, double *z) {
+	double l = 0;
+	double zz[LSQ_MAX_ISOFORMS];
+#pragma unroll
+	for (int j = 0; j < LSQ_MAX_ISOFORMS; ++j) zz[j] = 0;
+	if (on) {
+		const int n_pairs = (int)A.n_methods * nc;
+		for (int q = (int)sub; q < n_pairs; q += EM_LANES) {
+			const int m = q / nc, c = q - m * nc + 1;
+			const unsigned long long k = A.cnt[(size_t)m * A.n_cls + cb + (unsigned)(c - 1)];
 			if (!k) continue;
+			const double *g = A.G + (size_t)m * A.n_iso + ib;
 			double s = 0;
-			for (int j = 0; j < K; ++j) if (c >> j & 1) s += th[j] * g[j];
-			ll += (double)k * log(s);
+#pragma unroll
+			for (int j = 0; j < LSQ_MAX_ISOFORMS; ++j) if (j < K && (c >> j & 1)) s += th[j] * g[j];
+			const double kd = (double)k;
+			l += kd * log(s);
+			if (s > 0) {
+#pragma unroll
+				for (int j = 0; j < LSQ_MAX_ISOFORMS; ++j) if (j < K && (c >> j & 1)) {
+					const double local = th[j] * g[j];
+					if (local > 0) zz[j] += kd * (local / s);
+				}
+			}
 		}
 	}
-	return ll;
+	ll = group_sum(l);
+#pragma unroll
+	for (int j = 0; j < LSQ_MAX_ISOFORMS; ++j) z[j] = group_sum(zz[j]);
 }
 
 __global__ void __launch_bounds__(256) lsq_em_kernel(EmArgs A) {
-	unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
-	if (e >= A.n_events) return;
-	const int K = A.K[e];
-	const unsigned cb = A.cls_base[e], ib = A.iso_base[e];
+	const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
+	const unsigned e = gid / EM_LANES, sub = gid % EM_LANES;
+	const bool ev_ok = e < A.n_events;
+	const int K = ev_ok ? A.K[e] : 1;
+	const unsigned cb = ev_ok ? A.cls_base[e] : 0, ib = ev_ok ? A.iso_base[e] : 0;
 	const int nc = (1 << K) - 1;
-	double th[LSQ_MAX_ISOFORMS], nw[LSQ_MAX_ISOFORMS];
-	unsigned long long total = 0;
-	for (unsigned m = 0; m < A.n_methods; ++m)
-		for (int c = 0; c < nc; ++c) total += A.cnt[(size_t)m * A.n_cls + cb + c];
+	double th[LSQ_MAX_ISOFORMS], z[LSQ_MAX_ISOFORMS];
+	double tot = 0;
+	if (ev_ok)
+		for (int q = (int)sub; q < (int)A.n_methods * nc; q += EM_LANES) {
+			const int m = q / nc, c = q - m * nc;
+			tot += (double)A.cnt[(size_t)m * A.n_cls + cb + (unsigned)c];      // exact: counts are far below 2^53
+		}
+	const double n_total = group_sum(tot);
+#pragma unroll
+	for (int j = 0; j < LSQ_MAX_ISOFORMS; ++j) th[j] = (K == 1) ? 1.0 : 1.0 / (double)K;   // solve/solve.cpp:798-802, read.h:642
 	unsigned iters = 0;
 	unsigned char flag = 0;
 	double ll = 0;
-	if (total == 0) {
-		for (int j = 0; j < K; ++j) th[j] = 1.0 / (double)K;         // solve/solve.cpp:798-800
-	} else if (K == 1) {
-		th[0] = 1;                                                    // solve/solve.cpp:801-802
-		ll = em_loglik(A, cb, ib, K, th);
-	} else {
-		for (int j = 0; j < K; ++j) th[j] = 1.0 / (double)K;
-		ll = em_loglik(A, cb, ib, K, th);
-		const double n_total = (double)total;
-		while (true) {
-			const double old_ll = ll;
-			for (int j = 0; j < K; ++j) nw[j] = 0;
-			for (unsigned m = 0; m < A.n_methods; ++m) {
-				const unsigned long long *n = A.cnt + (size_t)m * A.n_cls + cb;
-				const double *g = A.G + (size_t)m * A.n_iso + ib;
-				for (int c = 1; c <= nc; ++c) {
-					unsigned long long k = n[c - 1];
-					if (!k) continue;
-					double s = 0;
-					for (int j = 0; j < K; ++j) if (c >> j & 1) s += th[j] * g[j];
-					if (s > 0)
-						for (int j = 0; j < K; ++j) if (c >> j & 1) {
-							double local = th[j] * g[j];
-							if (local > 0) nw[j] += (double)k * (local / s);
-						}
-				}
-			}
-			for (int j = 0; j < K; ++j) th[j] = nw[j] / n_total;
-			ll = em_loglik(A, cb, ib, K, th);
+	// no reads: theta stays 1/K, log-likelihood 0; one isoform: theta = 1 (solve/solve.cpp:798-802)
+	bool run = ev_ok && n_total > 0 && K > 1;
+	em_pass(A, cb, ib, K, nc, sub, ev_ok && n_total > 0, th, ll, z);
+	while (__any(run)) {
+		// theta' = z(theta) / n; then one pass at theta' gives ll(theta') and z(theta')
+		double nth[LSQ_MAX_ISOFORMS], nll, nz[LSQ_MAX_ISOFORMS];
+#pragma unroll
+		for (int j = 0; j < LSQ_MAX_ISOFORMS; ++j) nth[j] = z[j] / n_total;
+		em_pass(A, cb, ib, K, nc, sub, run, nth, nll, nz);
+		if (run) {
+			const double crit = fabs(1.0 - ll / nll);       // read.h:659, floating abs
+#pragma unroll
+			for (int j = 0; j < LSQ_MAX_ISOFORMS; ++j) { th[j] = nth[j]; z[j] = nz[j]; }
+			ll = nll;
 			++iters;
-			const double crit = fabs(1.0 - old_ll / ll);
 			if (fabs(crit - 1E-6) < 1E-11) flag |= 1;
-			if (!(crit > 1E-6)) break;
-			if (iters >= 1000000u) { flag |= 2; break; }
+			if (!(crit > 1E-6)) run = false;
+			else if (iters >= 1000000u) { flag |= 2; run = false; }
 		}
 	}
-	for (int j = 0; j < K; ++j) A.theta[ib + j] = th[j];
-	A.logll[e] = ll;
-	A.iters[e] = iters;
-	A.flags[e] = flag;
+	if (ev_ok && sub == 0) {
+		for (int j = 0; j < K; ++j) A.theta[ib + j] = th[j];
+		A.logll[e] = ll;
+		A.iters[e] = iters;
+		A.flags[e] = flag;
+	}
 }
 
 template <class T>
@@ -1035,7 +1055,7 @@ static int run_solve(lsq_ctx *c) {
 		A.n_events = n_ev; A.n_methods = (unsigned)E.n_methods; A.n_cls = E.n_cls_total; A.n_iso = E.n_iso_total;
 		A.K = c->dK.p; A.cls_base = c->cls_base.p; A.iso_base = c->iso_base.p;
 		A.cnt = c->cnt.p; A.G = c->G.p; A.theta = c->theta.p; A.logll = c->logll.p; A.iters = c->iters.p; A.flags = c->flags.p;
-		hipLaunchKernelGGL(lsq_em_kernel, dim3((n_ev + 255) / 256), dim3(256), 0, st, A);
+		hipLaunchKernelGGL(lsq_em_kernel, dim3((n_ev * EM_LANES + 255) / 256), dim3(256), 0, st, A);
 		HIP_TRY(hipGetLastError());
 	}
 	HIP_TRY(hipEventRecord(c->ev3, st));
