@@ -273,6 +273,7 @@ struct FastCtx {                       // wave-uniform state of the bucket being
 	ExcEntry *exc;
 	unsigned *exc_count;
 	unsigned exc_cap;
+	unsigned ablate;
 };
 
 __device__ inline void emit_exception(const FastCtx &C, unsigned r, unsigned i, unsigned scan) {
@@ -309,7 +310,7 @@ __device__ inline bool fast_trip(const FastCtx &C, const int4 v, const int total
 		exc = exc || touching;
 		covers = covers && !touching;
 	}
-	if (exc) emit_exception(C, r, i, 0u);
+	if (exc && !(C.ablate & 128u)) emit_exception(C, r, i, 0u);
 	const int sx[4] = {(int)w1.x, (int)w1.z, (int)w2.x, (int)w2.z};
 	const int sy[4] = {(int)w1.y, (int)w1.w, (int)w2.y, (int)w2.w};
 	const unsigned abut = (w0.y >> FAST_ABUT_SHIFT) & 7u;
@@ -333,20 +334,23 @@ __device__ inline bool fast_trip(const FastCtx &C, const int4 v, const int total
 	// (double)matched / total > 0.98  <=>  50*matched > 49*total (both below 2^18 here)
 	const unsigned long long tbl = ((unsigned long long)w0.w << 32) | w0.z;
 	const unsigned cls = (unsigned)(tbl >> (4u * mask)) & 0xFu;
-	if (covers && cls != 0 && 50 * matched > 49 * total)
-		atomicAdd(&C.hist[(w0.y & 0xFFFFu) + cls - 1], (1ull << 40) | (unsigned long long)(unsigned)matched);
+	if (covers && cls != 0 && 50 * matched > 49 * total) {
+		if (!(C.ablate & 2u)) atomicAdd(&C.hist[(w0.y & 0xFFFFu) + cls - 1], (1ull << 40) | (unsigned long long)(unsigned)matched);
+		else asm volatile("" ::"v"(matched), "v"(cls));
+	}
 	return started && (!(p <= ge) || (w0.y & FAST_FLAG_OVERLAPS_NEXT)) && i + 1 < C.n_events;
 }
 
 // Parked reads.  The streaming loop settles the commonest shapes with one or two table looks
-// (cells); every other read of the tile is parked (tile-local read index | event to start at
-// << 16) and the general walk then runs over the parked reads densely, instead of stalling a
-// 64-lane wave on its hardest lane.
+// (cells); every other read is parked -- its blocks, the event to start at, its position in the
+// workgroup's range -- and the general walk runs over the parked reads a full wave at a time,
+// instead of stalling a 64-lane wave on its hardest lane.
 //
-// Each wave streams its own part of the workgroup's range through its own LDS tile and its own
-// parking area: no workgroup barrier inside the stream, a slow wave never holds up the others.
-constexpr unsigned WAVE_TILE_WORDS = 256;                     // 16-byte words per wave tile (4 KiB): 512 / 256 reads
-constexpr unsigned WAVE_QUEUE = WAVE_TILE_WORDS * 2;          // 4-byte entries (2 KiB): one per read of a tile at most
+// Each wave streams its own part of the workgroup's range straight from HBM into registers
+// (next words in flight while the current ones are processed) and owns its parking area: no
+// workgroup barrier inside the stream, a slow wave never holds up the others.
+constexpr int STREAM_WORDS = 2;                               // 16-byte words per lane in flight / in work
+constexpr unsigned WAVE_QUEUE_WORDS = 256;                    // 16-byte words of parking per wave (4 KiB)
 constexpr unsigned WAVES = COUNT_BLOCK / 64;
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -359,28 +363,77 @@ __device__ inline void wave_sync_lds() {
 	__builtin_amdgcn_wave_barrier();
 }
 
+// The parking area is a ring of reads waiting for their next look: (blocks, event to look at,
+// position in the range).  The general walk takes 64 of them at a time -- every lane busy, one
+// event record each -- and a read that needs a further event goes back to the tail.  While the
+// stream is running the walk only runs on full waves; what is left stays for the next time.
+template <int NB>
+struct Ring {
+	static constexpr unsigned CAP = WAVE_QUEUE_WORDS / NB;      // entries
+	uint4 *q;
+	unsigned head = 0, tail = 0;                                 // running counters (the same in every lane)
+	__device__ inline unsigned live() const { return tail - head; }
+	__device__ inline void push(bool want, unsigned lane, const uint4 e0, const uint4 e1) {
+		const unsigned long long m = __ballot(want);
+		const unsigned at = (tail + (unsigned)__popcll(m & ((1ull << lane) - 1ull))) % CAP;
+		if (want) {
+			if (NB == 1) q[at] = e0;
+			else { q[2 * at] = e0; q[2 * at + 1] = e1; }
+		}
+		tail += (unsigned)__popcll(m);
+	}
+};
+
+template <int NB>
+__device__ inline void walk_parked(const FastCtx &C, Ring<NB> &R, const bool to_empty) {
+	const unsigned lane = threadIdx.x & 63u;
+	wave_sync_lds();
+#pragma unroll 1
+	while (R.live() >= (to_empty ? 1u : 64u)) {
+		const unsigned n = min(R.live(), 64u);
+		const bool on = lane < n;
+		const unsigned at = (R.head + (on ? lane : 0u)) % Ring<NB>::CAP;
+		uint4 e0, e1 = make_uint4(0, 0, 0, 0);
+		if (NB == 1) e0 = R.q[at];
+		else { e0 = R.q[2 * at]; e1 = R.q[2 * at + 1]; }
+		R.head += n;
+		int4 rd; unsigned i, rel;
+		if (NB == 1) { rd = make_int4((int)e0.x, (int)e0.y, (int)e0.x, (int)e0.y); i = e0.z; rel = e0.w; }
+		else { rd = make_int4((int)e0.x, (int)e0.y, (int)e0.z, (int)e0.w); i = e1.x; rel = e1.y; }
+		const int total = NB == 1 ? rd.y - rd.x : (rd.y - rd.x) + (rd.w - rd.z);
+		const bool more = fast_trip<NB>(C, rd, total, rel, i, on) && !(C.ablate & 64u);
+		wave_sync_lds();
+		if (NB == 1) e0.z = i + 1u; else e1.x = i + 1u;
+		R.push(more, lane, e0, e1);
+		wave_sync_lds();
+	}
+}
+
 // RPW = reads per 16-byte word: 2 (pool 1: one block) or 1 (pool 2: two blocks)
 template <int RPW>
 __device__ inline void stream_pool_fast(FastCtx &C, const unsigned *bins, const uint4 *cells, const unsigned n_cells, const BucketDesc &d,
-                                        const CountArgs &A, uint4 *wave_tile, unsigned *wave_queue, const uint4 *src_generic,
+                                        const CountArgs &A, uint4 *queue, const uint4 *src_generic,
                                         const unsigned long long g0, const unsigned long long g1) {
 	constexpr int NB = RPW == 2 ? 1 : 2;
+	constexpr unsigned TILE = 64u * STREAM_WORDS;        // words per wave step
 	C.pool = RPW == 2 ? 0u : 1u;
 	C.slot0 = g0;
 	global_words src = (global_words)src_generic;       // kernel-argument memory: global address space
 	const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-	// words [w0, w1) of the workgroup; this wave takes a contiguous quarter, in whole tiles
+	// words [w0, w1) of the workgroup; this wave takes a contiguous quarter, in whole steps
 	const unsigned long long w0 = g0 / RPW, w1 = (g1 + RPW - 1) / RPW;
-	const unsigned long long per_wave = ((w1 - w0 + WAVES - 1) / WAVES + WAVE_TILE_WORDS - 1) / WAVE_TILE_WORDS * WAVE_TILE_WORDS;
-	const unsigned long long ww0 = min(w0 + wave * per_wave, w1), ww1 = min(ww0 + per_wave, w1);
-	uint4 nxt[4];
-	auto fetch = [&](unsigned long long wt) {
-		const unsigned n = (unsigned)min((unsigned long long)WAVE_TILE_WORDS, ww1 - wt);
+	const unsigned n_words = (unsigned)(w1 - w0);                                   // a workgroup's range stays below 2^21 reads
+	const unsigned per_wave = ((n_words + WAVES - 1) / WAVES + TILE - 1) / TILE * TILE;
+	const unsigned ww0 = min(wave * per_wave, n_words), ww1 = min(ww0 + per_wave, n_words);   // relative to w0
+	const unsigned first_rel = (unsigned)(g0 - w0 * RPW);                            // 0 or 1: reads of word w0 before the range
+	const unsigned n_rel = (unsigned)(g1 - g0);
+	uint4 nxt[STREAM_WORDS];
+	auto fetch = [&](unsigned wt) {
 #pragma unroll
-		for (int k = 0; k < 4; ++k) {
-			const unsigned w = (unsigned)k * 64u + lane;
+		for (int k = 0; k < STREAM_WORDS; ++k) {
+			const unsigned w = wt + (unsigned)k * 64u + lane;
 			u32x4 t = {0u, 0u, 0u, 0u};
-			if (w < n) t = src[wt + w];
+			if (w < ww1) t = src[w0 + w];
 			nxt[k] = make_uint4(t.x, t.y, t.z, t.w);
 		}
 	};
@@ -389,38 +442,44 @@ __device__ inline void stream_pool_fast(FastCtx &C, const unsigned *bins, const 
 		unsigned bin = rel <= 0 ? 0u : ((unsigned)rel >> d.shift);
 		return bins[min(bin, d.n_bins - 1u)];               // first event | first cell << 16
 	};
+	Ring<NB> R;
+	R.q = queue;
+	auto park_entry = [&](bool park, uint4 e0, uint4 e1) {
+		R.push(park, lane, e0, e1);
+		if (R.live() >= 64u) {                                 // wave-uniform
+			if (!(A.ablate & 32u)) walk_parked<NB>(C, R, false);
+			else R.head = R.tail;
+		}
+	};
 	if (ww0 < ww1) fetch(ww0);
-	for (unsigned long long wt = ww0; wt < ww1; wt += WAVE_TILE_WORDS) {
+	for (unsigned wt = ww0; wt < ww1; wt += TILE) {
+		uint4 cur[STREAM_WORDS];
 #pragma unroll
-		for (int k = 0; k < 4; ++k) wave_tile[k * 64 + lane] = nxt[k];
-		wave_sync_lds();
-		if (wt + WAVE_TILE_WORDS < ww1) fetch(wt + WAVE_TILE_WORDS);
-		const unsigned long long r_base = wt * RPW;
-		// tile-relative bounds of the reads that belong to the workgroup's range
-		const unsigned lo_r = g0 > r_base ? (unsigned)(g0 - r_base) : 0u;
-		const unsigned hi_r = (unsigned)min((unsigned long long)(WAVE_TILE_WORDS * RPW), g1 - r_base);
-		const unsigned rel0 = (unsigned)(r_base + lo_r - g0) - lo_r;      // position of tile read r in the range: rel0 + r
-		unsigned qn = 0;                                                   // parked so far (the same in every lane)
-#pragma unroll 1
-		for (int k = 0; k < 4 * RPW; ++k) {
-			const unsigned r = (unsigned)k * 64u + lane;
-			const bool in = r >= lo_r && r < hi_r;
-			bool park;
-			unsigned entry;
+		for (int k = 0; k < STREAM_WORDS; ++k) cur[k] = nxt[k];
+		if (wt + TILE < ww1) fetch(wt + TILE);
+#pragma unroll
+		for (int k = 0; k < STREAM_WORDS; ++k) {
+			const unsigned w = wt + (unsigned)k * 64u + lane;           // word, relative to w0
 			if (RPW == 2) {
-				const int2 rd = reinterpret_cast<const int2 *>(wave_tile)[r];
-				const unsigned bw = bin_word(rd.x);
-				if (A.ablate & 1u) { asm volatile("" ::"v"(bw), "v"(rd.x), "v"(rd.y)); continue; }
-				// one block inside one cell: one histogram add, nothing else to decide
-				const unsigned ci = bw >> 16;
-				const uint4 cw = cells[min(ci, n_cells - 1u)];
-				const bool hit = in && ci < n_cells && (int)cw.x <= rd.x && rd.y <= (int)cw.y && !(A.ablate & 8u);
-				if (hit && cw.z != CELL_NO_CLASS) atomicAdd(&C.hist[cw.z], (1ull << 40) | (unsigned long long)(unsigned)(rd.y - rd.x));
-				park = in && !hit && !(A.ablate & 16u);
-				entry = r | ((bw & 0xFFFFu) << 16);
+#pragma unroll
+				for (int h = 0; h < 2; ++h) {
+					const int ra = h == 0 ? (int)cur[k].x : (int)cur[k].z, rb = h == 0 ? (int)cur[k].y : (int)cur[k].w;
+					const unsigned rel = w * 2u + (unsigned)h - first_rel;      // position in the range (wraps above n_rel when outside)
+					const bool in = w < ww1 && rel < n_rel;
+					const unsigned bw = bin_word(ra);
+					if (A.ablate & 1u) { asm volatile("" ::"v"(bw), "v"(ra), "v"(rb)); continue; }
+					// one block inside one cell: one histogram add, nothing else to decide
+					const unsigned ci = bw >> 16;
+					const uint4 cw = cells[min(ci, n_cells - 1u)];
+					const bool hit = in && ci < n_cells && (int)cw.x <= ra && rb <= (int)cw.y && !(A.ablate & 8u);
+					if (hit && cw.z != CELL_NO_CLASS) atomicAdd(&C.hist[cw.z], (1ull << 40) | (unsigned long long)(unsigned)(rb - ra));
+					park_entry(in && !hit && !(A.ablate & 16u), make_uint4((unsigned)ra, (unsigned)rb, bw & 0xFFFFu, rel), make_uint4(0, 0, 0, 0));
+				}
 			} else {
-				const uint4 u = wave_tile[r];
+				const uint4 u = cur[k];
 				const int4 rd = make_int4((int)u.x, (int)u.y, (int)u.z, (int)u.w);
+				const unsigned rel = w - first_rel;
+				const bool in = w < ww1 && rel < n_rel;
 				const unsigned bw1 = bin_word(rd.x), bw2 = bin_word(rd.z);
 				if (A.ablate & 1u) { asm volatile("" ::"v"(bw1), "v"(bw2), "v"(rd.x), "v"(rd.y), "v"(rd.z), "v"(rd.w)); continue; }
 				// the usual junction read: block 1 runs to the end of one segment, block 2 starts on the
@@ -438,33 +497,11 @@ __device__ inline void stream_pool_fast(FastCtx &C, const unsigned *bins, const 
 					const unsigned cls = (unsigned)(tbl >> (4u * mask)) & 0xFu;
 					if (cls) atomicAdd(&C.hist[(w0r.y & 0xFFFFu) + cls - 1], (1ull << 40) | (unsigned long long)(unsigned)((rd.y - rd.x) + (rd.w - rd.z)));
 				}
-				park = in && !hit && !(A.ablate & 16u);
-				entry = r | ((bw1 & 0xFFFFu) << 16);
-			}
-			// park: ranks by ballot, no atomic
-			const unsigned long long m = __ballot(park);
-			if (park) wave_queue[qn + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = entry;
-			qn += (unsigned)__popcll(m);
-		}
-		wave_sync_lds();
-		// dense pass of the general walk over what this tile parked
-		if (!(A.ablate & 32u)) {
-#pragma unroll 1
-			for (unsigned j0 = 0; j0 < qn; j0 += 64u) {
-				const unsigned j = j0 + lane;
-				bool more = j < qn;
-				const unsigned e = wave_queue[more ? j : 0u];
-				const unsigned r = e & 0xFFFFu;
-				unsigned i = e >> 16;
-				int4 rd;
-				if (NB == 1) { const int2 t = reinterpret_cast<const int2 *>(wave_tile)[r]; rd = make_int4(t.x, t.y, t.x, t.y); }
-				else { const uint4 u = wave_tile[r]; rd = make_int4((int)u.x, (int)u.y, (int)u.z, (int)u.w); }
-				const int total = NB == 1 ? rd.y - rd.x : (rd.y - rd.x) + (rd.w - rd.z);
-				while (more) { more = fast_trip<NB>(C, rd, total, rel0 + r, i, true); ++i; }
+				park_entry(in && !hit && !(A.ablate & 16u), u, make_uint4(bw1 & 0xFFFFu, rel, 0u, 0u));
 			}
 		}
-		wave_sync_lds();
 	}
+	if (R.live() && !(A.ablate & 32u)) walk_parked<NB>(C, R, true);
 }
 
 #ifndef LSQ_FAST_WAVES
@@ -473,8 +510,7 @@ __device__ inline void stream_pool_fast(FastCtx &C, const unsigned *bins, const 
 __global__ void __launch_bounds__(COUNT_BLOCK, LSQ_FAST_WAVES) lsq_count_fast_kernel(CountArgs A) {
 	extern __shared__ __align__(16) unsigned char lds[];
 	const unsigned tid = threadIdx.x;
-	uint4 *wave_tile = reinterpret_cast<uint4 *>(lds + A.tables_lds_bytes) + (tid >> 6) * WAVE_TILE_WORDS;
-	unsigned *wave_queue = reinterpret_cast<unsigned *>(lds + A.tables_lds_bytes + WAVES * WAVE_TILE_WORDS * 16) + (tid >> 6) * WAVE_QUEUE;
+	uint4 *wave_queue = reinterpret_cast<uint4 *>(lds + A.tables_lds_bytes) + (tid >> 6) * WAVE_QUEUE_WORDS;
 	const unsigned long long s_begin = A.total_slots * blockIdx.x / gridDim.x;
 	const unsigned long long s_end = A.total_slots * (blockIdx.x + 1ull) / gridDim.x;
 	if (s_begin >= s_end) return;
@@ -505,7 +541,7 @@ __global__ void __launch_bounds__(COUNT_BLOCK, LSQ_FAST_WAVES) lsq_count_fast_ke
 		C.hist = reinterpret_cast<unsigned long long *>(lds + d.hist_off);
 		C.n_events = d.n_events; C.bucket = b;
 		C.slot0 = 0; C.pool = 0;
-		C.exc = A.exc; C.exc_count = A.exc_count; C.exc_cap = A.exc_cap;
+		C.exc = A.exc; C.exc_count = A.exc_count; C.exc_cap = A.exc_cap; C.ablate = A.ablate;
 		const unsigned long long l0 = (s_begin > bs ? s_begin : bs) - bs;
 		const unsigned long long l1 = (s_end < be ? s_end : be) - bs;
 		const unsigned long long n1 = A.p1_off[b + 1] - A.p1_off[b];
@@ -513,12 +549,12 @@ __global__ void __launch_bounds__(COUNT_BLOCK, LSQ_FAST_WAVES) lsq_count_fast_ke
 		// ---- pool 1
 		if (l0 < n1) {
 			const unsigned long long base = A.p1_off[b];
-			stream_pool_fast<2>(C, bins, cells, d.iso_off, d, A, wave_tile, wave_queue, reinterpret_cast<const uint4 *>(A.p1), base + l0, base + (l1 < n1 ? l1 : n1));
+			stream_pool_fast<2>(C, bins, cells, d.iso_off, d, A, wave_queue, reinterpret_cast<const uint4 *>(A.p1), base + l0, base + (l1 < n1 ? l1 : n1));
 		}
 		// ---- pool 2
 		if (l1 > n1 && l0 < n1 + n2) {
 			const unsigned long long base = A.p2_off[b];
-			stream_pool_fast<1>(C, bins, cells, d.iso_off, d, A, wave_tile, wave_queue, reinterpret_cast<const uint4 *>(A.p2), base + ((l0 > n1 ? l0 : n1) - n1),
+			stream_pool_fast<1>(C, bins, cells, d.iso_off, d, A, wave_queue, reinterpret_cast<const uint4 *>(A.p2), base + ((l0 > n1 ? l0 : n1) - n1),
 			                    base + ((l1 < n1 + n2 ? l1 : n1 + n2) - n1));
 		}
 		// (reads with three or more blocks are left to the cleanup kernel)
@@ -961,7 +997,7 @@ static int run_count(lsq_ctx *c, bool all_reads) {
 	HIP_TRY(hipMemsetAsync(c->exc_count.p, 0, c->exc_count.n * sizeof(unsigned), st));
 	HIP_TRY(hipEventRecord(c->ev0, st));      // ev0..ev1 brackets the count kernel launches only
 	const unsigned tables_bytes = (std::max<unsigned>(E.max_lds_bytes, 16) + 15u) & ~15u;
-	const unsigned lds_bytes = tables_bytes + WAVES * (WAVE_TILE_WORDS * 16 + WAVE_QUEUE * 4);
+	const unsigned lds_bytes = tables_bytes + WAVES * WAVE_QUEUE_WORDS * 16;
 	if (lds_bytes > 160 * 1024) return fail(LSQ_E_UNSUPPORTED, "bucket tables + read tile exceed the CU's LDS");
 	if (lds_bytes > 64 * 1024) {
 		HIP_TRY(hipFuncSetAttribute((const void *)lsq_count_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
