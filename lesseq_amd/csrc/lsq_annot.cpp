@@ -290,7 +290,7 @@ static int plan_device(lsq_events &E) {
 	std::vector<std::vector<int32_t>> per_chrom(E.chroms.names.size());
 	for (size_t i = 0; i < n; ++i) per_chrom[E.ev[i].chrom_id].push_back((int32_t)i);
 	auto ev_bytes = [&](const Event &e) -> uint32_t {
-		return std::max(48u + 16u * (uint32_t)e.N, 16u + 8u * (uint32_t)e.N + 4u * (uint32_t)e.K) + 8u * ((1u << e.K) - 1u);
+		return std::max(48u + 40u * (uint32_t)e.N + 20u, 16u + 8u * (uint32_t)e.N + 4u * (uint32_t)e.K) + 8u * ((1u << e.K) - 1u);
 	};
 	for (size_t c = 0; c < per_chrom.size(); ++c) {
 		auto &lst = per_chrom[c];
@@ -353,36 +353,80 @@ static int plan_device(lsq_events &E) {
 			d.kind = fast ? 1u : 0u;
 			auto align16 = [](uint32_t x) { return (x + 15u) & ~15u; };
 			uint32_t off = 0;
-			uint32_t bins_off = off; off = align16(off + (fast ? 4u : 2u) * d.n_bins);
-			// cells (packed buckets only): segments of events whose span meets no other span
+			uint32_t bins_off = off; off = align16(off + (fast ? 16u : 2u) * d.n_bins);
+			// cells (packed buckets only): see struct Cell
 			std::vector<Cell> cells;
+			std::vector<uint32_t> cell_info;
 			if (fast) {
+				struct SegRef { int64_t sx, sy; uint32_t ev, k, cls_off; };
+				std::vector<SegRef> segs_all;
+				std::vector<int64_t> bps;
+				std::vector<int64_t> first_bases;
+				auto cls_of = [&](const Event &e, uint32_t m) -> uint32_t {          // contiguous-run rule, common/read.h:44-79
+					uint32_t hi_b = 31u - (uint32_t)__builtin_clz(m), lo_b = (uint32_t)__builtin_ctz(m);
+					uint32_t span = ((2u << hi_b) - 1u) & ~((1u << lo_b) - 1u), cls = 0;
+					for (int q = 0; q < e.K; ++q) { uint32_t iso = (uint32_t)e.iso_mask[q] & 0xFu; if ((m & ~iso) == 0 && (iso & span) == m) cls |= 1u << q; }
+					return cls;
+				};
 				uint32_t co2 = 0;
 				for (size_t k = b_begin; k < i; ++k) {
 					const Event &e = E.ev[lst[k]];
-					bool alone = true;
-					for (size_t k2 = b_begin; k2 < i && alone; ++k2)
-						if (k2 != k && E.ev[lst[k2]].gene_start <= e.gene_end && e.gene_start <= E.ev[lst[k2]].gene_end) alone = false;
-					if (alone) {
-						for (int sgi = 0; sgi < e.N; ++sgi) {
-							Cell c;
-							c.lo = (int32_t)e.seg_s[sgi] + (e.seg_s[sgi] == e.gene_start ? 1 : 0);
-							c.hi = (int32_t)e.seg_e[sgi];
-							uint32_t cls = 0;
-							for (int q = 0; q < e.K; ++q) if (e.iso_mask[q] >> sgi & 1) cls |= 1u << q;   // a single segment is a contiguous run of every isoform that holds it
-							c.slot = cls ? co2 + cls - 1 : CELL_NO_CLASS;
-							c.pad = ((uint32_t)(k - b_begin) << 8) | (uint32_t)sgi;
-							if (c.lo < c.hi) cells.push_back(c);
-						}
+					for (int sgi = 0; sgi < e.N; ++sgi) {
+						segs_all.push_back({e.seg_s[sgi], e.seg_e[sgi], (uint32_t)(k - b_begin), (uint32_t)sgi, co2});
+						bps.push_back(e.seg_s[sgi]); bps.push_back(e.seg_e[sgi]);
 					}
+					first_bases.push_back(e.gene_start);
+					bps.push_back(e.gene_start + 1);
 					co2 += (1u << e.K) - 1u;
 				}
-				std::sort(cells.begin(), cells.end(), [](const Cell &x, const Cell &y) { return x.lo < y.lo; });
-				if (cells.size() > 65000) cells.clear();
+				std::sort(bps.begin(), bps.end());
+				bps.erase(std::unique(bps.begin(), bps.end()), bps.end());
+				std::sort(first_bases.begin(), first_bases.end());
+				std::sort(segs_all.begin(), segs_all.end(), [](const SegRef &x, const SegRef &y) { return x.sx < y.sx; });
+				struct Tmp { Cell c; uint32_t info; uint32_t ev, k; bool single; };
+				std::vector<Tmp> tmp;
+				for (size_t q = 0; q + 1 < bps.size(); ++q) {
+					const int64_t x0 = bps[q], x1 = bps[q + 1];
+					if (std::binary_search(first_bases.begin(), first_bases.end(), x0) && x1 == x0 + 1) continue;   // first base of a span
+					const SegRef *own[3]; int n_own = 0;
+					for (size_t r = 0; r < segs_all.size() && segs_all[r].sx <= x0; ++r)
+						if (segs_all[r].sy >= x1) { if (n_own < 3) own[n_own] = &segs_all[r]; ++n_own; }
+					if (n_own == 0 || n_own > 2) continue;
+					Tmp t;
+					t.c.lo = (int32_t)x0; t.c.hi = (int32_t)x1; t.c.hi2 = (int32_t)x1;
+					auto slot_of = [&](const SegRef *sr, uint32_t mask) -> uint32_t {
+						const Event &e = E.ev[lst[b_begin + sr->ev]];
+						uint32_t cls = cls_of(e, mask);
+						return cls ? sr->cls_off + cls - 1 : CELL_NONE;
+					};
+					uint32_t sa = slot_of(own[0], 1u << own[0]->k);
+					uint32_t sb = n_own == 2 ? slot_of(own[1], 1u << own[1]->k) : CELL_NONE;
+					t.c.slots = sa | (sb << 16);
+					t.single = n_own == 1;
+					t.ev = own[0]->ev; t.k = own[0]->k;
+					t.info = n_own == 1 ? ((own[0]->ev << 8) | (own[0]->k << 2) | (own[0]->sy == x1 ? 2u : 0u) | (own[0]->sx == x0 ? 1u : 0u)) : CELL_INFO_SHARED;
+					tmp.push_back(t);
+				}
+				// a single-owner cell that reaches its segment's end, followed at once by a single-owner cell
+				// of the same event's next segment: reads may run from the one into the other
+				for (size_t q = 0; q + 1 < tmp.size(); ++q) {
+					Tmp &x = tmp[q]; const Tmp &y = tmp[q + 1];
+					if (x.single && y.single && (x.info & 2u) && (y.info & 1u) && x.ev == y.ev && y.k == x.k + 1 && y.c.lo == x.c.hi) {
+						const Event &e = E.ev[lst[b_begin + x.ev]];
+						uint32_t cls = cls_of(e, (1u << x.k) | (1u << y.k));
+						uint32_t co3 = 0;
+						for (size_t k3 = b_begin; k3 < b_begin + x.ev; ++k3) co3 += (1u << E.ev[lst[k3]].K) - 1u;
+						x.c.hi2 = y.c.hi;
+						x.c.slots = (x.c.slots & 0xFFFFu) | ((cls ? co3 + cls - 1 : CELL_NONE) << 16);
+					}
+				}
+				if (tmp.size() <= 65000)
+					for (const Tmp &t : tmp) { cells.push_back(t.c); cell_info.push_back(t.info); }
 			}
 			if (fast) {
 				d.ev_off = off; off = align16(off + (uint32_t)sizeof(FastRec) * d.n_events);
-				d.seg_off = off; off = align16(off + (uint32_t)sizeof(Cell) * (uint32_t)cells.size());   // cells
+				d.seg_off = off; off = align16(off + (uint32_t)sizeof(Cell) * (uint32_t)cells.size());   // cells, then their info words
+				off = align16(off + 4u * (uint32_t)cells.size());
 				d.iso_off = (uint32_t)cells.size();                                                       // cell count
 			} else {
 				d.ev_off = off; off = align16(off + 16 * d.n_events);
@@ -401,7 +445,10 @@ static int plan_device(lsq_events &E) {
 			uint8_t *img = E.images.data() + d.img_off;
 			uint16_t *bins = reinterpret_cast<uint16_t *>(img + bins_off);
 			uint32_t *bins32 = reinterpret_cast<uint32_t *>(img + bins_off);
-			if (fast && !cells.empty()) memcpy(img + d.seg_off, cells.data(), cells.size() * sizeof(Cell));
+			if (fast && !cells.empty()) {
+				memcpy(img + d.seg_off, cells.data(), cells.size() * sizeof(Cell));
+				memcpy(img + d.seg_off + ((cells.size() * sizeof(Cell) + 15u) & ~(size_t)15u), cell_info.data(), cell_info.size() * 4u);
+			}
 			EventRec *recs = reinterpret_cast<EventRec *>(img + d.ev_off);
 			FastRec *frecs = reinterpret_cast<FastRec *>(img + d.ev_off);
 			int32_t *segs = reinterpret_cast<int32_t *>(img + d.seg_off);
@@ -466,8 +513,13 @@ static int plan_device(lsq_events &E) {
 				// never reach a later bin: `first` is min{i : ge_i >= bin_lo} for every k
 				while (first < d.n_events && ends[first] < bin_lo) ++first;
 				if (fast) {
-					while (first_cell < cells.size() && cells[first_cell].hi <= bin_lo) ++first_cell;   // first cell that can hold a base >= bin_lo
-					bins32[k] = first | ((uint32_t)first_cell << 16);
+					// packed buckets: 16-byte bin record = first cell that can hold a base >= bin_lo | first event
+					// << 16, then the ends of that cell and the two after it: the cell that holds a base p of
+					// the bin is found by counting the ends that are <= p
+					while (first_cell < cells.size() && cells[first_cell].hi <= bin_lo) ++first_cell;
+					uint32_t *rec = bins32 + 4 * k;
+					rec[0] = (uint32_t)first_cell | (first << 16);
+					for (size_t q = 0; q < 3; ++q) rec[1 + q] = (uint32_t)(first_cell + q < cells.size() ? cells[first_cell + q].hi : INT32_MAX);
 				} else bins[k] = (uint16_t)first;
 			}
 			if (E.chrom_first_bucket[c] < 0) E.chrom_first_bucket[c] = (int32_t)E.buckets.size();

@@ -66,6 +66,7 @@ struct CountArgs {
 	struct ExcEntry *exc;              // exception list (rare (read, event) pairs the fast kernel hands to the cleanup kernel)
 	unsigned *exc_count;               // [0] entries appended, [1] set to 1 by the cleanup kernel when [0] > exc_cap
 	unsigned exc_cap;
+	unsigned long long *dbg;            // developer counters (LSQ_ABLATE & 256): parked one-block, parked two-block, walk steps, walk lanes
 };
 
 struct LdsView {
@@ -274,6 +275,7 @@ struct FastCtx {                       // wave-uniform state of the bucket being
 	unsigned *exc_count;
 	unsigned exc_cap;
 	unsigned ablate;
+	unsigned long long *dbg;
 };
 
 __device__ inline void emit_exception(const FastCtx &C, unsigned r, unsigned i, unsigned scan) {
@@ -392,6 +394,7 @@ __device__ inline void walk_parked(const FastCtx &C, Ring<NB> &R, const bool to_
 	while (R.live() >= (to_empty ? 1u : 64u)) {
 		const unsigned n = min(R.live(), 64u);
 		const bool on = lane < n;
+		if ((C.ablate & 256u) && lane == 0) { atomicAdd(&C.dbg[2], 1ull); atomicAdd(&C.dbg[3], (unsigned long long)n); }
 		const unsigned at = (R.head + (on ? lane : 0u)) % Ring<NB>::CAP;
 		uint4 e0, e1 = make_uint4(0, 0, 0, 0);
 		if (NB == 1) e0 = R.q[at];
@@ -411,7 +414,7 @@ __device__ inline void walk_parked(const FastCtx &C, Ring<NB> &R, const bool to_
 
 // RPW = reads per 16-byte word: 2 (pool 1: one block) or 1 (pool 2: two blocks)
 template <int RPW>
-__device__ inline void stream_pool_fast(FastCtx &C, const unsigned *bins, const uint4 *cells, const unsigned n_cells, const BucketDesc &d,
+__device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uint4 *cells, const unsigned *cell_info, const unsigned n_cells, const BucketDesc &d,
                                         const CountArgs &A, uint4 *queue, const uint4 *src_generic,
                                         const unsigned long long g0, const unsigned long long g1) {
 	constexpr int NB = RPW == 2 ? 1 : 2;
@@ -437,14 +440,18 @@ __device__ inline void stream_pool_fast(FastCtx &C, const unsigned *bins, const 
 			nxt[k] = make_uint4(t.x, t.y, t.z, t.w);
 		}
 	};
-	auto bin_word = [&](int p) {
+	// bin record of position p -> (cell that can hold p, first event of the bin)
+	auto locate = [&](int p, unsigned &cell, unsigned &first_event) {
 		const int rel = p - d.lo;
 		unsigned bin = rel <= 0 ? 0u : ((unsigned)rel >> d.shift);
-		return bins[min(bin, d.n_bins - 1u)];               // first event | first cell << 16
+		const uint4 br = bins[min(bin, d.n_bins - 1u)];     // first cell | first event << 16, ends of that cell and the next two
+		cell = (br.x & 0xFFFFu) + (unsigned)(p >= (int)br.y) + (unsigned)(p >= (int)br.z) + (unsigned)(p >= (int)br.w);
+		first_event = br.x >> 16;
 	};
 	Ring<NB> R;
 	R.q = queue;
 	auto park_entry = [&](bool park, uint4 e0, uint4 e1) {
+		if ((A.ablate & 256u) && park) atomicAdd(&A.dbg[NB - 1], 1ull);
 		R.push(park, lane, e0, e1);
 		if (R.live() >= 64u) {                                 // wave-uniform
 			if (!(A.ablate & 32u)) walk_parked<NB>(C, R, false);
@@ -466,38 +473,48 @@ __device__ inline void stream_pool_fast(FastCtx &C, const unsigned *bins, const 
 					const int ra = h == 0 ? (int)cur[k].x : (int)cur[k].z, rb = h == 0 ? (int)cur[k].y : (int)cur[k].w;
 					const unsigned rel = w * 2u + (unsigned)h - first_rel;      // position in the range (wraps above n_rel when outside)
 					const bool in = w < ww1 && rel < n_rel;
-					const unsigned bw = bin_word(ra);
-					if (A.ablate & 1u) { asm volatile("" ::"v"(bw), "v"(ra), "v"(rb)); continue; }
-					// one block inside one cell: one histogram add, nothing else to decide
-					const unsigned ci = bw >> 16;
-					const uint4 cw = cells[min(ci, n_cells - 1u)];
-					const bool hit = in && ci < n_cells && (int)cw.x <= ra && rb <= (int)cw.y && !(A.ablate & 8u);
-					if (hit && cw.z != CELL_NO_CLASS) atomicAdd(&C.hist[cw.z], (1ull << 40) | (unsigned long long)(unsigned)(rb - ra));
-					park_entry(in && !hit && !(A.ablate & 16u), make_uint4((unsigned)ra, (unsigned)rb, bw & 0xFFFFu, rel), make_uint4(0, 0, 0, 0));
+					unsigned ci, evf;
+					locate(ra, ci, evf);
+					if (A.ablate & 1u) { asm volatile("" ::"v"(ci), "v"(evf), "v"(ra), "v"(rb)); continue; }
+					// one block inside one cell (or running from it into the owner's next segment):
+					// one or two histogram adds, nothing else to decide
+					const uint4 cw = cells[min(ci, n_cells - 1u)];           // lo, hi, hi2, slots
+					const bool contains = in && ci < n_cells && (int)cw.x <= ra && ra < (int)cw.y && !(A.ablate & 8u);
+					const bool inside = contains && rb <= (int)cw.y;
+					const bool cross = contains && !inside && rb <= (int)cw.z;
+					const unsigned sa = cw.w & 0xFFFFu, sb = cw.w >> 16;
+					const unsigned long long add = (1ull << 40) | (unsigned long long)(unsigned)(rb - ra);
+					if (inside && sa != CELL_NONE) atomicAdd(&C.hist[sa], add);
+					if (((inside && cw.z == cw.y) || cross) && sb != CELL_NONE) atomicAdd(&C.hist[sb], add);
+					const bool hit = inside || cross;
+					park_entry(in && !hit && !(A.ablate & 16u), make_uint4((unsigned)ra, (unsigned)rb, evf, rel), make_uint4(0, 0, 0, 0));
 				}
 			} else {
 				const uint4 u = cur[k];
 				const int4 rd = make_int4((int)u.x, (int)u.y, (int)u.z, (int)u.w);
 				const unsigned rel = w - first_rel;
 				const bool in = w < ww1 && rel < n_rel;
-				const unsigned bw1 = bin_word(rd.x), bw2 = bin_word(rd.z);
-				if (A.ablate & 1u) { asm volatile("" ::"v"(bw1), "v"(bw2), "v"(rd.x), "v"(rd.y), "v"(rd.z), "v"(rd.w)); continue; }
+				unsigned c1, c2, evf, evf2;
+				locate(rd.x, c1, evf);
+				locate(rd.z, c2, evf2);
+				if (A.ablate & 1u) { asm volatile("" ::"v"(c1), "v"(c2), "v"(evf), "v"(rd.x), "v"(rd.y), "v"(rd.z), "v"(rd.w)); continue; }
 				// the usual junction read: block 1 runs to the end of one segment, block 2 starts on the
 				// first base of a later segment of the same event and ends inside it
-				const unsigned c1 = bw1 >> 16, c2 = bw2 >> 16;
 				const uint4 cw1 = cells[min(c1, n_cells - 1u)], cw2 = cells[min(c2, n_cells - 1u)];
-				const bool hit = in && c1 < n_cells && c2 < n_cells && (int)cw1.x <= rd.x && rd.y == (int)cw1.y &&
-				                 rd.z == (int)cw2.x && rd.w <= (int)cw2.y && (cw1.w >> 8) == (cw2.w >> 8) && (cw2.w & 0xFFu) > (cw1.w & 0xFFu) &&
-				                 !(A.ablate & 8u);
+				const unsigned i1 = cell_info[min(c1, n_cells - 1u)], i2 = cell_info[min(c2, n_cells - 1u)];
+				const bool hit = in && c1 < n_cells && c2 < n_cells && i1 != CELL_INFO_SHARED && i2 != CELL_INFO_SHARED &&
+				                 (int)cw1.x <= rd.x && rd.y == (int)cw1.y && (i1 & 2u) &&          // block 1 ends on its segment's end
+				                 rd.z == (int)cw2.x && (i2 & 1u) && rd.w <= (int)cw2.y &&          // block 2 starts on its segment's start
+				                 (i1 >> 8) == (i2 >> 8) && ((i2 >> 2) & 0x3Fu) > ((i1 >> 2) & 0x3Fu) && !(A.ablate & 8u);
 				if (hit) {
-					const unsigned ev = cw1.w >> 8;
+					const unsigned ev = i1 >> 8;
 					const uint4 w0r = C.recs[3u * ev];
 					const unsigned long long tbl = ((unsigned long long)w0r.w << 32) | w0r.z;
-					const unsigned mask = (1u << (cw1.w & 0xFFu)) | (1u << (cw2.w & 0xFFu));
+					const unsigned mask = (1u << ((i1 >> 2) & 0x3Fu)) | (1u << ((i2 >> 2) & 0x3Fu));
 					const unsigned cls = (unsigned)(tbl >> (4u * mask)) & 0xFu;
 					if (cls) atomicAdd(&C.hist[(w0r.y & 0xFFFFu) + cls - 1], (1ull << 40) | (unsigned long long)(unsigned)((rd.y - rd.x) + (rd.w - rd.z)));
 				}
-				park_entry(in && !hit && !(A.ablate & 16u), u, make_uint4(bw1 & 0xFFFFu, rel, 0u, 0u));
+				park_entry(in && !hit && !(A.ablate & 16u), u, make_uint4(evf, rel, 0u, 0u));
 			}
 		}
 	}
@@ -534,14 +551,15 @@ __global__ void __launch_bounds__(COUNT_BLOCK, LSQ_FAST_WAVES) lsq_count_fast_ke
 			for (unsigned i = tid; i < d.n_cls; i += COUNT_BLOCK) h[i] = 0;
 		}
 		__syncthreads();
-		const unsigned *bins = reinterpret_cast<const unsigned *>(lds);
+		const uint4 *bins = reinterpret_cast<const uint4 *>(lds);
 		const uint4 *cells = reinterpret_cast<const uint4 *>(lds + d.seg_off);
+		const unsigned *cell_info = reinterpret_cast<const unsigned *>(lds + d.seg_off + 16u * d.iso_off);
 		FastCtx C;
 		C.recs = reinterpret_cast<const uint4 *>(lds + d.ev_off);
 		C.hist = reinterpret_cast<unsigned long long *>(lds + d.hist_off);
 		C.n_events = d.n_events; C.bucket = b;
 		C.slot0 = 0; C.pool = 0;
-		C.exc = A.exc; C.exc_count = A.exc_count; C.exc_cap = A.exc_cap; C.ablate = A.ablate;
+		C.exc = A.exc; C.exc_count = A.exc_count; C.exc_cap = A.exc_cap; C.ablate = A.ablate; C.dbg = A.dbg;
 		const unsigned long long l0 = (s_begin > bs ? s_begin : bs) - bs;
 		const unsigned long long l1 = (s_end < be ? s_end : be) - bs;
 		const unsigned long long n1 = A.p1_off[b + 1] - A.p1_off[b];
@@ -549,12 +567,12 @@ __global__ void __launch_bounds__(COUNT_BLOCK, LSQ_FAST_WAVES) lsq_count_fast_ke
 		// ---- pool 1
 		if (l0 < n1) {
 			const unsigned long long base = A.p1_off[b];
-			stream_pool_fast<2>(C, bins, cells, d.iso_off, d, A, wave_queue, reinterpret_cast<const uint4 *>(A.p1), base + l0, base + (l1 < n1 ? l1 : n1));
+			stream_pool_fast<2>(C, bins, cells, cell_info, d.iso_off, d, A, wave_queue, reinterpret_cast<const uint4 *>(A.p1), base + l0, base + (l1 < n1 ? l1 : n1));
 		}
 		// ---- pool 2
 		if (l1 > n1 && l0 < n1 + n2) {
 			const unsigned long long base = A.p2_off[b];
-			stream_pool_fast<1>(C, bins, cells, d.iso_off, d, A, wave_queue, reinterpret_cast<const uint4 *>(A.p2), base + ((l0 > n1 ? l0 : n1) - n1),
+			stream_pool_fast<1>(C, bins, cells, cell_info, d.iso_off, d, A, wave_queue, reinterpret_cast<const uint4 *>(A.p2), base + ((l0 > n1 ? l0 : n1) - n1),
 			                    base + ((l1 < n1 + n2 ? l1 : n1 + n2) - n1));
 		}
 		// (reads with three or more blocks are left to the cleanup kernel)
@@ -579,7 +597,7 @@ __global__ void __launch_bounds__(COUNT_BLOCK, LSQ_FAST_WAVES) lsq_count_fast_ke
 // =====================================================================================
 struct GlobalBucket {
 	const BucketDesc *d;
-	const unsigned *bins;          // packed buckets: first event | first cell << 16
+	const unsigned *bins;          // packed buckets: 16-byte bin records, word 0 = first cell | first event << 16
 	const uint4 *recs;
 };
 
@@ -631,7 +649,7 @@ __device__ inline unsigned first_event_for(const GlobalBucket &G, int p) {
 	const int rel = p - d.lo;
 	unsigned bin = rel <= 0 ? 0u : ((unsigned)rel >> d.shift);
 	bin = min(bin, d.n_bins - 1u);
-	return G.bins[bin] & 0xFFFFu;
+	return G.bins[4u * bin] >> 16;
 }
 
 __device__ inline unsigned bucket_of_slot(const unsigned long long *off, unsigned n_buckets, unsigned long long g) {
@@ -834,6 +852,7 @@ struct lsq_ctx {
 	DevBuf<unsigned long long> cnt, bases;
 	DevBuf<ExcEntry> exc;                  // shared by the methods (launches are serialised on the stream)
 	DevBuf<unsigned> exc_count;            // per method: [2m] appended, [2m+1] overflow flag
+	DevBuf<unsigned long long> dbg;
 	bool redo_checked = true;
 	MethodReads reads[LSQ_MAX_METHODS];
 	bool counted = false, solved = false;
@@ -934,6 +953,7 @@ int lsq_events_upload(lsq_ctx *c, const lsq_events *E) {
 	if ((rc = c->iters.alloc(n_ev))) return rc;
 	if ((rc = c->flags.alloc(n_ev))) return rc;
 	if ((rc = c->exc_count.alloc(2 * LSQ_MAX_METHODS))) return rc;
+	if ((rc = c->dbg.alloc(8))) return rc;
 	if ((rc = upload_strand_ranks(c))) return rc;
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	return LSQ_OK;
@@ -995,6 +1015,7 @@ static int run_count(lsq_ctx *c, bool all_reads) {
 		HIP_TRY(hipMemsetAsync(c->bases.p, 0, (size_t)M * n_cls * sizeof(unsigned long long), st));
 	}
 	HIP_TRY(hipMemsetAsync(c->exc_count.p, 0, c->exc_count.n * sizeof(unsigned), st));
+	HIP_TRY(hipMemsetAsync(c->dbg.p, 0, 8 * sizeof(unsigned long long), st));
 	HIP_TRY(hipEventRecord(c->ev0, st));      // ev0..ev1 brackets the count kernel launches only
 	const unsigned tables_bytes = (std::max<unsigned>(E.max_lds_bytes, 16) + 15u) & ~15u;
 	const unsigned lds_bytes = tables_bytes + WAVES * WAVE_QUEUE_WORDS * 16;
@@ -1027,6 +1048,7 @@ static int run_count(lsq_ctx *c, bool all_reads) {
 		A.total_slots = mr.total_slots;
 		A.cnt = c->cnt.p + (size_t)m * n_cls; A.bases = c->bases.p + (size_t)m * n_cls;
 		A.exc = c->exc.p; A.exc_count = c->exc_count.p + 2 * m; A.exc_cap = (unsigned)c->exc.n;
+		A.dbg = c->dbg.p;
 		const unsigned long long n_p1 = mr.p1.n / 2, n_p2 = mr.p2.n / 4, n_pn = mr.pn_strand.n;
 		if (c->has_fast) {
 			if (!all_reads) {
@@ -1184,6 +1206,17 @@ int lsq_results_copy_device(lsq_ctx *c, void *d_class_count, void *d_theta, void
 int lsq_results_device_order(const lsq_ctx *c, int32_t *dev2out) {
 	if (!c || !c->E || !dev2out) return fail(LSQ_E_ARG, "null argument");
 	memcpy(dev2out, c->E->dev2out.data(), c->E->dev2out.size() * sizeof(int32_t));
+	return LSQ_OK;
+}
+
+// developer aid (not in the header): counters filled when LSQ_ABLATE & 256
+int lsq_debug_counters(lsq_ctx *c, unsigned long long *out8) {
+	HIP_TRY(hipSetDevice(c->device));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	HIP_TRY(hipMemcpy(out8, c->dbg.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	std::vector<unsigned> h(c->exc_count.n);
+	HIP_TRY(hipMemcpy(h.data(), c->exc_count.p, h.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+	out8[4] = h[0]; out8[5] = h[1];
 	return LSQ_OK;
 }
 

@@ -100,16 +100,26 @@ constexpr uint32_t FAST_ABUT_SHIFT = 16;
 constexpr uint32_t FAST_FLAG_OVERLAPS_NEXT = 1u << 19;
 constexpr uint32_t FAST_NSEG_SHIFT = 24;
 
-// Shortcut for the commonest read: one block that lies inside one segment of an event whose span
-// no other event touches, and does not start on the span's first base.  Such a read is valid for
-// exactly that event with matched == its length, and its class is that of the single segment.
+// Shortcut table of a packed bucket.  A cell is a stretch of coordinates over which the set of
+// segments (of any event of the bucket) that cover it does not change, with one or two such
+// segments ("owners").  A one-block read that lies inside a cell is valid for exactly its owners'
+// events, with matched == its length and the class of the single segment; the first base of an
+// event's span is left out of every cell (the span-start tie rule decides there).
+//   lo, hi : the cell; hi2 > hi: the owner's next segment starts at hi and the stretch [hi, hi2)
+//            has that segment as only owner -- a read that starts in the cell and ends in
+//            (hi, hi2] matches both segments (slot2)
+//   slots  : low 16 bits owner A's histogram slot; high 16 bits owner B's (hi2 == hi) or the
+//            slot of the two-segment run (hi2 > hi); 0xFFFF = no compatible isoform / absent
 struct Cell {
-	int32_t lo, hi;        // a read [a,b) with lo <= a and b <= hi qualifies
-	uint32_t slot;         // histogram slot inside the bucket, or CELL_NO_CLASS
-	uint32_t pad;          // event index in the bucket << 8 | segment index
+	int32_t lo, hi;
+	int32_t hi2;
+	uint32_t slots;
 };
 static_assert(sizeof(Cell) == 16, "Cell layout");
-constexpr uint32_t CELL_NO_CLASS = 0xFFFFFFFFu;
+constexpr uint32_t CELL_NONE = 0xFFFFu;
+// per cell, for junction reads: owner event << 8 | segment << 2 | hi is the segment's end << 1 |
+// lo is the segment's start; CELL_INFO_SHARED for two-owner cells
+constexpr uint32_t CELL_INFO_SHARED = 0xFFFFFFFFu;
 
 struct TieRec {            // global memory, device event order; read only on start ties
 	uint8_t strand_id;
