@@ -271,8 +271,8 @@ static const int64_t COORD_LIMIT = (int64_t)1 << 30;
 // workgroup staging and flush cost low and the occupancy high; the price is a longer cut list
 // for the ingest-time bucket lookup.  LSQ_LDS_BUDGET overrides (tests use it to vary the split).
 static uint32_t lds_budget_bytes() {
-	if (const char *e = getenv("LSQ_LDS_BUDGET")) { long v = atol(e); if (v >= 512 && v <= 120 * 1024) return (uint32_t)v; }
-	return 4096;
+	if (const char *e = getenv("LSQ_LDS_BUDGET")) { long v = atol(e); if (v >= 512 && v <= 96 * 1024) return (uint32_t)v; }
+	return 8192;
 }
 
 // Builds buckets + LDS images from the compiled events.
@@ -290,7 +290,8 @@ static int plan_device(lsq_events &E) {
 	std::vector<std::vector<int32_t>> per_chrom(E.chroms.names.size());
 	for (size_t i = 0; i < n; ++i) per_chrom[E.ev[i].chrom_id].push_back((int32_t)i);
 	auto ev_bytes = [&](const Event &e) -> uint32_t {
-		return std::max(48u + 40u * (uint32_t)e.N + 20u, 16u + 8u * (uint32_t)e.N + 4u * (uint32_t)e.K) + 8u * ((1u << e.K) - 1u);
+		// packed bucket: record 48 B, ~1.5 cells of 20 B per segment, 8 bin records of 16 B, class histogram
+		return std::max(48u + 40u * (uint32_t)e.N + 20u + 128u, 16u + 8u * (uint32_t)e.N + 4u * (uint32_t)e.K) + 8u * ((1u << e.K) - 1u);
 	};
 	for (size_t c = 0; c < per_chrom.size(); ++c) {
 		auto &lst = per_chrom[c];
@@ -324,7 +325,7 @@ static int plan_device(lsq_events &E) {
 				uint32_t cap = E.lds_budget;
 				if (n_ev > 0 && (bytes + cb > cap || n_ev + cn > 60000)) break;
 				// a single cluster may exceed the budget as long as it fits the CU's LDS
-				if (n_ev == 0 && (cb > 120u * 1024u || cn > 60000))
+				if (n_ev == 0 && (cb > 96u * 1024u || cn > 60000))
 					return fail(LSQ_E_UNSUPPORTED, "%zu mutually overlapping events on %s need %u bytes of LDS tables (budget %u): not supported by the device path yet",
 					            cn, E.chroms.names[c].c_str(), cb, E.lds_budget);
 				bytes += cb; n_ev += cn; i = j;
@@ -436,7 +437,7 @@ static int plan_device(lsq_events &E) {
 			d.img_bytes = off;
 			d.hist_off = off; off += 8 * ncls;
 			d.n_cls = ncls;
-			if (off > 160u * 1024u) return fail(LSQ_E_UNSUPPORTED, "internal: bucket of %u events needs %u bytes of LDS", d.n_events, off);
+			if (off > 128u * 1024u) return fail(LSQ_E_UNSUPPORTED, "bucket of %u events on %s needs %u bytes of LDS tables", d.n_events, E.chroms.names[c].c_str(), off);
 			E.max_lds_bytes = std::max(E.max_lds_bytes, off);
 			d.img_off = (uint32_t)E.images.size();
 			d.cls_base = E.n_cls_total;

@@ -351,8 +351,12 @@ __device__ inline bool fast_trip(const FastCtx &C, const int4 v, const int total
 // Each wave streams its own part of the workgroup's range straight from HBM into registers
 // (next words in flight while the current ones are processed) and owns its parking area: no
 // workgroup barrier inside the stream, a slow wave never holds up the others.
-constexpr int STREAM_WORDS = 2;                               // 16-byte words per lane in flight / in work
-constexpr unsigned WAVE_QUEUE_WORDS = 256;                    // 16-byte words of parking per wave (4 KiB)
+#ifndef LSQ_STREAM_WORDS
+#define LSQ_STREAM_WORDS 2
+#endif
+constexpr int STREAM_WORDS = LSQ_STREAM_WORDS;                // 16-byte words per lane in flight
+constexpr int GROUP_WORDS = 2;                                // words per lane looked up together (independent chains)
+constexpr unsigned WAVE_QUEUE_WORDS = 384;                    // 16-byte words of parking per wave (6 KiB): 63 left over + one step's worth
 constexpr unsigned WAVES = COUNT_BLOCK / 64;
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -450,14 +454,6 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 	};
 	Ring<NB> R;
 	R.q = queue;
-	auto park_entry = [&](bool park, uint4 e0, uint4 e1) {
-		if ((A.ablate & 256u) && park) atomicAdd(&A.dbg[NB - 1], 1ull);
-		R.push(park, lane, e0, e1);
-		if (R.live() >= 64u) {                                 // wave-uniform
-			if (!(A.ablate & 32u)) walk_parked<NB>(C, R, false);
-			else R.head = R.tail;
-		}
-	};
 	if (ww0 < ww1) fetch(ww0);
 	for (unsigned wt = ww0; wt < ww1; wt += TILE) {
 		uint4 cur[STREAM_WORDS];
@@ -465,7 +461,14 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 		for (int k = 0; k < STREAM_WORDS; ++k) cur[k] = nxt[k];
 		if (wt + TILE < ww1) fetch(wt + TILE);
 #pragma unroll
-		for (int k = 0; k < STREAM_WORDS; ++k) {
+		for (int k0 = 0; k0 < STREAM_WORDS; k0 += GROUP_WORDS) {
+		// the reads of a group are looked up first (independent chains), parking comes after
+		constexpr int N_READS = GROUP_WORDS * RPW;
+		bool park[N_READS];
+		uint4 pe0[N_READS], pe1[N_READS];
+#pragma unroll
+		for (int kg = 0; kg < GROUP_WORDS; ++kg) {
+			const int k = k0 + kg;
 			const unsigned w = wt + (unsigned)k * 64u + lane;           // word, relative to w0
 			if (RPW == 2) {
 #pragma unroll
@@ -475,7 +478,6 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 					const bool in = w < ww1 && rel < n_rel;
 					unsigned ci, evf;
 					locate(ra, ci, evf);
-					if (A.ablate & 1u) { asm volatile("" ::"v"(ci), "v"(evf), "v"(ra), "v"(rb)); continue; }
 					// one block inside one cell (or running from it into the owner's next segment):
 					// one or two histogram adds, nothing else to decide
 					const uint4 cw = cells[min(ci, n_cells - 1u)];           // lo, hi, hi2, slots
@@ -484,10 +486,13 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 					const bool cross = contains && !inside && rb <= (int)cw.z;
 					const unsigned sa = cw.w & 0xFFFFu, sb = cw.w >> 16;
 					const unsigned long long add = (1ull << 40) | (unsigned long long)(unsigned)(rb - ra);
-					if (inside && sa != CELL_NONE) atomicAdd(&C.hist[sa], add);
-					if (((inside && cw.z == cw.y) || cross) && sb != CELL_NONE) atomicAdd(&C.hist[sb], add);
-					const bool hit = inside || cross;
-					park_entry(in && !hit && !(A.ablate & 16u), make_uint4((unsigned)ra, (unsigned)rb, evf, rel), make_uint4(0, 0, 0, 0));
+					if (!(A.ablate & 1u)) {
+						if (inside && sa != CELL_NONE) atomicAdd(&C.hist[sa], add);
+						if (((inside && cw.z == cw.y) || cross) && sb != CELL_NONE) atomicAdd(&C.hist[sb], add);
+					} else asm volatile("" ::"v"(sa), "v"(sb));
+					park[kg * 2 + h] = in && !(inside || cross) && !(A.ablate & 17u);
+					pe0[kg * 2 + h] = make_uint4((unsigned)ra, (unsigned)rb, evf, rel);
+					pe1[kg * 2 + h] = make_uint4(0, 0, 0, 0);
 				}
 			} else {
 				const uint4 u = cur[k];
@@ -497,7 +502,6 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 				unsigned c1, c2, evf, evf2;
 				locate(rd.x, c1, evf);
 				locate(rd.z, c2, evf2);
-				if (A.ablate & 1u) { asm volatile("" ::"v"(c1), "v"(c2), "v"(evf), "v"(rd.x), "v"(rd.y), "v"(rd.z), "v"(rd.w)); continue; }
 				// the usual junction read: block 1 runs to the end of one segment, block 2 starts on the
 				// first base of a later segment of the same event and ends inside it
 				const uint4 cw1 = cells[min(c1, n_cells - 1u)], cw2 = cells[min(c2, n_cells - 1u)];
@@ -506,7 +510,7 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 				                 (int)cw1.x <= rd.x && rd.y == (int)cw1.y && (i1 & 2u) &&          // block 1 ends on its segment's end
 				                 rd.z == (int)cw2.x && (i2 & 1u) && rd.w <= (int)cw2.y &&          // block 2 starts on its segment's start
 				                 (i1 >> 8) == (i2 >> 8) && ((i2 >> 2) & 0x3Fu) > ((i1 >> 2) & 0x3Fu) && !(A.ablate & 8u);
-				if (hit) {
+				if (hit && !(A.ablate & 1u)) {
 					const unsigned ev = i1 >> 8;
 					const uint4 w0r = C.recs[3u * ev];
 					const unsigned long long tbl = ((unsigned long long)w0r.w << 32) | w0r.z;
@@ -514,8 +518,20 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 					const unsigned cls = (unsigned)(tbl >> (4u * mask)) & 0xFu;
 					if (cls) atomicAdd(&C.hist[(w0r.y & 0xFFFFu) + cls - 1], (1ull << 40) | (unsigned long long)(unsigned)((rd.y - rd.x) + (rd.w - rd.z)));
 				}
-				park_entry(in && !hit && !(A.ablate & 16u), u, make_uint4(evf, rel, 0u, 0u));
+				park[kg] = in && !hit && !(A.ablate & 17u);
+				pe0[kg] = u;
+				pe1[kg] = make_uint4(evf, rel, 0u, 0u);
 			}
+		}
+#pragma unroll
+		for (int q = 0; q < N_READS; ++q) {
+			if ((A.ablate & 256u) && park[q]) atomicAdd(&A.dbg[NB - 1], 1ull);
+			R.push(park[q], lane, pe0[q], pe1[q]);
+		}
+		if (R.live() >= 64u) {                                 // wave-uniform
+			if (!(A.ablate & 32u)) walk_parked<NB>(C, R, false);
+			else R.head = R.tail;
+		}
 		}
 	}
 	if (R.live() && !(A.ablate & 32u)) walk_parked<NB>(C, R, true);
@@ -1025,7 +1041,7 @@ static int run_count(lsq_ctx *c, bool all_reads) {
 		HIP_TRY(hipFuncSetAttribute((const void *)lsq_count_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
 	}
 	unsigned per_cu = std::max(1u, std::min(2048u / COUNT_BLOCK, (160u * 1024u) / lds_bytes));
-	unsigned mult = 1;
+	unsigned mult = 2;
 	if (const char *e = getenv("LSQ_GRID_MULT")) { int v = atoi(e); if (v >= 1 && v <= 64) mult = (unsigned)v; }
 	for (int m = 0; m < M; ++m) {
 		MethodReads &mr = c->reads[m];

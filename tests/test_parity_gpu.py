@@ -151,7 +151,7 @@ def test_results_do_not_depend_on_launch_geometry(tmp_path, monkeypatch):
     a_dir = str(tmp_path)
     L.synth_write(spec, a_dir, "g", write_mrf=False)
     results = []
-    for budget, mult in (("4096", "1"), ("1024", "2"), ("65536", "7"), ("120000", "16")):
+    for budget, mult in (("8192", "2"), ("1024", "1"), ("65536", "7"), ("90000", "16")):
         monkeypatch.setenv("LSQ_LDS_BUDGET", budget)
         monkeypatch.setenv("LSQ_GRID_MULT", mult)
         a = L.Annotation(os.path.join(a_dir, "g.interval"), os.path.join(a_dir, "g.map"))
