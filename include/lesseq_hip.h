@@ -97,6 +97,11 @@ uint64_t lsq_events_isoform_length(const lsq_events *e, int64_t ev, int iso);
 uint64_t lsq_events_ars(const lsq_events *e, int method, int64_t ev, int iso);
 int lsq_events_span(const lsq_events *e, int64_t ev, int64_t *gene_start, int64_t *gene_end);
 int64_t lsq_events_num_buckets(const lsq_events *e);
+/* Restricts the device plan to events [first_event, first_event + n_events) of the output order
+ * (the reference's own scale-out unit, count/count.cpp:204-215) while the covered regions -- and so
+ * the load-time read filter -- stay those of the whole selected range: every shard then gives
+ * exactly the rows the unsharded run gives for its events.  Call before lsq_events_upload. */
+int lsq_events_set_shard(lsq_events *e, uint64_t first_event, uint64_t n_events);
 
 /* Replaces count/count.cpp:279-336 (== solve/solve.cpp:429-486) minus the containment
  * filter: parses an MRF_SINGLE file into blocks in file order.  A lexical_cast failure

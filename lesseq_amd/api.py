@@ -110,6 +110,9 @@ class Events:
         check(lib.lsq_events_span(self.h, ev, C.byref(s), C.byref(e)))
         return s.value, e.value
 
+    def set_shard(self, first_event, n_events):
+        check(lib.lsq_events_set_shard(self.h, first_event, n_events))
+
     def chrom_id(self, name):
         return lib.lsq_events_chrom_id(self.h, _b(name))
 

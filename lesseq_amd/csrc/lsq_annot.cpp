@@ -276,7 +276,7 @@ static uint32_t lds_budget_bytes() {
 }
 
 // Builds buckets + LDS images from the compiled events.
-static int plan_device(lsq_events &E) {
+int plan_device(lsq_events &E) {
 	const size_t n = E.ev.size();
 	E.lds_budget = lds_budget_bytes();
 	E.buckets.clear(); E.images.clear(); E.dev2out.clear(); E.ties.clear();
@@ -288,7 +288,8 @@ static int plan_device(lsq_events &E) {
 
 	// events per chromosome, ordered by span start
 	std::vector<std::vector<int32_t>> per_chrom(E.chroms.names.size());
-	for (size_t i = 0; i < n; ++i) per_chrom[E.ev[i].chrom_id].push_back((int32_t)i);
+	for (size_t i = 0; i < n; ++i)
+		if (i >= E.shard_first && i - E.shard_first < E.shard_count) per_chrom[E.ev[i].chrom_id].push_back((int32_t)i);
 	auto ev_bytes = [&](const Event &e) -> uint32_t {
 		// packed bucket: record 48 B, ~1.5 cells of 20 B per segment, 8 bin records of 16 B, class histogram
 		return std::max(48u + 40u * (uint32_t)e.N + 20u + 128u, 16u + 8u * (uint32_t)e.N + 4u * (uint32_t)e.K) + 8u * ((1u << e.K) - 1u);
@@ -350,7 +351,7 @@ static int plan_device(lsq_events &E) {
 			while (want < 8 * d.n_events && want < 4096) want <<= 1;
 			uint32_t shift = 0;
 			while ((((uint64_t)(hi - lo)) >> shift) >= want) ++shift;
-			d.n_bins = want; d.shift = shift; d.lo = (int32_t)lo;
+			d.n_bins = want; d.shift = shift; d.lo = (int32_t)lo; d.hi = (int32_t)hi;
 			d.kind = fast ? 1u : 0u;
 			auto align16 = [](uint32_t x) { return (x + 15u) & ~15u; };
 			uint32_t off = 0;
@@ -672,6 +673,14 @@ uint64_t lsq_events_ars(const lsq_events *e, int method, int64_t ev, int iso) {
 }
 int lsq_events_span(const lsq_events *e, int64_t ev, int64_t *gs, int64_t *ge) { EV_OR(LSQ_E_ARG); *gs = e->ev[ev].gene_start; *ge = e->ev[ev].gene_end; return LSQ_OK; }
 int64_t lsq_events_num_buckets(const lsq_events *e) { return e ? (int64_t)e->buckets.size() : 0; }
+
+int lsq_events_set_shard(lsq_events *e, uint64_t first_event, uint64_t n_events) {
+	if (!e) return fail(LSQ_E_ARG, "null argument");
+	if (first_event > e->ev.size()) return fail(LSQ_E_ARG, "shard starts past the last event");
+	e->shard_first = first_event;
+	e->shard_count = n_events;
+	return plan_device(*e);
+}
 
 int lsq_events_chrom_id(lsq_events *e, const char *chrom) {
 	if (!e || !chrom) return LSQ_E_ARG;

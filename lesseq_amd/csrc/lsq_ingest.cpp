@@ -42,7 +42,9 @@ inline int bucket_of(const lsq_events &E, int chrom, int64_t p) {
 	if (first < 0) return -1;
 	const std::vector<int32_t> &cuts = E.cut_lo[chrom];
 	size_t k = std::upper_bound(cuts.begin(), cuts.end(), (int32_t)p) - cuts.begin();
-	return first + (int)(k == 0 ? 0 : k - 1);
+	if (k == 0) return -1;                                   // left of the chromosome's first span
+	const int b = first + (int)(k - 1);
+	return p > E.buckets[b].hi ? -1 : b;                     // right of the bucket's last span: no event can want the read
 }
 
 } // namespace

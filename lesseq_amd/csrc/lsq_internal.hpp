@@ -72,7 +72,7 @@ struct BucketDesc {
 	uint32_t ev_base;      // first event of the bucket in device event order
 	int32_t chrom_id;
 	uint32_t kind;         // 0: generic records (EventRec + segments + masks); 1: packed 48-byte FastRec
-	uint32_t pad;
+	int32_t hi;            // largest span end in the bucket (reads that start right of it have no candidate)
 };
 static_assert(sizeof(BucketDesc) == 64, "BucketDesc is copied to the device verbatim");
 
@@ -153,6 +153,7 @@ struct lsq_events {
 	lsq::Dict chroms, strands;
 	std::vector<lsq::IntervalList> covered;        // by chrom id (events' chromosomes)
 	// ---- device plan
+	uint64_t shard_first = 0, shard_count = UINT64_MAX;   // events (output order) this process works on
 	uint32_t lds_budget = 0;
 	std::vector<lsq::BucketDesc> buckets;          // sorted by (chrom_id, lo)
 	std::vector<uint8_t> images;                   // all bucket images
@@ -211,6 +212,7 @@ struct PooledReads {
 
 // host ingest: containment filter + add_interval merge + bucket/pool scatter
 int ingest_reads(const lsq_events &ev, const lsq_reads &rd, int n_threads, PooledReads &out);
+int plan_device(lsq_events &E);
 
 int host_threads(int requested);
 

@@ -1,0 +1,95 @@
+"""Multi-GPU driver for the count + solve path: one process per GPU, events sharded by index.
+
+Events are independent (the reference already scales out by running disjoint
+gene_begin_idx..gene_end_idx slices, count/count.cpp:204-215).  Here every rank loads the whole
+selected range -- so the covered regions, hence the load-time read filter, are those of the
+unsharded run -- restricts its device plan to a contiguous slice of the output-ordered events
+(lsq_events_set_shard), counts and solves its slice on its GPU, and the fixed-stride per-event
+outputs (class counts, class bases, theta, log-likelihood) are combined over the process group:
+RCCL over xGMI with backend "nccl", gloo on CPU tensors in the tests.  Slices are disjoint, so the
+sum over ranks of zero-padded arrays IS the concatenation; integer sums keep it exact.
+"""
+import numpy as np
+
+from . import api
+
+
+def shard_bounds(n_events, world, weights=None):
+    """Contiguous slices [(first, count)] of the output-ordered events, balanced by `weights`
+    (estimated reads per event) when given, else by event count."""
+    if weights is None:
+        weights = np.ones(n_events, np.float64)
+    w = np.asarray(weights, np.float64)
+    assert len(w) == n_events
+    cum = np.concatenate([[0.0], np.cumsum(w)])
+    total = cum[-1]
+    cuts = [0]
+    for r in range(1, world):
+        target = total * r / world
+        cuts.append(int(np.searchsorted(cum, target, side="left")))
+    cuts.append(n_events)
+    cuts = [min(max(c, 0), n_events) for c in cuts]
+    for i in range(1, len(cuts)):
+        cuts[i] = max(cuts[i], cuts[i - 1])
+    return [(cuts[r], cuts[r + 1] - cuts[r]) for r in range(world)]
+
+
+def combine(arrays, group=None, device=None):
+    """all-reduce(SUM) of zero-padded per-rank arrays; uint64 travels as int64 (counts < 2^63)."""
+    import torch
+    import torch.distributed as dist
+    out = []
+    for a in arrays:
+        a = np.ascontiguousarray(a)
+        view = a.view(np.int64) if a.dtype == np.uint64 else a
+        t = torch.from_numpy(view.copy())
+        if device is not None:
+            t = t.to(device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        r = t.cpu().numpy()
+        out.append(r.view(np.uint64) if a.dtype == np.uint64 else r)
+    return out
+
+
+def parse_cli(tool, argv):
+    per = 5 if tool == "solve" else 4
+    groups = [argv[9 + i * per: 9 + (i + 1) * per] for i in range((len(argv) - 9) // per)]
+    return dict(isoforms=argv[4], g2i=argv[6], begin=int(argv[7]), end=int(argv[8]),
+                read_types=tuple(g[1] for g in groups), read_lengths=tuple(int(g[2]) for g in groups),
+                read_paths=[g[3] for g in groups], total_read_bases=[float(g[4]) for g in groups] if tool == "solve" else None)
+
+
+def run_sharded(tool, argv, rank, world, device_index=0, group=None, comm_device=None, weights=None):
+    """count / solve over `world` ranks.  Returns the table text on every rank (they all hold the
+    combined arrays after the all-reduce); byte-identical to the single-process run."""
+    a = parse_cli(tool, argv)
+    ann = api.Annotation(a["isoforms"], a["g2i"], a["begin"], a["end"])
+    ev = api.Events(ann, a["read_types"], a["read_lengths"])
+    first, count = shard_bounds(len(ev), world, weights)[rank]
+    ev.set_shard(first, count)
+    ctx = api.Context(device_index)
+    ctx.upload_events(ev)
+    for m, path in enumerate(a["read_paths"]):
+        ctx.upload_reads(m, api.Reads.from_mrf(path, ev))
+    ctx.count()
+    if tool == "solve":
+        ctx.solve()
+    cnt, bases = ctx.counts()
+    parts = [cnt, bases]
+    if tool == "solve":
+        theta, ll, iters, flags = ctx.solution()
+        # events outside the slice hold zeros
+        off = ev.class_offsets()
+        mask_ev = np.zeros(len(ev), bool)
+        mask_ev[first:first + count] = True
+        io = np.concatenate([[0], np.cumsum([ev.K(i) for i in range(len(ev))])])
+        for i in np.nonzero(~mask_ev)[0]:
+            theta[io[i]:io[i + 1]] = 0.0
+            ll[i] = 0.0
+        parts += [theta, ll]
+    ctx.close()
+    if world > 1:
+        parts = combine(parts, group, comm_device)
+    if tool == "count":
+        return api.format_count(ev, parts[0])
+    return api.format_solve(ev, parts[0], parts[1], parts[2], parts[3], a["total_read_bases"])

@@ -1,0 +1,124 @@
+"""The N > 1 path on CPU: slicing of the output-ordered events and the combination of per-rank,
+zero-padded per-event outputs over a gloo process group of two ranks (the same code runs over
+RCCL with backend "nccl" on GPUs).  The device work itself is covered by the -m gpu tests."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import lesseq_amd as L
+from lesseq_amd import dist as ld
+from test_oracle_golden import GOLD
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_shard_bounds_cover_every_event_once():
+    for n, w in ((10, 3), (1, 4), (0, 2), (50000, 8), (7, 7)):
+        b = ld.shard_bounds(n, w)
+        assert len(b) == w and b[0][0] == 0 and sum(c for _, c in b) == n
+        for (f0, c0), (f1, _) in zip(b, b[1:]):
+            assert f0 + c0 == f1
+    # balanced by weight: one heavy event gets a slice of its own
+    wts = np.ones(100)
+    wts[10] = 1000.0
+    b = ld.shard_bounds(100, 4, wts)
+    sums = [wts[f:f + c].sum() for f, c in b]
+    assert max(sums) <= 1000.0 + 50
+
+
+def _worker(rank, world, port, iv, mp_path, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ann = L.Annotation(iv, mp_path)
+        ev = L.Events(ann, ("SHORT_READ",), (100,))
+        n_ev = len(ev)
+        off = ev.class_offsets()
+        n_cls, n_iso = off[-1], ev.total_isoforms
+        # what a rank's GPU would hand back: values only inside its slice of the events
+        first, count = ld.shard_bounds(n_ev, world)[rank]
+        full_cnt = (np.arange(n_cls, dtype=np.uint64) * 2654435761 % 1000003).reshape(1, -1)
+        full_bases = full_cnt * np.uint64(97)
+        full_theta = (np.arange(n_iso) % 7 + 1) / 8.0
+        full_ll = -np.arange(n_ev, dtype=np.float64) - 1.5
+        io = np.concatenate([[0], np.cumsum([ev.K(i) for i in range(n_ev)])])
+        cnt, bases = np.zeros_like(full_cnt), np.zeros_like(full_bases)
+        theta, ll = np.zeros_like(full_theta), np.zeros_like(full_ll)
+        lo_c, hi_c = off[first], off[first + count]
+        cnt[:, lo_c:hi_c] = full_cnt[:, lo_c:hi_c]
+        bases[:, lo_c:hi_c] = full_bases[:, lo_c:hi_c]
+        theta[io[first]:io[first + count]] = full_theta[io[first]:io[first + count]]
+        ll[first:first + count] = full_ll[first:first + count]
+        g_cnt, g_bases, g_theta, g_ll = ld.combine([cnt, bases, theta, ll])
+        ok = (np.array_equal(g_cnt, full_cnt) and np.array_equal(g_bases, full_bases)
+              and np.array_equal(g_theta, full_theta) and np.array_equal(g_ll, full_ll))
+        text = L.format_solve(ev, g_cnt, g_bases, g_theta, g_ll, [1e6])
+        ref = L.format_solve(ev, full_cnt, full_bases, full_theta, full_ll, [1e6])
+        q.put((rank, ok and text == ref and L.format_count(ev, g_cnt) == L.format_count(ev, full_cnt)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_gloo_combine_and_format():
+    d = os.path.join(GOLD, "events_s1")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, os.path.join(d, "ev.interval"), os.path.join(d, "ev.map"), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def _gpu_worker(rank, world, port, argv_count, argv_solve, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        c = ld.run_sharded("count", argv_count, rank, world, device_index=0)
+        s = ld.run_sharded("solve", argv_solve, rank, world, device_index=0)
+        q.put((rank, c, s))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_sharded_run_equals_single_process(tmp_path):
+    """two ranks (sharing the one GPU of the test box, gloo for the exchange) give the byte-identical
+    count table and the identical solve table of the unsharded run"""
+    spec = L.SynthSpec(31, 300, 60000, 100, 3, L.EVENT_TYPES)
+    L.synth_write(spec, str(tmp_path), "d")
+    base = ["0", "d", "./", "LH_GENE_TXT", str(tmp_path / "d.interval"), "UCSC_GENE2ISOFORM", str(tmp_path / "d.map"),
+            "0", "100000000", "MRF_SINGLE", "SHORT_READ", "100", str(tmp_path / "d.mrf")]
+    rc, single_count = L.cli_run("count", base)
+    rc2, single_solve = L.cli_run("solve", base + ["6000000"])
+    assert rc == rc2 == 0
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, base, base + ["6000000"], q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, c, s in res:
+        assert c == single_count
+        assert s == single_solve
