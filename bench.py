@@ -102,7 +102,7 @@ def main():
         g_theta = torch.zeros(world * t_theta.numel(), dtype=torch.float64, device=dev)
         g_ll = torch.zeros(world * t_ll.numel(), dtype=torch.float64, device=dev)
 
-    count_ms, solve_ms = [], []
+    count_ms, solve_ms, fast_ms = [], [], []
 
     def step(record):
         ctx.count()
@@ -117,6 +117,7 @@ def main():
             c, s = ctx.timing()        # HIP events on the library's stream (synchronises it)
             count_ms.append(c)
             solve_ms.append(s)
+            fast_ms.append(ctx.fast_kernel_ms())
 
     def fence():
         ctx.synchronize()
@@ -156,13 +157,20 @@ def main():
 
     if rank == 0:
         ck = float(np.mean(count_ms))
+        fk = float(np.mean(fast_ms))
         off = ev.class_offsets()
         ev_bytes = 0
         for i in range(0, n_ev):
             K, N = ev.K(i), ev.N(i)
             ev_bytes += 8 * N + 8 * K + 16 + 8 * ((1 << K) - 1) + 8
         alg_bytes = 8.0 * retained_blocks + ev_bytes
-        achieved = alg_bytes / (ck * 1e-3) / 1e9
+        achieved = alg_bytes / (fk * 1e-3) / 1e9
+        # HBM bytes per launch of the same kernel from the committed rocprofv3 PMC passes (tools/bench_prof.sh)
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic_%s.json" % a.workload)
+        if world == 1 and os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("count_fast_kernel_hbm_bytes_per_launch")
+            traffic_src = "profiles/r01_traffic_%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; 2 x FETCH_SIZE + WRITE_SIZE)" % a.workload
         out = {
             "metric": "MRF reads/sec through count+solve",
             "value": total_retained * a.steps / elapsed,
@@ -181,16 +189,17 @@ def main():
                 "events_per_gpu": n_ev, "mrf_reads_per_gpu": n_mrf_reads, "retained_reads_per_gpu": retained,
                 "retained_blocks_per_gpu": retained_blocks, "buckets": ev.num_buckets,
                 "reads_counted": "retained reads (those that pass the load-time containment filter, count/count.cpp:319); off-target reads are dropped at ingest",
-                "count_kernel_ms": ck, "em_kernel_ms": float(np.mean(solve_ms)),
+                "count_kernels_ms": ck, "count_fast_kernel_ms": fk, "em_kernel_ms": float(np.mean(solve_ms)),
                 "valid_read_assignments": int(cnt.sum()), "em_flagged_events": int((flags & 1).sum()),
                 "em_max_iters": int(iters.max()) if n_ev else 0,
                 "generate_s": t_gen, "ingest_s": t_ingest,
                 "parallelism": "events sharded by rank; RCCL all-gather of per-event outputs" if world > 1 else "single GPU",
             },
             "roofline": {
-                "bound": "hbm", "kernel": "lsq_count_kernel",
+                "bound": "hbm", "kernel": "lsq_count_fast_kernel",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": alg_bytes,
             },
         }

@@ -182,6 +182,9 @@ int lsq_results_device_order(const lsq_ctx *c, int32_t *dev2out /* n_events */);
 /* Device timing of the last lsq_count / lsq_solve (ms, from HIP events on the context
  * stream) and the count kernel's launch geometry; for bench.py. */
 int lsq_last_timing(lsq_ctx *c, float *count_ms, float *solve_ms);
+/* Duration of the last lsq_count's lsq_count_fast_kernel launches alone (summed over read files),
+ * from HIP events recorded immediately around each launch. */
+int lsq_last_fast_kernel_ms(lsq_ctx *c, float *ms);
 
 /* ------------------------------------------------------------------------------------
  * Output rows (host): replaces count/count.cpp:486-492 and solve/solve.cpp:808-847

@@ -225,6 +225,11 @@ class Context:
         check(lib.lsq_results_device_order(self.h, _ptr(o, i32)))
         return o[:len(self.events)]
 
+    def fast_kernel_ms(self):
+        a = C.c_float()
+        check(lib.lsq_last_fast_kernel_ms(self.h, C.byref(a)))
+        return a.value
+
     def counts(self):
         """(class_count, class_bases) as uint64 arrays of shape [n_methods, n_classes], output order"""
         n = lib.lsq_results_num_classes(self.h)

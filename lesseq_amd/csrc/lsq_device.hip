@@ -858,6 +858,8 @@ struct lsq_ctx {
 	int n_cu = 256;
 	hipStream_t stream = nullptr;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+	hipEvent_t evf0[LSQ_MAX_METHODS] = {}, evf1[LSQ_MAX_METHODS] = {};   // around each method's lsq_count_fast_kernel launch
+	int fast_launched = 0;
 	const lsq_events *E = nullptr;          // must outlive the uploads made from it
 	DevBuf<BucketDesc> buckets;
 	DevBuf<uint8_t> images, strand_rank, dK;
@@ -909,6 +911,7 @@ int lsq_ctx_create(int device_id, lsq_ctx **out) {
 	HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 	HIP_TRY(hipEventCreate(&c->ev0)); HIP_TRY(hipEventCreate(&c->ev1));
 	HIP_TRY(hipEventCreate(&c->ev2)); HIP_TRY(hipEventCreate(&c->ev3));
+	for (int m = 0; m < LSQ_MAX_METHODS; ++m) { HIP_TRY(hipEventCreate(&c->evf0[m])); HIP_TRY(hipEventCreate(&c->evf1[m])); }
 	*out = c.release();
 	return LSQ_OK;
 }
@@ -921,6 +924,7 @@ void lsq_ctx_destroy(lsq_ctx *c) {
 	if (c->ev1) (void)hipEventDestroy(c->ev1);
 	if (c->ev2) (void)hipEventDestroy(c->ev2);
 	if (c->ev3) (void)hipEventDestroy(c->ev3);
+	for (int m = 0; m < LSQ_MAX_METHODS; ++m) { if (c->evf0[m]) (void)hipEventDestroy(c->evf0[m]); if (c->evf1[m]) (void)hipEventDestroy(c->evf1[m]); }
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
 }
@@ -1032,6 +1036,7 @@ static int run_count(lsq_ctx *c, bool all_reads) {
 	}
 	HIP_TRY(hipMemsetAsync(c->exc_count.p, 0, c->exc_count.n * sizeof(unsigned), st));
 	HIP_TRY(hipMemsetAsync(c->dbg.p, 0, 8 * sizeof(unsigned long long), st));
+	c->fast_launched = 0;
 	HIP_TRY(hipEventRecord(c->ev0, st));      // ev0..ev1 brackets the count kernel launches only
 	const unsigned tables_bytes = (std::max<unsigned>(E.max_lds_bytes, 16) + 15u) & ~15u;
 	const unsigned lds_bytes = tables_bytes + WAVES * WAVE_QUEUE_WORDS * 16;
@@ -1068,8 +1073,11 @@ static int run_count(lsq_ctx *c, bool all_reads) {
 		const unsigned long long n_p1 = mr.p1.n / 2, n_p2 = mr.p2.n / 4, n_pn = mr.pn_strand.n;
 		if (c->has_fast) {
 			if (!all_reads) {
+				HIP_TRY(hipEventRecord(c->evf0[m], st));
 				hipLaunchKernelGGL(lsq_count_fast_kernel, dim3((unsigned)grid), dim3(COUNT_BLOCK), lds_bytes, st, A);
 				HIP_TRY(hipGetLastError());
+				HIP_TRY(hipEventRecord(c->evf1[m], st));
+				c->fast_launched |= 1 << m;
 			}
 			const unsigned long long work = all_reads ? n_p1 + n_p2 + n_pn : std::max<unsigned long long>(n_pn, 65536);
 			const unsigned cgrid = (unsigned)std::min<unsigned long long>((work + 255) / 256, (unsigned long long)c->n_cu * 8);
@@ -1146,7 +1154,7 @@ int lsq_solve(lsq_ctx *c) {
 	return LSQ_OK;
 }
 
-int64_t lsq_results_num_classes(const lsq_ctx *c) { return (c && c->E) ? (int64_t)c->E->n_cls_total : 0; }
+int64_t lsq_results_num_classes(const lsq_ctx *c) { return (c && c->E) ? (int64_t)c->E->class_off.back() : 0; }
 
 int lsq_results_class_offsets(const lsq_ctx *c, uint64_t *class_off) {
 	if (!c || !c->E || !class_off) return fail(LSQ_E_ARG, "null argument");
@@ -1160,20 +1168,24 @@ int lsq_results_counts(lsq_ctx *c, uint64_t *class_count, uint64_t *class_bases)
 	HIP_TRY(hipSetDevice(c->device));
 	{ int rc = ensure_counts_complete(c); if (rc) return rc; }
 	const lsq_events &E = *c->E;
-	const size_t n_cls = E.n_cls_total, M = (size_t)E.n_methods;
+	// device arrays hold the classes of this process's events (device order); the caller's arrays
+	// hold every selected event's classes (output order), zero outside the shard
+	const size_t n_cls = E.n_cls_total, n_out = (size_t)E.class_off.back(), M = (size_t)E.n_methods;
 	std::vector<unsigned long long> hc(std::max<size_t>(M * n_cls, 1)), hb(std::max<size_t>(M * n_cls, 1));
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	if (M * n_cls) {
 		HIP_TRY(hipMemcpy(hc.data(), c->cnt.p, M * n_cls * sizeof(unsigned long long), hipMemcpyDeviceToHost));
 		HIP_TRY(hipMemcpy(hb.data(), c->bases.p, M * n_cls * sizeof(unsigned long long), hipMemcpyDeviceToHost));
 	}
+	memset(class_count, 0, M * n_out * sizeof(uint64_t));
+	if (class_bases) memset(class_bases, 0, M * n_out * sizeof(uint64_t));
 	for (size_t d = 0; d < E.dev2out.size(); ++d) {
 		const size_t o = (size_t)E.dev2out[d];
 		const size_t nc = (1u << E.ev[o].K) - 1u;
 		for (size_t m = 0; m < M; ++m)
 			for (size_t k = 0; k < nc; ++k) {
-				class_count[m * n_cls + E.class_off[o] + k] = hc[m * n_cls + E.dev_cls_base[d] + k];
-				if (class_bases) class_bases[m * n_cls + E.class_off[o] + k] = hb[m * n_cls + E.dev_cls_base[d] + k];
+				class_count[m * n_out + E.class_off[o] + k] = hc[m * n_cls + E.dev_cls_base[d] + k];
+				if (class_bases) class_bases[m * n_out + E.class_off[o] + k] = hb[m * n_cls + E.dev_cls_base[d] + k];
 			}
 	}
 	return LSQ_OK;
@@ -1195,6 +1207,12 @@ int lsq_results_solve(lsq_ctx *c, double *theta, double *logll, uint32_t *em_ite
 		HIP_TRY(hipMemcpy(hl.data(), c->logll.p, n_ev * sizeof(double), hipMemcpyDeviceToHost));
 		HIP_TRY(hipMemcpy(hi.data(), c->iters.p, n_ev * sizeof(uint32_t), hipMemcpyDeviceToHost));
 		HIP_TRY(hipMemcpy(hf.data(), c->flags.p, n_ev * sizeof(uint8_t), hipMemcpyDeviceToHost));
+	}
+	for (size_t o = 0; o < E.ev.size(); ++o) {        // events outside the shard: zeros
+		for (int j = 0; j < E.ev[o].K; ++j) theta[E.iso_off[o] + j] = 0.0;
+		logll[o] = 0.0;
+		if (em_iters) em_iters[o] = 0;
+		if (em_flags) em_flags[o] = 0;
 	}
 	for (size_t d = 0; d < n_ev; ++d) {
 		const size_t o = (size_t)E.dev2out[d];
@@ -1233,6 +1251,15 @@ int lsq_debug_counters(lsq_ctx *c, unsigned long long *out8) {
 	std::vector<unsigned> h(c->exc_count.n);
 	HIP_TRY(hipMemcpy(h.data(), c->exc_count.p, h.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
 	out8[4] = h[0]; out8[5] = h[1];
+	return LSQ_OK;
+}
+
+int lsq_last_fast_kernel_ms(lsq_ctx *c, float *ms) {
+	if (!c || !ms) return fail(LSQ_E_ARG, "null argument");
+	HIP_TRY(hipSetDevice(c->device));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	*ms = 0;
+	for (int m = 0; m < LSQ_MAX_METHODS; ++m) if (c->fast_launched >> m & 1) { float t = 0; HIP_TRY(hipEventElapsedTime(&t, c->evf0[m], c->evf1[m])); *ms += t; }
 	return LSQ_OK;
 }
 

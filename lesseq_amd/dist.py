@@ -78,15 +78,7 @@ def run_sharded(tool, argv, rank, world, device_index=0, group=None, comm_device
     parts = [cnt, bases]
     if tool == "solve":
         theta, ll, iters, flags = ctx.solution()
-        # events outside the slice hold zeros
-        off = ev.class_offsets()
-        mask_ev = np.zeros(len(ev), bool)
-        mask_ev[first:first + count] = True
-        io = np.concatenate([[0], np.cumsum([ev.K(i) for i in range(len(ev))])])
-        for i in np.nonzero(~mask_ev)[0]:
-            theta[io[i]:io[i + 1]] = 0.0
-            ll[i] = 0.0
-        parts += [theta, ll]
+        parts += [theta, ll]          # events outside the slice hold zeros
     ctx.close()
     if world > 1:
         parts = combine(parts, group, comm_device)
