@@ -775,6 +775,42 @@ __device__ inline void em_pass(const EmArgs &A, unsigned cb, unsigned ib, int K,
 	for (int j = 0; j < LSQ_MAX_ISOFORMS; ++j) z[j] = group_sum(zz[j]);
 }
 
+// An event's (method, class) counts and G values in registers when there are at most two pairs
+// per lane and three isoforms (every LESSeq local event with up to two read files): the passes
+// then touch no memory, and the latency of one pass is what bounds the kernel (the slowest
+// event of the batch runs ~160 dependent passes).
+constexpr int EM_CACHED_PAIRS = 2, EM_CACHED_K = 3;
+struct EmCache {
+	double kd[EM_CACHED_PAIRS];
+	double g[EM_CACHED_PAIRS][EM_CACHED_K];
+	int cls[EM_CACHED_PAIRS];
+};
+
+__device__ inline void em_pass_cached(const EmCache &E, const double *th, bool on, double &ll, double *z) {
+	double l = 0, zz[EM_CACHED_K] = {0, 0, 0};
+#pragma unroll
+	for (int t = 0; t < EM_CACHED_PAIRS; ++t) {
+		const double kd = E.kd[t];
+		if (on && kd != 0) {
+			const int c = E.cls[t];
+			double s = 0;
+#pragma unroll
+			for (int j = 0; j < EM_CACHED_K; ++j) if (c >> j & 1) s += th[j] * E.g[t][j];
+			l += kd * log(s);
+			if (s > 0) {
+#pragma unroll
+				for (int j = 0; j < EM_CACHED_K; ++j) if (c >> j & 1) {
+					const double local = th[j] * E.g[t][j];
+					if (local > 0) zz[j] += kd * (local / s);
+				}
+			}
+		}
+	}
+	ll = group_sum(l);
+#pragma unroll
+	for (int j = 0; j < EM_CACHED_K; ++j) z[j] = group_sum(zz[j]);
+}
+
 __global__ void __launch_bounds__(256) lsq_em_kernel(EmArgs A) {
 	const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
 	const unsigned e = gid / EM_LANES, sub = gid % EM_LANES;
@@ -782,13 +818,35 @@ __global__ void __launch_bounds__(256) lsq_em_kernel(EmArgs A) {
 	const int K = ev_ok ? A.K[e] : 1;
 	const unsigned cb = ev_ok ? A.cls_base[e] : 0, ib = ev_ok ? A.iso_base[e] : 0;
 	const int nc = (1 << K) - 1;
+	const int n_pairs = (int)A.n_methods * nc;
+	const bool cached = K <= EM_CACHED_K && n_pairs <= EM_LANES * EM_CACHED_PAIRS;
 	double th[LSQ_MAX_ISOFORMS], z[LSQ_MAX_ISOFORMS];
+#pragma unroll
+	for (int j = 0; j < LSQ_MAX_ISOFORMS; ++j) z[j] = 0;
+	EmCache C;
 	double tot = 0;
-	if (ev_ok)
-		for (int q = (int)sub; q < (int)A.n_methods * nc; q += EM_LANES) {
+#pragma unroll
+	for (int t = 0; t < EM_CACHED_PAIRS; ++t) {
+		C.kd[t] = 0; C.cls[t] = 0;
+#pragma unroll
+		for (int j = 0; j < EM_CACHED_K; ++j) C.g[t][j] = 0;
+	}
+	if (ev_ok) {
+		for (int q = (int)sub; q < n_pairs; q += EM_LANES) {
 			const int m = q / nc, c = q - m * nc;
-			tot += (double)A.cnt[(size_t)m * A.n_cls + cb + (unsigned)c];      // exact: counts are far below 2^53
+			const double kd = (double)A.cnt[(size_t)m * A.n_cls + cb + (unsigned)c];      // exact: counts are far below 2^53
+			tot += kd;
+			const int t = (q - (int)sub) / EM_LANES;
+			if (cached && t < EM_CACHED_PAIRS) {
+#pragma unroll
+				for (int tt = 0; tt < EM_CACHED_PAIRS; ++tt) if (tt == t) {
+					C.kd[tt] = kd; C.cls[tt] = c + 1;
+#pragma unroll
+					for (int j = 0; j < EM_CACHED_K; ++j) C.g[tt][j] = j < K ? A.G[(size_t)m * A.n_iso + ib + j] : 0.0;
+				}
+			}
 		}
+	}
 	const double n_total = group_sum(tot);
 #pragma unroll
 	for (int j = 0; j < LSQ_MAX_ISOFORMS; ++j) th[j] = (K == 1) ? 1.0 : 1.0 / (double)K;   // solve/solve.cpp:798-802, read.h:642
@@ -797,13 +855,16 @@ __global__ void __launch_bounds__(256) lsq_em_kernel(EmArgs A) {
 	double ll = 0;
 	// no reads: theta stays 1/K, log-likelihood 0; one isoform: theta = 1 (solve/solve.cpp:798-802)
 	bool run = ev_ok && n_total > 0 && K > 1;
-	em_pass(A, cb, ib, K, nc, sub, ev_ok && n_total > 0, th, ll, z);
+	const bool any_reads = ev_ok && n_total > 0;
+	if (cached) em_pass_cached(C, th, any_reads, ll, z);
+	else em_pass(A, cb, ib, K, nc, sub, any_reads, th, ll, z);
 	while (__any(run)) {
 		// theta' = z(theta) / n; then one pass at theta' gives ll(theta') and z(theta')
 		double nth[LSQ_MAX_ISOFORMS], nll, nz[LSQ_MAX_ISOFORMS];
 #pragma unroll
-		for (int j = 0; j < LSQ_MAX_ISOFORMS; ++j) nth[j] = z[j] / n_total;
-		em_pass(A, cb, ib, K, nc, sub, run, nth, nll, nz);
+		for (int j = 0; j < LSQ_MAX_ISOFORMS; ++j) { nth[j] = z[j] / n_total; nz[j] = 0; }
+		if (cached) em_pass_cached(C, nth, run, nll, nz);
+		else em_pass(A, cb, ib, K, nc, sub, run, nth, nll, nz);
 		if (run) {
 			const double crit = fabs(1.0 - ll / nll);       // read.h:659, floating abs
 #pragma unroll
