@@ -668,12 +668,6 @@ __device__ inline unsigned first_event_for(const GlobalBucket &G, int p) {
 	return G.bins[4u * bin] >> 16;
 }
 
-__device__ inline unsigned bucket_of_slot(const unsigned long long *off, unsigned n_buckets, unsigned long long g) {
-	unsigned lo = 0, hi = n_buckets;           // last bucket with off[b] <= g
-	while (hi - lo > 1) { unsigned mid = (lo + hi) >> 1; if (off[mid] <= g) lo = mid; else hi = mid; }
-	return lo;
-}
-
 __global__ void __launch_bounds__(256) lsq_count_cleanup_kernel(CountArgs A, unsigned long long n_p1, unsigned long long n_p2,
                                                                 unsigned long long n_pn, int all_reads) {
 	const unsigned long long gtid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -692,30 +686,29 @@ __global__ void __launch_bounds__(256) lsq_count_cleanup_kernel(CountArgs A, uns
 			if (pool == 0) { blk[0] = A.p1[e.slot]; eval_read_global(A, G, blk, 1, i, scan, A.p1_strand[e.slot], A.p1_line[e.slot]); }
 			else { const int4 v = A.p2[e.slot]; blk[0] = make_int2(v.x, v.y); blk[1] = make_int2(v.z, v.w); eval_read_global(A, G, blk, 2, i, scan, A.p2_strand[e.slot], A.p2_line[e.slot]); }
 		}
-	} else {
-		for (unsigned long long g = gtid; g < n_p1; g += gsz) {
-			const unsigned b = bucket_of_slot(A.p1_off, A.n_buckets, g);
-			if (A.buckets[b].kind != 1) continue;
-			const GlobalBucket G = global_bucket(A, b);
-			int2 blk[1] = {A.p1[g]};
-			eval_read_global(A, G, blk, 1, first_event_for(G, blk[0].x), true, A.p1_strand[g], A.p1_line[g]);
-		}
-		for (unsigned long long g = gtid; g < n_p2; g += gsz) {
-			const unsigned b = bucket_of_slot(A.p2_off, A.n_buckets, g);
-			if (A.buckets[b].kind != 1) continue;
-			const GlobalBucket G = global_bucket(A, b);
-			const int4 v = A.p2[g];
-			int2 blk[2] = {make_int2(v.x, v.y), make_int2(v.z, v.w)};
-			eval_read_global(A, G, blk, 2, first_event_for(G, v.x), true, A.p2_strand[g], A.p2_line[g]);
-		}
 	}
-	// ---- reads with three or more blocks
-	for (unsigned long long g = gtid; g < n_pn; g += gsz) {
-		const unsigned b = bucket_of_slot(A.pn_off, A.n_buckets, g);
+	// ---- per bucket, one wave at a time: the reads with three or more blocks (and, in all_reads
+	// mode, every one- and two-block read as well)
+	const unsigned lane = threadIdx.x & 63u;
+	const unsigned wave_id = (unsigned)(gtid >> 6), n_waves = (unsigned)(gsz >> 6);
+	for (unsigned b = wave_id; b < A.n_buckets; b += n_waves) {
 		if (A.buckets[b].kind != 1) continue;
 		const GlobalBucket G = global_bucket(A, b);
-		const unsigned o0 = A.pn_blk_off[g], o1 = A.pn_blk_off[g + 1];
-		eval_read_global(A, G, A.pn_se + o0, (int)(o1 - o0), first_event_for(G, A.pn_se[o0].x), true, A.pn_strand[g], A.pn_line[g]);
+		for (unsigned long long g = A.pn_off[b] + lane; g < A.pn_off[b + 1]; g += 64u) {
+			const unsigned o0 = A.pn_blk_off[g], o1 = A.pn_blk_off[g + 1];
+			eval_read_global(A, G, A.pn_se + o0, (int)(o1 - o0), first_event_for(G, A.pn_se[o0].x), true, A.pn_strand[g], A.pn_line[g]);
+		}
+		if (all_reads) {
+			for (unsigned long long g = A.p1_off[b] + lane; g < A.p1_off[b + 1]; g += 64u) {
+				int2 blk[1] = {A.p1[g]};
+				eval_read_global(A, G, blk, 1, first_event_for(G, blk[0].x), true, A.p1_strand[g], A.p1_line[g]);
+			}
+			for (unsigned long long g = A.p2_off[b] + lane; g < A.p2_off[b + 1]; g += 64u) {
+				const int4 v = A.p2[g];
+				int2 blk[2] = {make_int2(v.x, v.y), make_int2(v.z, v.w)};
+				eval_read_global(A, G, blk, 2, first_event_for(G, v.x), true, A.p2_strand[g], A.p2_line[g]);
+			}
+		}
 	}
 }
 
@@ -1151,8 +1144,8 @@ static int run_count(lsq_ctx *c, bool all_reads) {
 				HIP_TRY(hipEventRecord(c->evf1[m], st));
 				c->fast_launched |= 1 << m;
 			}
-			const unsigned long long work = all_reads ? n_p1 + n_p2 + n_pn : std::max<unsigned long long>(n_pn, 65536);
-			const unsigned cgrid = (unsigned)std::min<unsigned long long>((work + 255) / 256, (unsigned long long)c->n_cu * 8);
+			// one wave per bucket at a time
+			const unsigned cgrid = (unsigned)std::min<unsigned long long>((E.buckets.size() + 3) / 4, (unsigned long long)c->n_cu * 8);
 			hipLaunchKernelGGL(lsq_count_cleanup_kernel, dim3(std::max(cgrid, 1u)), dim3(256), 0, st, A, n_p1, n_p2, n_pn, all_reads ? 1 : 0);
 			HIP_TRY(hipGetLastError());
 		}
