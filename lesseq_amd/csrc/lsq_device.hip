@@ -59,7 +59,7 @@ struct CountArgs {
 	unsigned tables_lds_bytes;         // LDS bytes reserved for the bucket image + histogram (16-byte multiple)
 	const int2 *p1; const unsigned char *p1_strand; const unsigned *p1_line;
 	const int4 *p2; const unsigned char *p2_strand; const unsigned *p2_line;
-	const unsigned *pn_blk_off; const int2 *pn_se; const unsigned char *pn_strand; const unsigned *pn_line;
+	const unsigned *pn_blk_off; const int2 *pn_se; const unsigned char *pn_strand; const unsigned *pn_line; const unsigned *pn_bucket;
 	const unsigned long long *p1_off, *p2_off, *pn_off, *slot_off;    // n_buckets + 1 each
 	unsigned long long total_slots;
 	unsigned long long *cnt, *bases;
@@ -687,18 +687,21 @@ __global__ void __launch_bounds__(256) lsq_count_cleanup_kernel(CountArgs A, uns
 			else { const int4 v = A.p2[e.slot]; blk[0] = make_int2(v.x, v.y); blk[1] = make_int2(v.z, v.w); eval_read_global(A, G, blk, 2, i, scan, A.p2_strand[e.slot], A.p2_line[e.slot]); }
 		}
 	}
-	// ---- per bucket, one wave at a time: the reads with three or more blocks (and, in all_reads
-	// mode, every one- and two-block read as well)
-	const unsigned lane = threadIdx.x & 63u;
-	const unsigned wave_id = (unsigned)(gtid >> 6), n_waves = (unsigned)(gsz >> 6);
-	for (unsigned b = wave_id; b < A.n_buckets; b += n_waves) {
+	// ---- the reads with three or more blocks, one lane each
+	for (unsigned long long g = gtid; g < n_pn; g += gsz) {
+		const unsigned b = A.pn_bucket[g];
 		if (A.buckets[b].kind != 1) continue;
 		const GlobalBucket G = global_bucket(A, b);
-		for (unsigned long long g = A.pn_off[b] + lane; g < A.pn_off[b + 1]; g += 64u) {
-			const unsigned o0 = A.pn_blk_off[g], o1 = A.pn_blk_off[g + 1];
-			eval_read_global(A, G, A.pn_se + o0, (int)(o1 - o0), first_event_for(G, A.pn_se[o0].x), true, A.pn_strand[g], A.pn_line[g]);
-		}
-		if (all_reads) {
+		const unsigned o0 = A.pn_blk_off[g], o1 = A.pn_blk_off[g + 1];
+		eval_read_global(A, G, A.pn_se + o0, (int)(o1 - o0), first_event_for(G, A.pn_se[o0].x), true, A.pn_strand[g], A.pn_line[g]);
+	}
+	// ---- all_reads mode: every one- and two-block read as well, bucket by bucket, one wave at a time
+	if (all_reads) {
+		const unsigned lane = threadIdx.x & 63u;
+		const unsigned wave_id = (unsigned)(gtid >> 6), n_waves = (unsigned)(gsz >> 6);
+		for (unsigned b = wave_id; b < A.n_buckets; b += n_waves) {
+			if (A.buckets[b].kind != 1) continue;
+			const GlobalBucket G = global_bucket(A, b);
 			for (unsigned long long g = A.p1_off[b] + lane; g < A.p1_off[b + 1]; g += 64u) {
 				int2 blk[1] = {A.p1[g]};
 				eval_read_global(A, G, blk, 1, first_event_for(G, blk[0].x), true, A.p1_strand[g], A.p1_line[g]);
@@ -912,7 +915,7 @@ struct MethodReads {
 	uint64_t n_retained = 0, n_retained_blocks = 0, total_slots = 0;
 	DevBuf<int32_t> p1, p2, pn_se;
 	DevBuf<uint8_t> p1_strand, p2_strand, pn_strand;
-	DevBuf<uint32_t> p1_line, p2_line, pn_line, pn_blk_off;
+	DevBuf<uint32_t> p1_line, p2_line, pn_line, pn_blk_off, pn_bucket;
 	DevBuf<unsigned long long> p1_off, p2_off, pn_off, slot_off;
 };
 
@@ -1068,6 +1071,7 @@ int lsq_reads_upload(lsq_ctx *c, int method, const lsq_reads *R) {
 	if ((rc = mr.pn_blk_off.upload(P.pn_blk_off.data(), P.pn_blk_off.size(), st))) return rc;
 	if ((rc = mr.pn_strand.upload(P.pn_strand.data(), P.pn_strand.size(), st))) return rc;
 	if ((rc = mr.pn_line.upload(P.pn_line.data(), P.pn_line.size(), st))) return rc;
+	if ((rc = mr.pn_bucket.upload(P.pn_bucket.data(), P.pn_bucket.size(), st))) return rc;
 	if ((rc = mr.p1_off.upload(o1.data(), B + 1, st))) return rc;
 	if ((rc = mr.p2_off.upload(o2.data(), B + 1, st))) return rc;
 	if ((rc = mr.pn_off.upload(on.data(), B + 1, st))) return rc;
@@ -1129,7 +1133,7 @@ static int run_count(lsq_ctx *c, bool all_reads) {
 		A.p1 = reinterpret_cast<const int2 *>(mr.p1.p); A.p1_strand = mr.p1_strand.p; A.p1_line = mr.p1_line.p;
 		A.p2 = reinterpret_cast<const int4 *>(mr.p2.p); A.p2_strand = mr.p2_strand.p; A.p2_line = mr.p2_line.p;
 		A.pn_blk_off = mr.pn_blk_off.p; A.pn_se = reinterpret_cast<const int2 *>(mr.pn_se.p);
-		A.pn_strand = mr.pn_strand.p; A.pn_line = mr.pn_line.p;
+		A.pn_strand = mr.pn_strand.p; A.pn_line = mr.pn_line.p; A.pn_bucket = mr.pn_bucket.p;
 		A.p1_off = mr.p1_off.p; A.p2_off = mr.p2_off.p; A.pn_off = mr.pn_off.p; A.slot_off = mr.slot_off.p;
 		A.total_slots = mr.total_slots;
 		A.cnt = c->cnt.p + (size_t)m * n_cls; A.bases = c->bases.p + (size_t)m * n_cls;
@@ -1144,8 +1148,8 @@ static int run_count(lsq_ctx *c, bool all_reads) {
 				HIP_TRY(hipEventRecord(c->evf1[m], st));
 				c->fast_launched |= 1 << m;
 			}
-			// one wave per bucket at a time
-			const unsigned cgrid = (unsigned)std::min<unsigned long long>((E.buckets.size() + 3) / 4, (unsigned long long)c->n_cu * 8);
+			const unsigned long long work = all_reads ? std::max<unsigned long long>(n_pn, 64ull * E.buckets.size()) : std::max<unsigned long long>(n_pn, 4096);
+			const unsigned cgrid = (unsigned)std::min<unsigned long long>((work + 255) / 256, (unsigned long long)c->n_cu * 32);
 			hipLaunchKernelGGL(lsq_count_cleanup_kernel, dim3(std::max(cgrid, 1u)), dim3(256), 0, st, A, n_p1, n_p2, n_pn, all_reads ? 1 : 0);
 			HIP_TRY(hipGetLastError());
 		}

@@ -102,7 +102,7 @@ int ingest_reads(const lsq_events &E, const lsq_reads &R, int n_threads, PooledR
 	if (ob > 0xFFFFFFF0ull) return fail(LSQ_E_RANGE, "too many blocks in multi-block reads");
 	out.p1_se.resize(o1 * 2); out.p1_strand.resize(o1); out.p1_line.resize(o1);
 	out.p2_se.resize(o2 * 4); out.p2_strand.resize(o2); out.p2_line.resize(o2);
-	out.pn_blk_off.resize(on + 1); out.pn_se.resize(ob * 2); out.pn_strand.resize(on); out.pn_line.resize(on);
+	out.pn_blk_off.resize(on + 1); out.pn_se.resize(ob * 2); out.pn_strand.resize(on); out.pn_line.resize(on); out.pn_bucket.resize(on);
 	out.pn_blk_off[on] = (uint32_t)ob;
 	{
 		std::vector<std::thread> th;
@@ -131,7 +131,7 @@ int ingest_reads(const lsq_events &E, const lsq_reads &R, int n_threads, PooledR
 					p[(size_t)bk * 4 + 3] += nb;
 					out.pn_blk_off[w] = (uint32_t)bo;
 					for (size_t q = 0; q < nb; ++q) { out.pn_se[2 * (bo + q)] = (int32_t)k.il.s[q]; out.pn_se[2 * (bo + q) + 1] = (int32_t)k.il.e[q]; }
-					out.pn_strand[w] = (uint8_t)k.strand; out.pn_line[w] = R.line_no[i];
+					out.pn_strand[w] = (uint8_t)k.strand; out.pn_line[w] = R.line_no[i]; out.pn_bucket[w] = (uint32_t)bk;
 				}
 			}
 		});

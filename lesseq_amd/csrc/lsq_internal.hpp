@@ -207,6 +207,7 @@ struct PooledReads {
 	std::vector<int32_t> pn_se;
 	std::vector<uint8_t> pn_strand;
 	std::vector<uint32_t> pn_line;
+	std::vector<uint32_t> pn_bucket;   // bucket of each pool-n read (the cleanup kernel works per read)
 	std::vector<uint64_t> pn_off;
 };
 
