@@ -462,6 +462,11 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 		if (wt + TILE < ww1) fetch(wt + TILE);
 #pragma unroll
 		for (int k0 = 0; k0 < STREAM_WORDS; k0 += GROUP_WORDS) {
+		if (A.ablate & 512u) {      // developer switch: stream only
+#pragma unroll
+			for (int kg = 0; kg < GROUP_WORDS; ++kg) asm volatile("" ::"v"(cur[k0 + kg].x), "v"(cur[k0 + kg].y), "v"(cur[k0 + kg].z), "v"(cur[k0 + kg].w));
+			continue;
+		}
 		// the reads of a group are looked up first (independent chains), parking comes after
 		constexpr int N_READS = GROUP_WORDS * RPW;
 		bool park[N_READS];

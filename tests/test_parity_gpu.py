@@ -204,3 +204,107 @@ def test_full_size_config2_linearity_and_sample(tmp_path):
     rc, otext, exact = ob.run("solve", argv)
     assert rc == 0
     compare_exact(gpu_exact(argv), exact, "config 2, first 1 M reads")
+
+
+def _write(path, text):
+    with open(path, "w") as f:
+        f.write(text)
+
+
+def test_empty_and_degenerate_inputs(tmp_path, monkeypatch):
+    """empty gene range, header-only read file, reads that all miss the events, a read file whose
+    last line is unterminated: same rows and exit status as the oracle"""
+    import golden_inputs as gi
+    gi.write_toy(str(tmp_path))
+    monkeypatch.chdir(tmp_path)
+    _write("empty.mrf", "AlignmentBlocks\n")
+    _write("offtarget.mrf", "AlignmentBlocks\n" + "".join("chr1:+:%d:%d:1:50\n" % (20000 + 7 * i, 20049 + 7 * i) for i in range(300))
+           + "chr7:-:5:54:1:50\nchr1:+:3001:3050:1:50")
+    base = ["0", "t", "./", "LH_GENE_TXT", "toy.interval", "UCSC_GENE2ISOFORM", "toy.map"]
+    for lo, hi, mrf in (("0", "10", "empty.mrf"), ("0", "10", "offtarget.mrf"), ("3", "3", "toy.mrf"), ("1", "2", "toy.mrf"), ("0", "1", "toy.mrf")):
+        argv = base + [lo, hi, "MRF_SINGLE", "SHORT_READ", "50", mrf]
+        rc, text = L.cli_run("count", argv)
+        orc, otext, _ = ob.run("count", argv)
+        assert (rc, text) == (orc, otext), (lo, hi, mrf)
+        rc, text = L.cli_run("solve", argv + ["1000"])
+        orc, otext, _ = ob.run("solve", argv + ["1000"])
+        assert rc == orc and ob.solve_text_close(text, otext), (lo, hi, mrf)
+
+
+def _random_gene_set(rng, n_genes, max_exons, max_iso, chroms=("c1", "c2"), spacing=4000):
+    """genes with up to `max_iso` isoforms over up to `max_exons` shared exon slots (so events get
+    many segments and isoforms: the generic kernel's territory)"""
+    iv, mp, genes = [], [], []
+    pos = {c: 500 for c in chroms}
+    for g in range(n_genes):
+        c = chroms[rng.randrange(len(chroms))]
+        n_slots = rng.randint(2, max_exons)
+        slots = []
+        p = pos[c]
+        for _ in range(n_slots):
+            ln = rng.randint(30, 160)
+            slots.append((p, p + ln))
+            p += ln + (0 if rng.random() < 0.15 else rng.randint(40, 400))
+        pos[c] = p + rng.randint(200, spacing)
+        K = rng.randint(1, max_iso)
+        forms = []
+        for k in range(K):
+            pick = sorted(rng.sample(range(n_slots), rng.randint(1, n_slots)))
+            ex = []
+            for i in pick:
+                s, e = slots[i]
+                if rng.random() < 0.2:      # alternative boundary inside the slot -> more segments
+                    cut = rng.randint(5, e - s - 5)
+                    s, e = (s + cut, e) if rng.random() < 0.5 else (s, s + cut)
+                ex.append((s, e))
+            forms.append(ex)
+            name = "G%d.%d" % (g, k)
+            iv.append(gi_line(name, c, "+" if g % 2 else "-", ex))
+            mp.append("G%d\t%s\n" % (g, name))
+        genes.append((c, "+" if g % 2 else "-", forms))
+    return "".join(iv), "".join(mp), genes
+
+
+def gi_line(name, chrom, strand, exons):
+    import golden_inputs as gi
+    return gi.interval_line(name, chrom, strand, exons)
+
+
+@pytest.mark.parametrize("seed,max_exons,max_iso,R", [(101, 6, 6, 40), (102, 12, 5, 75), (103, 20, 3, 120), (104, 4, 2, 150)])
+def test_many_segments_isoforms_and_blocks_vs_oracle(seed, max_exons, max_iso, R, tmp_path):
+    """events with up to 6 isoforms / dozens of segments (generic kernel), short exons under long
+    reads (three and more blocks per read: cleanup kernel), mixed with packed buckets"""
+    import random
+    import golden_inputs as gi
+    rng = random.Random(seed)
+    iv, mp, genes = _random_gene_set(rng, 60, max_exons, max_iso)
+    reads = []
+    for _ in range(6000):
+        c, strand, forms = genes[rng.randrange(len(genes))]
+        f = sorted(forms[rng.randrange(len(forms))])
+        tlen = sum(e - s for s, e in f)
+        u = rng.random()
+        if u < 0.8 and tlen > 10:
+            ln = min(tlen, rng.choice([R, R, R // 2, R + 30]))
+            t0 = rng.randint(0, tlen - ln)
+            bl = gi.transcript_blocks(f, t0, ln)
+        elif u < 0.9:
+            s0 = f[0][0] + rng.randint(-3, 3)
+            bl = [(max(s0, 0), max(s0, 0) + rng.choice([10, R]))]
+        else:
+            s0 = rng.randint(f[0][0], f[-1][1])
+            bl = [(s0, s0 + R // 2), (s0 + R // 2 + rng.randint(0, 90), s0 + R + rng.randint(91, 150))]
+        reads.append(gi.mrf_line(c, strand if rng.random() < 0.85 else "+", bl))
+    _write(tmp_path / "m.interval", iv)
+    _write(tmp_path / "m.map", mp)
+    _write(tmp_path / "m.mrf", "AlignmentBlocks\n" + "".join(reads))
+    argv = ["0", "m", "./", "LH_GENE_TXT", str(tmp_path / "m.interval"), "UCSC_GENE2ISOFORM", str(tmp_path / "m.map"),
+            "0", "100000", "MRF_SINGLE", "SHORT_READ", str(R), str(tmp_path / "m.mrf"), str(6000 * R)]
+    rc, otext, exact = ob.run("solve", argv)
+    assert rc == 0
+    got = gpu_exact(argv)
+    compare_exact(got, exact, "seed %d" % seed)
+    assert sum(sum(g["supports"]) for g in got) > 1500
+    rc, text = L.cli_run("count", argv[:-1])
+    rc2, ctext, _ = ob.run("count", argv[:-1])
+    assert rc == rc2 == 0 and text == ctext
