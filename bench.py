@@ -48,7 +48,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-sample", type=int, default=5_000_000, help="reads in the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=15_000_000, help="reads in the cpu_baseline sample (0 = skip)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
