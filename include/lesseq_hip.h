@@ -97,6 +97,7 @@ uint64_t lsq_events_isoform_length(const lsq_events *e, int64_t ev, int iso);
 uint64_t lsq_events_ars(const lsq_events *e, int method, int64_t ev, int iso);
 int lsq_events_span(const lsq_events *e, int64_t ev, int64_t *gene_start, int64_t *gene_end);
 int64_t lsq_events_num_buckets(const lsq_events *e);
+int64_t lsq_events_lds_table_bytes(const lsq_events *e);   /* largest bucket image + histogram */
 /* Restricts the device plan to events [first_event, first_event + n_events) of the output order
  * (the reference's own scale-out unit, count/count.cpp:204-215) while the covered regions -- and so
  * the load-time read filter -- stay those of the whole selected range: every shard then gives

@@ -70,6 +70,10 @@ class Events:
     def num_buckets(self):
         return lib.lsq_events_num_buckets(self.h)
 
+    @property
+    def lds_table_bytes(self):
+        return lib.lsq_events_lds_table_bytes(self.h)
+
     def gene_name(self, ev):
         return lib.lsq_events_gene_name(self.h, ev).decode()
 

@@ -46,6 +46,7 @@ for bud in budgets:
             L.lib.lsq_debug_counters(ctx.h, buf)
             print("   dbg: parked1=%d parked2=%d walk_steps=%d walk_lanes=%d exceptions=%d  (retained %d)" % (buf[0], buf[1], buf[2], buf[3], buf[4], ctx.retained(0)))
         print("abl=%d " % abl, end="")
+        print("lds=%d " % ev.lds_table_bytes, end="")
         print("%s budget=%6d buckets=%5d mult=%2d count_ms med=%.4f min=%.4f  %.0f GB/s (%.1f%% of 8TB/s)  em_ms=%.4f ingest_s=%.2f check=%s" % (
             wl, bud, ev.num_buckets, m, t, min(ts), 8.0 * nb / t / 1e6, 100 * 8.0 * nb / t / 1e6 / 8000, float(np.median(es)), ti, "ok" if chk == ref else "MISMATCH"), flush=True)
     ctx.close()
