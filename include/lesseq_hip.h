@@ -141,10 +141,12 @@ int lsq_ctx_synchronize(lsq_ctx *c);
 int lsq_events_upload(lsq_ctx *c, const lsq_events *e);
 
 /* Replaces the retained-read state the reference builds at count/count.cpp:319-324 and
- * :348-364: applies the per-block containment filter against the covered regions, merges
- * kept blocks with interval_list::add_interval semantics, and stores each retained read in
- * the bucket of its first kept base, split into 1-block / 2-block / n-block pools
- * (structure-of-arrays in HBM).  method in [0, n_methods). */
+ * :348-364.  The parsed blocks are copied to the device as they are; HIP kernels apply the
+ * per-block containment filter against the covered regions, merge kept blocks with
+ * interval_list::add_interval semantics, and store each retained read in the bucket of its
+ * first kept base, split into 1-block / 2-block / n-block pools (structure-of-arrays in
+ * HBM).  A read may keep at most 16 separate blocks (LSQ_E_RANGE beyond).  method in
+ * [0, n_methods). */
 int lsq_reads_upload(lsq_ctx *c, int method, const lsq_reads *r);
 uint64_t lsq_reads_retained(const lsq_ctx *c, int method);      /* "loaded N reads" log line */
 uint64_t lsq_reads_retained_blocks(const lsq_ctx *c, int method);

@@ -59,7 +59,7 @@ struct CountArgs {
 	unsigned tables_lds_bytes;         // LDS bytes reserved for the bucket image + histogram (16-byte multiple)
 	const int2 *p1; const unsigned char *p1_strand; const unsigned *p1_line;
 	const int4 *p2; const unsigned char *p2_strand; const unsigned *p2_line;
-	const unsigned *pn_blk_off; const int2 *pn_se; const unsigned char *pn_strand; const unsigned *pn_line; const unsigned *pn_bucket;
+	const unsigned *pn_blk_off; const unsigned *pn_nblk; const int2 *pn_se; const unsigned char *pn_strand; const unsigned *pn_line; const unsigned *pn_bucket;
 	const unsigned long long *p1_off, *p2_off, *pn_off, *slot_off;    // n_buckets + 1 each
 	unsigned long long total_slots;
 	unsigned long long *cnt, *bases;
@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(COUNT_BLOCK) lsq_count_generic_kernel(CountArg
 				process_read<2>(L, d, A, rd, nullptr, 2, (rd.y - rd.x) + (rd.w - rd.z), A.p2_strand, A.p2_line, g);
 			} else {
 				const unsigned long long g = A.pn_off[b] + (i - n1 - n2);
-				const unsigned o0 = A.pn_blk_off[g], o1 = A.pn_blk_off[g + 1];
+				const unsigned o0 = A.pn_blk_off[g], o1 = o0 + A.pn_nblk[g];
 				const int2 *blk = A.pn_se + o0;
 				int total = 0;
 				for (unsigned k = o0; k < o1; ++k) { int2 v = A.pn_se[k]; total += v.y - v.x; }
@@ -697,7 +697,7 @@ __global__ void __launch_bounds__(256) lsq_count_cleanup_kernel(CountArgs A, uns
 		const unsigned b = A.pn_bucket[g];
 		if (A.buckets[b].kind != 1) continue;
 		const GlobalBucket G = global_bucket(A, b);
-		const unsigned o0 = A.pn_blk_off[g], o1 = A.pn_blk_off[g + 1];
+		const unsigned o0 = A.pn_blk_off[g], o1 = o0 + A.pn_nblk[g];
 		eval_read_global(A, G, A.pn_se + o0, (int)(o1 - o0), first_event_for(G, A.pn_se[o0].x), true, A.pn_strand[g], A.pn_line[g]);
 	}
 	// ---- all_reads mode: every one- and two-block read as well, bucket by bucket, one wave at a time
@@ -896,6 +896,194 @@ __global__ void __launch_bounds__(256) lsq_em_kernel(EmArgs A) {
 	}
 }
 
+// =====================================================================================
+// Ingest on the device: from parsed blocks in file order to the bucketed, pooled arrays.
+//   classify: per read, the per-block containment filter against the covered regions of the
+//             block's own chromosome (count/count.cpp:319, interval_list.hpp:396-422), the
+//             interval_list merge of the kept blocks (:323, interval_list.hpp:462-503),
+//             chromosome/strand of the last kept block (:321-322), the bucket of the first
+//             merged base and the pool (1, 2, 3+ blocks); per (bucket, pool) counts
+//   scan    : exclusive prefix sums -> pool offsets per bucket
+//   scatter : every retained read to its place (order inside a bucket is whatever the atomics
+//             give; the count kernels only add integers, so results do not depend on it)
+// This replaces the reference's load-time filter and its read index (count/count.cpp:348-364).
+// =====================================================================================
+constexpr int INGEST_MAX_BLOCKS = 16;                  // merged blocks per read the device ingest handles
+constexpr unsigned INGEST_NO_KEY = 0xFFFFFFFFu;
+
+struct IngestTables {
+	const unsigned *cov_off;       // per chromosome id: range of its covered intervals
+	const int *cov_s, *cov_e;
+	const unsigned *cut_off;       // per chromosome id: range of its bucket cuts
+	const int *cut_lo;
+	const int *chrom_first_bucket;
+	const BucketDesc *buckets;
+	unsigned n_chrom;
+};
+
+struct IngestRaw {
+	unsigned long long n_reads;
+	const unsigned long long *blk_off;
+	const unsigned *line_no;
+	const int *blk_start, *blk_end;
+	const unsigned short *blk_chrom;
+	const unsigned char *blk_strand;
+};
+
+struct IngestWork {
+	unsigned *key;                 // per read: bucket * 4 + pool, or INGEST_NO_KEY
+	unsigned char *nb;             // per read: merged blocks
+	unsigned char *strand;         // per read: strand id of the last kept block
+	int *ms, *me;                  // merged blocks, at the read's original block offset
+	unsigned long long *counts;    // [4 * n_buckets]: reads of pool 0/1/2, blocks of pool 2
+	unsigned long long *cursors;   // [4 * n_buckets]
+	unsigned long long *totals;    // [0] retained reads, [1] retained blocks, [2] error flag
+};
+
+// interval_list::add_interval on a small sorted array (see lsq::IntervalList::add)
+__device__ inline bool small_add_interval(int *s, int *e, int &n, int start, int end) {
+	if (!(start < end)) return true;
+	int ss = 0, se = 0, es = 0, ee = 0;
+	for (int i = 0; i < n; ++i) { ss += s[i] < start; se += e[i] < start; es += s[i] < end; ee += e[i] < end; }
+	const bool start_inside = (ss - se == 1), end_inside = (es - ee == 1);
+	// starts: erase [ss, es), insert `start` at ss unless start_inside; ends: erase [se, ee), insert `end` at se unless end_inside
+	const int ns = n - (es - ss) + (start_inside ? 0 : 1);
+	if (ns > INGEST_MAX_BLOCKS) return false;
+	int ts[INGEST_MAX_BLOCKS], te[INGEST_MAX_BLOCKS];
+	int k = 0;
+	for (int i = 0; i < ss; ++i) ts[k++] = s[i];
+	if (!start_inside) ts[k++] = start;
+	for (int i = es; i < n; ++i) ts[k++] = s[i];
+	k = 0;
+	for (int i = 0; i < se; ++i) te[k++] = e[i];
+	if (!end_inside) te[k++] = end;
+	for (int i = ee; i < n; ++i) te[k++] = e[i];
+	n = ns;
+	for (int i = 0; i < n; ++i) { s[i] = ts[i]; e[i] = te[i]; }
+	return true;
+}
+
+__device__ inline bool covered_contains(const IngestTables &T, unsigned chrom, int start, int end) {
+	if (!(start < end)) return true;
+	const unsigned lo0 = T.cov_off[chrom], hi0 = T.cov_off[chrom + 1];
+	unsigned lo = lo0, hi = hi0;                      // lower_bound(starts, start)
+	while (lo < hi) { const unsigned mid = (lo + hi) >> 1; if (T.cov_s[mid] < start) lo = mid + 1; else hi = mid; }
+	if (lo < hi0 && T.cov_s[lo] <= start && end <= T.cov_e[lo]) return true;
+	if (lo > lo0 && T.cov_s[lo - 1] <= start && end <= T.cov_e[lo - 1]) return true;
+	return false;
+}
+
+__global__ void __launch_bounds__(256) lsq_ingest_classify_kernel(IngestTables T, IngestRaw R, IngestWork W) {
+	const unsigned long long gsz = (unsigned long long)gridDim.x * blockDim.x;
+	unsigned long long kept_reads = 0, kept_blocks = 0;
+	for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < R.n_reads; i += gsz) {
+		const unsigned long long b0 = R.blk_off[i], b1 = R.blk_off[i + 1];
+		int s[INGEST_MAX_BLOCKS], e[INGEST_MAX_BLOCKS];
+		int n = 0, chrom = -1;
+		unsigned strand = 0;
+		bool any = false, ok = true;
+		for (unsigned long long j = b0; j < b1; ++j) {
+			const unsigned c = R.blk_chrom[j];
+			if (c >= T.n_chrom) continue;
+			const int bs = R.blk_start[j], be = R.blk_end[j];
+			if (!covered_contains(T, c, bs, be)) continue;
+			any = true; chrom = (int)c; strand = R.blk_strand[j];
+			ok = small_add_interval(s, e, n, bs, be) && ok;
+		}
+		unsigned key = INGEST_NO_KEY;
+		if (any && n > 0) {
+			++kept_reads; kept_blocks += (unsigned)n;
+			int tot = 0;
+			for (int q = 0; q < n; ++q) tot += e[q] - s[q];
+			if (!ok || tot >= (1 << 18)) atomicMax(&W.totals[2], 1ull);
+			// bucket of the first merged base
+			const int first = T.chrom_first_bucket[chrom];
+			if (first >= 0) {
+				const unsigned c0 = T.cut_off[chrom], c1 = T.cut_off[chrom + 1];
+				unsigned lo = c0, hi = c1;                  // upper_bound(cuts, p)
+				while (lo < hi) { const unsigned mid = (lo + hi) >> 1; if (T.cut_lo[mid] <= s[0]) lo = mid + 1; else hi = mid; }
+				if (lo > c0) {
+					const unsigned b = (unsigned)first + (lo - c0 - 1);
+					if (s[0] <= T.buckets[b].hi) {
+						const unsigned pool = n == 1 ? 0u : (n == 2 ? 1u : 2u);
+						key = b * 4u + pool;
+						atomicAdd(&W.counts[key], 1ull);
+						if (pool == 2) atomicAdd(&W.counts[b * 4u + 3u], (unsigned long long)n);
+					}
+				}
+			}
+			for (int q = 0; q < n; ++q) { W.ms[b0 + q] = s[q]; W.me[b0 + q] = e[q]; }
+		}
+		W.key[i] = key;
+		W.nb[i] = (unsigned char)n;
+		W.strand[i] = (unsigned char)strand;
+	}
+	if (kept_reads) { atomicAdd(&W.totals[0], kept_reads); atomicAdd(&W.totals[1], kept_blocks); }
+}
+
+// one workgroup: exclusive prefix sums over the buckets
+__global__ void __launch_bounds__(1024) lsq_ingest_scan_kernel(const unsigned long long *counts, unsigned n_buckets,
+                                                               unsigned long long *p1_off, unsigned long long *p2_off,
+                                                               unsigned long long *pn_off, unsigned long long *pnb_off, unsigned long long *slot_off) {
+	__shared__ unsigned long long part[4][1024];
+	const unsigned tid = threadIdx.x;
+	const unsigned per = (n_buckets + 1023u) / 1024u;
+	const unsigned b0 = min(tid * per, n_buckets), b1 = min(b0 + per, n_buckets);
+	unsigned long long acc[4] = {0, 0, 0, 0};
+	for (unsigned b = b0; b < b1; ++b) for (int q = 0; q < 4; ++q) acc[q] += counts[b * 4u + q];
+	for (int q = 0; q < 4; ++q) part[q][tid] = acc[q];
+	__syncthreads();
+	if (tid < 4) {          // one lane per column: serial exclusive scan of 1024 partial sums
+		unsigned long long run = 0;
+		for (unsigned t = 0; t < 1024; ++t) { const unsigned long long v = part[tid][t]; part[tid][t] = run; run += v; }
+	}
+	__syncthreads();
+	unsigned long long run[4] = {part[0][tid], part[1][tid], part[2][tid], part[3][tid]};
+	for (unsigned b = b0; b < b1; ++b) {
+		p1_off[b] = run[0]; p2_off[b] = run[1]; pn_off[b] = run[2]; pnb_off[b] = run[3];
+		slot_off[b] = run[0] + run[1] + run[2];
+		for (int q = 0; q < 4; ++q) run[q] += counts[b * 4u + q];
+	}
+	if (tid == 1023) {      // the last lane's running sums are the totals (lanes past the last bucket add nothing)
+		p1_off[n_buckets] = run[0]; p2_off[n_buckets] = run[1]; pn_off[n_buckets] = run[2]; pnb_off[n_buckets] = run[3];
+		slot_off[n_buckets] = run[0] + run[1] + run[2];
+	}
+}
+
+struct IngestOut {
+	int2 *p1; unsigned char *p1_strand; unsigned *p1_line;
+	int4 *p2; unsigned char *p2_strand; unsigned *p2_line;
+	unsigned *pn_blk_off, *pn_nblk, *pn_line, *pn_bucket; unsigned char *pn_strand; int2 *pn_se;
+	const unsigned long long *p1_off, *p2_off, *pn_off, *pnb_off;
+};
+
+__global__ void __launch_bounds__(256) lsq_ingest_scatter_kernel(IngestRaw R, IngestWork W, IngestOut O) {
+	const unsigned long long gsz = (unsigned long long)gridDim.x * blockDim.x;
+	for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < R.n_reads; i += gsz) {
+		const unsigned key = W.key[i];
+		if (key == INGEST_NO_KEY) continue;
+		const unsigned b = key >> 2, pool = key & 3u;
+		const unsigned long long b0 = R.blk_off[i];
+		const unsigned long long at = atomicAdd(&W.cursors[key], 1ull);
+		if (pool == 0) {
+			const unsigned long long w = O.p1_off[b] + at;
+			O.p1[w] = make_int2(W.ms[b0], W.me[b0]);
+			O.p1_strand[w] = W.strand[i]; O.p1_line[w] = R.line_no[i];
+		} else if (pool == 1) {
+			const unsigned long long w = O.p2_off[b] + at;
+			O.p2[w] = make_int4(W.ms[b0], W.me[b0], W.ms[b0 + 1], W.me[b0 + 1]);
+			O.p2_strand[w] = W.strand[i]; O.p2_line[w] = R.line_no[i];
+		} else {
+			const unsigned n = W.nb[i];
+			const unsigned long long w = O.pn_off[b] + at;
+			const unsigned long long bo = O.pnb_off[b] + atomicAdd(&W.cursors[b * 4u + 3u], (unsigned long long)n);
+			O.pn_blk_off[w] = (unsigned)bo; O.pn_nblk[w] = n; O.pn_bucket[w] = b;
+			O.pn_strand[w] = W.strand[i]; O.pn_line[w] = R.line_no[i];
+			for (unsigned q = 0; q < n; ++q) O.pn_se[bo + q] = make_int2(W.ms[b0 + q], W.me[b0 + q]);
+		}
+	}
+}
+
 template <class T>
 struct DevBuf {
 	T *p = nullptr;
@@ -920,8 +1108,8 @@ struct MethodReads {
 	uint64_t n_retained = 0, n_retained_blocks = 0, total_slots = 0;
 	DevBuf<int32_t> p1, p2, pn_se;
 	DevBuf<uint8_t> p1_strand, p2_strand, pn_strand;
-	DevBuf<uint32_t> p1_line, p2_line, pn_line, pn_blk_off, pn_bucket;
-	DevBuf<unsigned long long> p1_off, p2_off, pn_off, slot_off;
+	DevBuf<uint32_t> p1_line, p2_line, pn_line, pn_blk_off, pn_nblk, pn_bucket;
+	DevBuf<unsigned long long> p1_off, p2_off, pn_off, pnb_off, slot_off;
 };
 
 } // namespace
@@ -943,6 +1131,9 @@ struct lsq_ctx {
 	DevBuf<unsigned long long> cnt, bases;
 	DevBuf<ExcEntry> exc;                  // shared by the methods (launches are serialised on the stream)
 	DevBuf<unsigned> exc_count;            // per method: [2m] appended, [2m+1] overflow flag
+	DevBuf<unsigned> cov_off, cut_off;     // ingest tables: covered regions and bucket cuts per chromosome id
+	DevBuf<int> cov_s, cov_e, cut_lo, chrom_first_bucket;
+	unsigned n_chrom_tables = 0;
 	DevBuf<unsigned long long> dbg;
 	bool redo_checked = true;
 	MethodReads reads[LSQ_MAX_METHODS];
@@ -1047,6 +1238,26 @@ int lsq_events_upload(lsq_ctx *c, const lsq_events *E) {
 	if ((rc = c->flags.alloc(n_ev))) return rc;
 	if ((rc = c->exc_count.alloc(2 * LSQ_MAX_METHODS))) return rc;
 	if ((rc = c->dbg.alloc(8))) return rc;
+	{
+		// ingest tables: covered regions (by chromosome id) and the bucket cuts
+		const size_t nc = E->covered.size();
+		std::vector<unsigned> cov_off(nc + 1, 0), cut_off(nc + 1, 0);
+		std::vector<int> cs, ce, cl, cfb(std::max<size_t>(nc, 1), -1);
+		for (size_t ch = 0; ch < nc; ++ch) {
+			for (size_t q = 0; q < E->covered[ch].s.size(); ++q) { cs.push_back((int)E->covered[ch].s[q]); ce.push_back((int)E->covered[ch].e[q]); }
+			cov_off[ch + 1] = (unsigned)cs.size();
+			if (ch < E->cut_lo.size()) for (int32_t v : E->cut_lo[ch]) cl.push_back(v);
+			cut_off[ch + 1] = (unsigned)cl.size();
+			if (ch < E->chrom_first_bucket.size()) cfb[ch] = E->chrom_first_bucket[ch];
+		}
+		c->n_chrom_tables = (unsigned)nc;
+		if ((rc = c->cov_off.upload(cov_off.data(), cov_off.size(), c->stream))) return rc;
+		if ((rc = c->cut_off.upload(cut_off.data(), cut_off.size(), c->stream))) return rc;
+		if ((rc = c->cov_s.upload(cs.data(), cs.size(), c->stream))) return rc;
+		if ((rc = c->cov_e.upload(ce.data(), ce.size(), c->stream))) return rc;
+		if ((rc = c->cut_lo.upload(cl.data(), cl.size(), c->stream))) return rc;
+		if ((rc = c->chrom_first_bucket.upload(cfb.data(), cfb.size(), c->stream))) return rc;
+	}
 	if ((rc = upload_strand_ranks(c))) return rc;
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	return LSQ_OK;
@@ -1057,40 +1268,85 @@ int lsq_reads_upload(lsq_ctx *c, int method, const lsq_reads *R) {
 	if (!c->E) return fail(LSQ_E_STATE, "lsq_events_upload must come first");
 	if (method < 0 || method >= c->E->n_methods) return fail(LSQ_E_ARG, "method %d out of range", method);
 	HIP_TRY(hipSetDevice(c->device));
-	PooledReads P;
-	int rc = ingest_reads(*c->E, *R, 0, P);
-	if (rc) return rc;
+	const lsq_events &E = *c->E;
 	MethodReads &mr = c->reads[method];
 	mr.present = false;
-	const size_t B = c->E->buckets.size();
-	std::vector<unsigned long long> slot(B + 1, 0), o1(B + 1), o2(B + 1), on(B + 1);
-	for (size_t b = 0; b <= B; ++b) { o1[b] = P.p1_off[b]; o2[b] = P.p2_off[b]; on[b] = P.pn_off[b]; slot[b] = o1[b] + o2[b] + on[b]; }
+	const unsigned B = (unsigned)E.buckets.size();
+	const uint64_t n = R->n_reads, nblk = R->n_blocks;
 	hipStream_t st = c->stream;
-	if ((rc = mr.p1.upload(P.p1_se.data(), P.p1_se.size(), st))) return rc;
-	if ((rc = mr.p1_strand.upload(P.p1_strand.data(), P.p1_strand.size(), st))) return rc;
-	if ((rc = mr.p1_line.upload(P.p1_line.data(), P.p1_line.size(), st))) return rc;
-	if ((rc = mr.p2.upload(P.p2_se.data(), P.p2_se.size(), st))) return rc;
-	if ((rc = mr.p2_strand.upload(P.p2_strand.data(), P.p2_strand.size(), st))) return rc;
-	if ((rc = mr.p2_line.upload(P.p2_line.data(), P.p2_line.size(), st))) return rc;
-	if ((rc = mr.pn_se.upload(P.pn_se.data(), P.pn_se.size(), st))) return rc;
-	if ((rc = mr.pn_blk_off.upload(P.pn_blk_off.data(), P.pn_blk_off.size(), st))) return rc;
-	if ((rc = mr.pn_strand.upload(P.pn_strand.data(), P.pn_strand.size(), st))) return rc;
-	if ((rc = mr.pn_line.upload(P.pn_line.data(), P.pn_line.size(), st))) return rc;
-	if ((rc = mr.pn_bucket.upload(P.pn_bucket.data(), P.pn_bucket.size(), st))) return rc;
-	if ((rc = mr.p1_off.upload(o1.data(), B + 1, st))) return rc;
-	if ((rc = mr.p2_off.upload(o2.data(), B + 1, st))) return rc;
-	if ((rc = mr.pn_off.upload(on.data(), B + 1, st))) return rc;
-	if ((rc = mr.slot_off.upload(slot.data(), B + 1, st))) return rc;
+	int rc;
+	// the parsed blocks, file order
+	DevBuf<unsigned long long> d_blk_off;
+	DevBuf<unsigned> d_line;
+	DevBuf<int> d_bs, d_be, d_ms, d_me;
+	DevBuf<unsigned short> d_bc;
+	DevBuf<unsigned char> d_bst, d_nb, d_strand;
+	DevBuf<unsigned> d_key;
+	DevBuf<unsigned long long> d_counts, d_cursors, d_totals;
+	const unsigned long long zero_off = 0;
+	if ((rc = d_blk_off.upload(n ? (const unsigned long long *)R->blk_off : &zero_off, n + 1, st))) return rc;
+	if ((rc = d_line.upload(R->line_no, n, st))) return rc;
+	if ((rc = d_bs.upload(R->blk_start, nblk, st))) return rc;
+	if ((rc = d_be.upload(R->blk_end, nblk, st))) return rc;
+	if ((rc = d_bc.upload(R->blk_chrom, nblk, st))) return rc;
+	if ((rc = d_bst.upload(R->blk_strand, nblk, st))) return rc;
+	if ((rc = d_ms.alloc(nblk)) || (rc = d_me.alloc(nblk)) || (rc = d_nb.alloc(n)) || (rc = d_strand.alloc(n)) || (rc = d_key.alloc(n))) return rc;
+	if ((rc = d_counts.alloc(4ull * B + 4)) || (rc = d_cursors.alloc(4ull * B + 4)) || (rc = d_totals.alloc(4))) return rc;
+	HIP_TRY(hipMemsetAsync(d_counts.p, 0, (4ull * B + 4) * 8, st));
+	HIP_TRY(hipMemsetAsync(d_cursors.p, 0, (4ull * B + 4) * 8, st));
+	HIP_TRY(hipMemsetAsync(d_totals.p, 0, 4 * 8, st));
+	IngestTables T;
+	T.cov_off = c->cov_off.p; T.cov_s = c->cov_s.p; T.cov_e = c->cov_e.p;
+	T.cut_off = c->cut_off.p; T.cut_lo = c->cut_lo.p; T.chrom_first_bucket = c->chrom_first_bucket.p;
+	T.buckets = c->buckets.p; T.n_chrom = c->n_chrom_tables;
+	IngestRaw Rw;
+	Rw.n_reads = n; Rw.blk_off = d_blk_off.p; Rw.line_no = d_line.p; Rw.blk_start = d_bs.p; Rw.blk_end = d_be.p;
+	Rw.blk_chrom = d_bc.p; Rw.blk_strand = d_bst.p;
+	IngestWork W;
+	W.key = d_key.p; W.nb = d_nb.p; W.strand = d_strand.p; W.ms = d_ms.p; W.me = d_me.p;
+	W.counts = d_counts.p; W.cursors = d_cursors.p; W.totals = d_totals.p;
+	const unsigned igrid = (unsigned)std::min<unsigned long long>((n + 255) / 256 + 1, (unsigned long long)c->n_cu * 16);
+	if (n) {
+		hipLaunchKernelGGL(lsq_ingest_classify_kernel, dim3(igrid), dim3(256), 0, st, T, Rw, W);
+		HIP_TRY(hipGetLastError());
+	}
+	if ((rc = mr.p1_off.alloc(B + 1)) || (rc = mr.p2_off.alloc(B + 1)) || (rc = mr.pn_off.alloc(B + 1)) || (rc = mr.pnb_off.alloc(B + 1)) || (rc = mr.slot_off.alloc(B + 1))) return rc;
+	hipLaunchKernelGGL(lsq_ingest_scan_kernel, dim3(1), dim3(1024), 0, st, d_counts.p, B, mr.p1_off.p, mr.p2_off.p, mr.pn_off.p, mr.pnb_off.p, mr.slot_off.p);
+	HIP_TRY(hipGetLastError());
+	unsigned long long tot[4] = {0, 0, 0, 0}, sums[4] = {0, 0, 0, 0};
+	HIP_TRY(hipMemcpyAsync(tot, d_totals.p, 4 * 8, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(&sums[0], mr.p1_off.p + B, 8, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(&sums[1], mr.p2_off.p + B, 8, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(&sums[2], mr.pn_off.p + B, 8, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(&sums[3], mr.pnb_off.p + B, 8, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	if (tot[2]) return fail(LSQ_E_RANGE, "a read covers 2^18 or more bases or keeps more than %d separate blocks: outside the device tables' range", INGEST_MAX_BLOCKS);
+	if (sums[3] > 0xFFFFFFF0ull) return fail(LSQ_E_RANGE, "too many blocks in multi-block reads");
+	const size_t n1 = (size_t)sums[0], n2 = (size_t)sums[1], nn = (size_t)sums[2], nnb = (size_t)sums[3];
+	if ((rc = mr.p1.alloc(2 * n1)) || (rc = mr.p1_strand.alloc(n1)) || (rc = mr.p1_line.alloc(n1))) return rc;
+	if ((rc = mr.p2.alloc(4 * n2)) || (rc = mr.p2_strand.alloc(n2)) || (rc = mr.p2_line.alloc(n2))) return rc;
+	if ((rc = mr.pn_se.alloc(2 * nnb)) || (rc = mr.pn_blk_off.alloc(nn)) || (rc = mr.pn_nblk.alloc(nn)) || (rc = mr.pn_strand.alloc(nn)) ||
+	    (rc = mr.pn_line.alloc(nn)) || (rc = mr.pn_bucket.alloc(nn))) return rc;
+	if (n) {
+		IngestOut O;
+		O.p1 = reinterpret_cast<int2 *>(mr.p1.p); O.p1_strand = mr.p1_strand.p; O.p1_line = mr.p1_line.p;
+		O.p2 = reinterpret_cast<int4 *>(mr.p2.p); O.p2_strand = mr.p2_strand.p; O.p2_line = mr.p2_line.p;
+		O.pn_blk_off = mr.pn_blk_off.p; O.pn_nblk = mr.pn_nblk.p; O.pn_line = mr.pn_line.p; O.pn_bucket = mr.pn_bucket.p;
+		O.pn_strand = mr.pn_strand.p; O.pn_se = reinterpret_cast<int2 *>(mr.pn_se.p);
+		O.p1_off = mr.p1_off.p; O.p2_off = mr.p2_off.p; O.pn_off = mr.pn_off.p; O.pnb_off = mr.pnb_off.p;
+		hipLaunchKernelGGL(lsq_ingest_scatter_kernel, dim3(igrid), dim3(256), 0, st, Rw, W, O);
+		HIP_TRY(hipGetLastError());
+	}
 	{
 		// exception list: a quarter of the one- and two-block reads, at least 64 Ki entries
-		const size_t want = std::max<size_t>(65536, (P.p1_strand.size() + P.p2_strand.size()) / 4);
+		const size_t want = std::max<size_t>(65536, (n1 + n2) / 4);
 		if (c->exc.n < want && (rc = c->exc.alloc(want))) return rc;
 	}
 	if ((rc = upload_strand_ranks(c))) return rc;      // the reads may have introduced new strand strings
 	HIP_TRY(hipStreamSynchronize(st));
-	mr.n_retained = P.n_retained;
-	mr.n_retained_blocks = P.n_retained_blocks;
-	mr.total_slots = slot[B];
+	mr.n_retained = tot[0];
+	mr.n_retained_blocks = tot[1];
+	mr.total_slots = n1 + n2 + nn;
 	mr.present = true;
 	c->counted = c->solved = false;
 	return LSQ_OK;
@@ -1137,7 +1393,7 @@ static int run_count(lsq_ctx *c, bool all_reads) {
 		if (const char *e = getenv("LSQ_ABLATE")) A.ablate = (unsigned)atoi(e);
 		A.p1 = reinterpret_cast<const int2 *>(mr.p1.p); A.p1_strand = mr.p1_strand.p; A.p1_line = mr.p1_line.p;
 		A.p2 = reinterpret_cast<const int4 *>(mr.p2.p); A.p2_strand = mr.p2_strand.p; A.p2_line = mr.p2_line.p;
-		A.pn_blk_off = mr.pn_blk_off.p; A.pn_se = reinterpret_cast<const int2 *>(mr.pn_se.p);
+		A.pn_blk_off = mr.pn_blk_off.p; A.pn_nblk = mr.pn_nblk.p; A.pn_se = reinterpret_cast<const int2 *>(mr.pn_se.p);
 		A.pn_strand = mr.pn_strand.p; A.pn_line = mr.pn_line.p; A.pn_bucket = mr.pn_bucket.p;
 		A.p1_off = mr.p1_off.p; A.p2_off = mr.p2_off.p; A.pn_off = mr.pn_off.p; A.slot_off = mr.slot_off.p;
 		A.total_slots = mr.total_slots;

@@ -189,32 +189,7 @@ struct lsq_reads {
 
 namespace lsq {
 
-// Retained reads of one method, bucketed and pooled: what is copied to HBM.
-struct PooledReads {
-	uint64_t n_retained = 0, n_retained_blocks = 0;
-	// pool 1: one merged block
-	std::vector<int32_t> p1_se;        // 2 per read
-	std::vector<uint8_t> p1_strand;
-	std::vector<uint32_t> p1_line;
-	std::vector<uint64_t> p1_off;      // per bucket, n_buckets+1
-	// pool 2: two merged blocks
-	std::vector<int32_t> p2_se;        // 4 per read
-	std::vector<uint8_t> p2_strand;
-	std::vector<uint32_t> p2_line;
-	std::vector<uint64_t> p2_off;
-	// pool n: three or more
-	std::vector<uint32_t> pn_blk_off;  // nN+1, into pn_se pairs
-	std::vector<int32_t> pn_se;
-	std::vector<uint8_t> pn_strand;
-	std::vector<uint32_t> pn_line;
-	std::vector<uint32_t> pn_bucket;   // bucket of each pool-n read (the cleanup kernel works per read)
-	std::vector<uint64_t> pn_off;
-};
-
-// host ingest: containment filter + add_interval merge + bucket/pool scatter
-int ingest_reads(const lsq_events &ev, const lsq_reads &rd, int n_threads, PooledReads &out);
 int plan_device(lsq_events &E);
-
 int host_threads(int requested);
 
 } // namespace lsq
