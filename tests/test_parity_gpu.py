@@ -308,3 +308,41 @@ def test_many_segments_isoforms_and_blocks_vs_oracle(seed, max_exons, max_iso, R
     rc, text = L.cli_run("count", argv[:-1])
     rc2, ctext, _ = ob.run("count", argv[:-1])
     assert rc == rc2 == 0 and text == ctext
+
+
+def test_many_block_reads_and_the_ingest_block_limit(tmp_path, monkeypatch):
+    """reads with up to 16 kept blocks go through the device ingest and the cleanup kernel like the
+    oracle's; a read that keeps more separate blocks is refused loudly (LSQ_E_RANGE), not dropped"""
+    import golden_inputs as gi
+    exons = [(1000 + 40 * i, 1000 + 40 * i + 25) for i in range(24)]       # 24 exons of 25 bp, 15 bp introns
+    iv = gi.interval_line("M.a", "c1", "+", exons) + gi.interval_line("M.b", "c1", "+", exons[:3] + exons[5:])
+    _write(tmp_path / "m.interval", iv)
+    _write(tmp_path / "m.map", "M\tM.a\nM\tM.b\n")
+    lines = ["AlignmentBlocks"]
+    for nb in (3, 5, 9, 12, 16):
+        for start in (0, 2, 4):
+            bl = [(s + 1, e) for s, e in exons[start:start + nb]]
+            bl[0] = (bl[0][0] + 3, bl[0][1])
+            lines.append(gi.mrf_line("c1", "+", bl).rstrip("\n"))
+    # the same blocks listed right-to-left: touching ones stay separate, order does not matter otherwise
+    lines.append(gi.mrf_line("c1", "+", list(reversed(exons[2:9]))).rstrip("\n"))
+    _write(tmp_path / "m.mrf", "\n".join(lines) + "\n")
+    monkeypatch.chdir(tmp_path)
+    argv = ["0", "m", "./", "LH_GENE_TXT", "m.interval", "UCSC_GENE2ISOFORM", "m.map", "0", "10", "MRF_SINGLE", "SHORT_READ", "100", "m.mrf"]
+    # 24 segments + 2 isoforms: a generic bucket
+    rc, text = L.cli_run("count", argv)
+    orc, otext, _ = ob.run("count", argv)
+    assert (rc, text) == (orc, otext) and rc == 0 and text.split("\t")[1] != "0"
+    rc, text = L.cli_run("solve", argv + ["5000"])
+    orc, otext, _ = ob.run("solve", argv + ["5000"])
+    assert rc == orc == 0 and ob.solve_text_close(text, otext)
+    # 17 separate kept blocks
+    _write(tmp_path / "big.mrf", "AlignmentBlocks\n" + gi.mrf_line("c1", "+", exons[:17]))
+    a = L.Annotation("m.interval", "m.map")
+    ev = L.Events(a, ("SHORT_READ",), (100,))
+    ctx = L.Context(0)
+    ctx.upload_events(ev)
+    with pytest.raises(L.LsqError) as ei:
+        ctx.upload_reads(0, L.Reads.from_mrf("big.mrf", ev))
+    assert ei.value.status == -5
+    ctx.close()
