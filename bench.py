@@ -64,10 +64,19 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the hot path has no CPU implementation")
+    # rehearsal on a one-GPU box (developer aid): LSQ_BENCH_REHEARSE=1 puts every rank on cuda:0 and
+    # moves the per-event outputs over gloo instead of RCCL; the driver never sets it
+    rehearse = os.environ.get("LSQ_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    comm_dev = torch.device("cpu") if (rehearse and world > 1) else dev
 
     W = WORKLOADS[a.workload]
     types = W["types"] or L.EVENT_TYPES
@@ -98,9 +107,9 @@ def main():
     t_theta = torch.zeros(max(n_iso, 1), dtype=torch.float64, device=dev)
     t_ll = torch.zeros(max(n_ev, 1), dtype=torch.float64, device=dev)
     if world > 1:
-        g_cnt = torch.zeros(world * t_cnt.numel(), dtype=torch.int64, device=dev)
-        g_theta = torch.zeros(world * t_theta.numel(), dtype=torch.float64, device=dev)
-        g_ll = torch.zeros(world * t_ll.numel(), dtype=torch.float64, device=dev)
+        g_cnt = torch.zeros(world * t_cnt.numel(), dtype=torch.int64, device=comm_dev)
+        g_theta = torch.zeros(world * t_theta.numel(), dtype=torch.float64, device=comm_dev)
+        g_ll = torch.zeros(world * t_ll.numel(), dtype=torch.float64, device=comm_dev)
 
     count_ms, solve_ms, fast_ms = [], [], []
 
@@ -110,9 +119,9 @@ def main():
         ctx.copy_results_device(t_cnt.data_ptr(), t_theta.data_ptr(), t_ll.data_ptr())
         if world > 1:
             ctx.synchronize()          # the library's stream -> visible to torch's stream
-            dist.all_gather_into_tensor(g_cnt, t_cnt)
-            dist.all_gather_into_tensor(g_theta, t_theta)
-            dist.all_gather_into_tensor(g_ll, t_ll)
+            dist.all_gather_into_tensor(g_cnt, t_cnt.to(comm_dev))
+            dist.all_gather_into_tensor(g_theta, t_theta.to(comm_dev))
+            dist.all_gather_into_tensor(g_ll, t_ll.to(comm_dev))
         if record:
             c, s = ctx.timing()        # HIP events on the library's stream (synchronises it)
             count_ms.append(c)
@@ -140,8 +149,8 @@ def main():
         step(True)
     fence()
 
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    tot = torch.tensor([float(retained), float(retained_blocks), float(n_mrf_reads)], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
+    tot = torch.tensor([float(retained), float(retained_blocks), float(n_mrf_reads)], dtype=torch.float64, device=comm_dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
