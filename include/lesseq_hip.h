@@ -123,6 +123,11 @@ uint64_t lsq_reads_count(const lsq_reads *r);
 uint64_t lsq_reads_num_blocks(const lsq_reads *r);
 int lsq_events_chrom_id(lsq_events *e, const char *chrom);     /* interns; >= 0 */
 int lsq_events_strand_id(lsq_events *e, const char *strand);   /* interns; >= 0 */
+const char *lsq_events_strand_name(const lsq_events *e, int strand_id);   /* NULL when unknown */
+/* The arrays of a read set (lsq_reads_wrap's layout); they live as long as the read set. */
+int lsq_reads_arrays(const lsq_reads *r, const uint64_t **blk_off, const uint32_t **line_no,
+                     const int32_t **blk_start, const int32_t **blk_end,
+                     const uint16_t **blk_chrom_id, const uint8_t **blk_strand_id);
 
 /* ------------------------------------------------------------------------------------
  * Device group
@@ -138,7 +143,7 @@ int lsq_ctx_synchronize(lsq_ctx *c);
 
 /* Uploads the compiled tables: per-bucket LDS images (bin directory, event records,
  * segments, isoform masks), tie-break records and G = 1/ARS. */
-int lsq_events_upload(lsq_ctx *c, const lsq_events *e);
+int lsq_events_upload(lsq_ctx *c, lsq_events *e);
 
 /* Replaces the retained-read state the reference builds at count/count.cpp:319-324 and
  * :348-364.  The parsed blocks are copied to the device as they are; HIP kernels apply the
@@ -148,6 +153,18 @@ int lsq_events_upload(lsq_ctx *c, const lsq_events *e);
  * HBM).  A read may keep at most 16 separate blocks (LSQ_E_RANGE beyond).  method in
  * [0, n_methods). */
 int lsq_reads_upload(lsq_ctx *c, int method, const lsq_reads *r);
+/* The same, from the MRF_SINGLE text itself: replaces count/count.cpp:279-336 and :348-364 in one
+ * call.  The file's bytes are copied to HBM and parsed there (newline scan, one lane per line, the
+ * reference's find/substr field arithmetic and lexical_cast<long> rules), then ingested as above;
+ * no parsed array ever exists on the host.  Status as lsq_mrf_parse (LSQ_E_FORMAT, LSQ_E_PARSE with
+ * the first failing line in lsq_last_error(), LSQ_E_IO); LSQ_E_UNSUPPORTED when the file holds a
+ * strand string longer than 7 bytes (lsq_mrf_parse + lsq_reads_upload take those). */
+int lsq_reads_upload_mrf(lsq_ctx *c, int method, const char *read_format, const char *path);
+/* The device parser's blocks copied back to the host (same arrays lsq_mrf_parse makes; for tools
+ * and tests).  Needs lsq_events_upload first. */
+int lsq_mrf_parse_device(lsq_ctx *c, const char *read_format, const char *path, lsq_reads **out);
+/* milliseconds of the last device parse: host-to-device copy of the text, and the parse kernels */
+int lsq_last_mrf_timing(lsq_ctx *c, float *h2d_ms, float *parse_ms);
 uint64_t lsq_reads_retained(const lsq_ctx *c, int method);      /* "loaded N reads" log line */
 uint64_t lsq_reads_retained_blocks(const lsq_ctx *c, int method);
 

@@ -171,6 +171,21 @@ class Reads:
     def num_blocks(self):
         return lib.lsq_reads_num_blocks(self.h)
 
+    def arrays(self):
+        """copies of (blk_off, line_no, blk_start, blk_end, blk_chrom_id, blk_strand_id)"""
+        ptrs = [vp() for _ in range(6)]
+        check(lib.lsq_reads_arrays(self.h, *[C.byref(p) for p in ptrs]))
+        n, nb = len(self), self.num_blocks
+        spec = ((np.uint64, n + 1), (np.uint32, n), (np.int32, nb), (np.int32, nb), (np.uint16, nb), (np.uint8, nb))
+        out = []
+        for p, (dt, cnt) in zip(ptrs, spec):
+            if cnt == 0 or not p.value:
+                out.append(np.zeros(cnt, dt))
+            else:
+                buf = (C.c_char * (cnt * np.dtype(dt).itemsize)).from_address(p.value)
+                out.append(np.frombuffer(buf, dtype=dt, count=cnt).copy())
+        return tuple(out)
+
 
 class Context:
     """One GPU: uploads, the count kernel, the EM kernel, result fetch"""
@@ -195,6 +210,21 @@ class Context:
 
     def upload_reads(self, method, reads):
         check(lib.lsq_reads_upload(self.h, method, reads.h))
+
+    def upload_reads_mrf(self, method, path, read_format="MRF_SINGLE"):
+        """MRF text -> HBM -> parsed and ingested on the device (lsq_reads_upload_mrf)"""
+        check(lib.lsq_reads_upload_mrf(self.h, method, _b(read_format), _b(path)))
+
+    def parse_mrf_device(self, path, read_format="MRF_SINGLE"):
+        """the device parser's blocks, copied back as a Reads (tests, tools)"""
+        h = vp()
+        check(lib.lsq_mrf_parse_device(self.h, _b(read_format), _b(path), C.byref(h)))
+        return Reads(h)
+
+    def mrf_timing(self):
+        a, b = C.c_float(), C.c_float()
+        check(lib.lsq_last_mrf_timing(self.h, C.byref(a), C.byref(b)))
+        return {"h2d_ms": a.value, "parse_ms": b.value}
 
     def retained(self, method):
         return lib.lsq_reads_retained(self.h, method)

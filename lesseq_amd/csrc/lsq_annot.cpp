@@ -689,6 +689,10 @@ int lsq_events_chrom_id(lsq_events *e, const char *chrom) {
 	if (id > 65000) return fail(LSQ_E_RANGE, "too many chromosome names");
 	return id;
 }
+const char *lsq_events_strand_name(const lsq_events *e, int id) {
+	if (!e || id < 0 || (size_t)id >= e->strands.names.size()) return nullptr;
+	return e->strands.names[id].c_str();
+}
 int lsq_events_strand_id(lsq_events *e, const char *strand) {
 	if (!e || !strand) return LSQ_E_ARG;
 	int id = e->strands.intern(strand);

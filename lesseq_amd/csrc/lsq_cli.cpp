@@ -83,6 +83,14 @@ int status_to_exit(int st) {
 	}
 }
 
+int precheck_reads_file(const char *fmt, const char *path) {
+	FILE *f = fopen(path, "rb");
+	if (!f) return fail(LSQ_E_IO, "cannot open reads file %s", path);
+	fclose(f);
+	if (strcmp(fmt, "MRF_SINGLE") != 0) return fail(LSQ_E_FORMAT, "Unknown file format error: %s", fmt);
+	return LSQ_OK;
+}
+
 struct Freer {
 	lsq_annotation *a = nullptr; lsq_events *e = nullptr; lsq_ctx *c = nullptr;
 	std::vector<lsq_reads *> r;
@@ -176,26 +184,27 @@ int run_count_solve(bool solve, int argc, const char *const *argv, std::string &
 	logf(2, "Built isoform structures for the %lld selected gene(s)", (long long)n_ev);
 	logf(2, "Loading the reads from %d sampling method(s)", M);
 	for (int m = 0; m < M; ++m) {
-		lsq_reads *r = nullptr;
-		st = lsq_mrf_parse(fmts[m], paths[m], F.e, 0, &r);
-		if (st) {
-			if (st == LSQ_E_PARSE) { logf(0, "%s", lsq_last_error()); logf(0, "Lexical_cast error when converting arguments to numeric values"); }
-			else logf(0, "%s", lsq_last_error());
-			return status_to_exit(st);
-		}
-		F.r.push_back(r);
+		// what the reference decides before it reads a line: the file opens (assert) and the format literal is known
+		st = precheck_reads_file(fmts[m], paths[m]);
+		if (st) { logf(0, "%s", lsq_last_error()); return status_to_exit(st); }
 		if (!F.c) {
-			// the GPU is first touched here, after the first read file parsed cleanly
 			int dev = 0;
 			if (const char *e = getenv("LSQ_DEVICE")) dev = atoi(e);
 			st = lsq_ctx_create(dev, &F.c);
 			if (!st) st = lsq_events_upload(F.c, F.e);
 			if (st) { logf(0, "%s", lsq_last_error()); return 3; }
 		}
-		st = lsq_reads_upload(F.c, m, r);
-		if (st) { logf(0, "%s", lsq_last_error()); return st == LSQ_E_DEVICE ? 3 : 2; }
+		// text -> HBM -> parsed and ingested there
+		st = lsq_reads_upload_mrf(F.c, m, fmts[m], paths[m]);
+		if (st == LSQ_E_UNSUPPORTED) {
+			// a strand string beyond the device parser's 7 bytes: the host parser reads such files
+			lsq_reads *r = nullptr;
+			st = lsq_mrf_parse(fmts[m], paths[m], F.e, 0, &r);
+			if (!st) { F.r.push_back(r); st = lsq_reads_upload(F.c, m, r); lsq_reads_free(r); F.r.back() = nullptr; }
+		}
+		if (st == LSQ_E_PARSE) { logf(0, "%s", lsq_last_error()); logf(0, "Lexical_cast error when converting arguments to numeric values"); return status_to_exit(st); }
+		if (st) { logf(0, "%s", lsq_last_error()); return st == LSQ_E_DEVICE ? 3 : (st == LSQ_E_IO || st == LSQ_E_FORMAT ? status_to_exit(st) : 2); }
 		logf(2, "Sampling method #%d: loaded %llu reads associated with the selected gene regions", m, (unsigned long long)lsq_reads_retained(F.c, m));
-		lsq_reads_free(r); F.r.back() = nullptr;
 	}
 	if (bad_type && n_ev > 0) { logf(0, "Unknown read type error: %s", bad_type_name.c_str()); return 1; }
 	logf(2, "Processing reads info for genes");

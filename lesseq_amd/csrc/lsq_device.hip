@@ -16,6 +16,10 @@
 // -> one LDS atomic on (event, class) carrying count and matched bases.  Per bucket the
 // histogram is flushed with global atomics; integer sums make the result order-independent.
 #include <hip/hip_runtime.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cmath>
@@ -26,6 +30,7 @@
 #include <vector>
 
 #include "lsq_internal.hpp"
+#include "lsq_mrf_line.hpp"
 
 using namespace lsq;
 
@@ -1121,7 +1126,7 @@ struct lsq_ctx {
 	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
 	hipEvent_t evf0[LSQ_MAX_METHODS] = {}, evf1[LSQ_MAX_METHODS] = {};   // around each method's lsq_count_fast_kernel launch
 	int fast_launched = 0;
-	const lsq_events *E = nullptr;          // must outlive the uploads made from it
+	lsq_events *E = nullptr;                // must outlive the uploads made from it (its strand dictionary grows with the reads)
 	DevBuf<BucketDesc> buckets;
 	DevBuf<uint8_t> images, strand_rank, dK;
 	DevBuf<TieRec> ties;
@@ -1140,6 +1145,7 @@ struct lsq_ctx {
 	bool counted = false, solved = false;
 	bool has_fast = false, has_generic = false;
 	float count_ms = 0, solve_ms = 0;
+	float mrf_h2d_ms = 0, mrf_parse_ms = 0;
 };
 
 static int upload_strand_ranks(lsq_ctx *c) {
@@ -1155,6 +1161,8 @@ static int upload_strand_ranks(lsq_ctx *c) {
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	return LSQ_OK;
 }
+
+#include "lsq_mrf_device.hpp"
 
 extern "C" {
 
@@ -1201,7 +1209,7 @@ int lsq_ctx_synchronize(lsq_ctx *c) {
 	return LSQ_OK;
 }
 
-int lsq_events_upload(lsq_ctx *c, const lsq_events *E) {
+int lsq_events_upload(lsq_ctx *c, lsq_events *E) {
 	if (!c || !E) return fail(LSQ_E_ARG, "null argument");
 	HIP_TRY(hipSetDevice(c->device));
 	if (E->max_lds_bytes > 160 * 1024) return fail(LSQ_E_UNSUPPORTED, "bucket tables exceed the CU's LDS");
@@ -1263,33 +1271,19 @@ int lsq_events_upload(lsq_ctx *c, const lsq_events *E) {
 	return LSQ_OK;
 }
 
-int lsq_reads_upload(lsq_ctx *c, int method, const lsq_reads *R) {
-	if (!c || !R) return fail(LSQ_E_ARG, "null argument");
-	if (!c->E) return fail(LSQ_E_STATE, "lsq_events_upload must come first");
-	if (method < 0 || method >= c->E->n_methods) return fail(LSQ_E_ARG, "method %d out of range", method);
-	HIP_TRY(hipSetDevice(c->device));
+// Runs the three ingest kernels over parsed blocks that are already on the device (file order).
+static int ingest_device(lsq_ctx *c, int method, const IngestRaw &Rw, uint64_t nblk) {
 	const lsq_events &E = *c->E;
 	MethodReads &mr = c->reads[method];
 	mr.present = false;
 	const unsigned B = (unsigned)E.buckets.size();
-	const uint64_t n = R->n_reads, nblk = R->n_blocks;
+	const uint64_t n = Rw.n_reads;
 	hipStream_t st = c->stream;
 	int rc;
-	// the parsed blocks, file order
-	DevBuf<unsigned long long> d_blk_off;
-	DevBuf<unsigned> d_line;
-	DevBuf<int> d_bs, d_be, d_ms, d_me;
-	DevBuf<unsigned short> d_bc;
-	DevBuf<unsigned char> d_bst, d_nb, d_strand;
+	DevBuf<int> d_ms, d_me;
+	DevBuf<unsigned char> d_nb, d_strand;
 	DevBuf<unsigned> d_key;
 	DevBuf<unsigned long long> d_counts, d_cursors, d_totals;
-	const unsigned long long zero_off = 0;
-	if ((rc = d_blk_off.upload(n ? (const unsigned long long *)R->blk_off : &zero_off, n + 1, st))) return rc;
-	if ((rc = d_line.upload(R->line_no, n, st))) return rc;
-	if ((rc = d_bs.upload(R->blk_start, nblk, st))) return rc;
-	if ((rc = d_be.upload(R->blk_end, nblk, st))) return rc;
-	if ((rc = d_bc.upload(R->blk_chrom, nblk, st))) return rc;
-	if ((rc = d_bst.upload(R->blk_strand, nblk, st))) return rc;
 	if ((rc = d_ms.alloc(nblk)) || (rc = d_me.alloc(nblk)) || (rc = d_nb.alloc(n)) || (rc = d_strand.alloc(n)) || (rc = d_key.alloc(n))) return rc;
 	if ((rc = d_counts.alloc(4ull * B + 4)) || (rc = d_cursors.alloc(4ull * B + 4)) || (rc = d_totals.alloc(4))) return rc;
 	HIP_TRY(hipMemsetAsync(d_counts.p, 0, (4ull * B + 4) * 8, st));
@@ -1299,9 +1293,6 @@ int lsq_reads_upload(lsq_ctx *c, int method, const lsq_reads *R) {
 	T.cov_off = c->cov_off.p; T.cov_s = c->cov_s.p; T.cov_e = c->cov_e.p;
 	T.cut_off = c->cut_off.p; T.cut_lo = c->cut_lo.p; T.chrom_first_bucket = c->chrom_first_bucket.p;
 	T.buckets = c->buckets.p; T.n_chrom = c->n_chrom_tables;
-	IngestRaw Rw;
-	Rw.n_reads = n; Rw.blk_off = d_blk_off.p; Rw.line_no = d_line.p; Rw.blk_start = d_bs.p; Rw.blk_end = d_be.p;
-	Rw.blk_chrom = d_bc.p; Rw.blk_strand = d_bst.p;
 	IngestWork W;
 	W.key = d_key.p; W.nb = d_nb.p; W.strand = d_strand.p; W.ms = d_ms.p; W.me = d_me.p;
 	W.counts = d_counts.p; W.cursors = d_cursors.p; W.totals = d_totals.p;
@@ -1349,6 +1340,76 @@ int lsq_reads_upload(lsq_ctx *c, int method, const lsq_reads *R) {
 	mr.total_slots = n1 + n2 + nn;
 	mr.present = true;
 	c->counted = c->solved = false;
+	return LSQ_OK;
+}
+
+int lsq_reads_upload(lsq_ctx *c, int method, const lsq_reads *R) {
+	if (!c || !R) return fail(LSQ_E_ARG, "null argument");
+	if (!c->E) return fail(LSQ_E_STATE, "lsq_events_upload must come first");
+	if (method < 0 || method >= c->E->n_methods) return fail(LSQ_E_ARG, "method %d out of range", method);
+	HIP_TRY(hipSetDevice(c->device));
+	const uint64_t n = R->n_reads, nblk = R->n_blocks;
+	hipStream_t st = c->stream;
+	int rc;
+	// the parsed blocks, file order
+	DevBuf<unsigned long long> d_blk_off;
+	DevBuf<unsigned> d_line;
+	DevBuf<int> d_bs, d_be;
+	DevBuf<unsigned short> d_bc;
+	DevBuf<unsigned char> d_bst;
+	const unsigned long long zero_off = 0;
+	if ((rc = d_blk_off.upload(n ? (const unsigned long long *)R->blk_off : &zero_off, n + 1, st))) return rc;
+	if ((rc = d_line.upload(R->line_no, n, st))) return rc;
+	if ((rc = d_bs.upload(R->blk_start, nblk, st))) return rc;
+	if ((rc = d_be.upload(R->blk_end, nblk, st))) return rc;
+	if ((rc = d_bc.upload(R->blk_chrom, nblk, st))) return rc;
+	if ((rc = d_bst.upload(R->blk_strand, nblk, st))) return rc;
+	IngestRaw Rw;
+	Rw.n_reads = n; Rw.blk_off = d_blk_off.p; Rw.line_no = d_line.p; Rw.blk_start = d_bs.p; Rw.blk_end = d_be.p;
+	Rw.blk_chrom = d_bc.p; Rw.blk_strand = d_bst.p;
+	return ingest_device(c, method, Rw, nblk);
+}
+
+int lsq_reads_upload_mrf(lsq_ctx *c, int method, const char *read_format, const char *path) {
+	if (!c) return fail(LSQ_E_ARG, "null argument");
+	if (!c->E) return fail(LSQ_E_STATE, "lsq_events_upload must come first");
+	if (method < 0 || method >= c->E->n_methods) return fail(LSQ_E_ARG, "method %d out of range", method);
+	HIP_TRY(hipSetDevice(c->device));
+	DevParsed P;
+	int rc = device_parse_mrf(c, read_format, path, P, &c->mrf_h2d_ms, &c->mrf_parse_ms);
+	if (rc) return rc;
+	IngestRaw Rw;
+	Rw.n_reads = P.n_reads; Rw.blk_off = P.blk_off.p; Rw.line_no = P.line_no.p; Rw.blk_start = P.bs.p; Rw.blk_end = P.be.p;
+	Rw.blk_chrom = P.bc.p; Rw.blk_strand = P.bst.p;
+	return ingest_device(c, method, Rw, P.n_blocks);
+}
+
+int lsq_mrf_parse_device(lsq_ctx *c, const char *read_format, const char *path, lsq_reads **out) {
+	if (!c || !out) return fail(LSQ_E_ARG, "null argument");
+	HIP_TRY(hipSetDevice(c->device));
+	DevParsed P;
+	int rc = device_parse_mrf(c, read_format, path, P, &c->mrf_h2d_ms, &c->mrf_parse_ms);
+	if (rc) return rc;
+	std::unique_ptr<lsq_reads> R(new lsq_reads);
+	R->o_blk_off.resize(P.n_reads + 1); R->o_line_no.resize(P.n_reads);
+	R->o_start.resize(P.n_blocks); R->o_end.resize(P.n_blocks); R->o_chrom.resize(P.n_blocks); R->o_strand.resize(P.n_blocks);
+	HIP_TRY(hipMemcpy(R->o_blk_off.data(), P.blk_off.p, (P.n_reads + 1) * 8, hipMemcpyDeviceToHost));
+	if (P.n_reads) HIP_TRY(hipMemcpy(R->o_line_no.data(), P.line_no.p, P.n_reads * 4, hipMemcpyDeviceToHost));
+	if (P.n_blocks) {
+		HIP_TRY(hipMemcpy(R->o_start.data(), P.bs.p, P.n_blocks * 4, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(R->o_end.data(), P.be.p, P.n_blocks * 4, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(R->o_chrom.data(), P.bc.p, P.n_blocks * 2, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(R->o_strand.data(), P.bst.p, P.n_blocks, hipMemcpyDeviceToHost));
+	}
+	R->adopt();
+	*out = R.release();
+	return LSQ_OK;
+}
+
+int lsq_last_mrf_timing(lsq_ctx *c, float *h2d_ms, float *parse_ms) {
+	if (!c) return fail(LSQ_E_ARG, "null context");
+	if (h2d_ms) *h2d_ms = c->mrf_h2d_ms;
+	if (parse_ms) *parse_ms = c->mrf_parse_ms;
 	return LSQ_OK;
 }
 

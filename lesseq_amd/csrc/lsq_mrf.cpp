@@ -13,6 +13,7 @@
 #include <thread>
 
 #include "lsq_internal.hpp"
+#include "lsq_mrf_line.hpp"
 
 using namespace lsq;
 
@@ -29,39 +30,7 @@ void lsq_reads::adopt() {
 
 namespace {
 
-const size_t NPOS = (size_t)-1;
 const uint16_t NOCHROM = 0xFFFF;
-
-struct View { const char *p; size_t n; };
-
-// std::string::find / substr on a (ptr,len) line, including their npos arithmetic: the
-// reference's field splitter leans on `npos + 1 == 0` for lines that run out of colons.
-inline size_t find_ch(View l, char c, size_t pos) {
-	if (pos >= l.n) return NPOS;
-	const void *q = memchr(l.p + pos, c, l.n - pos);
-	return q ? (size_t)((const char *)q - l.p) : NPOS;
-}
-inline View sub(View l, size_t pos, size_t cnt) {
-	if (pos > l.n) pos = l.n;
-	size_t avail = l.n - pos;
-	return View{l.p + pos, cnt < avail ? cnt : avail};
-}
-// boost::lexical_cast<long>: the whole field, optional sign, decimal digits, no overflow
-inline bool cast_long(View f, int64_t &out) {
-	if (f.n == 0) return false;
-	size_t i = (f.p[0] == '+' || f.p[0] == '-') ? 1 : 0;
-	if (i == f.n) return false;
-	uint64_t v = 0;
-	for (size_t j = i; j < f.n; ++j) {
-		unsigned d = (unsigned char)f.p[j] - '0';
-		if (d > 9) return false;
-		if (v > (UINT64_MAX - d) / 10) return false;
-		v = v * 10 + d;
-	}
-	if (f.p[0] == '-') { if (v > (uint64_t)INT64_MAX + 1) return false; out = (int64_t)(0 - v); }
-	else { if (v > (uint64_t)INT64_MAX) return false; out = (int64_t)v; }
-	return true;
-}
 
 struct Chunk {
 	const char *begin, *end;        // whole lines
@@ -86,33 +55,13 @@ void parse_chunk(Chunk &ck, lsq_events *E) {
 	while (p < ck.end) {
 		const char *nl = (const char *)memchr(p, '\n', (size_t)(ck.end - p));
 		if (!nl) break;
-		View line{p, (size_t)(nl - p)};
+		MrfView line{p, (size_t)(nl - p)};
 		p = nl + 1;
 		++line_num;
-		if ((line.n >= 1 && line.p[0] == '#') || (line.n == 15 && memcmp(line.p, "AlignmentBlocks", 15) == 0)) continue;
+		if (mrf_line_is_skipped(line)) continue;
 		uint64_t nb = 0;
-		size_t last_comma = 0;
-		while (last_comma != NPOS) {
-			size_t colon = find_ch(line, ':', last_comma);
-			size_t cpos = last_comma == 0 ? 0 : last_comma + 1;
-			View chr = sub(line, cpos, colon - cpos);
-			size_t old_colon = colon;
-			colon = find_ch(line, ':', colon + 1);
-			View strand = sub(line, old_colon + 1, colon - old_colon - 1);
-			old_colon = colon;
-			colon = find_ch(line, ':', colon + 1);
-			int64_t start, end;
-			bool ok = cast_long(sub(line, old_colon + 1, colon - old_colon - 1), start);
-			if (ok) {
-				old_colon = colon;
-				colon = find_ch(line, ':', colon + 1);
-				ok = cast_long(sub(line, old_colon + 1, colon - old_colon - 1), end);
-			}
-			if (!ok) {
-				ck.status = LSQ_E_PARSE;
-				ck.err = "#" + std::to_string(line_num) + ":" + std::string(line.p, line.n);
-				return;
-			}
+		int bad_status = LSQ_OK;
+		const bool ok = mrf_split_line(line, [&](MrfView chr, MrfView strand, int64_t start, int64_t end) {
 			// chromosome: only names the events know can ever pass the containment filter
 			if (last_chrom_id == -2 || last_chrom.size() != chr.n || memcmp(last_chrom.data(), chr.p, chr.n) != 0) {
 				last_chrom.assign(chr.p, chr.n);
@@ -122,10 +71,10 @@ void parse_chunk(Chunk &ck, lsq_events *E) {
 			int sid = -1;
 			for (auto &c : sc) if (c.id >= 0 && c.s.size() == strand.n && memcmp(c.s.data(), strand.p, strand.n) == 0) { sid = c.id; break; }
 			if (sid < 0) {
-				std::string s(strand.p, strand.n);
-				sid = E->strands.intern(s);
-				if (sid > 255) { ck.status = LSQ_E_RANGE; ck.err = "more than 256 distinct strand strings"; return; }
-				sc[1] = sc[0]; sc[0].s = s; sc[0].id = sid;
+				std::string st(strand.p, strand.n);
+				sid = E->strands.intern(st);
+				if (sid > 255) { bad_status = LSQ_E_RANGE; sid = 0; }
+				sc[1] = sc[0]; sc[0].s = st; sc[0].id = sid;
 			}
 			int64_t s0 = start - 1;
 			uint16_t cid = (uint16_t)last_chrom_id;
@@ -135,7 +84,12 @@ void parse_chunk(Chunk &ck, lsq_events *E) {
 			ck.bc.push_back(cid);
 			ck.bst.push_back((uint8_t)sid);
 			++nb;
-			last_comma = find_ch(line, ',', colon);
+		});
+		if (bad_status != LSQ_OK) { ck.status = bad_status; ck.err = "more than 256 distinct strand strings"; return; }
+		if (!ok) {
+			ck.status = LSQ_E_PARSE;
+			ck.err = "#" + std::to_string(line_num) + ":" + std::string(line.p, line.n);
+			return;
 		}
 		if (line_num > 0xFFFFFFFFull) { ck.status = LSQ_E_RANGE; ck.err = "more than 2^32 lines"; return; }
 		ck.blk_cnt.push_back(nb);
@@ -252,6 +206,17 @@ int lsq_reads_wrap(uint64_t n_reads, const uint64_t *blk_off, const uint32_t *li
 	R->blk_start = blk_start; R->blk_end = blk_end;
 	R->blk_chrom = blk_chrom_id; R->blk_strand = blk_strand_id;
 	*out = R.release();
+	return LSQ_OK;
+}
+int lsq_reads_arrays(const lsq_reads *r, const uint64_t **blk_off, const uint32_t **line_no, const int32_t **blk_start,
+                     const int32_t **blk_end, const uint16_t **blk_chrom_id, const uint8_t **blk_strand_id) {
+	if (!r) return fail(LSQ_E_ARG, "null read set");
+	if (blk_off) *blk_off = r->blk_off;
+	if (line_no) *line_no = r->line_no;
+	if (blk_start) *blk_start = r->blk_start;
+	if (blk_end) *blk_end = r->blk_end;
+	if (blk_chrom_id) *blk_chrom_id = r->blk_chrom;
+	if (blk_strand_id) *blk_strand_id = r->blk_strand;
 	return LSQ_OK;
 }
 void lsq_reads_free(lsq_reads *r) { delete r; }

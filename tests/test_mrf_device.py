@@ -1,0 +1,188 @@
+"""The device MRF parser (lsq_reads_upload_mrf / lsq_mrf_parse_device) against the host parser
+(lsq_mrf_parse), which the CPU suite pins to the oracle and so to the reference's loader
+(count/count.cpp:279-336)."""
+import os
+
+import numpy as np
+import pytest
+
+import lesseq_amd as L
+from test_oracle_golden import CASES, load_case
+
+pytestmark = pytest.mark.gpu
+
+
+def strand_names(ev, ids):
+    return [L.lib.lsq_events_strand_name(ev.h, int(i)) for i in ids]
+
+
+def parsed_equal(ev, host, dev):
+    h, d = host.arrays(), dev.arrays()
+    assert len(host) == len(dev) and host.num_blocks == dev.num_blocks
+    for k in range(5):
+        assert np.array_equal(h[k], d[k]), ("blk_off", "line_no", "blk_start", "blk_end", "blk_chrom")[k]
+    # strand ids are handed out in order of first sight, which differs between the parsers: compare the strings
+    hu, du = np.unique(h[5]), np.unique(d[5])
+    hmap = {int(i): n for i, n in zip(hu, strand_names(ev, hu))}
+    dmap = {int(i): n for i, n in zip(du, strand_names(ev, du))}
+    assert None not in hmap.values() and None not in dmap.values()
+    assert [hmap[int(i)] for i in h[5]] == [dmap[int(i)] for i in d[5]]
+
+
+def setup(interval, gmap, R=50, rtype="SHORT_READ"):
+    a = L.Annotation(interval, gmap, 0, 10 ** 9)
+    ev = L.Events(a, (rtype,), (R,))
+    ctx = L.Context(0)
+    ctx.upload_events(ev)
+    return ev, ctx
+
+
+@pytest.mark.parametrize("name", [c for c in CASES if c != "errors"])
+def test_device_parser_equals_host_parser_on_golden_inputs(name, tmp_path, monkeypatch):
+    c, d = load_case(name, tmp_path)
+    monkeypatch.chdir(d)
+    seen = set()
+    for r in c["count"]:
+        argv = r["argv"]
+        key = (argv[4], argv[6], argv[12])
+        if key in seen or r["exit"] != 0:
+            continue
+        seen.add(key)
+        ev, ctx = setup(argv[4], argv[6], int(argv[11]), argv[10])
+        parsed_equal(ev, L.Reads.from_mrf(argv[12], ev), ctx.parse_mrf_device(argv[12]))
+        ctx.close()
+
+
+ANNOT = ("i1\tc1\t+\t100\t400\t2\t100,300,\t200,400,\n"
+         "i2\tc1\t+\t100\t400\t1\t100,\t400,\n"
+         "j1\tc2\t-\t1000\t1500\t1\t1000,\t1500,\n")
+GMAP = "g\ti1\ng\ti2\nh\tj1\n"
+
+
+def write_annot(tmp_path):
+    (tmp_path / "a.interval").write_text(ANNOT)
+    (tmp_path / "a.map").write_text(GMAP)
+    return str(tmp_path / "a.interval"), str(tmp_path / "a.map")
+
+
+ODD_LINES = [
+    "c1:+:101:150:1:50",
+    "c1:+:101:150",                                   # no query fields: the end field runs to the line's end
+    "c1:+:101:150:1:50,c1:+:301:350:51:100",
+    "c1:+:301:350:51:100,c1:+:101:150:1:50",          # blocks out of order
+    "# a comment line takes a line number",
+    "AlignmentBlocks",
+    "AlignmentBlocks ",                               # not the literal: a cast failure?  no -- see below
+    "zz:+:5:9:1:5",                                   # chromosome no event knows
+    "c1:+:5000000000:5000000010:1:10",                # beyond int32: can never be contained
+    "c1:+:-5:10:1:10",
+    "c1:+:+120:+130:1:10",
+    "c1::120:130:1:10",                               # empty strand
+    "c1:strand7:120:130:1:10",                        # 7-byte strand
+    "c2:-:1001:1050:1:50\tACGT\tIIII",
+    "c1:.:101:150:1:50,c2:*:1001:1050:1:50",          # chromosome / strand of the last kept block
+    "c1:+:101:150:1:50,",                             # trailing comma: a second, field-less block?  see below
+]
+
+
+def good_odd_lines():
+    # lines 7 and 16 of ODD_LINES fail the cast in the reference; they belong to the error test
+    return [l for i, l in enumerate(ODD_LINES) if i not in (6, 15)]
+
+
+def test_odd_lines_and_unterminated_tail(tmp_path):
+    iv, mp = write_annot(tmp_path)
+    p = tmp_path / "odd.mrf"
+    p.write_text("AlignmentBlocks\n" + "\n".join(good_odd_lines()) + "\n" + "c1:+:101:150:1:50")   # last line has no newline
+    ev, ctx = setup(iv, mp)
+    host, dev = L.Reads.from_mrf(str(p), ev), ctx.parse_mrf_device(str(p))
+    assert len(host) == len(good_odd_lines()) - 2      # comment + AlignmentBlocks skipped, tail never seen
+    parsed_equal(ev, host, dev)
+    # and through the whole path
+    ctx.upload_reads(0, host)
+    ctx.count()
+    a = ctx.counts()
+    kept = ctx.retained(0)
+    ctx.upload_reads_mrf(0, str(p))
+    ctx.count()
+    b = ctx.counts()
+    assert ctx.retained(0) == kept > 0
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    ctx.close()
+
+
+@pytest.mark.parametrize("bad", [ODD_LINES[6], ODD_LINES[15], "", "c1:+:10x:20:1:10", "c1:+:10:20\r", "c1:+:99999999999999999999:5:1:1", "c1:+"])
+def test_first_failing_line_is_reported_like_the_host_parser(bad, tmp_path):
+    iv, mp = write_annot(tmp_path)
+    lines = ["c1:+:101:150:1:50"] * 700
+    lines[300] = bad
+    lines[650] = "c1:+:x:150:1:50"
+    p = tmp_path / "bad.mrf"
+    p.write_text("AlignmentBlocks\n" + "\n".join(lines) + "\n")
+    ev, ctx = setup(iv, mp)
+    with pytest.raises(L.LsqError) as eh:
+        L.Reads.from_mrf(str(p), ev)
+    with pytest.raises(L.LsqError) as ed:
+        ctx.parse_mrf_device(str(p))
+    assert eh.value.status == ed.value.status == -4      # LSQ_E_PARSE
+    assert str(eh.value) == str(ed.value)
+    assert "#301:" in str(ed.value)
+    with pytest.raises(L.LsqError):
+        ctx.upload_reads_mrf(0, str(p))
+    ctx.close()
+
+
+def test_format_io_and_long_strand(tmp_path):
+    iv, mp = write_annot(tmp_path)
+    ev, ctx = setup(iv, mp)
+    p = tmp_path / "x.mrf"
+    p.write_text("AlignmentBlocks\nc1:+:101:150:1:50\n")
+    with pytest.raises(L.LsqError, match="Unknown file format"):
+        ctx.upload_reads_mrf(0, str(p), read_format="MRF_PAIRED")
+    with pytest.raises(L.LsqError, match="cannot open"):
+        ctx.upload_reads_mrf(0, str(tmp_path / "absent.mrf"))
+    p.write_text("AlignmentBlocks\nc1:eightchr:101:150:1:50\n")
+    with pytest.raises(L.LsqError, match="7 bytes"):
+        ctx.upload_reads_mrf(0, str(p))
+    # the command line takes such a file through the host parser and still prints the reference's rows
+    argv = ["0", "x", "./", "LH_GENE_TXT", iv, "UCSC_GENE2ISOFORM", mp, "0", "10", "MRF_SINGLE", "SHORT_READ", "50", str(p)]
+    rc, text = L.cli_run("count", argv)
+    assert rc == 0 and text.startswith("g\t")
+    ctx.close()
+
+
+@pytest.mark.parametrize("text", ["", "AlignmentBlocks", "AlignmentBlocks\n", "\n", "AlignmentBlocks\nc1:+:101:150:1:50"])
+def test_files_without_data_lines(text, tmp_path):
+    iv, mp = write_annot(tmp_path)
+    ev, ctx = setup(iv, mp)
+    p = tmp_path / "e.mrf"
+    p.write_text(text)
+    dev = ctx.parse_mrf_device(str(p))
+    assert len(dev) == 0 and dev.num_blocks == 0 and len(L.Reads.from_mrf(str(p), ev)) == 0
+    ctx.upload_reads_mrf(0, str(p))
+    ctx.count()
+    assert ctx.retained(0) == 0 and int(ctx.counts()[0].sum()) == 0
+    ctx.close()
+
+
+def test_two_million_lines_tile_boundaries_and_results(tmp_path):
+    spec = L.SynthSpec(21, 3000, 2_000_000, 100, 6, L.EVENT_TYPES, False, 0.10)
+    L.synth_write(spec, str(tmp_path), "s")
+    ev, ctx = setup(str(tmp_path / "s.interval"), str(tmp_path / "s.map"), 100)
+    mrf = str(tmp_path / "s.mrf")
+    host = L.Reads.from_mrf(mrf, ev)
+    dev = ctx.parse_mrf_device(mrf)
+    assert len(host) == 2_000_000
+    parsed_equal(ev, host, dev)
+    ctx.upload_reads(0, host)
+    ctx.count(); ctx.solve()
+    a, s1 = ctx.counts(), ctx.solution()
+    ctx.upload_reads_mrf(0, mrf)
+    ctx.count(); ctx.solve()
+    b, s2 = ctx.counts(), ctx.solution()
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert np.array_equal(s1[0], s2[0]) and np.array_equal(s1[1], s2[1], equal_nan=True)
+    t = ctx.mrf_timing()
+    assert t["parse_ms"] > 0
+    print("device parse of %d MB: h2d %.1f ms, kernels %.1f ms" % (os.path.getsize(mrf) >> 20, t["h2d_ms"], t["parse_ms"]))
+    ctx.close()
