@@ -352,6 +352,7 @@ int plan_device(lsq_events &E) {
 			uint32_t shift = 0;
 			while ((((uint64_t)(hi - lo)) >> shift) >= want) ++shift;
 			d.n_bins = want; d.shift = shift; d.lo = (int32_t)lo; d.hi = (int32_t)hi;
+			if (getenv("LSQ_DUMP_PLAN")) fprintf(stderr, "bucket lo=%lld hi=%lld events=%u bins=%u shift=%u\n", (long long)lo, (long long)hi, d.n_events, want, shift);
 			d.kind = fast ? 1u : 0u;
 			auto align16 = [](uint32_t x) { return (x + 15u) & ~15u; };
 			uint32_t off = 0;

@@ -66,6 +66,7 @@ struct CountArgs {
 	const int4 *p2; const unsigned char *p2_strand; const unsigned *p2_line;
 	const unsigned *pn_blk_off; const unsigned *pn_nblk; const int2 *pn_se; const unsigned char *pn_strand; const unsigned *pn_line; const unsigned *pn_bucket;
 	const unsigned long long *p1_off, *p2_off, *pn_off, *slot_off;    // n_buckets + 1 each
+	const unsigned *wg_first;          // per workgroup of the fast kernel's grid: the bucket its slot range starts in
 	unsigned long long total_slots;
 	unsigned long long *cnt, *bases;
 	struct ExcEntry *exc;              // exception list (rare (read, event) pairs the fast kernel hands to the cleanup kernel)
@@ -271,6 +272,8 @@ __device__ inline unsigned run_bits(const int (&sy)[4], unsigned abut, int r0, i
 }
 
 struct FastCtx {                       // wave-uniform state of the bucket being processed
+	const uint4 *bins;                 // 16-byte bin records: first cell | first event << 16, ends of that cell and the next two
+	int lo; unsigned shift, n_bins;    // bin of p: (p - lo) >> shift, clamped
 	const uint4 *recs;
 	unsigned long long *hist;
 	unsigned n_events, bucket;
@@ -292,6 +295,46 @@ __device__ inline void emit_exception(const FastCtx &C, unsigned r, unsigned i, 
 		e.ev_pool_scan = i | (C.pool << 30) | (scan << 31);
 		C.exc[slot] = e;
 	}
+}
+
+constexpr unsigned PARK_EVENT_UNKNOWN = 0x7FFFFFFFu;
+// A read whose first base lies in a cell with one owner can only ever count for that owner: every
+// other event whose span covers the base has no segment there, so the read's first block starts in
+// none of its segments and nothing matches (common/read.h:204-274).  Such a read is parked with
+// the owner as the event to look at and this flag: one look, no scan of the following events.
+constexpr unsigned PARK_ONE_EVENT = 0x80000000u;
+
+// sum over the 64 lanes (DPP row shifts and row broadcasts; the total lands in lane 63)
+__device__ inline unsigned wave_sum_u32(unsigned v) {
+	v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
+	v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
+	v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
+	v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8
+	v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);   // row_bcast:15 into rows 1 and 3
+	v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);   // row_bcast:31 into rows 2 and 3
+	return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// Histogram adds of a whole wave, merged by slot before they reach LDS: neighbouring reads of the
+// start-ordered pools mostly land in the same compatibility class, and 64 atomics on one LDS
+// address would run one after the other.  Up to AGG_ROUNDS distinct slots are summed across the
+// wave (one atomic each); whatever is left falls back to one atomic per lane.
+constexpr int AGG_ROUNDS = 3;
+__device__ inline void hist_add_merged(unsigned long long *hist, bool want, const unsigned slot, const unsigned len) {
+	const unsigned lane = threadIdx.x & 63u;
+#pragma unroll 1
+	for (int round = 0; round < AGG_ROUNDS; ++round) {
+		const unsigned long long m = __ballot(want);
+		if (!m) return;
+		const unsigned lead = (unsigned)__ffsll((long long)m) - 1u;
+		const unsigned s0 = (unsigned)__builtin_amdgcn_readlane((int)slot, lead);
+		const bool same = want && slot == s0;
+		const unsigned n = (unsigned)__popcll(__ballot(same));
+		const unsigned sum = wave_sum_u32(same ? len : 0u);
+		if (lane == lead) atomicAdd(&hist[s0], ((unsigned long long)n << 40) | sum);
+		want = want && !same;
+	}
+	if (want) atomicAdd(&hist[slot], (1ull << 40) | len);
 }
 
 // One read against ONE packed event record (index i).  Returns true when a further event has
@@ -341,8 +384,9 @@ __device__ inline bool fast_trip(const FastCtx &C, const int4 v, const int total
 	// (double)matched / total > 0.98  <=>  50*matched > 49*total (both below 2^18 here)
 	const unsigned long long tbl = ((unsigned long long)w0.w << 32) | w0.z;
 	const unsigned cls = (unsigned)(tbl >> (4u * mask)) & 0xFu;
-	if (covers && cls != 0 && 50 * matched > 49 * total) {
-		if (!(C.ablate & 2u)) atomicAdd(&C.hist[(w0.y & 0xFFFFu) + cls - 1], (1ull << 40) | (unsigned long long)(unsigned)matched);
+	{
+		const bool add = covers && cls != 0 && 50 * matched > 49 * total;
+		if (!(C.ablate & 2u)) { if (add) atomicAdd(&C.hist[(w0.y & 0xFFFFu) + cls - 1u], (1ull << 40) | (unsigned long long)(unsigned)matched); }
 		else asm volatile("" ::"v"(matched), "v"(cls));
 	}
 	return started && (!(p <= ge) || (w0.y & FAST_FLAG_OVERLAPS_NEXT)) && i + 1 < C.n_events;
@@ -361,7 +405,7 @@ __device__ inline bool fast_trip(const FastCtx &C, const int4 v, const int total
 #endif
 constexpr int STREAM_WORDS = LSQ_STREAM_WORDS;                // 16-byte words per lane in flight
 constexpr int GROUP_WORDS = 2;                                // words per lane looked up together (independent chains)
-constexpr unsigned WAVE_QUEUE_WORDS = 384;                    // 16-byte words of parking per wave (6 KiB): 63 left over + one step's worth
+constexpr unsigned WAVE_QUEUE_WORDS = 256;                    // 16-byte words of parking per wave (4 KiB): 63 left over + what is pushed between two walks
 constexpr unsigned WAVES = COUNT_BLOCK / 64;
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -410,12 +454,22 @@ __device__ inline void walk_parked(const FastCtx &C, Ring<NB> &R, const bool to_
 		else { e0 = R.q[2 * at]; e1 = R.q[2 * at + 1]; }
 		R.head += n;
 		int4 rd; unsigned i, rel;
-		if (NB == 1) { rd = make_int4((int)e0.x, (int)e0.y, (int)e0.x, (int)e0.y); i = e0.z; rel = e0.w; }
+		const unsigned ev_word = NB == 1 ? e0.z : e1.x;
+		const bool one_event = (ev_word & PARK_ONE_EVENT) != 0;
+		if (NB == 1) { e0.z &= ~PARK_ONE_EVENT; } else { e1.x &= ~PARK_ONE_EVENT; }
+		if (NB == 1) {
+			rd = make_int4((int)e0.x, (int)e0.y, (int)e0.x, (int)e0.y); i = e0.z; rel = e0.w;
+			// parked without a look at the bin directory: the first event of the read's bin
+			const int brel = rd.x - C.lo;
+			const unsigned bin = brel <= 0 ? 0u : min((unsigned)brel >> C.shift, C.n_bins - 1u);
+			const unsigned first = reinterpret_cast<const unsigned *>(C.bins)[4u * bin] >> 16;
+			if (i == PARK_EVENT_UNKNOWN) { i = first; e0.z = first; }
+		}
 		else { rd = make_int4((int)e0.x, (int)e0.y, (int)e0.z, (int)e0.w); i = e1.x; rel = e1.y; }
 		const int total = NB == 1 ? rd.y - rd.x : (rd.y - rd.x) + (rd.w - rd.z);
-		const bool more = fast_trip<NB>(C, rd, total, rel, i, on) && !(C.ablate & 64u);
+		const bool more = fast_trip<NB>(C, rd, total, rel, i, on) && !one_event && !(C.ablate & 64u);
 		wave_sync_lds();
-		if (NB == 1) e0.z = i + 1u; else e1.x = i + 1u;
+		if (NB == 1) e0.z = i + 1u; else e1.x = i + 1u;     // (i is the resolved event)
 		R.push(more, lane, e0, e1);
 		wave_sync_lds();
 	}
@@ -432,18 +486,19 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 	C.slot0 = g0;
 	global_words src = (global_words)src_generic;       // kernel-argument memory: global address space
 	const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-	// words [w0, w1) of the workgroup; this wave takes a contiguous quarter, in whole steps
+	// words [w0, w1) of the workgroup, dealt to its waves a step at a time (wave, wave + 4, ...): the
+	// reads that need the general walk sit together in the start-ordered pool, and a contiguous
+	// quarter per wave would leave three waves waiting for the one that got them
 	const unsigned long long w0 = g0 / RPW, w1 = (g1 + RPW - 1) / RPW;
 	const unsigned n_words = (unsigned)(w1 - w0);                                   // a workgroup's range stays below 2^21 reads
-	const unsigned per_wave = ((n_words + WAVES - 1) / WAVES + TILE - 1) / TILE * TILE;
-	const unsigned ww0 = min(wave * per_wave, n_words), ww1 = min(ww0 + per_wave, n_words);   // relative to w0
+	const unsigned ww0 = min(wave * TILE, n_words), ww1 = n_words;                   // relative to w0
 	const unsigned first_rel = (unsigned)(g0 - w0 * RPW);                            // 0 or 1: reads of word w0 before the range
 	const unsigned n_rel = (unsigned)(g1 - g0);
 	uint4 nxt[STREAM_WORDS];
 	auto fetch = [&](unsigned wt) {
 #pragma unroll
 		for (int k = 0; k < STREAM_WORDS; ++k) {
-			const unsigned w = wt + (unsigned)k * 64u + lane;
+			const unsigned w = wt + lane * (unsigned)STREAM_WORDS + (unsigned)k;      // a lane's words are neighbours in the pool
 			u32x4 t = {0u, 0u, 0u, 0u};
 			if (w < ww1) t = src[w0 + w];
 			nxt[k] = make_uint4(t.x, t.y, t.z, t.w);
@@ -460,11 +515,11 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 	Ring<NB> R;
 	R.q = queue;
 	if (ww0 < ww1) fetch(ww0);
-	for (unsigned wt = ww0; wt < ww1; wt += TILE) {
+	for (unsigned wt = ww0; wt < ww1; wt += WAVES * TILE) {
 		uint4 cur[STREAM_WORDS];
 #pragma unroll
 		for (int k = 0; k < STREAM_WORDS; ++k) cur[k] = nxt[k];
-		if (wt + TILE < ww1) fetch(wt + TILE);
+		if (wt + WAVES * TILE < ww1) fetch(wt + WAVES * TILE);
 #pragma unroll
 		for (int k0 = 0; k0 < STREAM_WORDS; k0 += GROUP_WORDS) {
 		if (A.ablate & 512u) {      // developer switch: stream only
@@ -479,30 +534,47 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 #pragma unroll
 		for (int kg = 0; kg < GROUP_WORDS; ++kg) {
 			const int k = k0 + kg;
-			const unsigned w = wt + (unsigned)k * 64u + lane;           // word, relative to w0
+			const unsigned w = wt + lane * (unsigned)STREAM_WORDS + (unsigned)k;           // word, relative to w0
 			if (RPW == 2) {
-#pragma unroll
-				for (int h = 0; h < 2; ++h) {
-					const int ra = h == 0 ? (int)cur[k].x : (int)cur[k].z, rb = h == 0 ? (int)cur[k].y : (int)cur[k].w;
-					const unsigned rel = w * 2u + (unsigned)h - first_rel;      // position in the range (wraps above n_rel when outside)
-					const bool in = w < ww1 && rel < n_rel;
+				// One look at the tables per lane and group: the lane's reads are neighbours in the
+				// start-ordered pool, so the cell of the first one is the cell of (nearly) all of
+				// them.  A read is decided against that cell -- inside it: the owners' slots; running
+				// into the owner's next segment: the two-segment slot -- and the lane adds its totals
+				// once.  Everything else (a different cell, no cell, a longer run) is parked.
+				if (kg == 0) {
 					unsigned ci, evf;
-					locate(ra, ci, evf);
-					// one block inside one cell (or running from it into the owner's next segment):
-					// one or two histogram adds, nothing else to decide
+					locate((int)cur[k0].x, ci, evf);
 					const uint4 cw = cells[min(ci, n_cells - 1u)];           // lo, hi, hi2, slots
-					const bool contains = in && ci < n_cells && (int)cw.x <= ra && ra < (int)cw.y && !(A.ablate & 8u);
-					const bool inside = contains && rb <= (int)cw.y;
-					const bool cross = contains && !inside && rb <= (int)cw.z;
+					const bool has = ci < n_cells && !(A.ablate & 8u);
+					const unsigned info = cell_info[min(ci, n_cells - 1u)];
+					const unsigned owner_word = info == CELL_INFO_SHARED ? PARK_EVENT_UNKNOWN : ((info >> 8) | PARK_ONE_EVENT);
+					const int lo = (int)cw.x, hi = (int)cw.y, hi2 = (int)cw.z;
+					const unsigned width = has ? (unsigned)(hi - lo) : 0u;
+					unsigned nA = 0, sA = 0, nX = 0, sX = 0;
+#pragma unroll
+					for (int j = 0; j < N_READS; ++j) {
+						const int kk = k0 + j / 2;
+						const int ra = (j & 1) ? (int)cur[kk].z : (int)cur[kk].x, rb = (j & 1) ? (int)cur[kk].w : (int)cur[kk].y;
+						const unsigned wj = wt + lane * (unsigned)STREAM_WORDS + (unsigned)kk;
+						const unsigned rel = wj * 2u + (unsigned)(j & 1) - first_rel;      // position in the range (wraps above n_rel when outside)
+						const bool in = wj < ww1 && rel < n_rel;
+						const bool m = in && (unsigned)(ra - lo) < width;
+						const bool a = m && rb <= hi;
+						const bool x = m && !a && rb <= hi2;
+						const unsigned len = (unsigned)(rb - ra);
+						nA += a ? 1u : 0u; sA += a ? len : 0u;
+						nX += x ? 1u : 0u; sX += x ? len : 0u;
+						park[j] = in && !a && !x && !(A.ablate & 17u);
+						pe0[j] = make_uint4((unsigned)ra, (unsigned)rb, m ? owner_word : PARK_EVENT_UNKNOWN, rel);
+						pe1[j] = make_uint4(0, 0, 0, 0);
+					}
 					const unsigned sa = cw.w & 0xFFFFu, sb = cw.w >> 16;
-					const unsigned long long add = (1ull << 40) | (unsigned long long)(unsigned)(rb - ra);
 					if (!(A.ablate & 1u)) {
-						if (inside && sa != CELL_NONE) atomicAdd(&C.hist[sa], add);
-						if (((inside && cw.z == cw.y) || cross) && sb != CELL_NONE) atomicAdd(&C.hist[sb], add);
-					} else asm volatile("" ::"v"(sa), "v"(sb));
-					park[kg * 2 + h] = in && !(inside || cross) && !(A.ablate & 17u);
-					pe0[kg * 2 + h] = make_uint4((unsigned)ra, (unsigned)rb, evf, rel);
-					pe1[kg * 2 + h] = make_uint4(0, 0, 0, 0);
+						const unsigned long long addA = ((unsigned long long)nA << 40) | sA;
+						if (nA && sa != CELL_NONE) atomicAdd(&C.hist[sa], addA);
+						if (nA && hi2 == hi && sb != CELL_NONE) atomicAdd(&C.hist[sb], addA);        // second owner of the cell
+						if (nX && sb != CELL_NONE) atomicAdd(&C.hist[sb], ((unsigned long long)nX << 40) | sX);
+					} else asm volatile("" ::"v"(nA), "v"(sA), "v"(nX), "v"(sX));
 				}
 			} else {
 				const uint4 u = cur[k];
@@ -520,31 +592,48 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 				                 (int)cw1.x <= rd.x && rd.y == (int)cw1.y && (i1 & 2u) &&          // block 1 ends on its segment's end
 				                 rd.z == (int)cw2.x && (i2 & 1u) && rd.w <= (int)cw2.y &&          // block 2 starts on its segment's start
 				                 (i1 >> 8) == (i2 >> 8) && ((i2 >> 2) & 0x3Fu) > ((i1 >> 2) & 0x3Fu) && !(A.ablate & 8u);
-				if (hit && !(A.ablate & 1u)) {
-					const unsigned ev = i1 >> 8;
+				if (!(A.ablate & 1u)) {
+					const unsigned ev = hit ? i1 >> 8 : 0u;
 					const uint4 w0r = C.recs[3u * ev];
 					const unsigned long long tbl = ((unsigned long long)w0r.w << 32) | w0r.z;
-					const unsigned mask = (1u << ((i1 >> 2) & 0x3Fu)) | (1u << ((i2 >> 2) & 0x3Fu));
+					const unsigned mask = (1u << ((i1 >> 2) & 0x3u)) | (1u << ((i2 >> 2) & 0x3u));
 					const unsigned cls = (unsigned)(tbl >> (4u * mask)) & 0xFu;
-					if (cls) atomicAdd(&C.hist[(w0r.y & 0xFFFFu) + cls - 1], (1ull << 40) | (unsigned long long)(unsigned)((rd.y - rd.x) + (rd.w - rd.z)));
+					if (hit && cls != 0) atomicAdd(&C.hist[(w0r.y & 0xFFFFu) + cls - 1u], (1ull << 40) | (unsigned long long)(unsigned)((rd.y - rd.x) + (rd.w - rd.z)));
 				}
 				park[kg] = in && !hit && !(A.ablate & 17u);
 				pe0[kg] = u;
-				pe1[kg] = make_uint4(evf, rel, 0u, 0u);
+				const bool owned1 = c1 < n_cells && i1 != CELL_INFO_SHARED && (int)cw1.x <= rd.x && rd.x < (int)cw1.y;
+				pe1[kg] = make_uint4(owned1 ? ((i1 >> 8) | PARK_ONE_EVENT) : evf, rel, 0u, 0u);
 			}
 		}
 #pragma unroll
 		for (int q = 0; q < N_READS; ++q) {
 			if ((A.ablate & 256u) && park[q]) atomicAdd(&A.dbg[NB - 1], 1ull);
 			R.push(park[q], lane, pe0[q], pe1[q]);
-		}
-		if (R.live() >= 64u) {                                 // wave-uniform
-			if (!(A.ablate & 32u)) walk_parked<NB>(C, R, false);
-			else R.head = R.tail;
+			// the ring holds what one walk leaves behind (< 64) plus 128 one-block or 64 two-block entries
+			if ((NB == 2 || (q & 1) == 1) && R.live() >= 64u) {             // wave-uniform
+				if (!(A.ablate & 32u)) walk_parked<NB>(C, R, false);
+				else R.head = R.tail;
+			}
 		}
 		}
 	}
 	if (R.live() && !(A.ablate & 32u)) walk_parked<NB>(C, R, true);
+}
+
+// the bucket each workgroup of the fast kernel starts in: a dependent chain of a dozen global loads
+// per workgroup, done once per read set and grid instead of at the head of every launch
+__global__ void __launch_bounds__(256) lsq_wg_plan_kernel(const unsigned long long *slot_off, unsigned n_buckets, unsigned long long total_slots,
+                                                          unsigned grid, unsigned *wg_first) {
+	const unsigned g = blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= grid) return;
+	const unsigned long long s_begin = total_slots * g / grid;
+	unsigned lo_b = 0, hi_b = n_buckets;
+	while (hi_b - lo_b > 1) {
+		const unsigned mid = (lo_b + hi_b) >> 1;
+		if (slot_off[mid] <= s_begin) lo_b = mid; else hi_b = mid;
+	}
+	wg_first[g] = lo_b;
 }
 
 #ifndef LSQ_FAST_WAVES
@@ -557,12 +646,7 @@ __global__ void __launch_bounds__(COUNT_BLOCK, LSQ_FAST_WAVES) lsq_count_fast_ke
 	const unsigned long long s_begin = A.total_slots * blockIdx.x / gridDim.x;
 	const unsigned long long s_end = A.total_slots * (blockIdx.x + 1ull) / gridDim.x;
 	if (s_begin >= s_end) return;
-	// last bucket whose first slot is <= s_begin
-	unsigned lo_b = 0, hi_b = A.n_buckets;
-	while (hi_b - lo_b > 1) {
-		unsigned mid = (lo_b + hi_b) >> 1;
-		if (A.slot_off[mid] <= s_begin) lo_b = mid; else hi_b = mid;
-	}
+	const unsigned lo_b = A.wg_first[blockIdx.x];     // last bucket whose first slot is <= s_begin (lsq_wg_plan_kernel)
 	for (unsigned b = lo_b; b < A.n_buckets && A.slot_off[b] < s_end; ++b) {
 		const unsigned long long bs = A.slot_off[b], be = A.slot_off[b + 1];
 		if (be <= s_begin || be == bs) continue;
@@ -581,6 +665,7 @@ __global__ void __launch_bounds__(COUNT_BLOCK, LSQ_FAST_WAVES) lsq_count_fast_ke
 		const uint4 *cells = reinterpret_cast<const uint4 *>(lds + d.seg_off);
 		const unsigned *cell_info = reinterpret_cast<const unsigned *>(lds + d.seg_off + 16u * d.iso_off);
 		FastCtx C;
+		C.bins = bins; C.lo = d.lo; C.shift = d.shift; C.n_bins = d.n_bins;
 		C.recs = reinterpret_cast<const uint4 *>(lds + d.ev_off);
 		C.hist = reinterpret_cast<unsigned long long *>(lds + d.hist_off);
 		C.n_events = d.n_events; C.bucket = b;
@@ -591,12 +676,12 @@ __global__ void __launch_bounds__(COUNT_BLOCK, LSQ_FAST_WAVES) lsq_count_fast_ke
 		const unsigned long long n1 = A.p1_off[b + 1] - A.p1_off[b];
 		const unsigned long long n2 = A.p2_off[b + 1] - A.p2_off[b];
 		// ---- pool 1
-		if (l0 < n1) {
+		if (l0 < n1 && !(A.ablate & 1024u)) {
 			const unsigned long long base = A.p1_off[b];
 			stream_pool_fast<2>(C, bins, cells, cell_info, d.iso_off, d, A, wave_queue, reinterpret_cast<const uint4 *>(A.p1), base + l0, base + (l1 < n1 ? l1 : n1));
 		}
 		// ---- pool 2
-		if (l1 > n1 && l0 < n1 + n2) {
+		if (l1 > n1 && l0 < n1 + n2 && !(A.ablate & 2048u)) {
 			const unsigned long long base = A.p2_off[b];
 			stream_pool_fast<1>(C, bins, cells, cell_info, d.iso_off, d, A, wave_queue, reinterpret_cast<const uint4 *>(A.p2), base + ((l0 > n1 ? l0 : n1) - n1),
 			                    base + ((l1 < n1 + n2 ? l1 : n1 + n2) - n1));
@@ -908,9 +993,13 @@ __global__ void __launch_bounds__(256) lsq_em_kernel(EmArgs A) {
 //             interval_list merge of the kept blocks (:323, interval_list.hpp:462-503),
 //             chromosome/strand of the last kept block (:321-322), the bucket of the first
 //             merged base and the pool (1, 2, 3+ blocks); per (bucket, pool) counts
-//   scan    : exclusive prefix sums -> pool offsets per bucket
-//   scatter : every retained read to its place (order inside a bucket is whatever the atomics
-//             give; the count kernels only add integers, so results do not depend on it)
+//   scan    : exclusive prefix sums -> offsets per (bucket, bin) for the one- and two-block pools
+//             (bin = the bucket's coordinate bin of the read's first base, the one the count kernel
+//             looks up), per bucket for the n-block pool
+//   scatter : every retained read to its place: a counting sort, so the reads of a bin -- which
+//             mostly share a cell -- sit together and a wave of the count kernel sees one or two
+//             cells at a time (order inside a bin is whatever the atomics give; the count kernels
+//             only add integers, so results do not depend on it)
 // This replaces the reference's load-time filter and its read index (count/count.cpp:348-364).
 // =====================================================================================
 constexpr int INGEST_MAX_BLOCKS = 16;                  // merged blocks per read the device ingest handles
@@ -923,6 +1012,7 @@ struct IngestTables {
 	const int *cut_lo;
 	const int *chrom_first_bucket;
 	const BucketDesc *buckets;
+	const unsigned *bin_base;      // per bucket: first of its bins in the fine counters (n_buckets + 1)
 	unsigned n_chrom;
 };
 
@@ -937,11 +1027,13 @@ struct IngestRaw {
 
 struct IngestWork {
 	unsigned *key;                 // per read: bucket * 4 + pool, or INGEST_NO_KEY
+	unsigned *fine;                // per read: bin_base[bucket] + bin of the first base
 	unsigned char *nb;             // per read: merged blocks
 	unsigned char *strand;         // per read: strand id of the last kept block
 	int *ms, *me;                  // merged blocks, at the read's original block offset
-	unsigned long long *counts;    // [4 * n_buckets]: reads of pool 0/1/2, blocks of pool 2
-	unsigned long long *cursors;   // [4 * n_buckets]
+	unsigned *cnt1, *cnt2;         // [n_fine]: one- / two-block reads per (bucket, bin)
+	unsigned *cntn, *cntnb;        // [n_buckets]: n-block reads, and their blocks
+	unsigned *cur1, *cur2, *curn, *curnb;   // scatter cursors, same shapes
 	unsigned long long *totals;    // [0] retained reads, [1] retained blocks, [2] error flag
 };
 
@@ -1012,8 +1104,14 @@ __global__ void __launch_bounds__(256) lsq_ingest_classify_kernel(IngestTables T
 					if (s[0] <= T.buckets[b].hi) {
 						const unsigned pool = n == 1 ? 0u : (n == 2 ? 1u : 2u);
 						key = b * 4u + pool;
-						atomicAdd(&W.counts[key], 1ull);
-						if (pool == 2) atomicAdd(&W.counts[b * 4u + 3u], (unsigned long long)n);
+						const BucketDesc &d = T.buckets[b];
+						const int rel = s[0] - d.lo;
+						const unsigned bin = rel <= 0 ? 0u : min((unsigned)rel >> d.shift, d.n_bins - 1u);
+						const unsigned fine = T.bin_base[b] + bin;
+						W.fine[i] = fine;
+						if (pool == 0) atomicAdd(&W.cnt1[fine], 1u);
+						else if (pool == 1) atomicAdd(&W.cnt2[fine], 1u);
+						else { atomicAdd(&W.cntn[b], 1u); atomicAdd(&W.cntnb[b], (unsigned)n); }
 					}
 				}
 			}
@@ -1026,40 +1124,39 @@ __global__ void __launch_bounds__(256) lsq_ingest_classify_kernel(IngestTables T
 	if (kept_reads) { atomicAdd(&W.totals[0], kept_reads); atomicAdd(&W.totals[1], kept_blocks); }
 }
 
-// one workgroup: exclusive prefix sums over the buckets
-__global__ void __launch_bounds__(1024) lsq_ingest_scan_kernel(const unsigned long long *counts, unsigned n_buckets,
-                                                               unsigned long long *p1_off, unsigned long long *p2_off,
-                                                               unsigned long long *pn_off, unsigned long long *pnb_off, unsigned long long *slot_off) {
-	__shared__ unsigned long long part[4][1024];
+// one workgroup: out[i] = sum of in[0..i), out[n] = total
+__global__ void __launch_bounds__(1024) lsq_scan_u32_kernel(const unsigned *in, unsigned long long n, unsigned long long *out) {
+	__shared__ unsigned long long part[1024];
 	const unsigned tid = threadIdx.x;
-	const unsigned per = (n_buckets + 1023u) / 1024u;
-	const unsigned b0 = min(tid * per, n_buckets), b1 = min(b0 + per, n_buckets);
-	unsigned long long acc[4] = {0, 0, 0, 0};
-	for (unsigned b = b0; b < b1; ++b) for (int q = 0; q < 4; ++q) acc[q] += counts[b * 4u + q];
-	for (int q = 0; q < 4; ++q) part[q][tid] = acc[q];
+	const unsigned long long per = (n + 1023ull) / 1024ull;
+	const unsigned long long b0 = min(tid * per, n), b1 = min(b0 + per, n);
+	unsigned long long acc = 0;
+	for (unsigned long long b = b0; b < b1; ++b) acc += in[b];
+	part[tid] = acc;
 	__syncthreads();
-	if (tid < 4) {          // one lane per column: serial exclusive scan of 1024 partial sums
-		unsigned long long run = 0;
-		for (unsigned t = 0; t < 1024; ++t) { const unsigned long long v = part[tid][t]; part[tid][t] = run; run += v; }
-	}
+	if (tid == 0) { unsigned long long run = 0; for (unsigned t = 0; t < 1024; ++t) { const unsigned long long v = part[t]; part[t] = run; run += v; } }
 	__syncthreads();
-	unsigned long long run[4] = {part[0][tid], part[1][tid], part[2][tid], part[3][tid]};
-	for (unsigned b = b0; b < b1; ++b) {
-		p1_off[b] = run[0]; p2_off[b] = run[1]; pn_off[b] = run[2]; pnb_off[b] = run[3];
-		slot_off[b] = run[0] + run[1] + run[2];
-		for (int q = 0; q < 4; ++q) run[q] += counts[b * 4u + q];
-	}
-	if (tid == 1023) {      // the last lane's running sums are the totals (lanes past the last bucket add nothing)
-		p1_off[n_buckets] = run[0]; p2_off[n_buckets] = run[1]; pn_off[n_buckets] = run[2]; pnb_off[n_buckets] = run[3];
-		slot_off[n_buckets] = run[0] + run[1] + run[2];
-	}
+	unsigned long long run = part[tid];
+	for (unsigned long long b = b0; b < b1; ++b) { out[b] = run; run += in[b]; }
+	if (tid == 1023) out[n] = run;
+}
+
+// per-bucket pool offsets out of the per-bin ones
+__global__ void __launch_bounds__(256) lsq_ingest_offsets_kernel(const unsigned *bin_base, unsigned n_buckets, const unsigned long long *off1,
+                                                                 const unsigned long long *off2, const unsigned long long *pn_off,
+                                                                 unsigned long long *p1_off, unsigned long long *p2_off, unsigned long long *slot_off) {
+	const unsigned b = blockIdx.x * blockDim.x + threadIdx.x;
+	if (b > n_buckets) return;
+	const unsigned long long a1 = off1[bin_base[b]], a2 = off2[bin_base[b]];
+	p1_off[b] = a1; p2_off[b] = a2;
+	slot_off[b] = a1 + a2 + pn_off[b];
 }
 
 struct IngestOut {
 	int2 *p1; unsigned char *p1_strand; unsigned *p1_line;
 	int4 *p2; unsigned char *p2_strand; unsigned *p2_line;
 	unsigned *pn_blk_off, *pn_nblk, *pn_line, *pn_bucket; unsigned char *pn_strand; int2 *pn_se;
-	const unsigned long long *p1_off, *p2_off, *pn_off, *pnb_off;
+	const unsigned long long *off1, *off2, *pn_off, *pnb_off;       // per (bucket, bin) / per bucket
 };
 
 __global__ void __launch_bounds__(256) lsq_ingest_scatter_kernel(IngestRaw R, IngestWork W, IngestOut O) {
@@ -1069,23 +1166,77 @@ __global__ void __launch_bounds__(256) lsq_ingest_scatter_kernel(IngestRaw R, In
 		if (key == INGEST_NO_KEY) continue;
 		const unsigned b = key >> 2, pool = key & 3u;
 		const unsigned long long b0 = R.blk_off[i];
-		const unsigned long long at = atomicAdd(&W.cursors[key], 1ull);
 		if (pool == 0) {
-			const unsigned long long w = O.p1_off[b] + at;
+			const unsigned fine = W.fine[i];
+			const unsigned long long w = O.off1[fine] + atomicAdd(&W.cur1[fine], 1u);
 			O.p1[w] = make_int2(W.ms[b0], W.me[b0]);
 			O.p1_strand[w] = W.strand[i]; O.p1_line[w] = R.line_no[i];
 		} else if (pool == 1) {
-			const unsigned long long w = O.p2_off[b] + at;
+			const unsigned fine = W.fine[i];
+			const unsigned long long w = O.off2[fine] + atomicAdd(&W.cur2[fine], 1u);
 			O.p2[w] = make_int4(W.ms[b0], W.me[b0], W.ms[b0 + 1], W.me[b0 + 1]);
 			O.p2_strand[w] = W.strand[i]; O.p2_line[w] = R.line_no[i];
 		} else {
 			const unsigned n = W.nb[i];
-			const unsigned long long w = O.pn_off[b] + at;
-			const unsigned long long bo = O.pnb_off[b] + atomicAdd(&W.cursors[b * 4u + 3u], (unsigned long long)n);
+			const unsigned long long w = O.pn_off[b] + atomicAdd(&W.curn[b], 1u);
+			const unsigned long long bo = O.pnb_off[b] + atomicAdd(&W.curnb[b], n);
 			O.pn_blk_off[w] = (unsigned)bo; O.pn_nblk[w] = n; O.pn_bucket[w] = b;
 			O.pn_strand[w] = W.strand[i]; O.pn_line[w] = R.line_no[i];
 			for (unsigned q = 0; q < n; ++q) O.pn_se[bo + q] = make_int2(W.ms[b0 + q], W.me[b0 + q]);
 		}
+	}
+}
+
+// Orders the reads of every (bucket, bin) by their first base: a counting sort in LDS over the
+// bin's coordinates, one wave per bin (the scatter above left the bin's reads together, in the
+// order its atomics gave).  This is the device form of the reference's read index, a std::set
+// ordered by start (count/count.cpp:348-364): a wave of the count kernel then sees the reads of
+// one cell, then those of the next.  Bins wider than BINSORT_MAX_W coordinates are copied as they
+// are -- the order only matters for speed.
+constexpr unsigned BINSORT_MAX_W = 2048;
+template <class ReadT>
+__global__ void __launch_bounds__(256) lsq_ingest_binsort_kernel(const BucketDesc *buckets, const unsigned *bin_base, unsigned n_buckets, unsigned n_fine,
+                                                                 const unsigned long long *off, const ReadT *in, const unsigned char *in_strand,
+                                                                 const unsigned *in_line, ReadT *out, unsigned char *out_strand, unsigned *out_line) {
+	__shared__ unsigned cnt_all[4][BINSORT_MAX_W];
+	const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	unsigned *cnt = cnt_all[wave];
+	for (unsigned fine = blockIdx.x * 4u + wave; fine < n_fine; fine += gridDim.x * 4u) {
+		const unsigned long long o0 = off[fine], o1 = off[fine + 1];
+		if (o0 == o1) continue;
+		const unsigned n = (unsigned)(o1 - o0);
+		unsigned lo_b = 0, hi_b = n_buckets;                 // bucket of the bin: last b with bin_base[b] <= fine
+		while (hi_b - lo_b > 1) { const unsigned mid = (lo_b + hi_b) >> 1; if (bin_base[mid] <= fine) lo_b = mid; else hi_b = mid; }
+		const BucketDesc &d = buckets[lo_b];
+		const unsigned W = d.shift < 31u ? (1u << d.shift) : 0x80000000u;
+		if (W > BINSORT_MAX_W || n < 3) {
+			for (unsigned i = lane; i < n; i += 64u) { out[o0 + i] = in[o0 + i]; out_strand[o0 + i] = in_strand[o0 + i]; out_line[o0 + i] = in_line[o0 + i]; }
+			continue;
+		}
+		const int bin_lo = d.lo + (int)((fine - bin_base[lo_b]) << d.shift);
+		for (unsigned k = lane; k < W; k += 64u) cnt[k] = 0;
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+		for (unsigned i = lane; i < n; i += 64u) {
+			const int rel = in[o0 + i].x - bin_lo;       // the first and last bins of a bucket also hold what lies beyond them
+			atomicAdd(&cnt[(unsigned)max(0, min(rel, (int)W - 1))], 1u);
+		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+		// exclusive prefix over the W counters: W/64 consecutive ones per lane
+		const unsigned per = (W + 63u) / 64u, k0 = min(lane * per, W), k1 = min(k0 + per, W);
+		unsigned acc = 0;
+		for (unsigned k = k0; k < k1; ++k) acc += cnt[k];
+		unsigned inc = acc;
+		for (unsigned dd = 1; dd < 64; dd <<= 1) { const unsigned t = __shfl_up(inc, dd); if (lane >= dd) inc += t; }
+		unsigned run = inc - acc;
+		for (unsigned k = k0; k < k1; ++k) { const unsigned v = cnt[k]; cnt[k] = run; run += v; }
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+		for (unsigned i = lane; i < n; i += 64u) {
+			const ReadT r = in[o0 + i];
+			const int rel = r.x - bin_lo;
+			const unsigned pos = atomicAdd(&cnt[(unsigned)max(0, min(rel, (int)W - 1))], 1u);
+			out[o0 + pos] = r; out_strand[o0 + pos] = in_strand[o0 + i]; out_line[o0 + pos] = in_line[o0 + i];
+		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
 	}
 }
 
@@ -1115,6 +1266,8 @@ struct MethodReads {
 	DevBuf<uint8_t> p1_strand, p2_strand, pn_strand;
 	DevBuf<uint32_t> p1_line, p2_line, pn_line, pn_blk_off, pn_nblk, pn_bucket;
 	DevBuf<unsigned long long> p1_off, p2_off, pn_off, pnb_off, slot_off;
+	DevBuf<unsigned> wg_first;             // lsq_wg_plan_kernel's table for `wg_grid` workgroups
+	unsigned long long wg_grid = 0;
 };
 
 } // namespace
@@ -1138,6 +1291,8 @@ struct lsq_ctx {
 	DevBuf<unsigned> exc_count;            // per method: [2m] appended, [2m+1] overflow flag
 	DevBuf<unsigned> cov_off, cut_off;     // ingest tables: covered regions and bucket cuts per chromosome id
 	DevBuf<int> cov_s, cov_e, cut_lo, chrom_first_bucket;
+	DevBuf<unsigned> bin_base;             // per bucket: first of its bins among all bins (n_buckets + 1)
+	size_t n_fine = 0;
 	unsigned n_chrom_tables = 0;
 	DevBuf<unsigned long long> dbg;
 	bool redo_checked = true;
@@ -1265,6 +1420,10 @@ int lsq_events_upload(lsq_ctx *c, lsq_events *E) {
 		if ((rc = c->cov_e.upload(ce.data(), ce.size(), c->stream))) return rc;
 		if ((rc = c->cut_lo.upload(cl.data(), cl.size(), c->stream))) return rc;
 		if ((rc = c->chrom_first_bucket.upload(cfb.data(), cfb.size(), c->stream))) return rc;
+		std::vector<unsigned> bb(E->buckets.size() + 1, 0);
+		for (size_t b = 0; b < E->buckets.size(); ++b) bb[b + 1] = bb[b] + E->buckets[b].n_bins;
+		c->n_fine = bb.back();
+		if ((rc = c->bin_base.upload(bb.data(), bb.size(), c->stream))) return rc;
 	}
 	if ((rc = upload_strand_ranks(c))) return rc;
 	HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1282,27 +1441,36 @@ static int ingest_device(lsq_ctx *c, int method, const IngestRaw &Rw, uint64_t n
 	int rc;
 	DevBuf<int> d_ms, d_me;
 	DevBuf<unsigned char> d_nb, d_strand;
-	DevBuf<unsigned> d_key;
-	DevBuf<unsigned long long> d_counts, d_cursors, d_totals;
-	if ((rc = d_ms.alloc(nblk)) || (rc = d_me.alloc(nblk)) || (rc = d_nb.alloc(n)) || (rc = d_strand.alloc(n)) || (rc = d_key.alloc(n))) return rc;
-	if ((rc = d_counts.alloc(4ull * B + 4)) || (rc = d_cursors.alloc(4ull * B + 4)) || (rc = d_totals.alloc(4))) return rc;
-	HIP_TRY(hipMemsetAsync(d_counts.p, 0, (4ull * B + 4) * 8, st));
-	HIP_TRY(hipMemsetAsync(d_cursors.p, 0, (4ull * B + 4) * 8, st));
+	DevBuf<unsigned> d_key, d_fine;
+	DevBuf<unsigned> d_cnt;                      // cnt1 | cnt2 | cntn | cntnb, then the four cursor arrays
+	DevBuf<unsigned long long> d_off1, d_off2, d_totals;
+	const size_t F = c->n_fine;                  // bins of all buckets
+	const size_t n_cnt = 2 * F + 2 * (size_t)B;
+	if ((rc = d_ms.alloc(nblk)) || (rc = d_me.alloc(nblk)) || (rc = d_nb.alloc(n)) || (rc = d_strand.alloc(n)) || (rc = d_key.alloc(n)) || (rc = d_fine.alloc(n))) return rc;
+	if ((rc = d_cnt.alloc(2 * n_cnt)) || (rc = d_off1.alloc(F + 1)) || (rc = d_off2.alloc(F + 1)) || (rc = d_totals.alloc(4))) return rc;
+	HIP_TRY(hipMemsetAsync(d_cnt.p, 0, std::max<size_t>(2 * n_cnt, 1) * 4, st));
 	HIP_TRY(hipMemsetAsync(d_totals.p, 0, 4 * 8, st));
 	IngestTables T;
 	T.cov_off = c->cov_off.p; T.cov_s = c->cov_s.p; T.cov_e = c->cov_e.p;
 	T.cut_off = c->cut_off.p; T.cut_lo = c->cut_lo.p; T.chrom_first_bucket = c->chrom_first_bucket.p;
-	T.buckets = c->buckets.p; T.n_chrom = c->n_chrom_tables;
+	T.buckets = c->buckets.p; T.bin_base = c->bin_base.p; T.n_chrom = c->n_chrom_tables;
 	IngestWork W;
-	W.key = d_key.p; W.nb = d_nb.p; W.strand = d_strand.p; W.ms = d_ms.p; W.me = d_me.p;
-	W.counts = d_counts.p; W.cursors = d_cursors.p; W.totals = d_totals.p;
+	W.key = d_key.p; W.fine = d_fine.p; W.nb = d_nb.p; W.strand = d_strand.p; W.ms = d_ms.p; W.me = d_me.p;
+	W.cnt1 = d_cnt.p; W.cnt2 = W.cnt1 + F; W.cntn = W.cnt2 + F; W.cntnb = W.cntn + B;
+	W.cur1 = d_cnt.p + n_cnt; W.cur2 = W.cur1 + F; W.curn = W.cur2 + F; W.curnb = W.curn + B;
+	W.totals = d_totals.p;
 	const unsigned igrid = (unsigned)std::min<unsigned long long>((n + 255) / 256 + 1, (unsigned long long)c->n_cu * 16);
 	if (n) {
 		hipLaunchKernelGGL(lsq_ingest_classify_kernel, dim3(igrid), dim3(256), 0, st, T, Rw, W);
 		HIP_TRY(hipGetLastError());
 	}
 	if ((rc = mr.p1_off.alloc(B + 1)) || (rc = mr.p2_off.alloc(B + 1)) || (rc = mr.pn_off.alloc(B + 1)) || (rc = mr.pnb_off.alloc(B + 1)) || (rc = mr.slot_off.alloc(B + 1))) return rc;
-	hipLaunchKernelGGL(lsq_ingest_scan_kernel, dim3(1), dim3(1024), 0, st, d_counts.p, B, mr.p1_off.p, mr.p2_off.p, mr.pn_off.p, mr.pnb_off.p, mr.slot_off.p);
+	hipLaunchKernelGGL(lsq_scan_u32_kernel, dim3(1), dim3(1024), 0, st, W.cnt1, (unsigned long long)F, d_off1.p);
+	hipLaunchKernelGGL(lsq_scan_u32_kernel, dim3(1), dim3(1024), 0, st, W.cnt2, (unsigned long long)F, d_off2.p);
+	hipLaunchKernelGGL(lsq_scan_u32_kernel, dim3(1), dim3(1024), 0, st, W.cntn, (unsigned long long)B, mr.pn_off.p);
+	hipLaunchKernelGGL(lsq_scan_u32_kernel, dim3(1), dim3(1024), 0, st, W.cntnb, (unsigned long long)B, mr.pnb_off.p);
+	hipLaunchKernelGGL(lsq_ingest_offsets_kernel, dim3(B / 256 + 1), dim3(256), 0, st, c->bin_base.p, B, d_off1.p, d_off2.p, mr.pn_off.p,
+	                   mr.p1_off.p, mr.p2_off.p, mr.slot_off.p);
 	HIP_TRY(hipGetLastError());
 	unsigned long long tot[4] = {0, 0, 0, 0}, sums[4] = {0, 0, 0, 0};
 	HIP_TRY(hipMemcpyAsync(tot, d_totals.p, 4 * 8, hipMemcpyDeviceToHost, st));
@@ -1313,20 +1481,34 @@ static int ingest_device(lsq_ctx *c, int method, const IngestRaw &Rw, uint64_t n
 	HIP_TRY(hipStreamSynchronize(st));
 	if (tot[2]) return fail(LSQ_E_RANGE, "a read covers 2^18 or more bases or keeps more than %d separate blocks: outside the device tables' range", INGEST_MAX_BLOCKS);
 	if (sums[3] > 0xFFFFFFF0ull) return fail(LSQ_E_RANGE, "too many blocks in multi-block reads");
+	if (n > 0xFFFFFFF0ull) return fail(LSQ_E_RANGE, "more than 2^32 reads in one file");
 	const size_t n1 = (size_t)sums[0], n2 = (size_t)sums[1], nn = (size_t)sums[2], nnb = (size_t)sums[3];
 	if ((rc = mr.p1.alloc(2 * n1)) || (rc = mr.p1_strand.alloc(n1)) || (rc = mr.p1_line.alloc(n1))) return rc;
 	if ((rc = mr.p2.alloc(4 * n2)) || (rc = mr.p2_strand.alloc(n2)) || (rc = mr.p2_line.alloc(n2))) return rc;
 	if ((rc = mr.pn_se.alloc(2 * nnb)) || (rc = mr.pn_blk_off.alloc(nn)) || (rc = mr.pn_nblk.alloc(nn)) || (rc = mr.pn_strand.alloc(nn)) ||
 	    (rc = mr.pn_line.alloc(nn)) || (rc = mr.pn_bucket.alloc(nn))) return rc;
 	if (n) {
+		// the scatter fills temporaries; the per-bin sort writes the pools
+		DevBuf<int32_t> t_p1, t_p2;
+		DevBuf<uint8_t> t_p1_strand, t_p2_strand;
+		DevBuf<uint32_t> t_p1_line, t_p2_line;
+		if ((rc = t_p1.alloc(2 * n1)) || (rc = t_p1_strand.alloc(n1)) || (rc = t_p1_line.alloc(n1))) return rc;
+		if ((rc = t_p2.alloc(4 * n2)) || (rc = t_p2_strand.alloc(n2)) || (rc = t_p2_line.alloc(n2))) return rc;
 		IngestOut O;
-		O.p1 = reinterpret_cast<int2 *>(mr.p1.p); O.p1_strand = mr.p1_strand.p; O.p1_line = mr.p1_line.p;
-		O.p2 = reinterpret_cast<int4 *>(mr.p2.p); O.p2_strand = mr.p2_strand.p; O.p2_line = mr.p2_line.p;
+		O.p1 = reinterpret_cast<int2 *>(t_p1.p); O.p1_strand = t_p1_strand.p; O.p1_line = t_p1_line.p;
+		O.p2 = reinterpret_cast<int4 *>(t_p2.p); O.p2_strand = t_p2_strand.p; O.p2_line = t_p2_line.p;
 		O.pn_blk_off = mr.pn_blk_off.p; O.pn_nblk = mr.pn_nblk.p; O.pn_line = mr.pn_line.p; O.pn_bucket = mr.pn_bucket.p;
 		O.pn_strand = mr.pn_strand.p; O.pn_se = reinterpret_cast<int2 *>(mr.pn_se.p);
-		O.p1_off = mr.p1_off.p; O.p2_off = mr.p2_off.p; O.pn_off = mr.pn_off.p; O.pnb_off = mr.pnb_off.p;
+		O.off1 = d_off1.p; O.off2 = d_off2.p; O.pn_off = mr.pn_off.p; O.pnb_off = mr.pnb_off.p;
 		hipLaunchKernelGGL(lsq_ingest_scatter_kernel, dim3(igrid), dim3(256), 0, st, Rw, W, O);
 		HIP_TRY(hipGetLastError());
+		const unsigned sgrid = (unsigned)std::min<size_t>(F / 4 + 1, (size_t)c->n_cu * 32);
+		if (n1) hipLaunchKernelGGL(lsq_ingest_binsort_kernel<int2>, dim3(sgrid), dim3(256), 0, st, c->buckets.p, c->bin_base.p, B, (unsigned)F, d_off1.p,
+		                           reinterpret_cast<const int2 *>(t_p1.p), t_p1_strand.p, t_p1_line.p, reinterpret_cast<int2 *>(mr.p1.p), mr.p1_strand.p, mr.p1_line.p);
+		if (n2) hipLaunchKernelGGL(lsq_ingest_binsort_kernel<int4>, dim3(sgrid), dim3(256), 0, st, c->buckets.p, c->bin_base.p, B, (unsigned)F, d_off2.p,
+		                           reinterpret_cast<const int4 *>(t_p2.p), t_p2_strand.p, t_p2_line.p, reinterpret_cast<int4 *>(mr.p2.p), mr.p2_strand.p, mr.p2_line.p);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipStreamSynchronize(st));            // the temporaries go out of scope here
 	}
 	{
 		// exception list: a quarter of the one- and two-block reads, at least 64 Ki entries
@@ -1338,6 +1520,7 @@ static int ingest_device(lsq_ctx *c, int method, const IngestRaw &Rw, uint64_t n
 	mr.n_retained = tot[0];
 	mr.n_retained_blocks = tot[1];
 	mr.total_slots = n1 + n2 + nn;
+	mr.wg_grid = 0;
 	mr.present = true;
 	c->counted = c->solved = false;
 	return LSQ_OK;
@@ -1446,8 +1629,17 @@ static int run_count(lsq_ctx *c, bool all_reads) {
 		// one workgroup's share must keep the packed LDS counters (24-bit count, 40-bit bases) exact
 		grid = std::max(grid, mr.total_slots / (1ull << 21) + 1);
 		grid = std::min<unsigned long long>(grid, std::max<unsigned long long>(mr.total_slots / 64, 1));
+		if (mr.wg_grid != grid) {
+			int rc = mr.wg_first.alloc((size_t)grid);
+			if (rc) return rc;
+			hipLaunchKernelGGL(lsq_wg_plan_kernel, dim3((unsigned)(grid / 256 + 1)), dim3(256), 0, st, mr.slot_off.p, (unsigned)E.buckets.size(), mr.total_slots,
+			                   (unsigned)grid, mr.wg_first.p);
+			HIP_TRY(hipGetLastError());
+			mr.wg_grid = grid;
+		}
 		CountArgs A;
 		A.buckets = c->buckets.p; A.images = c->images.p; A.ties = c->ties.p; A.strand_rank = c->strand_rank.p;
+		A.wg_first = mr.wg_first.p;
 		A.n_buckets = (unsigned)E.buckets.size();
 		A.tables_lds_bytes = tables_bytes;
 		A.ablate = 0;
@@ -1642,6 +1834,16 @@ int lsq_debug_counters(lsq_ctx *c, unsigned long long *out8) {
 	std::vector<unsigned> h(c->exc_count.n);
 	HIP_TRY(hipMemcpy(h.data(), c->exc_count.p, h.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
 	out8[4] = h[0]; out8[5] = h[1];
+	return LSQ_OK;
+}
+
+// developer aid (not in the header): per-bucket slot offsets of a method (n_buckets + 1 values)
+int lsq_debug_slot_offsets(lsq_ctx *c, int method, unsigned long long *out, unsigned long long n) {
+	HIP_TRY(hipSetDevice(c->device));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	const MethodReads &mr = c->reads[method];
+	if (n > mr.slot_off.n) n = mr.slot_off.n;
+	HIP_TRY(hipMemcpy(out, mr.slot_off.p, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
 	return LSQ_OK;
 }
 

@@ -82,23 +82,6 @@ __global__ void __launch_bounds__(256) lsq_mrf_newline_pos_kernel(const unsigned
 	while (bits) { const unsigned j = (unsigned)__ffs((int)bits) - 1u; bits &= bits - 1u; nl_pos[w++] = at + j; }
 }
 
-// one workgroup: out[i] = sum of in[0..i), out[n] = total
-__global__ void __launch_bounds__(1024) lsq_scan_u32_kernel(const unsigned *in, unsigned long long n, unsigned long long *out) {
-	__shared__ unsigned long long part[1024];
-	const unsigned tid = threadIdx.x;
-	const unsigned long long per = (n + 1023ull) / 1024ull;
-	const unsigned long long b0 = min(tid * per, n), b1 = min(b0 + per, n);
-	unsigned long long acc = 0;
-	for (unsigned long long b = b0; b < b1; ++b) acc += in[b];
-	part[tid] = acc;
-	__syncthreads();
-	if (tid == 0) { unsigned long long run = 0; for (unsigned t = 0; t < 1024; ++t) { const unsigned long long v = part[t]; part[t] = run; run += v; } }
-	__syncthreads();
-	unsigned long long run = part[tid];
-	for (unsigned long long b = b0; b < b1; ++b) { out[b] = run; run += in[b]; }
-	if (tid == 1023) out[n] = run;
-}
-
 __device__ inline lsq::MrfView mrf_data_line(const unsigned char *text, const unsigned long long *nl_pos, unsigned long long L) {
 	const unsigned long long a = nl_pos[L - 1] + 1, b = nl_pos[L];
 	return lsq::MrfView{reinterpret_cast<const char *>(text) + a, (size_t)(b - a)};

@@ -27,6 +27,20 @@ for bud in budgets:
     t0 = time.time(); ctx.upload_reads(0, reads); ti = time.time() - t0
     del reads
     nb = ctx.retained_blocks(0)
+    if os.environ.get("KB_DIST"):
+        import ctypes as C
+        B = L.lib.lsq_events_num_buckets(ev.h)
+        buf = (C.c_ulonglong * (B + 1))()
+        L.lib.lsq_debug_slot_offsets(ctx.h, 0, buf, B + 1)
+        so = np.array(buf[:], dtype=np.int64)
+        sz = np.diff(so)
+        print("   buckets=%d reads/bucket: min=%d p10=%d median=%d mean=%.0f p90=%d max=%d empty=%d" % (B, sz.min(), np.percentile(sz, 10), np.median(sz), sz.mean(), np.percentile(sz, 90), sz.max(), int((sz == 0).sum())))
+        G = 2560
+        bounds = so[-1] * np.arange(G + 1) // G
+        first = np.searchsorted(so, bounds[:-1], side="right") - 1
+        last = np.searchsorted(so, bounds[1:] - 1, side="right") - 1
+        span = last - first + 1
+        print("   grid=%d buckets touched per workgroup: mean=%.2f p90=%d max=%d" % (G, span.mean(), np.percentile(span, 90), span.max()))
     for m in mults:
       for abl in [int(x) for x in os.environ.get("KB_ABLATE", "0").split(",")]:
         os.environ["LSQ_ABLATE"] = str(abl)
