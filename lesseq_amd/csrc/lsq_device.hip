@@ -62,6 +62,7 @@ struct CountArgs {
 	unsigned n_buckets;
 	unsigned ablate;                   // developer switch (LSQ_ABLATE): 1 skip per-read work, 2 skip LDS atomics, 4 skip flush, 8 skip record look
 	unsigned tables_lds_bytes;         // LDS bytes reserved for the bucket image + histogram (16-byte multiple)
+	unsigned double_buffer;            // 1: two table buffers in LDS, the next bucket staged while this one streams
 	const int2 *p1; const unsigned char *p1_strand; const unsigned *p1_line;
 	const int4 *p2; const unsigned char *p2_strand; const unsigned *p2_line;
 	const unsigned *pn_blk_off; const unsigned *pn_nblk; const int2 *pn_se; const unsigned char *pn_strand; const unsigned *pn_line; const unsigned *pn_bucket;
@@ -476,10 +477,10 @@ __device__ inline void walk_parked(const FastCtx &C, Ring<NB> &R, const bool to_
 }
 
 // RPW = reads per 16-byte word: 2 (pool 1: one block) or 1 (pool 2: two blocks)
-template <int RPW>
+template <int RPW, class Between>
 __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uint4 *cells, const unsigned *cell_info, const unsigned n_cells, const BucketDesc &d,
                                         const CountArgs &A, uint4 *queue, const uint4 *src_generic,
-                                        const unsigned long long g0, const unsigned long long g1) {
+                                        const unsigned long long g0, const unsigned long long g1, Between &&between) {
 	constexpr int NB = RPW == 2 ? 1 : 2;
 	constexpr unsigned TILE = 64u * STREAM_WORDS;        // words per wave step
 	C.pool = RPW == 2 ? 0u : 1u;
@@ -515,6 +516,7 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 	Ring<NB> R;
 	R.q = queue;
 	if (ww0 < ww1) fetch(ww0);
+	between();          // runs while the first words are in flight (every wave calls it, whatever its share)
 	for (unsigned wt = ww0; wt < ww1; wt += WAVES * TILE) {
 		uint4 cur[STREAM_WORDS];
 #pragma unroll
@@ -639,53 +641,114 @@ __global__ void __launch_bounds__(256) lsq_wg_plan_kernel(const unsigned long lo
 #ifndef LSQ_FAST_WAVES
 #define LSQ_FAST_WAVES 1
 #endif
+// What a workgroup needs to know about one bucket visit; found with scalar loads, kept in LDS
+// beside the bucket's tables while the bucket before it is still being streamed.
+struct BucketVisit {
+	BucketDesc d;
+	unsigned long long bs, be;            // the bucket's slots
+	unsigned long long p1o, p1n, p2o, p2n;   // first read and count of its one- and two-block pools
+	unsigned b, valid;
+};
+constexpr unsigned VISIT_LDS_BYTES = 128;
+static_assert(sizeof(BucketVisit) <= VISIT_LDS_BYTES, "BucketVisit has a fixed LDS slot");
+
+// next packed bucket at or after b that holds slots of [s_begin, s_end); n_buckets when there is none
+__device__ inline unsigned find_bucket(const CountArgs &A, unsigned b, const unsigned long long s_begin, const unsigned long long s_end) {
+	for (b = (unsigned)__builtin_amdgcn_readfirstlane((int)b); b < A.n_buckets; ++b) {
+		const unsigned long long bs = A.slot_off[b], be = A.slot_off[b + 1];
+		const unsigned kind = A.buckets[b].kind;
+		if (bs >= s_end) return A.n_buckets;
+		if (be <= s_begin || be == bs || kind != 1) continue;
+		return b;
+	}
+	return A.n_buckets;
+}
+
+// tables of bucket b into an LDS buffer: the image, a cleared histogram, the visit record
+__device__ inline void stage_bucket(const CountArgs &A, const unsigned b, unsigned char *buf) {
+	const unsigned tid = threadIdx.x;
+	unsigned *rec = reinterpret_cast<unsigned *>(buf + A.tables_lds_bytes - VISIT_LDS_BYTES);
+	if (b >= A.n_buckets) {
+		if (tid == 0) rec[29] = 0u;
+		return;
+	}
+	const BucketDesc d = A.buckets[b];
+	const unsigned long long bs = A.slot_off[b], be = A.slot_off[b + 1];
+	const unsigned long long p1a = A.p1_off[b], p1b = A.p1_off[b + 1], p2a = A.p2_off[b], p2b = A.p2_off[b + 1];
+	global_words src = (global_words)(A.images + d.img_off);
+	uint4 *dst = reinterpret_cast<uint4 *>(buf);
+	for (unsigned i = tid; i < d.img_bytes / 16; i += COUNT_BLOCK) { const u32x4 t = src[i]; dst[i] = make_uint4(t.x, t.y, t.z, t.w); }
+	unsigned long long *h = reinterpret_cast<unsigned long long *>(buf + d.hist_off);
+	for (unsigned i = tid; i < d.n_cls; i += COUNT_BLOCK) h[i] = 0;
+	if (tid == 0) {
+		rec[0] = d.img_off; rec[1] = d.img_bytes; rec[2] = d.n_events; rec[3] = d.n_bins; rec[4] = (unsigned)d.lo; rec[5] = d.shift;
+		rec[6] = d.ev_off; rec[7] = d.seg_off; rec[8] = d.iso_off; rec[9] = d.hist_off; rec[10] = d.n_cls; rec[11] = d.cls_base;
+		rec[12] = d.ev_base; rec[13] = (unsigned)d.chrom_id; rec[14] = d.kind; rec[15] = (unsigned)d.hi;
+		unsigned long long *r64 = reinterpret_cast<unsigned long long *>(rec + 16);
+		r64[0] = bs; r64[1] = be; r64[2] = p1a; r64[3] = p1b - p1a; r64[4] = p2a; r64[5] = p2b - p2a;
+		rec[28] = b; rec[29] = 1u;
+	}
+}
+
 __global__ void __launch_bounds__(COUNT_BLOCK, LSQ_FAST_WAVES) lsq_count_fast_kernel(CountArgs A) {
+	// LDS: two table buffers (the bucket being streamed; the next one, staged meanwhile), then the waves' rings
 	extern __shared__ __align__(16) unsigned char lds[];
 	const unsigned tid = threadIdx.x;
-	uint4 *wave_queue = reinterpret_cast<uint4 *>(lds + A.tables_lds_bytes) + (tid >> 6) * WAVE_QUEUE_WORDS;
+	uint4 *wave_queue = reinterpret_cast<uint4 *>(lds + (1u + A.double_buffer) * A.tables_lds_bytes) + (tid >> 6) * WAVE_QUEUE_WORDS;
 	const unsigned long long s_begin = A.total_slots * blockIdx.x / gridDim.x;
 	const unsigned long long s_end = A.total_slots * (blockIdx.x + 1ull) / gridDim.x;
 	if (s_begin >= s_end) return;
-	const unsigned lo_b = A.wg_first[blockIdx.x];     // last bucket whose first slot is <= s_begin (lsq_wg_plan_kernel)
-	for (unsigned b = lo_b; b < A.n_buckets && A.slot_off[b] < s_end; ++b) {
-		const unsigned long long bs = A.slot_off[b], be = A.slot_off[b + 1];
-		if (be <= s_begin || be == bs) continue;
-		const BucketDesc d = A.buckets[b];
-		if (d.kind != 1) continue;
-		// ---- stage the image, clear the histogram
-		{
-			global_words src = (global_words)(A.images + d.img_off);
-			uint4 *dst = reinterpret_cast<uint4 *>(lds);
-			for (unsigned i = tid; i < d.img_bytes / 16; i += COUNT_BLOCK) { const u32x4 t = src[i]; dst[i] = make_uint4(t.x, t.y, t.z, t.w); }
-			unsigned long long *h = reinterpret_cast<unsigned long long *>(lds + d.hist_off);
-			for (unsigned i = tid; i < d.n_cls; i += COUNT_BLOCK) h[i] = 0;
-		}
-		__syncthreads();
-		const uint4 *bins = reinterpret_cast<const uint4 *>(lds);
-		const uint4 *cells = reinterpret_cast<const uint4 *>(lds + d.seg_off);
-		const unsigned *cell_info = reinterpret_cast<const unsigned *>(lds + d.seg_off + 16u * d.iso_off);
+	if (A.ablate & 4096u) return;       // developer switch: dispatch cost only
+	unsigned cur = 0;
+	{
+		const unsigned b0 = find_bucket(A, A.wg_first[blockIdx.x], s_begin, s_end);   // wg_first: lsq_wg_plan_kernel
+		if (b0 >= A.n_buckets) return;
+		stage_bucket(A, b0, lds);
+	}
+	__syncthreads();
+	if (A.ablate & 8192u) return;       // developer switch: dispatch + first staging
+	for (;;) {
+		unsigned char *buf = lds + cur * A.tables_lds_bytes, *other = lds + (cur ^ 1u) * A.tables_lds_bytes;
+		// the visit record, wave-uniform: every dword through readfirstlane so that it lives in scalar registers
+		const unsigned *rec = reinterpret_cast<const unsigned *>(buf + A.tables_lds_bytes - VISIT_LDS_BYTES);
+		auto r32 = [&](unsigned q) { return (unsigned)__builtin_amdgcn_readfirstlane((int)rec[q]); };
+		auto r64 = [&](unsigned q) { return (unsigned long long)r32(q) | ((unsigned long long)r32(q + 1) << 32); };
+		BucketVisit V;
+		V.d.img_off = r32(0); V.d.img_bytes = r32(1); V.d.n_events = r32(2); V.d.n_bins = r32(3); V.d.lo = (int)r32(4); V.d.shift = r32(5);
+		V.d.ev_off = r32(6); V.d.seg_off = r32(7); V.d.iso_off = r32(8); V.d.hist_off = r32(9); V.d.n_cls = r32(10); V.d.cls_base = r32(11);
+		V.d.ev_base = r32(12); V.d.chrom_id = (int)r32(13); V.d.kind = r32(14); V.d.hi = (int)r32(15);
+		V.bs = r64(16); V.be = r64(18); V.p1o = r64(20); V.p1n = r64(22); V.p2o = r64(24); V.p2n = r64(26);
+		V.b = r32(28); V.valid = r32(29);
+		const BucketDesc &d = V.d;
+		const unsigned b = V.b;
+		// the next bucket's tables go to the other buffer while this bucket's first reads are on their way
+		bool staged = false;
+		auto stage_next = [&]() {
+			if (staged || !A.double_buffer) return;
+			staged = true;
+			stage_bucket(A, find_bucket(A, b + 1u, s_begin, s_end), other);
+		};
+		const uint4 *bins = reinterpret_cast<const uint4 *>(buf);
+		const uint4 *cells = reinterpret_cast<const uint4 *>(buf + d.seg_off);
+		const unsigned *cell_info = reinterpret_cast<const unsigned *>(buf + d.seg_off + 16u * d.iso_off);
 		FastCtx C;
 		C.bins = bins; C.lo = d.lo; C.shift = d.shift; C.n_bins = d.n_bins;
-		C.recs = reinterpret_cast<const uint4 *>(lds + d.ev_off);
-		C.hist = reinterpret_cast<unsigned long long *>(lds + d.hist_off);
+		C.recs = reinterpret_cast<const uint4 *>(buf + d.ev_off);
+		C.hist = reinterpret_cast<unsigned long long *>(buf + d.hist_off);
 		C.n_events = d.n_events; C.bucket = b;
 		C.slot0 = 0; C.pool = 0;
 		C.exc = A.exc; C.exc_count = A.exc_count; C.exc_cap = A.exc_cap; C.ablate = A.ablate; C.dbg = A.dbg;
-		const unsigned long long l0 = (s_begin > bs ? s_begin : bs) - bs;
-		const unsigned long long l1 = (s_end < be ? s_end : be) - bs;
-		const unsigned long long n1 = A.p1_off[b + 1] - A.p1_off[b];
-		const unsigned long long n2 = A.p2_off[b + 1] - A.p2_off[b];
+		const unsigned long long l0 = (s_begin > V.bs ? s_begin : V.bs) - V.bs;
+		const unsigned long long l1 = (s_end < V.be ? s_end : V.be) - V.bs;
+		const unsigned long long n1 = V.p1n, n2 = V.p2n;
 		// ---- pool 1
-		if (l0 < n1 && !(A.ablate & 1024u)) {
-			const unsigned long long base = A.p1_off[b];
-			stream_pool_fast<2>(C, bins, cells, cell_info, d.iso_off, d, A, wave_queue, reinterpret_cast<const uint4 *>(A.p1), base + l0, base + (l1 < n1 ? l1 : n1));
-		}
+		if (l0 < n1 && !(A.ablate & 1024u))
+			stream_pool_fast<2>(C, bins, cells, cell_info, d.iso_off, d, A, wave_queue, reinterpret_cast<const uint4 *>(A.p1), V.p1o + l0, V.p1o + (l1 < n1 ? l1 : n1), stage_next);
 		// ---- pool 2
-		if (l1 > n1 && l0 < n1 + n2 && !(A.ablate & 2048u)) {
-			const unsigned long long base = A.p2_off[b];
-			stream_pool_fast<1>(C, bins, cells, cell_info, d.iso_off, d, A, wave_queue, reinterpret_cast<const uint4 *>(A.p2), base + ((l0 > n1 ? l0 : n1) - n1),
-			                    base + ((l1 < n1 + n2 ? l1 : n1 + n2) - n1));
-		}
+		if (l1 > n1 && l0 < n1 + n2 && !(A.ablate & 2048u))
+			stream_pool_fast<1>(C, bins, cells, cell_info, d.iso_off, d, A, wave_queue, reinterpret_cast<const uint4 *>(A.p2), V.p2o + ((l0 > n1 ? l0 : n1) - n1),
+			                    V.p2o + ((l1 < n1 + n2 ? l1 : n1 + n2) - n1), stage_next);
+		stage_next();
 		// (reads with three or more blocks are left to the cleanup kernel)
 		__syncthreads();
 		// ---- flush
@@ -696,7 +759,18 @@ __global__ void __launch_bounds__(COUNT_BLOCK, LSQ_FAST_WAVES) lsq_count_fast_ke
 				atomicAdd(&A.bases[d.cls_base + i], v & BASES_MASK);
 			}
 		}
-		__syncthreads();
+		if (!A.double_buffer) {
+			// tables too large to hold twice: the next bucket is staged between two barriers
+			__syncthreads();
+			stage_bucket(A, find_bucket(A, b + 1u, s_begin, s_end), lds);
+			__syncthreads();
+			if (!reinterpret_cast<const unsigned *>(lds + A.tables_lds_bytes - VISIT_LDS_BYTES)[29]) break;
+			continue;
+		}
+		const unsigned more = reinterpret_cast<const unsigned *>(other + A.tables_lds_bytes - VISIT_LDS_BYTES)[29];
+		if (!more) break;
+		__syncthreads();        // this buffer is written again while the next bucket streams
+		cur ^= 1u;
 	}
 }
 
@@ -1612,8 +1686,10 @@ static int run_count(lsq_ctx *c, bool all_reads) {
 	HIP_TRY(hipMemsetAsync(c->dbg.p, 0, 8 * sizeof(unsigned long long), st));
 	c->fast_launched = 0;
 	HIP_TRY(hipEventRecord(c->ev0, st));      // ev0..ev1 brackets the count kernel launches only
-	const unsigned tables_bytes = (std::max<unsigned>(E.max_lds_bytes, 16) + 15u) & ~15u;
-	const unsigned lds_bytes = tables_bytes + WAVES * WAVE_QUEUE_WORDS * 16;
+	const unsigned generic_tables_bytes = (std::max<unsigned>(E.max_lds_bytes, 16) + 15u) & ~15u;
+	const unsigned tables_bytes = generic_tables_bytes + VISIT_LDS_BYTES;            // fast kernel: + the visit record, twice (two buffers)
+	const unsigned double_buffer = 2u * tables_bytes + WAVES * WAVE_QUEUE_WORDS * 16 <= 64u * 1024u ? 1u : 0u;
+	const unsigned lds_bytes = (1u + double_buffer) * tables_bytes + WAVES * WAVE_QUEUE_WORDS * 16;
 	if (lds_bytes > 160 * 1024) return fail(LSQ_E_UNSUPPORTED, "bucket tables + read tile exceed the CU's LDS");
 	if (lds_bytes > 64 * 1024) {
 		HIP_TRY(hipFuncSetAttribute((const void *)lsq_count_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -1642,6 +1718,7 @@ static int run_count(lsq_ctx *c, bool all_reads) {
 		A.wg_first = mr.wg_first.p;
 		A.n_buckets = (unsigned)E.buckets.size();
 		A.tables_lds_bytes = tables_bytes;
+		A.double_buffer = double_buffer;
 		A.ablate = 0;
 		if (const char *e = getenv("LSQ_ABLATE")) A.ablate = (unsigned)atoi(e);
 		A.p1 = reinterpret_cast<const int2 *>(mr.p1.p); A.p1_strand = mr.p1_strand.p; A.p1_line = mr.p1_line.p;
@@ -1668,7 +1745,7 @@ static int run_count(lsq_ctx *c, bool all_reads) {
 			HIP_TRY(hipGetLastError());
 		}
 		if (c->has_generic) {
-			hipLaunchKernelGGL(lsq_count_generic_kernel, dim3((unsigned)grid), dim3(COUNT_BLOCK), tables_bytes, st, A);
+			hipLaunchKernelGGL(lsq_count_generic_kernel, dim3((unsigned)grid), dim3(COUNT_BLOCK), generic_tables_bytes, st, A);
 			HIP_TRY(hipGetLastError());
 		}
 	}
