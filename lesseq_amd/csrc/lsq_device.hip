@@ -902,9 +902,18 @@ struct EmArgs {
 // lanes of an event hold the same theta and take the same decisions.
 constexpr int EM_LANES = 4;
 
+// sum over the four lanes of an event (an aligned quad): two DPP quad permutes per 32-bit half,
+// plain VALU moves with no trip through the LDS crossbar
+template <int CTRL>
+__device__ inline double quad_perm_f64(double x) {
+	int lo = __double2loint(x), hi = __double2hiint(x);
+	lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+	hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+	return __hiloint2double(hi, lo);
+}
 __device__ inline double group_sum(double x) {
-	x += __shfl_xor(x, 1);
-	x += __shfl_xor(x, 2);
+	x += quad_perm_f64<0xB1>(x);      // quad_perm:[1,0,3,2]
+	x += quad_perm_f64<0x4E>(x);      // quad_perm:[2,3,0,1]
 	return x;
 }
 
@@ -960,6 +969,31 @@ __device__ inline double fast_recip(double s) {
 	return r;
 }
 
+// log(s) for normal positive s to about 1 ulp (everything else goes to the library): exponent and
+// mantissa m in [sqrt(1/2), sqrt(2)), log m = 2 atanh(z) with z = (m-1)/(m+1), |z| < 0.172, as an
+// odd series in z evaluated by Estrin's scheme -- a dependent chain of about 20 operations, a
+// third of the library routine's.  The stop rule compares log-likelihoods to 1e-6; events whose
+// criterion comes within 1e-11 of it are flagged whatever the logarithm used.
+__device__ inline double fast_log(double s) {
+	const unsigned long long bits = (unsigned long long)__double_as_longlong(s);
+	const unsigned ex = (unsigned)(bits >> 52);
+	if (ex - 1u >= 0x7FEu) return log(s);                       // zero, subnormal, negative, inf, nan
+	double m = __longlong_as_double((long long)((bits & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull));
+	int e = (int)ex - 1023;
+	if (m > 1.4142135623730951) { m *= 0.5; e += 1; }
+	const double f = m - 1.0;
+	const double z = f * fast_recip(2.0 + f);
+	const double w = z * z, w2 = w * w, w4 = w2 * w2, w8 = w4 * w4;
+	// 1/3 + w/5 + w^2/7 + ... + w^9/21
+	const double p01 = fma(w, 1.0 / 5.0, 1.0 / 3.0), p23 = fma(w, 1.0 / 9.0, 1.0 / 7.0), p45 = fma(w, 1.0 / 13.0, 1.0 / 11.0),
+	             p67 = fma(w, 1.0 / 17.0, 1.0 / 15.0), p89 = fma(w, 1.0 / 21.0, 1.0 / 19.0);
+	const double q0 = fma(w2, p23, p01), q1 = fma(w2, p67, p45);
+	const double poly = fma(w8, p89, fma(w4, q1, q0));
+	const double lm = fma(z * w, 2.0 * poly, 2.0 * z);
+	const double ed = (double)e;
+	return fma(ed, 0.69314718055994528623, fma(ed, 2.3190468138462995584e-17, lm));
+}
+
 __device__ inline void em_pass_cached(const EmCache &E, const double *th, bool on, double &ll, double *z) {
 	double l = 0, zz[EM_CACHED_K] = {0, 0, 0};
 #pragma unroll
@@ -970,7 +1004,7 @@ __device__ inline void em_pass_cached(const EmCache &E, const double *th, bool o
 			double s = 0;
 #pragma unroll
 			for (int j = 0; j < EM_CACHED_K; ++j) if (c >> j & 1) s += th[j] * E.g[t][j];
-			l += kd * log(s);
+			l += kd * fast_log(s);
 			if (s > 0) {
 				const double kr = kd * fast_recip(s);
 #pragma unroll
@@ -980,6 +1014,28 @@ __device__ inline void em_pass_cached(const EmCache &E, const double *th, bool o
 				}
 			}
 		}
+	}
+	ll = group_sum(l);
+#pragma unroll
+	for (int j = 0; j < EM_CACHED_K; ++j) z[j] = group_sum(zz[j]);
+}
+
+// The register-cached pass with the class masks folded into G (an isoform outside the class has
+// G = 0: its term adds an exact zero, so sums and their order are those of em_pass_cached).
+__device__ inline void em_pass_lean(const double (&kd)[EM_CACHED_PAIRS], const double (&gm)[EM_CACHED_PAIRS][EM_CACHED_K], const double (&th)[EM_CACHED_K],
+                                    const bool on, double &ll, double (&z)[EM_CACHED_K]) {
+	double l = 0, zz[EM_CACHED_K] = {0, 0, 0};
+#pragma unroll
+	for (int t = 0; t < EM_CACHED_PAIRS; ++t) {
+		double local[EM_CACHED_K], sm = 0;
+#pragma unroll
+		for (int j = 0; j < EM_CACHED_K; ++j) { local[j] = th[j] * gm[t][j]; sm += local[j]; }
+		const bool on_t = on && kd[t] != 0;
+		const double term = kd[t] * fast_log(on_t ? sm : 1.0);     // an empty pair slot must not send the wave down the library path
+		l += on_t ? term : 0.0;
+		const double kr = (on_t && sm > 0) ? kd[t] * fast_recip(sm) : 0.0;
+#pragma unroll
+		for (int j = 0; j < EM_CACHED_K; ++j) zz[j] += local[j] * kr;
 	}
 	ll = group_sum(l);
 #pragma unroll
@@ -1032,6 +1088,40 @@ __global__ void __launch_bounds__(256) lsq_em_kernel(EmArgs A) {
 	// no reads: theta stays 1/K, log-likelihood 0; one isoform: theta = 1 (solve/solve.cpp:798-802)
 	bool run = ev_ok && n_total > 0 && K > 1;
 	const bool any_reads = ev_ok && n_total > 0;
+	if (__all(cached || !ev_ok)) {
+		// every event of the wave fits the registers: a loop with nothing but the lean pass in it
+		double gm[EM_CACHED_PAIRS][EM_CACHED_K], t3[EM_CACHED_K], z3[EM_CACHED_K];
+#pragma unroll
+		for (int t = 0; t < EM_CACHED_PAIRS; ++t)
+#pragma unroll
+			for (int j = 0; j < EM_CACHED_K; ++j) gm[t][j] = (C.cls[t] >> j & 1) ? C.g[t][j] : 0.0;
+#pragma unroll
+		for (int j = 0; j < EM_CACHED_K; ++j) t3[j] = th[j];
+		em_pass_lean(C.kd, gm, t3, any_reads, ll, z3);
+		while (__any(run)) {
+			double n3[EM_CACHED_K], nll, nz3[EM_CACHED_K];
+#pragma unroll
+			for (int j = 0; j < EM_CACHED_K; ++j) n3[j] = z3[j] * inv_n;
+			em_pass_lean(C.kd, gm, n3, run, nll, nz3);
+			const unsigned nll_ex = (unsigned)((unsigned long long)__double_as_longlong(nll) >> 52) & 0x7FFu;
+			const double crit = (nll_ex - 1u < 0x7FEu) ? fabs(1.0 - ll * fast_recip(nll)) : fabs(1.0 - ll / nll);   // read.h:659
+			const bool go = run;
+#pragma unroll
+			for (int j = 0; j < EM_CACHED_K; ++j) { t3[j] = go ? n3[j] : t3[j]; z3[j] = go ? nz3[j] : z3[j]; }
+			ll = go ? nll : ll;
+			iters += go ? 1u : 0u;
+			if (go && fabs(crit - 1E-6) < 1E-11) flag |= 1;
+			if (go && !(crit > 1E-6)) run = false;
+			else if (go && iters >= 1000000u) { flag |= 2; run = false; }
+		}
+		if (ev_ok && sub == 0) {
+			for (int j = 0; j < K; ++j) A.theta[ib + j] = j == 0 ? t3[0] : (j == 1 ? t3[1] : t3[2]);
+			A.logll[e] = ll;
+			A.iters[e] = iters;
+			A.flags[e] = flag;
+		}
+		return;
+	}
 	if (cached) em_pass_cached(C, th, any_reads, ll, z);
 	else em_pass(A, cb, ib, K, nc, sub, any_reads, th, ll, z);
 	while (__any(run)) {
@@ -1042,7 +1132,11 @@ __global__ void __launch_bounds__(256) lsq_em_kernel(EmArgs A) {
 		if (cached) em_pass_cached(C, nth, run, nll, nz);
 		else em_pass(A, cb, ib, K, nc, sub, run, nth, nll, nz);
 		if (run) {
-			const double crit = fabs(1.0 - ll / nll);       // read.h:659, floating abs
+			// read.h:659, floating abs; the quotient through the reciprocal when the passes are the
+			// register-cached ones (1 ulp, against a guard band of 1e-11 around the threshold)
+			const unsigned nll_ex = (unsigned)((unsigned long long)__double_as_longlong(nll) >> 52) & 0x7FFu;
+			const bool nll_normal = nll_ex - 1u < 0x7FEu;     // -inf, nan, zero keep the division's own answers
+			const double crit = (cached && nll_normal) ? fabs(1.0 - ll * fast_recip(nll)) : fabs(1.0 - ll / nll);
 #pragma unroll
 			for (int j = 0; j < LSQ_MAX_ISOFORMS; ++j) { th[j] = nth[j]; z[j] = nz[j]; }
 			ll = nll;
