@@ -292,7 +292,7 @@ int plan_device(lsq_events &E) {
 		if (i >= E.shard_first && i - E.shard_first < E.shard_count) per_chrom[E.ev[i].chrom_id].push_back((int32_t)i);
 	auto ev_bytes = [&](const Event &e) -> uint32_t {
 		// packed bucket: record 48 B, ~1.5 cells of 20 B per segment, 8 bin records of 16 B, class histogram
-		return std::max(48u + 40u * (uint32_t)e.N + 20u + 128u, 16u + 8u * (uint32_t)e.N + 4u * (uint32_t)e.K) + 8u * ((1u << e.K) - 1u);
+		return std::max(48u + 40u * (uint32_t)e.N + 20u + 128u, 16u + 8u * (uint32_t)e.N + 4u * (uint32_t)e.K) + 8u * HIST_REPLICAS * ((1u << e.K) - 1u);
 	};
 	for (size_t c = 0; c < per_chrom.size(); ++c) {
 		auto &lst = per_chrom[c];
@@ -437,7 +437,7 @@ int plan_device(lsq_events &E) {
 				d.iso_off = off; off = align16(off + 4 * niso);
 			}
 			d.img_bytes = off;
-			d.hist_off = off; off += 8 * ncls;
+			d.hist_off = off; off += 8 * HIST_REPLICAS * hist_stride(ncls);
 			d.n_cls = ncls;
 			if (off > 128u * 1024u) return fail(LSQ_E_UNSUPPORTED, "bucket of %u events on %s needs %u bytes of LDS tables", d.n_events, E.chroms.names[c].c_str(), off);
 			E.max_lds_bytes = std::max(E.max_lds_bytes, off);

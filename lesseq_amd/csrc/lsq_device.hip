@@ -571,7 +571,7 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 						pe1[j] = make_uint4(0, 0, 0, 0);
 					}
 					const unsigned sa = cw.w & 0xFFFFu, sb = cw.w >> 16;
-					if (!(A.ablate & 1u)) {
+					if (!(A.ablate & (1u | 16384u))) {
 						const unsigned long long addA = ((unsigned long long)nA << 40) | sA;
 						if (nA && sa != CELL_NONE) atomicAdd(&C.hist[sa], addA);
 						if (nA && hi2 == hi && sb != CELL_NONE) atomicAdd(&C.hist[sb], addA);        // second owner of the cell
@@ -679,7 +679,7 @@ __device__ inline void stage_bucket(const CountArgs &A, const unsigned b, unsign
 	uint4 *dst = reinterpret_cast<uint4 *>(buf);
 	for (unsigned i = tid; i < d.img_bytes / 16; i += COUNT_BLOCK) { const u32x4 t = src[i]; dst[i] = make_uint4(t.x, t.y, t.z, t.w); }
 	unsigned long long *h = reinterpret_cast<unsigned long long *>(buf + d.hist_off);
-	for (unsigned i = tid; i < d.n_cls; i += COUNT_BLOCK) h[i] = 0;
+	for (unsigned i = tid; i < HIST_REPLICAS * (d.n_cls | 1u); i += COUNT_BLOCK) h[i] = 0;
 	if (tid == 0) {
 		rec[0] = d.img_off; rec[1] = d.img_bytes; rec[2] = d.n_events; rec[3] = d.n_bins; rec[4] = (unsigned)d.lo; rec[5] = d.shift;
 		rec[6] = d.ev_off; rec[7] = d.seg_off; rec[8] = d.iso_off; rec[9] = d.hist_off; rec[10] = d.n_cls; rec[11] = d.cls_base;
@@ -734,7 +734,7 @@ __global__ void __launch_bounds__(COUNT_BLOCK, LSQ_FAST_WAVES) lsq_count_fast_ke
 		FastCtx C;
 		C.bins = bins; C.lo = d.lo; C.shift = d.shift; C.n_bins = d.n_bins;
 		C.recs = reinterpret_cast<const uint4 *>(buf + d.ev_off);
-		C.hist = reinterpret_cast<unsigned long long *>(buf + d.hist_off);
+		C.hist = reinterpret_cast<unsigned long long *>(buf + d.hist_off) + (tid & (HIST_REPLICAS - 1u)) * (d.n_cls | 1u);   // this lane's copy
 		C.n_events = d.n_events; C.bucket = b;
 		C.slot0 = 0; C.pool = 0;
 		C.exc = A.exc; C.exc_count = A.exc_count; C.exc_cap = A.exc_cap; C.ablate = A.ablate; C.dbg = A.dbg;
@@ -753,7 +753,10 @@ __global__ void __launch_bounds__(COUNT_BLOCK, LSQ_FAST_WAVES) lsq_count_fast_ke
 		__syncthreads();
 		// ---- flush
 		for (unsigned i = tid; i < d.n_cls; i += COUNT_BLOCK) {
-			unsigned long long v = C.hist[i];
+			const unsigned long long *h0 = reinterpret_cast<const unsigned long long *>(buf + d.hist_off) + i;
+			unsigned long long v = 0;
+#pragma unroll
+			for (unsigned r = 0; r < HIST_REPLICAS; ++r) v += h0[r * (d.n_cls | 1u)];       // counts stay below 2^24, bases below 2^40
 			if (v && !(A.ablate & 4u)) {
 				atomicAdd(&A.cnt[d.cls_base + i], v >> 40);
 				atomicAdd(&A.bases[d.cls_base + i], v & BASES_MASK);
@@ -1782,7 +1785,8 @@ static int run_count(lsq_ctx *c, bool all_reads) {
 	HIP_TRY(hipEventRecord(c->ev0, st));      // ev0..ev1 brackets the count kernel launches only
 	const unsigned generic_tables_bytes = (std::max<unsigned>(E.max_lds_bytes, 16) + 15u) & ~15u;
 	const unsigned tables_bytes = generic_tables_bytes + VISIT_LDS_BYTES;            // fast kernel: + the visit record, twice (two buffers)
-	const unsigned double_buffer = 2u * tables_bytes + WAVES * WAVE_QUEUE_WORDS * 16 <= 64u * 1024u ? 1u : 0u;
+	// two table buffers (next bucket staged while this one streams) cost a workgroup per CU and measured slower; developer switch only
+	const unsigned double_buffer = (2u * tables_bytes + WAVES * WAVE_QUEUE_WORDS * 16 <= 64u * 1024u && getenv("LSQ_DBUF")) ? 1u : 0u;
 	const unsigned lds_bytes = (1u + double_buffer) * tables_bytes + WAVES * WAVE_QUEUE_WORDS * 16;
 	if (lds_bytes > 160 * 1024) return fail(LSQ_E_UNSUPPORTED, "bucket tables + read tile exceed the CU's LDS");
 	if (lds_bytes > 64 * 1024) {

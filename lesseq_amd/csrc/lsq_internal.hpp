@@ -117,6 +117,11 @@ struct Cell {
 };
 static_assert(sizeof(Cell) == 16, "Cell layout");
 constexpr uint32_t CELL_NONE = 0xFFFFu;
+// The LDS histogram of a bucket is kept HIST_REPLICAS times (lane & (R-1) picks the copy; copies
+// are (n_cls | 1) entries apart so that they start in different banks): neighbouring reads of the
+// start-ordered pools land in the same class, and atomics on one LDS address run one after the other.
+constexpr uint32_t HIST_REPLICAS = 4;
+inline uint32_t hist_stride(uint32_t n_cls) { return n_cls | 1u; }
 // per cell, for junction reads: owner event << 8 | segment << 2 | hi is the segment's end << 1 |
 // lo is the segment's start; CELL_INFO_SHARED for two-owner cells
 constexpr uint32_t CELL_INFO_SHARED = 0xFFFFFFFFu;
