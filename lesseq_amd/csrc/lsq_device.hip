@@ -1101,21 +1101,31 @@ __global__ void __launch_bounds__(256) lsq_em_kernel(EmArgs A) {
 #pragma unroll
 		for (int j = 0; j < EM_CACHED_K; ++j) t3[j] = th[j];
 		em_pass_lean(C.kd, gm, t3, any_reads, ll, z3);
+		// The pass for theta(t+2) starts from z(t+1) as soon as that exists, without waiting for
+		// the stop test on ll(t+1): the test (a reciprocal, a compare, a ballot) then runs beside
+		// the next pass instead of between two passes.  One pass per event is thrown away.
+		double c3[EM_CACHED_K], cll, cz3[EM_CACHED_K];           // candidate: theta(t+1), its log-likelihood and numerators
+#pragma unroll
+		for (int j = 0; j < EM_CACHED_K; ++j) c3[j] = z3[j] * inv_n;
+		em_pass_lean(C.kd, gm, c3, run, cll, cz3);
 		while (__any(run)) {
 			double n3[EM_CACHED_K], nll, nz3[EM_CACHED_K];
 #pragma unroll
-			for (int j = 0; j < EM_CACHED_K; ++j) n3[j] = z3[j] * inv_n;
-			em_pass_lean(C.kd, gm, n3, run, nll, nz3);
-			const unsigned nll_ex = (unsigned)((unsigned long long)__double_as_longlong(nll) >> 52) & 0x7FFu;
-			const double crit = (nll_ex - 1u < 0x7FEu) ? fabs(1.0 - ll * fast_recip(nll)) : fabs(1.0 - ll / nll);   // read.h:659
+			for (int j = 0; j < EM_CACHED_K; ++j) n3[j] = cz3[j] * inv_n;
+			em_pass_lean(C.kd, gm, n3, run, nll, nz3);            // speculative: theta(t+2)
+			const unsigned cll_ex = (unsigned)((unsigned long long)__double_as_longlong(cll) >> 52) & 0x7FFu;
+			const double crit = (cll_ex - 1u < 0x7FEu) ? fabs(1.0 - ll * fast_recip(cll)) : fabs(1.0 - ll / cll);   // read.h:659
 			const bool go = run;
 #pragma unroll
-			for (int j = 0; j < EM_CACHED_K; ++j) { t3[j] = go ? n3[j] : t3[j]; z3[j] = go ? nz3[j] : z3[j]; }
-			ll = go ? nll : ll;
+			for (int j = 0; j < EM_CACHED_K; ++j) { t3[j] = go ? c3[j] : t3[j]; z3[j] = go ? cz3[j] : z3[j]; }
+			ll = go ? cll : ll;
 			iters += go ? 1u : 0u;
 			if (go && fabs(crit - 1E-6) < 1E-11) flag |= 1;
 			if (go && !(crit > 1E-6)) run = false;
 			else if (go && iters >= 1000000u) { flag |= 2; run = false; }
+#pragma unroll
+			for (int j = 0; j < EM_CACHED_K; ++j) { c3[j] = n3[j]; cz3[j] = nz3[j]; }
+			cll = nll;
 		}
 		if (ev_ok && sub == 0) {
 			for (int j = 0; j < K; ++j) A.theta[ib + j] = j == 0 ? t3[0] : (j == 1 ? t3[1] : t3[2]);
