@@ -42,7 +42,10 @@ using namespace lsq;
 
 namespace {
 
-constexpr int COUNT_BLOCK = 256;
+#ifndef LSQ_COUNT_BLOCK
+#define LSQ_COUNT_BLOCK 256
+#endif
+constexpr int COUNT_BLOCK = LSQ_COUNT_BLOCK;       // threads per workgroup of the count kernels
 constexpr unsigned long long BASES_MASK = (1ull << 40) - 1;
 
 // A (read, event) pair the fast kernel does not settle itself: span-start ties that need the
@@ -314,28 +317,6 @@ __device__ inline unsigned wave_sum_u32(unsigned v) {
 	v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);   // row_bcast:15 into rows 1 and 3
 	v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);   // row_bcast:31 into rows 2 and 3
 	return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-}
-
-// Histogram adds of a whole wave, merged by slot before they reach LDS: neighbouring reads of the
-// start-ordered pools mostly land in the same compatibility class, and 64 atomics on one LDS
-// address would run one after the other.  Up to AGG_ROUNDS distinct slots are summed across the
-// wave (one atomic each); whatever is left falls back to one atomic per lane.
-constexpr int AGG_ROUNDS = 3;
-__device__ inline void hist_add_merged(unsigned long long *hist, bool want, const unsigned slot, const unsigned len) {
-	const unsigned lane = threadIdx.x & 63u;
-#pragma unroll 1
-	for (int round = 0; round < AGG_ROUNDS; ++round) {
-		const unsigned long long m = __ballot(want);
-		if (!m) return;
-		const unsigned lead = (unsigned)__ffsll((long long)m) - 1u;
-		const unsigned s0 = (unsigned)__builtin_amdgcn_readlane((int)slot, lead);
-		const bool same = want && slot == s0;
-		const unsigned n = (unsigned)__popcll(__ballot(same));
-		const unsigned sum = wave_sum_u32(same ? len : 0u);
-		if (lane == lead) atomicAdd(&hist[s0], ((unsigned long long)n << 40) | sum);
-		want = want && !same;
-	}
-	if (want) atomicAdd(&hist[slot], (1ull << 40) | len);
 }
 
 // One read against ONE packed event record (index i).  Returns true when a further event has
@@ -890,6 +871,8 @@ __global__ void __launch_bounds__(256) lsq_count_cleanup_kernel(CountArgs A, uns
 // ---- EM: one event per lane (common/read.h:592-660 on compatibility classes) ----------------
 struct EmArgs {
 	unsigned n_events, n_methods, n_cls, n_iso;
+	unsigned n_places;                 // entries of `order`
+	const unsigned *order;             // device event per place of the EM grid
 	const unsigned char *K;
 	const unsigned *cls_base, *iso_base;
 	const unsigned long long *cnt;     // [method][n_cls]
@@ -1025,30 +1008,152 @@ __device__ inline void em_pass_cached(const EmCache &E, const double *th, bool o
 
 // The register-cached pass with the class masks folded into G (an isoform outside the class has
 // G = 0: its term adds an exact zero, so sums and their order are those of em_pass_cached).
-__device__ inline void em_pass_lean(const double (&kd)[EM_CACHED_PAIRS], const double (&gm)[EM_CACHED_PAIRS][EM_CACHED_K], const double (&th)[EM_CACHED_K],
-                                    const bool on, double &ll, double (&z)[EM_CACHED_K]) {
-	double l = 0, zz[EM_CACHED_K] = {0, 0, 0};
+// What a pass leaves behind per pair for the next one: the mixture s, its reciprocal and its
+// logarithm.  Passes follow one another with small steps in s (that is what makes slow events
+// slow), so log s(t+1) = log s(t) + log1p(d) with d = (s(t+1) - s(t)) / s(t), and for |d| < 2^-5 a
+// twelve-term series gives log1p to 1e-19: a chain of six operations instead of the logarithm's twenty.
+// A wave takes the series only when every live pair of every lane is inside that range.
+template <int SLOTS>
+struct EmPairState { double s[SLOTS], r[SLOTS], lg[SLOTS]; };
+
+__device__ inline double log1p_small(double d) {
+	// d (1 - d/2 + d^2/3 - ... - d^11/12), |d| < 2^-5: the first term left out is below 1e-19
+	const double w = d * d, w2 = w * w, w4 = w2 * w2;
+	const double a0 = fma(d, -1.0 / 2.0, 1.0), a1 = fma(d, -1.0 / 4.0, 1.0 / 3.0), a2 = fma(d, -1.0 / 6.0, 1.0 / 5.0),
+	             a3 = fma(d, -1.0 / 8.0, 1.0 / 7.0), a4 = fma(d, -1.0 / 10.0, 1.0 / 9.0), a5 = fma(d, -1.0 / 12.0, 1.0 / 11.0);
+	const double b0 = fma(w, a1, a0), b1 = fma(w, a3, a2), b2 = fma(w, a5, a4);
+	return d * fma(w4, b2, fma(w2, b1, b0));
+}
+
+template <int SLOTS, int KK>
+__device__ inline void em_pass_lean(const double (&kd)[SLOTS], const double (&gm)[SLOTS][KK], const double (&th)[KK],
+                                    const bool on, EmPairState<SLOTS> &P, double &ll, double (&z)[KK], unsigned *n_full = nullptr) {
+	double l = 0, zz[KK];
 #pragma unroll
-	for (int t = 0; t < EM_CACHED_PAIRS; ++t) {
-		double local[EM_CACHED_K], sm = 0;
+	for (int j = 0; j < KK; ++j) zz[j] = 0;
+	double local[SLOTS][KK], sm[SLOTS], safe[SLOTS], r[SLOTS], d[SLOTS];
+	bool on_t[SLOTS], far = false;
 #pragma unroll
-		for (int j = 0; j < EM_CACHED_K; ++j) { local[j] = th[j] * gm[t][j]; sm += local[j]; }
-		const bool on_t = on && kd[t] != 0;
-		const double term = kd[t] * fast_log(on_t ? sm : 1.0);     // an empty pair slot must not send the wave down the library path
-		l += on_t ? term : 0.0;
-		const double kr = (on_t && sm > 0) ? kd[t] * fast_recip(sm) : 0.0;
+	for (int t = 0; t < SLOTS; ++t) {
+		sm[t] = 0;
 #pragma unroll
-		for (int j = 0; j < EM_CACHED_K; ++j) zz[j] += local[j] * kr;
+		for (int j = 0; j < KK; ++j) { local[t][j] = th[j] * gm[t][j]; sm[t] += local[t][j]; }
+		on_t[t] = on && kd[t] != 0;
+		safe[t] = (on_t[t] && sm[t] > 0) ? sm[t] : 1.0;     // an empty pair slot must not send the wave down the library path
+		r[t] = fast_recip(safe[t]);
+		d[t] = (safe[t] - P.s[t]) * P.r[t];
+		far = far || (on_t[t] && !(fabs(d[t]) < 0.03125));
+		if (on_t[t] && !(sm[t] > 0)) far = true;             // log of zero: the full routine gives the reference's -inf
+	}
+#if defined(LSQ_EM_FORCE_SERIES)
+	const bool full = false;
+#elif defined(LSQ_EM_FORCE_FULL)
+	const bool full = true;
+#else
+	const bool full = __any(far);
+#endif
+#ifdef LSQ_EM_DEBUG
+	if (n_full && full) ++*n_full;
+#endif
+#pragma unroll
+	for (int t = 0; t < SLOTS; ++t) {
+#ifdef LSQ_EM_NOLOG      // developer probe: the pass without its logarithm
+		const double lg = sm[t];
+#else
+		double lg = P.lg[t] + log1p_small(d[t]);
+		if (full) {                                  // wave-uniform, taken a handful of times per event
+			asm volatile("" ::: "memory");           // keeps the compiler from flattening the branch into both computations
+			lg = fast_log(on_t[t] ? sm[t] : 1.0);
+		}
+#endif
+		P.s[t] = safe[t]; P.r[t] = r[t]; P.lg[t] = lg;
+		const double term = kd[t] * lg;
+		l += on_t[t] ? term : 0.0;
+		const double kr = (on_t[t] && sm[t] > 0) ? kd[t] * r[t] : 0.0;
+#pragma unroll
+		for (int j = 0; j < KK; ++j) zz[j] += local[t][j] * kr;
 	}
 	ll = group_sum(l);
 #pragma unroll
-	for (int j = 0; j < EM_CACHED_K; ++j) z[j] = group_sum(zz[j]);
+	for (int j = 0; j < KK; ++j) z[j] = group_sum(zz[j]);
+}
+
+// The whole EM of a wave whose events all fit SLOTS (method, class) pairs per lane and KK isoforms,
+// in registers.  The pass for theta(t+2) starts from z(t+1) as soon as that exists, without waiting
+// for the stop test on ll(t+1): the test (a reciprocal, a compare, a ballot) runs beside the next
+// pass instead of between two passes.  One pass per event is thrown away.
+template <int SLOTS, int KK>
+__device__ inline void em_lean(const EmArgs &A, const EmCache &C, const unsigned e, const unsigned sub, const bool ev_ok, const int K, const unsigned ib,
+                               const double inv_n, const bool any_reads, bool run) {
+	double kd[SLOTS], gm[SLOTS][KK], t3[KK], z3[KK];
+#pragma unroll
+	for (int t = 0; t < SLOTS; ++t) {
+		kd[t] = C.kd[t];
+#pragma unroll
+		for (int j = 0; j < KK; ++j) gm[t][j] = (C.cls[t] >> j & 1) ? C.g[t][j] : 0.0;
+	}
+#pragma unroll
+	for (int j = 0; j < KK; ++j) t3[j] = (K == 1) ? 1.0 : 1.0 / (double)K;   // solve/solve.cpp:798-802, read.h:642
+	EmPairState<SLOTS> P;
+#pragma unroll
+	for (int t = 0; t < SLOTS; ++t) { P.s[t] = 1.0; P.r[t] = 1.0; P.lg[t] = 0.0; }
+	unsigned iters = 0;
+	unsigned char flag = 0;
+	double ll = 0;
+	em_pass_lean<SLOTS, KK>(kd, gm, t3, any_reads, P, ll, z3);
+	double c3[KK], cll, cz3[KK];           // candidate: theta(t+1), its log-likelihood and numerators
+#pragma unroll
+	for (int j = 0; j < KK; ++j) c3[j] = z3[j] * inv_n;
+	em_pass_lean<SLOTS, KK>(kd, gm, c3, run, P, cll, cz3);
+#ifdef LSQ_EM_DEBUG
+	unsigned dbg_full = 0, dbg_pass = 0;
+#endif
+	while (__any(run)) {
+		double n3[KK], nll, nz3[KK];
+#pragma unroll
+		for (int j = 0; j < KK; ++j) n3[j] = cz3[j] * inv_n;
+#ifdef LSQ_EM_DEBUG
+		em_pass_lean<SLOTS, KK>(kd, gm, n3, run, P, nll, nz3, &dbg_full); ++dbg_pass;
+#else
+		em_pass_lean<SLOTS, KK>(kd, gm, n3, run, P, nll, nz3);         // speculative: theta(t+2)
+#endif
+		const unsigned cll_ex = (unsigned)((unsigned long long)__double_as_longlong(cll) >> 52) & 0x7FFu;
+		// read.h:659, floating abs; -inf, nan, zero keep the division's own answers
+		const double crit = (cll_ex - 1u < 0x7FEu) ? fabs(1.0 - ll * fast_recip(cll)) : fabs(1.0 - ll / cll);
+		const bool go = run;
+#pragma unroll
+		for (int j = 0; j < KK; ++j) { t3[j] = go ? c3[j] : t3[j]; z3[j] = go ? cz3[j] : z3[j]; }
+		ll = go ? cll : ll;
+		iters += go ? 1u : 0u;
+		if (go && fabs(crit - 1E-6) < 1E-11) flag |= 1;
+		if (go && !(crit > 1E-6)) run = false;
+		else if (go && iters >= 1000000u) { flag |= 2; run = false; }
+#ifdef LSQ_EM_PROBE      // developer probe: event 0 runs a fixed number of passes (latency of a lone wave)
+		if (e == 0) run = iters < (unsigned)LSQ_EM_PROBE;
+#endif
+#pragma unroll
+		for (int j = 0; j < KK; ++j) { c3[j] = n3[j]; cz3[j] = nz3[j]; }
+		cll = nll;
+	}
+#ifdef LSQ_EM_DEBUG
+	if ((threadIdx.x & 63u) == 0 && dbg_pass > 100) printf("wave %u passes %u full %u\n", (blockIdx.x * blockDim.x + threadIdx.x) / 64u, dbg_pass, dbg_full);
+#endif
+	if (ev_ok && sub == 0) {
+#pragma unroll
+		for (int j = 0; j < KK; ++j) if (j < K) A.theta[ib + j] = t3[j];
+		A.logll[e] = ll;
+		A.iters[e] = iters;
+		A.flags[e] = flag;
+	}
 }
 
 __global__ void __launch_bounds__(256) lsq_em_kernel(EmArgs A) {
 	const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
-	const unsigned e = gid / EM_LANES, sub = gid % EM_LANES;
-	const bool ev_ok = e < A.n_events;
+	const unsigned place = gid / EM_LANES, sub = gid % EM_LANES;
+	// events in the order of A.order: the small ones (two isoforms, one pair per lane) first, then the
+	// rest, each group filling whole waves (0xFFFFFFFF = empty place)
+	const unsigned e = place < A.n_places ? A.order[place] : 0xFFFFFFFFu;
+	const bool ev_ok = e != 0xFFFFFFFFu;
 	const int K = ev_ok ? A.K[e] : 1;
 	const unsigned cb = ev_ok ? A.cls_base[e] : 0, ib = ev_ok ? A.iso_base[e] : 0;
 	const int nc = (1 << K) - 1;
@@ -1091,50 +1196,11 @@ __global__ void __launch_bounds__(256) lsq_em_kernel(EmArgs A) {
 	// no reads: theta stays 1/K, log-likelihood 0; one isoform: theta = 1 (solve/solve.cpp:798-802)
 	bool run = ev_ok && n_total > 0 && K > 1;
 	const bool any_reads = ev_ok && n_total > 0;
-	if (__all(cached || !ev_ok)) {
-		// every event of the wave fits the registers: a loop with nothing but the lean pass in it
-		double gm[EM_CACHED_PAIRS][EM_CACHED_K], t3[EM_CACHED_K], z3[EM_CACHED_K];
-#pragma unroll
-		for (int t = 0; t < EM_CACHED_PAIRS; ++t)
-#pragma unroll
-			for (int j = 0; j < EM_CACHED_K; ++j) gm[t][j] = (C.cls[t] >> j & 1) ? C.g[t][j] : 0.0;
-#pragma unroll
-		for (int j = 0; j < EM_CACHED_K; ++j) t3[j] = th[j];
-		em_pass_lean(C.kd, gm, t3, any_reads, ll, z3);
-		// The pass for theta(t+2) starts from z(t+1) as soon as that exists, without waiting for
-		// the stop test on ll(t+1): the test (a reciprocal, a compare, a ballot) then runs beside
-		// the next pass instead of between two passes.  One pass per event is thrown away.
-		double c3[EM_CACHED_K], cll, cz3[EM_CACHED_K];           // candidate: theta(t+1), its log-likelihood and numerators
-#pragma unroll
-		for (int j = 0; j < EM_CACHED_K; ++j) c3[j] = z3[j] * inv_n;
-		em_pass_lean(C.kd, gm, c3, run, cll, cz3);
-		while (__any(run)) {
-			double n3[EM_CACHED_K], nll, nz3[EM_CACHED_K];
-#pragma unroll
-			for (int j = 0; j < EM_CACHED_K; ++j) n3[j] = cz3[j] * inv_n;
-			em_pass_lean(C.kd, gm, n3, run, nll, nz3);            // speculative: theta(t+2)
-			const unsigned cll_ex = (unsigned)((unsigned long long)__double_as_longlong(cll) >> 52) & 0x7FFu;
-			const double crit = (cll_ex - 1u < 0x7FEu) ? fabs(1.0 - ll * fast_recip(cll)) : fabs(1.0 - ll / cll);   // read.h:659
-			const bool go = run;
-#pragma unroll
-			for (int j = 0; j < EM_CACHED_K; ++j) { t3[j] = go ? c3[j] : t3[j]; z3[j] = go ? cz3[j] : z3[j]; }
-			ll = go ? cll : ll;
-			iters += go ? 1u : 0u;
-			if (go && fabs(crit - 1E-6) < 1E-11) flag |= 1;
-			if (go && !(crit > 1E-6)) run = false;
-			else if (go && iters >= 1000000u) { flag |= 2; run = false; }
-#pragma unroll
-			for (int j = 0; j < EM_CACHED_K; ++j) { c3[j] = n3[j]; cz3[j] = nz3[j]; }
-			cll = nll;
-		}
-		if (ev_ok && sub == 0) {
-			for (int j = 0; j < K; ++j) A.theta[ib + j] = j == 0 ? t3[0] : (j == 1 ? t3[1] : t3[2]);
-			A.logll[e] = ll;
-			A.iters[e] = iters;
-			A.flags[e] = flag;
-		}
-		return;
-	}
+	// every event of the wave fits the registers: a loop with nothing but the lean pass in it
+#ifndef LSQ_EM_NO_ONE_SLOT
+	if (__all(!ev_ok || (cached && K <= 2 && n_pairs <= EM_LANES))) { em_lean<1, 2>(A, C, e, sub, ev_ok, K, ib, inv_n, any_reads, run); return; }
+#endif
+	if (__all(!ev_ok || cached)) { em_lean<EM_CACHED_PAIRS, EM_CACHED_K>(A, C, e, sub, ev_ok, K, ib, inv_n, any_reads, run); return; }
 	if (cached) em_pass_cached(C, th, any_reads, ll, z);
 	else em_pass(A, cb, ib, K, nc, sub, any_reads, th, ll, z);
 	while (__any(run)) {
@@ -1464,7 +1530,8 @@ struct lsq_ctx {
 	DevBuf<BucketDesc> buckets;
 	DevBuf<uint8_t> images, strand_rank, dK;
 	DevBuf<TieRec> ties;
-	DevBuf<uint32_t> cls_base, iso_base, iters;
+	DevBuf<uint32_t> cls_base, iso_base, iters, em_order;
+	unsigned em_places = 0;
 	DevBuf<double> G, theta, logll;
 	DevBuf<uint8_t> flags;
 	DevBuf<unsigned long long> cnt, bases;
@@ -1561,6 +1628,23 @@ int lsq_events_upload(lsq_ctx *c, lsq_events *E) {
 	if ((rc = c->dK.upload(E->dev_K.data(), E->dev_K.size(), c->stream))) return rc;
 	if ((rc = c->cls_base.upload(E->dev_cls_base.data(), E->dev_cls_base.size(), c->stream))) return rc;
 	if ((rc = c->iso_base.upload(E->dev_iso_base.data(), E->dev_iso_base.size(), c->stream))) return rc;
+	{
+		// EM places: events with at most two isoforms and one (method, class) pair per lane first, then
+		// the others; each group padded to whole waves (16 events) so that a wave runs one loop shape
+		const size_t n_dev = E->dev2out.size();
+		std::vector<uint32_t> order;
+		order.reserve(n_dev + 32);
+		for (int pass = 0; pass < 2; ++pass) {
+			for (size_t d = 0; d < n_dev; ++d) {
+				const int K = E->dev_K[d];
+				const bool small = K <= 2 && E->n_methods * ((1 << K) - 1) <= EM_LANES;
+				if (small == (pass == 0)) order.push_back((uint32_t)d);
+			}
+			while (order.size() % (64 / EM_LANES)) order.push_back(0xFFFFFFFFu);
+		}
+		c->em_places = (unsigned)order.size();
+		if ((rc = c->em_order.upload(order.data(), order.size(), c->stream))) return rc;
+	}
 	// G = 1/ARS (common/read.h:331-340), device isoform order, per method
 	const size_t n_iso = E->n_iso_total, M = (size_t)E->n_methods;
 	std::vector<double> G(std::max<size_t>(M * n_iso, 1), 0.0);
@@ -1904,8 +1988,9 @@ static int run_solve(lsq_ctx *c) {
 		EmArgs A;
 		A.n_events = n_ev; A.n_methods = (unsigned)E.n_methods; A.n_cls = E.n_cls_total; A.n_iso = E.n_iso_total;
 		A.K = c->dK.p; A.cls_base = c->cls_base.p; A.iso_base = c->iso_base.p;
+		A.n_places = c->em_places; A.order = c->em_order.p;
 		A.cnt = c->cnt.p; A.G = c->G.p; A.theta = c->theta.p; A.logll = c->logll.p; A.iters = c->iters.p; A.flags = c->flags.p;
-		hipLaunchKernelGGL(lsq_em_kernel, dim3((n_ev * EM_LANES + 255) / 256), dim3(256), 0, st, A);
+		hipLaunchKernelGGL(lsq_em_kernel, dim3((c->em_places * EM_LANES + 255) / 256), dim3(256), 0, st, A);
 		HIP_TRY(hipGetLastError());
 	}
 	HIP_TRY(hipEventRecord(c->ev3, st));

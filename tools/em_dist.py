@@ -24,3 +24,7 @@ w = np.concatenate([it_dev, np.zeros(pad, it_dev.dtype)]).reshape(-1, 16).max(ax
 print("waves", len(w), "wave max iters: mean %.1f median %d p90 %d max %d  sum %d" % (w.mean(), np.median(w), np.percentile(w, 90), w.max(), w.sum()))
 wg = np.concatenate([w, np.zeros((-len(w)) % 4, w.dtype)]).reshape(-1, 4)
 print("sum over waves / 1024 SIMDs = %.1f iterations per SIMD" % (w.sum() / 1024.0))
+Ks = np.array([ev.K(int(i)) for i in d2o])
+for k in sorted(set(Ks.tolist())):
+    sel = it_dev[Ks == k]
+    print("K=%d events=%d iters mean %.1f p99 %d max %d; top5 %s" % (k, len(sel), sel.mean(), np.percentile(sel, 99), sel.max(), np.sort(sel)[-5:]))
