@@ -1506,6 +1506,9 @@ struct DevBuf {
 	}
 };
 
+template <class T>
+struct DevView { T *p = nullptr; size_t n = 0; };     // a slice of somebody else's allocation
+
 struct MethodReads {
 	bool present = false;
 	uint64_t n_retained = 0, n_retained_blocks = 0, total_slots = 0;
@@ -1534,15 +1537,15 @@ struct lsq_ctx {
 	unsigned em_places = 0;
 	DevBuf<double> G, theta, logll;
 	DevBuf<uint8_t> flags;
-	DevBuf<unsigned long long> cnt, bases;
+	DevBuf<unsigned long long> counters;   // cnt | bases | exc_count | dbg in one allocation: one memset per count
+	DevView<unsigned long long> cnt, bases, dbg;
 	DevBuf<ExcEntry> exc;                  // shared by the methods (launches are serialised on the stream)
-	DevBuf<unsigned> exc_count;            // per method: [2m] appended, [2m+1] overflow flag
+	DevView<unsigned> exc_count;           // per method: [2m] appended, [2m+1] overflow flag
 	DevBuf<unsigned> cov_off, cut_off;     // ingest tables: covered regions and bucket cuts per chromosome id
 	DevBuf<int> cov_s, cov_e, cut_lo, chrom_first_bucket;
 	DevBuf<unsigned> bin_base;             // per bucket: first of its bins among all bins (n_buckets + 1)
 	size_t n_fine = 0;
 	unsigned n_chrom_tables = 0;
-	DevBuf<unsigned long long> dbg;
 	bool redo_checked = true;
 	MethodReads reads[LSQ_MAX_METHODS];
 	bool counted = false, solved = false;
@@ -1658,14 +1661,18 @@ int lsq_events_upload(lsq_ctx *c, lsq_events *E) {
 	}
 	if ((rc = c->G.upload(G.data(), M * n_iso, c->stream))) return rc;
 	const size_t n_cls = E->n_cls_total, n_ev = E->dev2out.size();
-	if ((rc = c->cnt.alloc(std::max<size_t>(M, 1) * n_cls))) return rc;
-	if ((rc = c->bases.alloc(std::max<size_t>(M, 1) * n_cls))) return rc;
+	{
+		const size_t per = std::max<size_t>(M, 1) * n_cls;
+		if ((rc = c->counters.alloc(2 * per + LSQ_MAX_METHODS + 8))) return rc;
+		c->cnt.p = c->counters.p; c->cnt.n = per;
+		c->bases.p = c->counters.p + per; c->bases.n = per;
+		c->exc_count.p = reinterpret_cast<unsigned *>(c->counters.p + 2 * per); c->exc_count.n = 2 * LSQ_MAX_METHODS;
+		c->dbg.p = c->counters.p + 2 * per + LSQ_MAX_METHODS; c->dbg.n = 8;
+	}
 	if ((rc = c->theta.alloc(n_iso))) return rc;
 	if ((rc = c->logll.alloc(n_ev))) return rc;
 	if ((rc = c->iters.alloc(n_ev))) return rc;
 	if ((rc = c->flags.alloc(n_ev))) return rc;
-	if ((rc = c->exc_count.alloc(2 * LSQ_MAX_METHODS))) return rc;
-	if ((rc = c->dbg.alloc(8))) return rc;
 	{
 		// ingest tables: covered regions (by chromosome id) and the bucket cuts
 		const size_t nc = E->covered.size();
@@ -1869,12 +1876,7 @@ static int run_count(lsq_ctx *c, bool all_reads) {
 	const size_t n_cls = E.n_cls_total;
 	const int M = E.n_methods;
 	hipStream_t st = c->stream;
-	if (M * n_cls) {
-		HIP_TRY(hipMemsetAsync(c->cnt.p, 0, (size_t)M * n_cls * sizeof(unsigned long long), st));
-		HIP_TRY(hipMemsetAsync(c->bases.p, 0, (size_t)M * n_cls * sizeof(unsigned long long), st));
-	}
-	HIP_TRY(hipMemsetAsync(c->exc_count.p, 0, c->exc_count.n * sizeof(unsigned), st));
-	HIP_TRY(hipMemsetAsync(c->dbg.p, 0, 8 * sizeof(unsigned long long), st));
+	HIP_TRY(hipMemsetAsync(c->counters.p, 0, c->counters.n * sizeof(unsigned long long), st));
 	c->fast_launched = 0;
 	HIP_TRY(hipEventRecord(c->ev0, st));      // ev0..ev1 brackets the count kernel launches only
 	const unsigned generic_tables_bytes = (std::max<unsigned>(E.max_lds_bytes, 16) + 15u) & ~15u;
@@ -2077,6 +2079,23 @@ int lsq_results_solve(lsq_ctx *c, double *theta, double *logll, uint32_t *em_ite
 	return LSQ_OK;
 }
 
+} // extern "C"
+
+namespace {
+// the three result arrays to the caller's device buffers in one launch (8-byte words)
+__global__ void __launch_bounds__(256) lsq_copy_results_kernel(unsigned long long *d0, const unsigned long long *s0, size_t n0, unsigned long long *d1,
+                                                               const unsigned long long *s1, size_t n1, unsigned long long *d2, const unsigned long long *s2, size_t n2) {
+	const size_t gsz = (size_t)gridDim.x * blockDim.x;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n0 + n1 + n2; i += gsz) {
+		if (i < n0) d0[i] = s0[i];
+		else if (i < n0 + n1) d1[i - n0] = s1[i - n0];
+		else d2[i - n0 - n1] = s2[i - n0 - n1];
+	}
+}
+} // namespace
+
+extern "C" {
+
 int lsq_results_copy_device(lsq_ctx *c, void *d_class_count, void *d_theta, void *d_logll) {
 	if (!c) return fail(LSQ_E_ARG, "null context");
 	if (!c->counted) return fail(LSQ_E_STATE, "lsq_count must come first");
@@ -2084,9 +2103,13 @@ int lsq_results_copy_device(lsq_ctx *c, void *d_class_count, void *d_theta, void
 	HIP_TRY(hipSetDevice(c->device));
 	const lsq_events &E = *c->E;
 	const size_t n_cls = E.n_cls_total, M = (size_t)E.n_methods;
-	if (d_class_count && M * n_cls) HIP_TRY(hipMemcpyAsync(d_class_count, c->cnt.p, M * n_cls * sizeof(unsigned long long), hipMemcpyDeviceToDevice, c->stream));
-	if (d_theta && E.n_iso_total) HIP_TRY(hipMemcpyAsync(d_theta, c->theta.p, (size_t)E.n_iso_total * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-	if (d_logll && !E.dev2out.empty()) HIP_TRY(hipMemcpyAsync(d_logll, c->logll.p, E.dev2out.size() * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+	const size_t n0 = d_class_count ? M * n_cls : 0, n1 = d_theta ? (size_t)E.n_iso_total : 0, n2 = d_logll ? E.dev2out.size() : 0;
+	if (n0 + n1 + n2) {
+		const unsigned grid = (unsigned)std::min<size_t>((n0 + n1 + n2 + 255) / 256, (size_t)c->n_cu * 8);
+		hipLaunchKernelGGL(lsq_copy_results_kernel, dim3(grid), dim3(256), 0, c->stream, (unsigned long long *)d_class_count, c->cnt.p, n0,
+		                   (unsigned long long *)d_theta, (const unsigned long long *)c->theta.p, n1, (unsigned long long *)d_logll, (const unsigned long long *)c->logll.p, n2);
+		HIP_TRY(hipGetLastError());
+	}
 	return LSQ_OK;
 }
 
