@@ -54,7 +54,7 @@ constexpr unsigned long long BASES_MASK = (1ull << 40) - 1;
 struct ExcEntry {
 	unsigned long long slot;       // index into the pool
 	unsigned bucket;
-	unsigned ev_pool_scan;         // event index in the bucket | pool << 30 | scan << 31
+	unsigned ev_pool_scan;         // event index in the bucket | pool << 29 (0 one block, 1 two blocks, 2 n blocks) | scan << 31
 };
 
 struct CountArgs {
@@ -72,6 +72,8 @@ struct CountArgs {
 	const unsigned long long *p1_off, *p2_off, *pn_off, *slot_off;    // n_buckets + 1 each
 	const unsigned *wg_first;          // per workgroup of the fast kernel's grid: the bucket its slot range starts in
 	unsigned long long total_slots;
+	unsigned long long n_pn;           // reads with three or more blocks
+	unsigned n_workers;                // leading workgroups of the fast kernel's grid that take them
 	unsigned long long *cnt, *bases;
 	struct ExcEntry *exc;              // exception list (rare (read, event) pairs the fast kernel hands to the cleanup kernel)
 	unsigned *exc_count;               // [0] entries appended, [1] set to 1 by the cleanup kernel when [0] > exc_cap
@@ -296,7 +298,7 @@ __device__ inline void emit_exception(const FastCtx &C, unsigned r, unsigned i, 
 		ExcEntry e;
 		e.slot = C.slot0 + r;
 		e.bucket = C.bucket;
-		e.ev_pool_scan = i | (C.pool << 30) | (scan << 31);
+		e.ev_pool_scan = i | (C.pool << 29) | (scan << 31);
 		C.exc[slot] = e;
 	}
 }
@@ -477,15 +479,16 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 	const unsigned first_rel = (unsigned)(g0 - w0 * RPW);                            // 0 or 1: reads of word w0 before the range
 	const unsigned n_rel = (unsigned)(g1 - g0);
 	uint4 nxt[STREAM_WORDS];
-	auto fetch = [&](unsigned wt) {
+	auto fetch_into = [&](uint4 (&dst)[STREAM_WORDS], unsigned wt) {
 #pragma unroll
 		for (int k = 0; k < STREAM_WORDS; ++k) {
 			const unsigned w = wt + lane * (unsigned)STREAM_WORDS + (unsigned)k;      // a lane's words are neighbours in the pool
 			u32x4 t = {0u, 0u, 0u, 0u};
 			if (w < ww1) t = src[w0 + w];
-			nxt[k] = make_uint4(t.x, t.y, t.z, t.w);
+			dst[k] = make_uint4(t.x, t.y, t.z, t.w);
 		}
 	};
+	auto fetch = [&](unsigned wt) { fetch_into(nxt, wt); };
 	// bin record of position p -> (cell that can hold p, first event of the bin)
 	auto locate = [&](int p, unsigned &cell, unsigned &first_event) {
 		const int rel = p - d.lo;
@@ -619,6 +622,58 @@ __global__ void __launch_bounds__(256) lsq_wg_plan_kernel(const unsigned long lo
 	wg_first[g] = lo_b;
 }
 
+// Reads with three or more blocks (about 1 % of a typical read set), inside the fast kernel's grid:
+// the first `n_workers` workgroups take them a lane each, tables read from global memory (L2), global
+// atomics -- latency-bound work that runs beside the streaming workgroups instead of in a kernel of
+// its own after them.  Same evaluation as the cleanup kernel's (candidate window, span-start rule,
+// branching segment walk); a span-start tie that needs the strand/name order goes to the exception
+// list.  No local arrays, no calls: the kernel keeps a zero-byte private segment.
+__device__ inline void pool_n_worker(const CountArgs &A, const unsigned long long n_pn, const unsigned n_workers) {
+	const unsigned long long gsz = (unsigned long long)n_workers * COUNT_BLOCK;
+	for (unsigned long long g = (unsigned long long)blockIdx.x * COUNT_BLOCK + threadIdx.x; g < n_pn; g += gsz) {
+		const unsigned b = A.pn_bucket[g];
+		const BucketDesc *d = A.buckets + b;
+		if (d->kind != 1) continue;
+		const unsigned *bins = reinterpret_cast<const unsigned *>(A.images + d->img_off);
+		const uint4 *recs = reinterpret_cast<const uint4 *>(A.images + d->img_off + d->ev_off);
+		const int2 *blk = A.pn_se + A.pn_blk_off[g];
+		const int nblk = (int)A.pn_nblk[g];
+		const int p = blk[0].x, q = blk[nblk - 1].y;
+		int total = 0;
+		for (int k = 0; k < nblk; ++k) total += blk[k].y - blk[k].x;
+		const int rel = p - d->lo;
+		const unsigned bin = rel <= 0 ? 0u : min((unsigned)rel >> d->shift, d->n_bins - 1u);
+		for (unsigned i = bins[4u * bin] >> 16; i < d->n_events; ++i) {
+			const uint4 w0 = recs[3u * i];
+			const int2 *segs = reinterpret_cast<const int2 *>(recs + 3u * i + 1u);     // four (start, end) pairs
+			const int gs = segs[0].x, ge = (int)w0.x;
+			if (gs > p) break;
+			bool cand = p <= ge;
+			if (cand && p == gs) {
+				if (q == ge) {
+					const unsigned slot = atomicAdd(A.exc_count, 1u);
+					if (slot < A.exc_cap) { ExcEntry e; e.slot = g; e.bucket = b; e.ev_pool_scan = i | (2u << 29); A.exc[slot] = e; }
+				}
+				cand = false;       // q < ge: ordered before the event; q == ge: the cleanup kernel decides
+				if (q > ge) cand = true;
+			}
+			if (cand) {
+				const int nseg = (int)((w0.y >> FAST_NSEG_SHIFT) & 7u);
+				Walk w;
+				for (int k = 0; k < nblk; ++k) { const int2 bk = blk[k]; if (!w.block(segs, nseg, bk.x, bk.y)) break; }
+				const unsigned long long tbl = ((unsigned long long)w0.w << 32) | w0.z;
+				const unsigned cls = w.mask < 16u ? (unsigned)(tbl >> (4u * w.mask)) & 0xFu : 0u;
+				if (cls != 0 && 50ll * w.matched > 49ll * total) {
+					const unsigned slot = d->cls_base + (w0.y & 0xFFFFu) + cls - 1;
+					atomicAdd(&A.cnt[slot], 1ull);
+					atomicAdd(&A.bases[slot], (unsigned long long)(unsigned)w.matched);
+				}
+			}
+			if (p <= ge && !(w0.y & FAST_FLAG_OVERLAPS_NEXT)) break;
+		}
+	}
+}
+
 #ifndef LSQ_FAST_WAVES
 #define LSQ_FAST_WAVES 1
 #endif
@@ -675,14 +730,16 @@ __global__ void __launch_bounds__(COUNT_BLOCK, LSQ_FAST_WAVES) lsq_count_fast_ke
 	// LDS: two table buffers (the bucket being streamed; the next one, staged meanwhile), then the waves' rings
 	extern __shared__ __align__(16) unsigned char lds[];
 	const unsigned tid = threadIdx.x;
+	if (blockIdx.x < A.n_workers) { pool_n_worker(A, A.n_pn, A.n_workers); return; }
+	const unsigned wg = blockIdx.x - A.n_workers, n_wg = gridDim.x - A.n_workers;     // the streaming workgroups
 	uint4 *wave_queue = reinterpret_cast<uint4 *>(lds + (1u + A.double_buffer) * A.tables_lds_bytes) + (tid >> 6) * WAVE_QUEUE_WORDS;
-	const unsigned long long s_begin = A.total_slots * blockIdx.x / gridDim.x;
-	const unsigned long long s_end = A.total_slots * (blockIdx.x + 1ull) / gridDim.x;
+	const unsigned long long s_begin = A.total_slots * wg / n_wg;
+	const unsigned long long s_end = A.total_slots * (wg + 1ull) / n_wg;
 	if (s_begin >= s_end) return;
 	if (A.ablate & 4096u) return;       // developer switch: dispatch cost only
 	unsigned cur = 0;
 	{
-		const unsigned b0 = find_bucket(A, A.wg_first[blockIdx.x], s_begin, s_end);   // wg_first: lsq_wg_plan_kernel
+		const unsigned b0 = find_bucket(A, A.wg_first[wg], s_begin, s_end);   // wg_first: lsq_wg_plan_kernel
 		if (b0 >= A.n_buckets) return;
 		stage_bucket(A, b0, lds);
 	}
@@ -833,15 +890,17 @@ __global__ void __launch_bounds__(256) lsq_count_cleanup_kernel(CountArgs A, uns
 		for (unsigned long long k = gtid; k < n; k += gsz) {
 			const ExcEntry e = A.exc[k];
 			const GlobalBucket G = global_bucket(A, e.bucket);
-			const unsigned i = e.ev_pool_scan & 0x3FFFFFFFu, pool = (e.ev_pool_scan >> 30) & 1u;
+			const unsigned i = e.ev_pool_scan & 0x1FFFFFFFu, pool = (e.ev_pool_scan >> 29) & 3u;
 			const bool scan = (e.ev_pool_scan >> 31) != 0;
 			int2 blk[2];
-			if (pool == 0) { blk[0] = A.p1[e.slot]; eval_read_global(A, G, blk, 1, i, scan, A.p1_strand[e.slot], A.p1_line[e.slot]); }
+			if (pool == 2) { const unsigned o0 = A.pn_blk_off[e.slot]; eval_read_global(A, G, A.pn_se + o0, (int)A.pn_nblk[e.slot], i, scan, A.pn_strand[e.slot], A.pn_line[e.slot]); }
+			else if (pool == 0) { blk[0] = A.p1[e.slot]; eval_read_global(A, G, blk, 1, i, scan, A.p1_strand[e.slot], A.p1_line[e.slot]); }
 			else { const int4 v = A.p2[e.slot]; blk[0] = make_int2(v.x, v.y); blk[1] = make_int2(v.z, v.w); eval_read_global(A, G, blk, 2, i, scan, A.p2_strand[e.slot], A.p2_line[e.slot]); }
 		}
 	}
-	// ---- the reads with three or more blocks, one lane each
-	for (unsigned long long g = gtid; g < n_pn; g += gsz) {
+	// ---- all_reads mode: the reads with three or more blocks, one lane each (otherwise the fast kernel's
+	// pool-n workers have done them)
+	for (unsigned long long g = gtid; all_reads && g < n_pn; g += gsz) {
 		const unsigned b = A.pn_bucket[g];
 		if (A.buckets[b].kind != 1) continue;
 		const GlobalBucket G = global_bucket(A, b);
@@ -1925,15 +1984,20 @@ static int run_count(lsq_ctx *c, bool all_reads) {
 		A.exc = c->exc.p; A.exc_count = c->exc_count.p + 2 * m; A.exc_cap = (unsigned)c->exc.n;
 		A.dbg = c->dbg.p;
 		const unsigned long long n_p1 = mr.p1.n / 2, n_p2 = mr.p2.n / 4, n_pn = mr.pn_strand.n;
+		// pool-n workers: one workgroup per CU at most, one lane per read and pass
+		A.n_pn = n_pn;
+		unsigned workers_per_cu = 2;
+		if (const char *e = getenv("LSQ_POOLN_WORKERS")) { int v = atoi(e); if (v >= 1 && v <= 8) workers_per_cu = (unsigned)v; }
+		A.n_workers = (unsigned)std::min<unsigned long long>((n_pn + COUNT_BLOCK - 1) / COUNT_BLOCK, (unsigned long long)c->n_cu * workers_per_cu);
 		if (c->has_fast) {
 			if (!all_reads) {
 				HIP_TRY(hipEventRecord(c->evf0[m], st));
-				hipLaunchKernelGGL(lsq_count_fast_kernel, dim3((unsigned)grid), dim3(COUNT_BLOCK), lds_bytes, st, A);
+				hipLaunchKernelGGL(lsq_count_fast_kernel, dim3((unsigned)grid + A.n_workers), dim3(COUNT_BLOCK), lds_bytes, st, A);
 				HIP_TRY(hipGetLastError());
 				HIP_TRY(hipEventRecord(c->evf1[m], st));
 				c->fast_launched |= 1 << m;
 			}
-			const unsigned long long work = all_reads ? std::max<unsigned long long>(n_pn, 64ull * E.buckets.size()) : std::max<unsigned long long>(n_pn, 4096);
+			const unsigned long long work = all_reads ? std::max<unsigned long long>(n_pn, 64ull * E.buckets.size()) : 4096ull;
 			const unsigned cgrid = (unsigned)std::min<unsigned long long>((work + 255) / 256, (unsigned long long)c->n_cu * 32);
 			hipLaunchKernelGGL(lsq_count_cleanup_kernel, dim3(std::max(cgrid, 1u)), dim3(256), 0, st, A, n_p1, n_p2, n_pn, all_reads ? 1 : 0);
 			HIP_TRY(hipGetLastError());
