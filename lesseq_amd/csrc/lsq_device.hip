@@ -27,6 +27,7 @@
 #include <memory>
 #include <numeric>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "lsq_internal.hpp"
@@ -537,23 +538,28 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 					const int lo = (int)cw.x, hi = (int)cw.y, hi2 = (int)cw.z;
 					const unsigned width = has ? (unsigned)(hi - lo) : 0u;
 					unsigned nA = 0, sA = 0, nX = 0, sX = 0;
+					// all but the first and last steps of a workgroup's range lie wholly inside it: no per-read range test there
+					const bool interior = wt + TILE <= ww1 && (wt > 0u || first_rel == 0u) && (wt + TILE) * 2u - first_rel <= n_rel;
+					auto decide = [&](auto whole_step) {
 #pragma unroll
-					for (int j = 0; j < N_READS; ++j) {
-						const int kk = k0 + j / 2;
-						const int ra = (j & 1) ? (int)cur[kk].z : (int)cur[kk].x, rb = (j & 1) ? (int)cur[kk].w : (int)cur[kk].y;
-						const unsigned wj = wt + lane * (unsigned)STREAM_WORDS + (unsigned)kk;
-						const unsigned rel = wj * 2u + (unsigned)(j & 1) - first_rel;      // position in the range (wraps above n_rel when outside)
-						const bool in = wj < ww1 && rel < n_rel;
-						const bool m = in && (unsigned)(ra - lo) < width;
-						const bool a = m && rb <= hi;
-						const bool x = m && !a && rb <= hi2;
-						const unsigned len = (unsigned)(rb - ra);
-						nA += a ? 1u : 0u; sA += a ? len : 0u;
-						nX += x ? 1u : 0u; sX += x ? len : 0u;
-						park[j] = in && !a && !x && !(A.ablate & 17u);
-						pe0[j] = make_uint4((unsigned)ra, (unsigned)rb, m ? owner_word : PARK_EVENT_UNKNOWN, rel);
-						pe1[j] = make_uint4(0, 0, 0, 0);
-					}
+						for (int j = 0; j < N_READS; ++j) {
+							const int kk = k0 + j / 2;
+							const int ra = (j & 1) ? (int)cur[kk].z : (int)cur[kk].x, rb = (j & 1) ? (int)cur[kk].w : (int)cur[kk].y;
+							const unsigned wj = wt + lane * (unsigned)STREAM_WORDS + (unsigned)kk;
+							const unsigned rel = wj * 2u + (unsigned)(j & 1) - first_rel;      // position in the range (wraps above n_rel when outside)
+							const bool in = decltype(whole_step)::value || (wj < ww1 && rel < n_rel);
+							const bool m = in && (unsigned)(ra - lo) < width;
+							const bool a = m && rb <= hi;
+							const bool x = m && !a && rb <= hi2;
+							const unsigned len = (unsigned)(rb - ra);
+							nA += a ? 1u : 0u; sA += a ? len : 0u;
+							nX += x ? 1u : 0u; sX += x ? len : 0u;
+							park[j] = in && !a && !x && !(A.ablate & 17u);
+							pe0[j] = make_uint4((unsigned)ra, (unsigned)rb, m ? owner_word : PARK_EVENT_UNKNOWN, rel);
+							pe1[j] = make_uint4(0, 0, 0, 0);
+						}
+					};
+					if (interior) decide(std::true_type{}); else decide(std::false_type{});
 					const unsigned sa = cw.w & 0xFFFFu, sb = cw.w >> 16;
 					if (!(A.ablate & (1u | 16384u))) {
 						const unsigned long long addA = ((unsigned long long)nA << 40) | sA;
