@@ -346,3 +346,44 @@ def test_many_block_reads_and_the_ingest_block_limit(tmp_path, monkeypatch):
         ctx.upload_reads(0, L.Reads.from_mrf("big.mrf", ev))
     assert ei.value.status == -5
     ctx.close()
+
+
+def test_long_introns_wide_bins_and_a_hot_spot(tmp_path):
+    """spans of megabases: the bucket's coordinate bins are far wider than the ingest's per-bin sort
+    handles (the reads of a bin stay in arrival order, so neighbouring lanes see different cells),
+    plus one exon that takes most of the reads"""
+    import random
+    import golden_inputs as gi
+    rng = random.Random(77)
+    R = 60
+    iv, mp, genes = [], [], []
+    p = 1000
+    for g in range(8):
+        ex = [(p, p + 220), (p + 1_500_000, p + 1_500_180), (p + 3_000_000, p + 3_000_260)]
+        forms = [ex, [ex[0], ex[2]]]
+        for k, f in enumerate(forms):
+            iv.append(gi_line("L%d.%d" % (g, k), "c1", "+", f))
+            mp.append("L%d\tL%d.%d\n" % (g, g, k))
+        genes.append(forms)
+        p += 400_000 if g % 2 else 3_400_000       # every other gene starts inside the previous one's span
+    reads = []
+    for n in range(40000):
+        forms = genes[0] if rng.random() < 0.6 else genes[rng.randrange(len(genes))]
+        f = forms[rng.randrange(2)]
+        tlen = sum(e - s for s, e in f)
+        ln = rng.choice([R, R, R, 25])
+        t0 = rng.randint(0, 150) if rng.random() < 0.5 else rng.randint(0, tlen - ln)
+        reads.append(gi.mrf_line("c1", "+", gi.transcript_blocks(f, min(t0, tlen - ln), ln)))
+    _write(tmp_path / "l.interval", "".join(iv))
+    _write(tmp_path / "l.map", "".join(mp))
+    _write(tmp_path / "l.mrf", "AlignmentBlocks\n" + "".join(reads))
+    argv = ["0", "l", "./", "LH_GENE_TXT", str(tmp_path / "l.interval"), "UCSC_GENE2ISOFORM", str(tmp_path / "l.map"),
+            "0", "100000", "MRF_SINGLE", "SHORT_READ", str(R), str(tmp_path / "l.mrf"), str(40000 * R)]
+    rc, otext, exact = ob.run("solve", argv)
+    assert rc == 0
+    got = gpu_exact(argv)
+    compare_exact(got, exact, "long introns")
+    assert sum(sum(g["supports"]) for g in got) > 30000
+    rc, text = L.cli_run("count", argv[:-1])
+    rc2, ctext, _ = ob.run("count", argv[:-1])
+    assert rc == rc2 == 0 and text == ctext
