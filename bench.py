@@ -160,9 +160,16 @@ def main():
     if world > 1:
         # the whole job's tables on every rank (untimed hand-off; over RCCL on a real multi-GPU node)
         ctx.synchronize()          # the library's stream -> visible to torch's stream
-        dist.all_gather_into_tensor(g_cnt, t_cnt.to(comm_dev))
-        dist.all_gather_into_tensor(g_theta, t_theta.to(comm_dev))
-        dist.all_gather_into_tensor(g_ll, t_ll.to(comm_dev))
+        gather_ms = []
+        for _ in range(3):         # first call sets the communicator up; the last is the one reported
+            torch.cuda.synchronize()
+            dist.barrier()
+            tg = time.perf_counter()
+            dist.all_gather_into_tensor(g_cnt, t_cnt.to(comm_dev))
+            dist.all_gather_into_tensor(g_theta, t_theta.to(comm_dev))
+            dist.all_gather_into_tensor(g_ll, t_ll.to(comm_dev))
+            torch.cuda.synchronize()
+            gather_ms.append((time.perf_counter() - tg) * 1e3)
         assert int(g_cnt.view(world, -1)[rank].sum().item()) == int(t_cnt.sum().item())
 
     # sanity of the resident result (every step recomputes it from zeroed tables)
@@ -210,6 +217,7 @@ def main():
                 "valid_read_assignments": int(cnt.sum()), "em_flagged_events": int((flags & 1).sum()),
                 "em_max_iters": int(iters.max()) if n_ev else 0,
                 "generate_s": t_gen, "ingest_s": t_ingest,
+                "gather_ms_after_loop": (gather_ms[-1] if world > 1 else None),
                 "parallelism": "events and their reads sharded by rank, no collective in the timed loop; one RCCL all-gather of the per-event tables after it" if world > 1 else "single GPU",
             },
             "roofline": {
