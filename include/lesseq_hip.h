@@ -58,10 +58,14 @@ typedef struct lsq_annotation lsq_annotation;   /* selected genes + their isofor
 typedef struct lsq_events lsq_events;           /* compiled event tables (host copy) */
 typedef struct lsq_reads lsq_reads;             /* parsed reads of one MRF file, file order */
 
-/* Replaces count/count.cpp:135-216 (== solve/solve.cpp:152-234 for these two formats):
- * loads LH_GENE_TXT + UCSC_GENE2ISOFORM, selects genes whose index in the bytewise-sorted
- * gene-name set lies in [gene_begin_idx, gene_end_idx).  Format literals other than
- * "LH_GENE_TXT" / "UCSC_GENE2ISOFORM" give LSQ_E_FORMAT. */
+/* Replaces count/count.cpp:135-216 and solve/solve.cpp:152-329: loads the isoforms and the
+ * gene -> isoform map, selects genes whose index in the bytewise-sorted gene-name set lies in
+ * [gene_begin_idx, gene_end_idx).  Isoform formats: "LH_GENE_TXT" (the only one `count` and
+ * `classify` take), and solve's "UCSC_GENE_TXT" (jsc/bioinfo/gene_anno.hpp:59-117),
+ * "UCSC_GFF", "WORMBASE_GFF2", "GENELETS_GFF3" (one line per exon; an isoform's exons are
+ * merged with interval_list::add_interval in file order, solve/solve.cpp:160-296).  Map
+ * formats: "UCSC_GENE2ISOFORM", and solve's "WORMBASE_GENE2ISOFORMS" (gene iso1;iso2;...).
+ * Any other literal gives LSQ_E_FORMAT; the executables keep count/classify to their two. */
 int lsq_annotation_load(const char *isoform_format, const char *isoforms_path,
                         const char *g2i_format, const char *g2i_path,
                         uint64_t gene_begin_idx, uint64_t gene_end_idx,

@@ -181,26 +181,102 @@ const char *lsq_last_error(void) { return lsq::g_err.c_str(); }
 int lsq_abi_version(void) { return LSQ_ABI_VERSION; }
 void lsq_free(void *p) { free(p); }
 
-// count/count.cpp:135-216
+// count/count.cpp:135-216; the formats beyond LH_GENE_TXT / UCSC_GENE2ISOFORM are solve's (solve/solve.cpp:152-329)
 int lsq_annotation_load(const char *isoform_format, const char *isoforms_path,
                         const char *g2i_format, const char *g2i_path,
                         uint64_t gene_begin_idx, uint64_t gene_end_idx, lsq_annotation **out) {
 	if (!isoform_format || !isoforms_path || !g2i_format || !g2i_path || !out) return fail(LSQ_E_ARG, "null argument");
 	std::vector<std::string> lines;
 	if (!read_lines(isoforms_path, lines)) return fail(LSQ_E_IO, "cannot open isoforms file %s", isoforms_path);
-	if (strcmp(isoform_format, "LH_GENE_TXT") != 0) return fail(LSQ_E_FORMAT, "Unknown file format error: %s", isoform_format);
 	std::unique_ptr<lsq_annotation> a(new lsq_annotation);
-	for (const std::string &line : lines) {
-		std::istringstream iss(line);
-		std::unique_ptr<IsoRec> r(new IsoRec);
-		std::string t_s, t_e, t_n, starts, ends;
-		iss >> r->name >> r->chrom >> r->strand >> t_s >> t_e >> t_n >> starts >> ends;
-		int64_t cnt = 0;
-		if (strict_long(t_s, r->txStart) && strict_long(t_e, r->txEnd) && strict_long(t_n, cnt) && cnt >= 0) {
-			r->exonCount = (uint64_t)cnt;
-			split_atol(starts, r->exonStarts);
-			split_atol(ends, r->exonEnds);
+	const std::string ifmt = isoform_format;
+	// isoforms given exon by exon (one line per exon, any order): name -> chromosome, strand and the
+	// exons merged by interval_list::add_interval in file order (solve/solve.cpp:160-204,236-296)
+	struct Grouped { std::string chrom, strand; IntervalList il; };
+	std::map<std::string, Grouped> grouped;           // std::map: the reference walks a std::set of the names
+	auto add_exon = [&](const std::string &iname, const std::string &chrom, const std::string &strand, int64_t start, int64_t end) {
+		Grouped &g = grouped[iname];
+		g.chrom = chrom; g.strand = strand;           // the last line of a name wins, as in the reference
+		g.il.add(start - 1, end);
+	};
+	auto trim_quotes = [](std::string &t) {
+		size_t b = 0, e = t.size();
+		while (b < e && t[b] == '"') ++b;
+		while (e > b && t[e - 1] == '"') --e;
+		t = t.substr(b, e - b);
+	};
+	if (ifmt == "LH_GENE_TXT" || ifmt == "UCSC_GENE_TXT") {
+		// LH_GENE_TXT: name chrom strand txStart txEnd exonCount exonStarts exonEnds (count/count.cpp:142-171);
+		// UCSC_GENE_TXT has cdsStart cdsEnd between txEnd and exonCount (jsc/bioinfo/gene_anno.hpp:59-101)
+		const bool ucsc = ifmt == "UCSC_GENE_TXT";
+		for (const std::string &line : lines) {
+			std::istringstream iss(line);
+			std::unique_ptr<IsoRec> r(new IsoRec);
+			std::string t_s, t_e, t_n, starts, ends, cds_s, cds_e;
+			iss >> r->name >> r->chrom >> r->strand >> t_s >> t_e;
+			if (ucsc) iss >> cds_s >> cds_e;
+			iss >> t_n >> starts >> ends;
+			int64_t cnt = 0, ignore = 0;
+			if (strict_long(t_s, r->txStart) && strict_long(t_e, r->txEnd) && (!ucsc || (strict_long(cds_s, ignore) && strict_long(cds_e, ignore))) &&
+			    strict_long(t_n, cnt) && cnt >= 0) {
+				r->exonCount = (uint64_t)cnt;
+				split_atol(starts, r->exonStarts);
+				split_atol(ends, r->exonEnds);
+			}
+			a->recs.push_back(std::move(r));
 		}
+	} else if (ifmt == "UCSC_GFF" || ifmt == "WORMBASE_GFF2") {
+		// chr source feature start end score strand frame [group] name; UCSC_GFF skips two header lines,
+		// WORMBASE_GFF2 has one more column before the name and its chromosomes lack the "chr"
+		const bool worm = ifmt == "WORMBASE_GFF2";
+		for (size_t li = worm ? 0 : 2; li < lines.size(); ++li) {
+			std::istringstream iss(lines[li]);
+			long start = 0, end = 0;
+			std::string iname, chr, tmp, strand;
+			iss >> chr >> tmp >> tmp >> start >> end >> tmp >> strand >> tmp;
+			if (worm) iss >> tmp;
+			iss >> iname;
+			if (iss.fail()) return fail(LSQ_E_ARG, "line %zu of %s does not have the %s columns (the reference reads uninitialised coordinates here)", li + 1, isoforms_path, isoform_format);
+			trim_quotes(iname);
+			add_exon(iname, worm ? "chr" + chr : chr, strand, start, end);
+		}
+	} else if (ifmt == "GENELETS_GFF3") {
+		// two header lines; "exon" lines name their isoforms in a Parent=a,b attribute (solve/solve.cpp:160-204)
+		for (size_t li = 2; li < lines.size(); ++li) {
+			std::istringstream iss(lines[li]);
+			std::string chr, tmp, type;
+			iss >> chr >> tmp >> type;
+			if (type != "exon") continue;
+			long start = 0, end = 0;
+			std::string strand, infos;
+			iss >> start >> end >> tmp >> strand >> tmp >> infos;
+			if (iss.fail()) return fail(LSQ_E_ARG, "exon line %zu of %s does not have the GENELETS_GFF3 columns (the reference reads uninitialised coordinates here)", li + 1, isoforms_path);
+			size_t i = 0;
+			while (i <= infos.size()) {
+				size_t j = infos.find(';', i);
+				if (j == std::string::npos) j = infos.size();
+				const std::string info = infos.substr(i, j - i);
+				if (info.size() > 7 && info.compare(0, 7, "Parent=") == 0) {
+					const std::string names = info.substr(7);
+					size_t u = 0;
+					while (u <= names.size()) {
+						size_t v = names.find(',', u);
+						if (v == std::string::npos) v = names.size();
+						if (v > u) add_exon(names.substr(u, v - u), "chr" + chr, strand, start, end);
+						u = v + 1;
+					}
+				}
+				i = j + 1;
+			}
+		}
+	} else {
+		return fail(LSQ_E_FORMAT, "Unknown file format error: %s", isoform_format);
+	}
+	for (auto &kv : grouped) {
+		std::unique_ptr<IsoRec> r(new IsoRec);
+		r->name = kv.first; r->chrom = kv.second.chrom; r->strand = kv.second.strand;
+		r->exonCount = kv.second.il.size();
+		r->exonStarts = kv.second.il.s; r->exonEnds = kv.second.il.e;
 		a->recs.push_back(std::move(r));
 	}
 	// iname2gap: the last record of a name wins (count/count.cpp:176-179)
@@ -209,16 +285,32 @@ int lsq_annotation_load(const char *isoform_format, const char *isoforms_path,
 
 	lines.clear();
 	if (!read_lines(g2i_path, lines)) return fail(LSQ_E_IO, "cannot open gene->isoform file %s", g2i_path);
-	if (strcmp(g2i_format, "UCSC_GENE2ISOFORM") != 0) return fail(LSQ_E_FORMAT, "Unknown file format error: %s", g2i_format);
+	const std::string gfmt = g2i_format;
+	if (gfmt != "UCSC_GENE2ISOFORM" && gfmt != "WORMBASE_GENE2ISOFORMS") return fail(LSQ_E_FORMAT, "Unknown file format error: %s", g2i_format);
 	std::map<std::string, std::vector<const IsoRec *>> genes;   // std::map: bytewise key order == std::set<string>
 	for (const std::string &line : lines) {
 		std::istringstream iss(line);
-		std::string g, i;
-		iss >> g >> i;
-		auto it = by_name.find(i);
-		if (it == by_name.end())
-			return fail(LSQ_E_ARG, "gene %s names isoform '%s' that is not in %s (the reference dereferences a null record here)", g.c_str(), i.c_str(), isoforms_path);
-		genes[g].push_back(it->second);
+		std::string g, names;
+		iss >> g >> names;
+		// UCSC_GENE2ISOFORM: gene isoform; WORMBASE_GENE2ISOFORMS: gene iso1;iso2;... (solve/solve.cpp:310-329)
+		std::vector<std::string> inames;
+		if (gfmt == "UCSC_GENE2ISOFORM") inames.push_back(names);
+		else {
+			size_t u = 0;
+			while (u < names.size()) {
+				size_t v = names.find(';', u);
+				if (v == std::string::npos) v = names.size();
+				if (v > u) inames.push_back(names.substr(u, v - u));
+				u = v + 1;
+			}
+			genes[g];      // the gene exists even with an empty list
+		}
+		for (const std::string &i : inames) {
+			auto it = by_name.find(i);
+			if (it == by_name.end())
+				return fail(LSQ_E_ARG, "gene %s names isoform '%s' that is not in %s (the reference dereferences a null record here)", g.c_str(), i.c_str(), isoforms_path);
+			genes[g].push_back(it->second);
+		}
 	}
 	a->n_genes_loaded = (int64_t)genes.size();
 	uint64_t idx = 0;

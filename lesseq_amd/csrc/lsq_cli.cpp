@@ -83,6 +83,21 @@ int status_to_exit(int st) {
 	}
 }
 
+// `count` and `classify` know LH_GENE_TXT and UCSC_GENE2ISOFORM only (count/count.cpp:141,188,
+// classify/classify.cpp:91,138); `solve` takes the wider set lsq_annotation_load reads.  The
+// reference opens a file (assert) before it looks at the format literal.
+int count_formats_only(const char *iso_fmt, const char *iso_path, const char *g2i_fmt, const char *g2i_path) {
+	FILE *f = fopen(iso_path, "rb");
+	if (!f) return LSQ_OK;                 // lsq_annotation_load reports the unopenable file
+	fclose(f);
+	if (strcmp(iso_fmt, "LH_GENE_TXT") != 0) return fail(LSQ_E_FORMAT, "Unknown file format error: %s", iso_fmt);
+	f = fopen(g2i_path, "rb");
+	if (!f) return LSQ_OK;
+	fclose(f);
+	if (strcmp(g2i_fmt, "UCSC_GENE2ISOFORM") != 0) return fail(LSQ_E_FORMAT, "Unknown file format error: %s", g2i_fmt);
+	return LSQ_OK;
+}
+
 int precheck_reads_file(const char *fmt, const char *path) {
 	FILE *f = fopen(path, "rb");
 	if (!f) return fail(LSQ_E_IO, "cannot open reads file %s", path);
@@ -106,7 +121,8 @@ int run_classify(int argc, const char *const *argv) {
 	unsigned long gb, ge;
 	if (!cast_ulong(argv[8], gb) || !cast_ulong(argv[9], ge)) { logf(0, "Lexical_cast error when converting arguments to numeric values"); return 1; }
 	Freer F;
-	int st = lsq_annotation_load(argv[4], argv[5], argv[6], argv[7], gb, ge, &F.a);
+	int st = count_formats_only(argv[4], argv[5], argv[6], argv[7]);
+	if (!st) st = lsq_annotation_load(argv[4], argv[5], argv[6], argv[7], gb, ge, &F.a);
 	if (st) { logf(0, "%s", lsq_last_error()); return status_to_exit(st); }
 	logf(2, "Loaded %lld isoforms", (long long)lsq_annotation_num_isoforms_loaded(F.a));
 	logf(2, "Loaded %lld genes", (long long)lsq_annotation_num_genes_loaded(F.a));
@@ -162,7 +178,8 @@ int run_count_solve(bool solve, int argc, const char *const *argv, std::string &
 	if (M > LSQ_MAX_METHODS) { logf(0, "more than %d read files", LSQ_MAX_METHODS); return 2; }
 	Freer F;
 	logf(2, "Loading isoforms...");
-	int st = lsq_annotation_load(argv[4], argv[5], argv[6], argv[7], gb, ge, &F.a);
+	int st = solve ? LSQ_OK : count_formats_only(argv[4], argv[5], argv[6], argv[7]);
+	if (!st) st = lsq_annotation_load(argv[4], argv[5], argv[6], argv[7], gb, ge, &F.a);
 	if (st) { logf(0, "%s", lsq_last_error()); return status_to_exit(st); }
 	logf(2, "Loaded %lld isoforms", (long long)lsq_annotation_num_isoforms_loaded(F.a));
 	logf(2, "Loaded %lld genes", (long long)lsq_annotation_num_genes_loaded(F.a));

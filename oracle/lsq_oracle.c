@@ -273,6 +273,17 @@ static int lexical_cast_double(const char *s, double *out) {
 	return 1;
 }
 
+/* `iss >> long` on one whitespace-delimited token of a well-formed file: optional sign and digits */
+static int stream_long(const char *s, size_t n, long *out) {
+	char t[64]; if (n == 0 || n > 62) return 0;
+	memcpy(t, s, n); t[n] = 0;
+	char *end; errno = 0;
+	long v = strtol(t, &end, 10);
+	if (end == t || errno == ERANGE) return 0;
+	*out = v;
+	return 1;
+}
+
 /* ------------------------------------------------------------------ text loaders */
 
 typedef struct { char *data; size_t len; } text_t;
@@ -661,41 +672,115 @@ static void err_line(const char *msg) { fprintf(stderr, "[oracle ERROR] %s\n", m
 
 static int run(const params_t *P, sink *out, exact_t *ex) {
 	text_t txt;
-	/* ---- isoforms: LH_GENE_TXT (count.cpp:141-171) */
-	if (strcmp(P->isoform_format, "LH_GENE_TXT") != 0) { err_line("Unknown file format error"); return 1; }
+	/* ---- isoforms: LH_GENE_TXT (count.cpp:141-171); `solve` also takes UCSC_GENE_TXT
+	 * (jsc/bioinfo/gene_anno.hpp:59-117), GENELETS_GFF3, UCSC_GFF and WORMBASE_GFF2
+	 * (solve.cpp:158-296).  The reference opens the file before it looks at the literal. */
 	if (!load_text(P->isoforms_path, &txt)) { err_line("cannot open isoforms file"); return 134; }
+	const int f_lh = strcmp(P->isoform_format, "LH_GENE_TXT") == 0;
+	const int f_ucsc = P->is_solve && strcmp(P->isoform_format, "UCSC_GENE_TXT") == 0;
+	const int f_gff = P->is_solve && strcmp(P->isoform_format, "UCSC_GFF") == 0;
+	const int f_worm = P->is_solve && strcmp(P->isoform_format, "WORMBASE_GFF2") == 0;
+	const int f_gen = P->is_solve && strcmp(P->isoform_format, "GENELETS_GFF3") == 0;
+	if (!(f_lh || f_ucsc || f_gff || f_worm || f_gen)) { err_line("Unknown file format error"); return 1; }
 	ga_entry **gas = NULL; int nga = 0, gacap = 0;
-	{
+	if (f_lh || f_ucsc) {
 		size_t pos = 0; const char *line; size_t n;
+		const int o = f_ucsc ? 2 : 0;          /* cdsStart cdsEnd sit between txEnd and exonCount */
 		while (next_line(&txt, &pos, &line, &n)) {
 			ga_entry *g = (ga_entry *)calloc(1, sizeof(ga_entry));
-			const char *tok[8]; size_t tn[8]; int nt = 0; size_t p = 0;
-			while (nt < 8 && next_tok(line, n, &p, &tok[nt], &tn[nt])) nt++;
+			const char *tok[10]; size_t tn[10]; int nt = 0; size_t p = 0;
+			while (nt < 8 + o && next_tok(line, n, &p, &tok[nt], &tn[nt])) nt++;
 			g->name = xstrndup(nt > 0 ? tok[0] : "", nt > 0 ? tn[0] : 0);
 			g->chrom = xstrndup(nt > 1 ? tok[1] : "", nt > 1 ? tn[1] : 0);
 			g->strand = xstrndup(nt > 2 ? tok[2] : "", nt > 2 ? tn[2] : 0);
 			int ok = nt > 3 && lexical_cast_long(tok[3], tn[3], &g->txStart);
 			ok = ok && nt > 4 && lexical_cast_long(tok[4], tn[4], &g->txEnd);
-			long ec = 0;
-			ok = ok && nt > 5 && lexical_cast_long(tok[5], tn[5], &ec) && ec >= 0;
+			long ec = 0, cds = 0;
+			if (f_ucsc) ok = ok && nt > 6 && lexical_cast_long(tok[5], tn[5], &cds) && lexical_cast_long(tok[6], tn[6], &cds);
+			ok = ok && nt > 5 + o && lexical_cast_long(tok[5 + o], tn[5 + o], &ec) && ec >= 0;
 			if (ok) {
 				g->exonCount = (unsigned long)ec;
-				if (nt > 6) g->nStarts = split_atol(tok[6], tn[6], &g->exonStarts);
-				if (nt > 7) g->nEnds = split_atol(tok[7], tn[7], &g->exonEnds);
+				if (nt > 6 + o) g->nStarts = split_atol(tok[6 + o], tn[6 + o], &g->exonStarts);
+				if (nt > 7 + o) g->nEnds = split_atol(tok[7 + o], tn[7 + o], &g->exonEnds);
 			}
 			if (nga == gacap) { gacap = gacap ? gacap * 2 : 256; gas = (ga_entry **)xrealloc(gas, sizeof(ga_entry *) * (size_t)gacap); }
 			gas[nga++] = g;
 		}
 		free(txt.data);
+	} else {
+		/* one line per exon: the exons of a name are merged with add_interval in file order; chromosome
+		 * and strand are those of the name's last line; names are walked in std::set order */
+		typedef struct { char *name, *chrom, *strand; ilist il; int ord; } grp_t;
+		grp_t *grp = NULL; int ngrp = 0, grpcap = 0;
+		size_t pos = 0; const char *line; size_t n; int li = 0;
+		while (next_line(&txt, &pos, &line, &n)) {
+			if (!f_worm && li++ < 2) continue;           /* two header lines (solve.cpp:164-165,240-241) */
+			const char *tok[12]; size_t tn[12]; int nt = 0; size_t p = 0;
+			while (nt < 12 && next_tok(line, n, &p, &tok[nt], &tn[nt])) nt++;
+			long start = 0, end = 0;
+			char chrom[512];
+			if (f_gen) {
+				if (nt < 3 || tn[2] != 4 || memcmp(tok[2], "exon", 4) != 0) continue;
+				if (nt < 9 || !stream_long(tok[3], tn[3], &start) || !stream_long(tok[4], tn[4], &end)) { err_line("malformed GENELETS_GFF3 exon line (reference reads uninitialised values)"); return 139; }
+				snprintf(chrom, sizeof chrom, "chr%.*s", (int)tn[0], tok[0]);
+				/* attributes ';'-separated; Parent=a,b names the isoforms */
+				const char *inf = tok[8]; size_t in = tn[8], i = 0;
+				while (i <= in) {
+					size_t j = i; while (j < in && inf[j] != ';') j++;
+					if (j - i > 7 && memcmp(inf + i, "Parent=", 7) == 0) {
+						size_t u = i + 7;
+						while (u <= j) {
+							size_t v = u; while (v < j && inf[v] != ',') v++;
+							if (v > u) {
+								int k; for (k = 0; k < ngrp; k++) if (strlen(grp[k].name) == v - u && memcmp(grp[k].name, inf + u, v - u) == 0) break;
+								if (k == ngrp) { if (ngrp == grpcap) { grpcap = grpcap ? grpcap * 2 : 64; grp = (grp_t *)xrealloc(grp, sizeof(grp_t) * (size_t)grpcap); } memset(&grp[k], 0, sizeof(grp_t)); grp[k].name = xstrndup(inf + u, v - u); ngrp++; }
+								free(grp[k].chrom); free(grp[k].strand);
+								grp[k].chrom = xstrndup(chrom, strlen(chrom)); grp[k].strand = xstrndup(tok[6], tn[6]);
+								lsqo_il_add(&grp[k].il, start - 1, end);
+							}
+							u = v + 1;
+						}
+					}
+					i = j + 1;
+				}
+			} else {
+				const int ni = f_worm ? 9 : 8;             /* WORMBASE_GFF2 has one more column before the name */
+				if (nt <= ni || !stream_long(tok[3], tn[3], &start) || !stream_long(tok[4], tn[4], &end)) { err_line("malformed GFF line (reference reads uninitialised values)"); return 139; }
+				if (f_worm) snprintf(chrom, sizeof chrom, "chr%.*s", (int)tn[0], tok[0]); else snprintf(chrom, sizeof chrom, "%.*s", (int)tn[0], tok[0]);
+				const char *nm = tok[ni]; size_t nn = tn[ni];
+				while (nn > 0 && nm[0] == '"') { nm++; nn--; }       /* trim_if(iname, is_any_of("\"")) */
+				while (nn > 0 && nm[nn - 1] == '"') nn--;
+				int k; for (k = 0; k < ngrp; k++) if (strlen(grp[k].name) == nn && memcmp(grp[k].name, nm, nn) == 0) break;
+				if (k == ngrp) { if (ngrp == grpcap) { grpcap = grpcap ? grpcap * 2 : 64; grp = (grp_t *)xrealloc(grp, sizeof(grp_t) * (size_t)grpcap); } memset(&grp[k], 0, sizeof(grp_t)); grp[k].name = xstrndup(nm, nn); ngrp++; }
+				free(grp[k].chrom); free(grp[k].strand);
+				grp[k].chrom = xstrndup(chrom, strlen(chrom)); grp[k].strand = xstrndup(tok[6], tn[6]);
+				lsqo_il_add(&grp[k].il, start - 1, end);
+			}
+		}
+		free(txt.data);
+		for (int k = 0; k < ngrp; k++) {
+			ga_entry *g = (ga_entry *)calloc(1, sizeof(ga_entry));
+			g->name = grp[k].name; g->chrom = grp[k].chrom; g->strand = grp[k].strand;
+			g->exonCount = (unsigned long)grp[k].il.n;
+			g->nStarts = g->nEnds = grp[k].il.n;
+			g->exonStarts = (long *)xmalloc(sizeof(long) * (size_t)(grp[k].il.n ? grp[k].il.n : 1));
+			g->exonEnds = (long *)xmalloc(sizeof(long) * (size_t)(grp[k].il.n ? grp[k].il.n : 1));
+			for (int q = 0; q < grp[k].il.n; q++) { g->exonStarts[q] = grp[k].il.s[q]; g->exonEnds[q] = grp[k].il.e[q]; }
+			if (nga == gacap) { gacap = gacap ? gacap * 2 : 256; gas = (ga_entry **)xrealloc(gas, sizeof(ga_entry *) * (size_t)gacap); }
+			gas[nga++] = g;
+		}
+		free(grp);
 	}
 	/* iname2gap: last duplicate wins (count.cpp:176-179); sorted (name, position) view */
 	g_sort_gas = gas;
 	int *ord = (int *)xmalloc(sizeof(int) * (size_t)(nga ? nga : 1));
 	for (int i = 0; i < nga; i++) ord[i] = i;
 	qsort(ord, (size_t)nga, sizeof(int), cmp_ga_ord);
-	/* ---- gene -> isoform map: UCSC_GENE2ISOFORM (count.cpp:188-195) */
-	if (strcmp(P->g2i_format, "UCSC_GENE2ISOFORM") != 0) { err_line("Unknown file format error"); return 1; }
+	/* ---- gene -> isoform map: UCSC_GENE2ISOFORM (count.cpp:188-195); `solve` also takes
+	 * WORMBASE_GENE2ISOFORMS: gene iso1;iso2;... (solve.cpp:318-329) */
 	if (!load_text(P->g2i_path, &txt)) { err_line("cannot open g2i file"); return 134; }
+	const int g_worm = P->is_solve && strcmp(P->g2i_format, "WORMBASE_GENE2ISOFORMS") == 0;
+	if (strcmp(P->g2i_format, "UCSC_GENE2ISOFORM") != 0 && !g_worm) { err_line("Unknown file format error"); return 1; }
 	gene_t *genes = NULL; int ngenes = 0, gcap = 0;
 	{
 		/* collect (gene, isoform) pairs, then group by gene name keeping file order inside a
@@ -706,8 +791,16 @@ static int run(const params_t *P, sink *out, exact_t *ex) {
 			const char *a = "", *b = ""; size_t an = 0, bn = 0; size_t p = 0;
 			next_tok(line, n, &p, &a, &an);
 			next_tok(line, n, &p, &b, &bn);
-			if (npairs == pcap) { pcap = pcap ? pcap * 2 : 256; pairs = (pair_t *)xrealloc(pairs, sizeof(pair_t) * (size_t)pcap); }
-			pairs[npairs].g = xstrndup(a, an); pairs[npairs].i = xstrndup(b, bn); pairs[npairs].ord = npairs; npairs++;
+			size_t u = 0;
+			do {
+				size_t v = u;
+				if (g_worm) { while (v < bn && b[v] != ';') v++; } else v = bn;
+				if (!g_worm || v > u) {
+					if (npairs == pcap) { pcap = pcap ? pcap * 2 : 256; pairs = (pair_t *)xrealloc(pairs, sizeof(pair_t) * (size_t)pcap); }
+					pairs[npairs].g = xstrndup(a, an); pairs[npairs].i = xstrndup(b + u, v - u); pairs[npairs].ord = npairs; npairs++;
+				}
+				u = v + 1;
+			} while (g_worm && u < bn);
 		}
 		qsort(pairs, (size_t)npairs, sizeof(pair_t), cmp_pair);
 		for (int q = 0; q < npairs; q++) {

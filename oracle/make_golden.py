@@ -165,6 +165,26 @@ def main():
                 "solve": [base + ["MRF_SINGLE", "SHORT_READ", "50", "toy.mrf", "abc"]]}
     case("errors", w, sp)
 
+    # the annotation formats only `solve` reads (solve/solve.cpp:158-329); `count` refuses them
+    def w(d):
+        return gi.write_formats(d)
+    def sp(info):
+        tail = ["0", "1000", "MRF_SINGLE", "SHORT_READ", str(info["R"]), "f.mrf"]
+        trb = [str(info["total_read_bases"])]
+        combos = [("LH_GENE_TXT", "f.interval", "UCSC_GENE2ISOFORM", "f.map"),
+                  ("UCSC_GENE_TXT", "f.ucsc.txt", "UCSC_GENE2ISOFORM", "f.map"),
+                  ("UCSC_GFF", "f.gff", "UCSC_GENE2ISOFORM", "f.map"),
+                  ("WORMBASE_GFF2", "f.worm.gff2", "WORMBASE_GENE2ISOFORMS", "f.worm.map"),
+                  ("GENELETS_GFF3", "f.genelets.gff3", "UCSC_GENE2ISOFORM", "f.map"),
+                  ("LH_GENE_TXT", "f.interval", "WORMBASE_GENE2ISOFORMS", "f.worm.map"),
+                  ("UCSC_GFF", "f.gff", "NO_SUCH_MAP", "f.map"),
+                  ("NO_SUCH_FORMAT", "f.gff", "UCSC_GENE2ISOFORM", "f.map")]
+        solve = [["0", "f", "./", a, b, c, dd] + tail + trb for (a, b, c, dd) in combos]
+        solve.append(["0", "f", "./", "UCSC_GFF", "f.gff", "UCSC_GENE2ISOFORM", "f.map", "3", "11", "MRF_SINGLE", "MEDIUM_READ", str(info["R"]), "f.mrf"] + trb)
+        count = [["0", "f", "./", a, b, c, dd] + tail for (a, b, c, dd) in combos[1:6]]
+        return {"count": count, "solve": solve}
+    case("formats", w, sp)
+
     # 6-significant-digit formatting of counts >= 1e6 (input regenerated by the tests)
     def w(d):
         return gi.write_fmt1m(d)

@@ -472,3 +472,69 @@ def write_fmt1m(d):
         for ln in fmt1m_lines():
             f.write(ln)
     return {"big_files": ["fmt1m.mrf"]}
+
+
+# ----------------------------------------------------------------------------- solve's other annotation formats
+
+def write_formats(d):
+    """One set of events written in every annotation format `solve` reads (solve/solve.cpp:158-329):
+    LH_GENE_TXT, UCSC_GENE_TXT, UCSC_GFF, WORMBASE_GFF2, GENELETS_GFF3 for the isoforms;
+    UCSC_GENE2ISOFORM and WORMBASE_GENE2ISOFORMS for the gene map.  The exon-per-line formats list
+    the exons out of order, some of them cut in two touching or overlapping pieces (the loader
+    merges them), and carry lines the loader must skip."""
+    rng = random.Random(41)
+    R = 60
+    chroms = ["chr1", "chr2", "chrX"]
+    events = gen_events(rng, 30, R, chroms)
+    lh, ucsc, g2i, worm_g2i = [], [], [], []
+    gff = ["track name=demo\n", "browser position chr1\n"]
+    gen3 = ["##gff-version 3\n", "##source demo\n"]
+    worm = []
+    exon_lines = []      # (iname, chrom, strand, start, end)
+    for e in events:
+        names = []
+        for k, form in enumerate(e["forms"]):
+            iname = "%s.%s" % (e["name"], "ab"[k])
+            names.append(iname)
+            lh.append(interval_line(iname, e["chrom"], e["strand"], form))
+            starts = ",".join(str(s) for s, _ in form) + ","
+            ends = ",".join(str(x) for _, x in form) + ","
+            ucsc.append("%s\t%s\t%s\t%d\t%d\t%d\t%d\t%d\t%s\t%s\n" % (iname, e["chrom"], e["strand"], form[0][0], form[-1][1],
+                                                                       form[0][0] + 3, form[-1][1] - 3, len(form), starts, ends))
+            g2i.append("%s\t%s\n" % (e["name"], iname))
+            for (s, x) in form:
+                pieces = [(s, x)]
+                u = rng.random()
+                if u < 0.2 and x - s > 20:                       # two touching pieces
+                    m = rng.randint(s + 5, x - 5)
+                    pieces = [(s, m), (m, x)]
+                elif u < 0.35 and x - s > 30:                    # two overlapping pieces
+                    m = rng.randint(s + 10, x - 10)
+                    pieces = [(s, m + 4), (m - 4, x)]
+                for (a, b) in pieces:
+                    exon_lines.append((iname, e["chrom"], e["strand"], a, b))
+        worm_g2i.append("%s\t%s\n" % (e["name"], ";".join(names)))
+    rng.shuffle(exon_lines)
+    for (iname, c, strand, a, b) in exon_lines:
+        gff.append("%s\tdemo\texon\t%d\t%d\t.\t%s\t.\t\"%s\"\n" % (c, a + 1, b, strand, iname))
+        worm.append("%s\tdemo\texon\t%d\t%d\t.\t%s\t.\tTranscript\t\"%s\"\n" % (c[3:], a + 1, b, strand, iname))
+    # GENELETS: exons shared by both isoforms of an event are written once with Parent=a,b
+    seen = {}
+    for (iname, c, strand, a, b) in exon_lines:
+        seen.setdefault((c, strand, a, b, iname.split(".")[0]), []).append(iname)
+    n = 0
+    for (c, strand, a, b, g), inames in seen.items():
+        n += 1
+        if n % 7 == 0:
+            gen3.append("%s\tdemo\tmRNA\t%d\t%d\t.\t%s\t.\tID=%s\n" % (c[3:], a + 1, b, strand, inames[0]))
+        gen3.append("%s\tdemo\texon\t%d\t%d\t.\t%s\t.\tID=ex%d;Parent=%s;Note=x\n" % (c[3:], a + 1, b, strand, n, ",".join(inames)))
+    reads = gen_reads(rng, events, 1200, R, chroms)
+    _w(os.path.join(d, "f.interval"), "".join(lh))
+    _w(os.path.join(d, "f.ucsc.txt"), "".join(ucsc))
+    _w(os.path.join(d, "f.gff"), "".join(gff))
+    _w(os.path.join(d, "f.worm.gff2"), "".join(worm))
+    _w(os.path.join(d, "f.genelets.gff3"), "".join(gen3))
+    _w(os.path.join(d, "f.map"), "".join(g2i))
+    _w(os.path.join(d, "f.worm.map"), "".join(worm_g2i))
+    _w(os.path.join(d, "f.mrf"), "AlignmentBlocks\n" + "".join(mrf_line(*r) for r in reads))
+    return {"total_read_bases": 1200 * R, "R": R}

@@ -50,7 +50,7 @@ def parse_map(path):
     return genes
 
 
-@pytest.mark.parametrize("name", [c for c in CASES if c not in ("errors", "fmt1m")])
+@pytest.mark.parametrize("name", [c for c in CASES if c not in ("errors", "fmt1m", "formats")])
 def test_event_compilation_matches_oracle(name, tmp_path):
     c, d = load_case(name, tmp_path)
     argv = c["count"][0]["argv"]
@@ -75,6 +75,61 @@ def test_event_compilation_matches_oracle(name, tmp_path):
             idx = [n for n in range(len(segs)) if mask >> n & 1]
             assert ev.ars(0, i, j) == ob.ars_total(seg_len, idx, R, rtype == "SHORT_READ"), (name, g, nm)
             assert ev.isoform_length(i, j) == sum(seg_len[n] for n in idx)
+
+
+def _event_tables(ev):
+    out = []
+    for i in range(len(ev)):
+        K = ev.K(i)
+        out.append((ev.gene_name(i), ev.chrom(i), ev.strand(i), ev.segments(i), ev.span(i),
+                    [(ev.isoform_name(i, j), ev.isoform_mask(i, j), ev.ars(0, i, j)) for j in range(K)]))
+    return out
+
+
+def test_solve_annotation_formats_compile_alike(tmp_path):
+    """the formats only `solve` reads (solve/solve.cpp:158-329): the column formats give the events of
+    LH_GENE_TXT; the exon-per-line formats give each other's, with every isoform's exons merged by
+    interval_list::add_interval in file order"""
+    c, d = load_case("formats", tmp_path)
+    p = lambda f: os.path.join(d, f)
+    def tables(ifmt, ipath, gfmt, gpath):
+        a = L.Annotation(p(ipath), p(gpath), 0, 1000, ifmt, gfmt)
+        return _event_tables(L.Events(a, ("SHORT_READ",), (60,)))
+    lh = tables("LH_GENE_TXT", "f.interval", "UCSC_GENE2ISOFORM", "f.map")
+    assert len(lh) == 30
+    assert tables("UCSC_GENE_TXT", "f.ucsc.txt", "UCSC_GENE2ISOFORM", "f.map") == lh
+    assert tables("LH_GENE_TXT", "f.interval", "WORMBASE_GENE2ISOFORMS", "f.worm.map") == lh
+    gff = tables("UCSC_GFF", "f.gff", "UCSC_GENE2ISOFORM", "f.map")
+    assert tables("WORMBASE_GFF2", "f.worm.gff2", "WORMBASE_GENE2ISOFORMS", "f.worm.map") == gff
+    assert tables("GENELETS_GFF3", "f.genelets.gff3", "UCSC_GENE2ISOFORM", "f.map") == gff
+    # expected from the file itself: exons of a name in file order through the oracle's interval list
+    per = {}
+    for line in open(p("f.gff")).read().split("\n")[2:-1]:
+        t = line.split("\t")
+        per.setdefault(t[8].strip('"'), []).append((int(t[3]) - 1, int(t[4])))
+    genes = parse_map(p("f.map"))
+    for (gname, chrom, strand, segs, span, isos) in gff:
+        exons = [x for nm in genes[gname] for x in ob.merge_intervals(per[nm])]
+        assert segs == ob.segments(exons), gname
+    assert gff != lh          # touching exons of one isoform are one exon in these formats
+    with pytest.raises(L.LsqError, match="Unknown file format"):
+        L.Annotation(p("f.gff"), p("f.map"), 0, 10, "UCSC_BED", "UCSC_GENE2ISOFORM")
+    with pytest.raises(L.LsqError, match="Unknown file format"):
+        L.Annotation(p("f.gff"), p("f.map"), 0, 10, "UCSC_GFF", "NO_SUCH_MAP")
+
+
+def test_count_and_classify_refuse_solve_only_formats(tmp_path, monkeypatch):
+    c, d = load_case("formats", tmp_path)
+    monkeypatch.chdir(d)
+    for r in c["count"]:
+        rc, text = L.cli_run("count", r["argv"])
+        assert rc == r["exit"] == 1 and text == ""
+    rc, _ = L.cli_run("classify", ["0", "f", str(tmp_path) + "/", "UCSC_GFF", "f.gff", "UCSC_GENE2ISOFORM", "f.map", "0", "10"])
+    assert rc == 1
+    for idx in (6, 7):          # unknown literals in `solve`
+        r = c["solve"][idx]
+        rc, text = L.cli_run("solve", r["argv"])
+        assert rc == r["exit"] == 1 and text == ""
 
 
 def test_interval_merge_is_order_dependent():
