@@ -39,6 +39,9 @@ WORKLOADS = {
                desc="BASELINE configs[1]: 10M synthetic 100bp reads over 5k SE/RI events, one chromosome"),
     "c1": dict(n_events=100, n_reads=10_000, R=100, n_chrom=1, types=("SE",), seed=1,
                desc="BASELINE configs[0]: 10k reads over 100 SE events (plumbing)"),
+    # one GPU's share of configs[4] (1 B reads / 200 k events over 8 GPUs), skewed read depth (hot genes)
+    "c5s": dict(n_events=25_000, n_reads=125_000_000, R=100, n_chrom=24, types=None, seed=5, zipf=True,
+                desc="one eighth of BASELINE configs[4]: 125M synthetic 100bp reads over 25k mixed events, Zipf read depth (hot genes), 24 chromosomes"),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 measured copy rate
 
@@ -81,7 +84,7 @@ def main():
 
     W = WORKLOADS[a.workload]
     types = W["types"] or L.EVENT_TYPES
-    spec = L.SynthSpec(W["seed"] + 1000 * rank, W["n_events"], W["n_reads"], W["R"], W["n_chrom"], types)
+    spec = L.SynthSpec(W["seed"] + 1000 * rank, W["n_events"], W["n_reads"], W["R"], W["n_chrom"], types, W.get("zipf", False))
     tmp = tempfile.mkdtemp(prefix="lsq_bench_r%d_" % rank)
 
     # ---- ingest (untimed): annotation -> compiled events -> reads -> bucketed pools in HBM

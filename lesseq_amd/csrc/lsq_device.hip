@@ -628,6 +628,27 @@ __global__ void __launch_bounds__(256) lsq_wg_plan_kernel(const unsigned long lo
 	wg_first[g] = lo_b;
 }
 
+// Global count/bases adds of a whole wave, merged by class before they reach L2: with skewed read
+// depth most lanes of a worker wave hit the classes of one hot event, and atomics on one address
+// run one after the other.  Up to four distinct classes are summed across the wave (ballot, DPP
+// sum, one atomic pair each); what is left adds lane by lane.  Every lane of the wave must call.
+__device__ inline void global_add_merged(unsigned long long *cnt, unsigned long long *bases, bool want, const unsigned slot, const unsigned matched) {
+	const unsigned lane = threadIdx.x & 63u;
+#pragma unroll 1
+	for (int round = 0; round < 4; ++round) {
+		const unsigned long long m = __ballot(want);
+		if (!m) return;
+		const unsigned lead = (unsigned)__ffsll((long long)m) - 1u;
+		const unsigned s0 = (unsigned)__builtin_amdgcn_readlane((int)slot, lead);
+		const bool same = want && slot == s0;
+		const unsigned n = (unsigned)__popcll(__ballot(same));
+		const unsigned sum = wave_sum_u32(same ? matched : 0u);       // reads are shorter than 2^18 bases
+		if (lane == lead) { atomicAdd(&cnt[s0], (unsigned long long)n); atomicAdd(&bases[s0], (unsigned long long)sum); }
+		want = want && !same;
+	}
+	if (want) { atomicAdd(&cnt[slot], 1ull); atomicAdd(&bases[slot], (unsigned long long)matched); }
+}
+
 // Reads with three or more blocks (about 1 % of a typical read set), inside the fast kernel's grid:
 // the first `n_workers` workgroups take them a lane each, tables read from global memory (L2), global
 // atomics -- latency-bound work that runs beside the streaming workgroups instead of in a kernel of
@@ -636,46 +657,59 @@ __global__ void __launch_bounds__(256) lsq_wg_plan_kernel(const unsigned long lo
 // list.  No local arrays, no calls: the kernel keeps a zero-byte private segment.
 __device__ inline void pool_n_worker(const CountArgs &A, const unsigned long long n_pn, const unsigned n_workers) {
 	const unsigned long long gsz = (unsigned long long)n_workers * COUNT_BLOCK;
-	for (unsigned long long g = (unsigned long long)blockIdx.x * COUNT_BLOCK + threadIdx.x; g < n_pn; g += gsz) {
-		const unsigned b = A.pn_bucket[g];
+	// wave-uniform loops (every lane takes every trip, idle or not): the merged adds need the whole wave
+	for (unsigned long long g0 = (unsigned long long)blockIdx.x * COUNT_BLOCK; g0 < n_pn; g0 += gsz) {
+		const unsigned long long g = g0 + threadIdx.x;
+		bool active = g < n_pn;
+		const unsigned b = active ? A.pn_bucket[g] : 0u;
 		const BucketDesc *d = A.buckets + b;
-		if (d->kind != 1) continue;
+		active = active && d->kind == 1;
 		const unsigned *bins = reinterpret_cast<const unsigned *>(A.images + d->img_off);
 		const uint4 *recs = reinterpret_cast<const uint4 *>(A.images + d->img_off + d->ev_off);
-		const int2 *blk = A.pn_se + A.pn_blk_off[g];
-		const int nblk = (int)A.pn_nblk[g];
-		const int p = blk[0].x, q = blk[nblk - 1].y;
-		int total = 0;
-		for (int k = 0; k < nblk; ++k) total += blk[k].y - blk[k].x;
-		const int rel = p - d->lo;
-		const unsigned bin = rel <= 0 ? 0u : min((unsigned)rel >> d->shift, d->n_bins - 1u);
-		for (unsigned i = bins[4u * bin] >> 16; i < d->n_events; ++i) {
-			const uint4 w0 = recs[3u * i];
-			const int2 *segs = reinterpret_cast<const int2 *>(recs + 3u * i + 1u);     // four (start, end) pairs
-			const int gs = segs[0].x, ge = (int)w0.x;
-			if (gs > p) break;
-			bool cand = p <= ge;
-			if (cand && p == gs) {
-				if (q == ge) {
-					const unsigned slot = atomicAdd(A.exc_count, 1u);
-					if (slot < A.exc_cap) { ExcEntry e; e.slot = g; e.bucket = b; e.ev_pool_scan = i | (2u << 29); A.exc[slot] = e; }
+		const int2 *blk = A.pn_se + (active ? A.pn_blk_off[g] : 0u);
+		const int nblk = active ? (int)A.pn_nblk[g] : 1;
+		int p = 0, q = 0, total = 0;
+		unsigned i = 0;
+		if (active) {
+			p = blk[0].x; q = blk[nblk - 1].y;
+			for (int k = 0; k < nblk; ++k) total += blk[k].y - blk[k].x;
+			const int rel = p - d->lo;
+			const unsigned bin = rel <= 0 ? 0u : min((unsigned)rel >> d->shift, d->n_bins - 1u);
+			i = bins[4u * bin] >> 16;
+		}
+		while (__any(active)) {
+			bool want = false;
+			unsigned slot = 0, matched = 0;
+			if (active) {
+				if (i >= d->n_events) active = false;
+				else {
+					const uint4 w0 = recs[3u * i];
+					const int2 *segs = reinterpret_cast<const int2 *>(recs + 3u * i + 1u);     // four (start, end) pairs
+					const int gs = segs[0].x, ge = (int)w0.x;
+					if (gs > p) active = false;
+					else {
+						bool cand = p <= ge;
+						if (cand && p == gs) {
+							if (q == ge) {
+								const unsigned at = atomicAdd(A.exc_count, 1u);
+								if (at < A.exc_cap) { ExcEntry e; e.slot = g; e.bucket = b; e.ev_pool_scan = i | (2u << 29); A.exc[at] = e; }
+							}
+							cand = q > ge;          // q < ge: ordered before the event; q == ge: the cleanup kernel decides
+						}
+						if (cand) {
+							const int nseg = (int)((w0.y >> FAST_NSEG_SHIFT) & 7u);
+							Walk w;
+							for (int k = 0; k < nblk; ++k) { const int2 bk = blk[k]; if (!w.block(segs, nseg, bk.x, bk.y)) break; }
+							const unsigned long long tbl = ((unsigned long long)w0.w << 32) | w0.z;
+							const unsigned cls = w.mask < 16u ? (unsigned)(tbl >> (4u * w.mask)) & 0xFu : 0u;
+							if (cls != 0 && 50ll * w.matched > 49ll * total) { want = true; slot = d->cls_base + (w0.y & 0xFFFFu) + cls - 1; matched = (unsigned)w.matched; }
+						}
+						if (p <= ge && !(w0.y & FAST_FLAG_OVERLAPS_NEXT)) active = false;
+						++i;
+					}
 				}
-				cand = false;       // q < ge: ordered before the event; q == ge: the cleanup kernel decides
-				if (q > ge) cand = true;
 			}
-			if (cand) {
-				const int nseg = (int)((w0.y >> FAST_NSEG_SHIFT) & 7u);
-				Walk w;
-				for (int k = 0; k < nblk; ++k) { const int2 bk = blk[k]; if (!w.block(segs, nseg, bk.x, bk.y)) break; }
-				const unsigned long long tbl = ((unsigned long long)w0.w << 32) | w0.z;
-				const unsigned cls = w.mask < 16u ? (unsigned)(tbl >> (4u * w.mask)) & 0xFu : 0u;
-				if (cls != 0 && 50ll * w.matched > 49ll * total) {
-					const unsigned slot = d->cls_base + (w0.y & 0xFFFFu) + cls - 1;
-					atomicAdd(&A.cnt[slot], 1ull);
-					atomicAdd(&A.bases[slot], (unsigned long long)(unsigned)w.matched);
-				}
-			}
-			if (p <= ge && !(w0.y & FAST_FLAG_OVERLAPS_NEXT)) break;
+			global_add_merged(A.cnt, A.bases, want, slot, matched);
 		}
 	}
 }
@@ -1581,6 +1615,7 @@ struct MethodReads {
 	DevBuf<uint8_t> p1_strand, p2_strand, pn_strand;
 	DevBuf<uint32_t> p1_line, p2_line, pn_line, pn_blk_off, pn_nblk, pn_bucket;
 	DevBuf<unsigned long long> p1_off, p2_off, pn_off, pnb_off, slot_off;
+	double skew = 1.0;                      // reads of the fullest bucket / mean reads per bucket
 	DevBuf<unsigned> wg_first;             // lsq_wg_plan_kernel's table for `wg_grid` workgroups
 	unsigned long long wg_grid = 0;
 };
@@ -1858,6 +1893,15 @@ static int ingest_device(lsq_ctx *c, int method, const IngestRaw &Rw, uint64_t n
 	mr.n_retained_blocks = tot[1];
 	mr.total_slots = n1 + n2 + nn;
 	mr.wg_grid = 0;
+	{
+		// how unevenly the reads fall on the buckets: with hot genes the reads that need the general walk
+		// fill whole workgroup shares, and smaller shares (more workgroups) even the load out
+		std::vector<unsigned long long> so(B + 1, 0);
+		HIP_TRY(hipMemcpy(so.data(), mr.slot_off.p, (B + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+		unsigned long long mx = 0;
+		for (unsigned b = 0; b < B; ++b) mx = std::max(mx, so[b + 1] - so[b]);
+		mr.skew = (B && mr.total_slots) ? (double)mx * (double)B / (double)mr.total_slots : 1.0;
+	}
 	mr.present = true;
 	c->counted = c->solved = false;
 	return LSQ_OK;
@@ -1955,11 +1999,14 @@ static int run_count(lsq_ctx *c, bool all_reads) {
 		HIP_TRY(hipFuncSetAttribute((const void *)lsq_count_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
 	}
 	unsigned per_cu = std::max(1u, std::min(2048u / COUNT_BLOCK, (160u * 1024u) / lds_bytes));
-	unsigned mult = 2;
-	if (const char *e = getenv("LSQ_GRID_MULT")) { int v = atoi(e); if (v >= 1 && v <= 64) mult = (unsigned)v; }
+	int mult_env = 0;
+	if (const char *e = getenv("LSQ_GRID_MULT")) { int v = atoi(e); if (v >= 1 && v <= 64) mult_env = v; }
 	for (int m = 0; m < M; ++m) {
 		MethodReads &mr = c->reads[m];
 		if (mr.total_slots == 0 || E.buckets.empty()) continue;
+		// workgroups per resident slot: 2 for even read depth (fewest table stagings), more when a few buckets
+		// hold most of the reads (measured on the skewed workload: 2 -> 0.48 ms, 8 -> 0.30 ms)
+		const unsigned mult = mult_env ? (unsigned)mult_env : (mr.skew >= 32.0 ? 8u : (mr.skew >= 4.0 ? 4u : 2u));
 		unsigned long long grid = (unsigned long long)c->n_cu * per_cu * mult;
 		// one workgroup's share must keep the packed LDS counters (24-bit count, 40-bit bases) exact
 		grid = std::max(grid, mr.total_slots / (1ull << 21) + 1);

@@ -13,7 +13,7 @@ budgets = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "4096").split(
 mults = [int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "1").split(",")]
 W = WORKLOADS[wl]
 types = W["types"] or L.EVENT_TYPES
-spec = L.SynthSpec(W["seed"], W["n_events"], W["n_reads"], W["R"], W["n_chrom"], types)
+spec = L.SynthSpec(W["seed"], W["n_events"], W["n_reads"], W["R"], W["n_chrom"], types, W.get("zipf", False))
 tmp = tempfile.mkdtemp()
 L.synth_write(spec, tmp, "w", write_mrf=False)
 ann = L.Annotation(tmp + "/w.interval", tmp + "/w.map")
