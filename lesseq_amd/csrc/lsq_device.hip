@@ -2010,7 +2010,12 @@ static int run_count(lsq_ctx *c, bool all_reads) {
 		unsigned long long grid = (unsigned long long)c->n_cu * per_cu * mult;
 		// one workgroup's share must keep the packed LDS counters (24-bit count, 40-bit bases) exact
 		grid = std::max(grid, mr.total_slots / (1ull << 21) + 1);
-		grid = std::min<unsigned long long>(grid, std::max<unsigned long long>(mr.total_slots / 64, 1));
+		{
+			// small read sets: a share below a few thousand reads is mostly table staging
+			unsigned long long min_share = 64;
+			if (const char *e = getenv("LSQ_MIN_WG_READS")) { long v = atol(e); if (v >= 64 && v <= (1 << 20)) min_share = (unsigned long long)v; }
+			grid = std::min<unsigned long long>(grid, std::max<unsigned long long>(mr.total_slots / min_share, 1));
+		}
 		if (mr.wg_grid != grid) {
 			int rc = mr.wg_first.alloc((size_t)grid);
 			if (rc) return rc;
