@@ -66,7 +66,6 @@ struct CountArgs {
 	unsigned n_buckets;
 	unsigned ablate;                   // developer switch (LSQ_ABLATE): 1 skip per-read work, 2 skip LDS atomics, 4 skip flush, 8 skip record look
 	unsigned tables_lds_bytes;         // LDS bytes reserved for the bucket image + histogram (16-byte multiple)
-	unsigned double_buffer;            // 1: two table buffers in LDS, the next bucket staged while this one streams
 	const int2 *p1; const unsigned char *p1_strand; const unsigned *p1_line;
 	const int4 *p2; const unsigned char *p2_strand; const unsigned *p2_line;
 	const unsigned *pn_blk_off; const unsigned *pn_nblk; const int2 *pn_se; const unsigned char *pn_strand; const unsigned *pn_line; const unsigned *pn_bucket;
@@ -461,10 +460,10 @@ __device__ inline void walk_parked(const FastCtx &C, Ring<NB> &R, const bool to_
 }
 
 // RPW = reads per 16-byte word: 2 (pool 1: one block) or 1 (pool 2: two blocks)
-template <int RPW, class Between>
+template <int RPW>
 __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uint4 *cells, const unsigned *cell_info, const unsigned n_cells, const BucketDesc &d,
                                         const CountArgs &A, uint4 *queue, const uint4 *src_generic,
-                                        const unsigned long long g0, const unsigned long long g1, Between &&between) {
+                                        const unsigned long long g0, const unsigned long long g1) {
 	constexpr int NB = RPW == 2 ? 1 : 2;
 	constexpr unsigned TILE = 64u * STREAM_WORDS;        // words per wave step
 	C.pool = RPW == 2 ? 0u : 1u;
@@ -501,7 +500,6 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 	Ring<NB> R;
 	R.q = queue;
 	if (ww0 < ww1) fetch(ww0);
-	between();          // runs while the first words are in flight (every wave calls it, whatever its share)
 	for (unsigned wt = ww0; wt < ww1; wt += WAVES * TILE) {
 		uint4 cur[STREAM_WORDS];
 #pragma unroll
@@ -767,17 +765,16 @@ __device__ inline void stage_bucket(const CountArgs &A, const unsigned b, unsign
 }
 
 __global__ void __launch_bounds__(COUNT_BLOCK, LSQ_FAST_WAVES) lsq_count_fast_kernel(CountArgs A) {
-	// LDS: two table buffers (the bucket being streamed; the next one, staged meanwhile), then the waves' rings
+	// LDS: the bucket's tables (image, histograms, visit record), then the waves' rings
 	extern __shared__ __align__(16) unsigned char lds[];
 	const unsigned tid = threadIdx.x;
 	if (blockIdx.x < A.n_workers) { pool_n_worker(A, A.n_pn, A.n_workers); return; }
 	const unsigned wg = blockIdx.x - A.n_workers, n_wg = gridDim.x - A.n_workers;     // the streaming workgroups
-	uint4 *wave_queue = reinterpret_cast<uint4 *>(lds + (1u + A.double_buffer) * A.tables_lds_bytes) + (tid >> 6) * WAVE_QUEUE_WORDS;
+	uint4 *wave_queue = reinterpret_cast<uint4 *>(lds + A.tables_lds_bytes) + (tid >> 6) * WAVE_QUEUE_WORDS;
 	const unsigned long long s_begin = A.total_slots * wg / n_wg;
 	const unsigned long long s_end = A.total_slots * (wg + 1ull) / n_wg;
 	if (s_begin >= s_end) return;
 	if (A.ablate & 4096u) return;       // developer switch: dispatch cost only
-	unsigned cur = 0;
 	{
 		const unsigned b0 = find_bucket(A, A.wg_first[wg], s_begin, s_end);   // wg_first: lsq_wg_plan_kernel
 		if (b0 >= A.n_buckets) return;
@@ -786,7 +783,7 @@ __global__ void __launch_bounds__(COUNT_BLOCK, LSQ_FAST_WAVES) lsq_count_fast_ke
 	__syncthreads();
 	if (A.ablate & 8192u) return;       // developer switch: dispatch + first staging
 	for (;;) {
-		unsigned char *buf = lds + cur * A.tables_lds_bytes, *other = lds + (cur ^ 1u) * A.tables_lds_bytes;
+		unsigned char *buf = lds;
 		// the visit record, wave-uniform: every dword through readfirstlane so that it lives in scalar registers
 		const unsigned *rec = reinterpret_cast<const unsigned *>(buf + A.tables_lds_bytes - VISIT_LDS_BYTES);
 		auto r32 = [&](unsigned q) { return (unsigned)__builtin_amdgcn_readfirstlane((int)rec[q]); };
@@ -799,13 +796,6 @@ __global__ void __launch_bounds__(COUNT_BLOCK, LSQ_FAST_WAVES) lsq_count_fast_ke
 		V.b = r32(28); V.valid = r32(29);
 		const BucketDesc &d = V.d;
 		const unsigned b = V.b;
-		// the next bucket's tables go to the other buffer while this bucket's first reads are on their way
-		bool staged = false;
-		auto stage_next = [&]() {
-			if (staged || !A.double_buffer) return;
-			staged = true;
-			stage_bucket(A, find_bucket(A, b + 1u, s_begin, s_end), other);
-		};
 		const uint4 *bins = reinterpret_cast<const uint4 *>(buf);
 		const uint4 *cells = reinterpret_cast<const uint4 *>(buf + d.seg_off);
 		const unsigned *cell_info = reinterpret_cast<const unsigned *>(buf + d.seg_off + 16u * d.iso_off);
@@ -821,13 +811,12 @@ __global__ void __launch_bounds__(COUNT_BLOCK, LSQ_FAST_WAVES) lsq_count_fast_ke
 		const unsigned long long n1 = V.p1n, n2 = V.p2n;
 		// ---- pool 1
 		if (l0 < n1 && !(A.ablate & 1024u))
-			stream_pool_fast<2>(C, bins, cells, cell_info, d.iso_off, d, A, wave_queue, reinterpret_cast<const uint4 *>(A.p1), V.p1o + l0, V.p1o + (l1 < n1 ? l1 : n1), stage_next);
+			stream_pool_fast<2>(C, bins, cells, cell_info, d.iso_off, d, A, wave_queue, reinterpret_cast<const uint4 *>(A.p1), V.p1o + l0, V.p1o + (l1 < n1 ? l1 : n1));
 		// ---- pool 2
 		if (l1 > n1 && l0 < n1 + n2 && !(A.ablate & 2048u))
 			stream_pool_fast<1>(C, bins, cells, cell_info, d.iso_off, d, A, wave_queue, reinterpret_cast<const uint4 *>(A.p2), V.p2o + ((l0 > n1 ? l0 : n1) - n1),
-			                    V.p2o + ((l1 < n1 + n2 ? l1 : n1 + n2) - n1), stage_next);
-		stage_next();
-		// (reads with three or more blocks are left to the cleanup kernel)
+			                    V.p2o + ((l1 < n1 + n2 ? l1 : n1 + n2) - n1));
+		// (reads with three or more blocks are the workers')
 		__syncthreads();
 		// ---- flush
 		for (unsigned i = tid; i < d.n_cls; i += COUNT_BLOCK) {
@@ -840,18 +829,12 @@ __global__ void __launch_bounds__(COUNT_BLOCK, LSQ_FAST_WAVES) lsq_count_fast_ke
 				atomicAdd(&A.bases[d.cls_base + i], v & BASES_MASK);
 			}
 		}
-		if (!A.double_buffer) {
-			// tables too large to hold twice: the next bucket is staged between two barriers
-			__syncthreads();
-			stage_bucket(A, find_bucket(A, b + 1u, s_begin, s_end), lds);
-			__syncthreads();
-			if (!reinterpret_cast<const unsigned *>(lds + A.tables_lds_bytes - VISIT_LDS_BYTES)[29]) break;
-			continue;
-		}
-		const unsigned more = reinterpret_cast<const unsigned *>(other + A.tables_lds_bytes - VISIT_LDS_BYTES)[29];
-		if (!more) break;
-		__syncthreads();        // this buffer is written again while the next bucket streams
-		cur ^= 1u;
+		// the next bucket of the share, staged between two barriers (a second table buffer, filled while
+		// this bucket streams, cost a resident workgroup per CU and measured slower)
+		__syncthreads();
+		stage_bucket(A, find_bucket(A, b + 1u, s_begin, s_end), lds);
+		__syncthreads();
+		if (!reinterpret_cast<const unsigned *>(lds + A.tables_lds_bytes - VISIT_LDS_BYTES)[29]) break;
 	}
 }
 
@@ -1989,10 +1972,8 @@ static int run_count(lsq_ctx *c, bool all_reads) {
 	c->fast_launched = 0;
 	HIP_TRY(hipEventRecord(c->ev0, st));      // ev0..ev1 brackets the count kernel launches only
 	const unsigned generic_tables_bytes = (std::max<unsigned>(E.max_lds_bytes, 16) + 15u) & ~15u;
-	const unsigned tables_bytes = generic_tables_bytes + VISIT_LDS_BYTES;            // fast kernel: + the visit record, twice (two buffers)
-	// two table buffers (next bucket staged while this one streams) cost a workgroup per CU and measured slower; developer switch only
-	const unsigned double_buffer = (2u * tables_bytes + WAVES * WAVE_QUEUE_WORDS * 16 <= 64u * 1024u && getenv("LSQ_DBUF")) ? 1u : 0u;
-	const unsigned lds_bytes = (1u + double_buffer) * tables_bytes + WAVES * WAVE_QUEUE_WORDS * 16;
+	const unsigned tables_bytes = generic_tables_bytes + VISIT_LDS_BYTES;            // fast kernel: + the visit record
+	const unsigned lds_bytes = tables_bytes + WAVES * WAVE_QUEUE_WORDS * 16;
 	if (lds_bytes > 160 * 1024) return fail(LSQ_E_UNSUPPORTED, "bucket tables + read tile exceed the CU's LDS");
 	if (lds_bytes > 64 * 1024) {
 		HIP_TRY(hipFuncSetAttribute((const void *)lsq_count_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -2010,12 +1991,7 @@ static int run_count(lsq_ctx *c, bool all_reads) {
 		unsigned long long grid = (unsigned long long)c->n_cu * per_cu * mult;
 		// one workgroup's share must keep the packed LDS counters (24-bit count, 40-bit bases) exact
 		grid = std::max(grid, mr.total_slots / (1ull << 21) + 1);
-		{
-			// small read sets: a share below a few thousand reads is mostly table staging
-			unsigned long long min_share = 64;
-			if (const char *e = getenv("LSQ_MIN_WG_READS")) { long v = atol(e); if (v >= 64 && v <= (1 << 20)) min_share = (unsigned long long)v; }
-			grid = std::min<unsigned long long>(grid, std::max<unsigned long long>(mr.total_slots / min_share, 1));
-		}
+		grid = std::min<unsigned long long>(grid, std::max<unsigned long long>(mr.total_slots / 64, 1));
 		if (mr.wg_grid != grid) {
 			int rc = mr.wg_first.alloc((size_t)grid);
 			if (rc) return rc;
@@ -2029,7 +2005,6 @@ static int run_count(lsq_ctx *c, bool all_reads) {
 		A.wg_first = mr.wg_first.p;
 		A.n_buckets = (unsigned)E.buckets.size();
 		A.tables_lds_bytes = tables_bytes;
-		A.double_buffer = double_buffer;
 		A.ablate = 0;
 		if (const char *e = getenv("LSQ_ABLATE")) A.ablate = (unsigned)atoi(e);
 		A.p1 = reinterpret_cast<const int2 *>(mr.p1.p); A.p1_strand = mr.p1_strand.p; A.p1_line = mr.p1_line.p;
@@ -2044,8 +2019,7 @@ static int run_count(lsq_ctx *c, bool all_reads) {
 		const unsigned long long n_p1 = mr.p1.n / 2, n_p2 = mr.p2.n / 4, n_pn = mr.pn_strand.n;
 		// pool-n workers: one workgroup per CU at most, one lane per read and pass
 		A.n_pn = n_pn;
-		unsigned workers_per_cu = 2;
-		if (const char *e = getenv("LSQ_POOLN_WORKERS")) { int v = atoi(e); if (v >= 1 && v <= 8) workers_per_cu = (unsigned)v; }
+		const unsigned workers_per_cu = 2;          // 1, 4 and 8 measured within 2 % of each other
 		A.n_workers = (unsigned)std::min<unsigned long long>((n_pn + COUNT_BLOCK - 1) / COUNT_BLOCK, (unsigned long long)c->n_cu * workers_per_cu);
 		if (c->has_fast) {
 			if (!all_reads) {
