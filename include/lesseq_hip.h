@@ -115,6 +115,12 @@ int lsq_events_set_shard(lsq_events *e, uint64_t first_event, uint64_t n_events)
  * id that matches no covered region). n_threads <= 0 picks the host's core count. */
 int lsq_mrf_parse(const char *read_format, const char *path, lsq_events *e,
                   int n_threads, lsq_reads **out);
+/* The same for any read format the reference's `solve` takes (solve/solve.cpp:413-634): "MRF_SINGLE"
+ * (this is then lsq_mrf_parse), and the name-keyed "UCSC_GFF" (a line per block), "UCSC_BED" (a line
+ * per read, kept or dropped as a whole by its span) and "WORMBASE_GFF3" (a line per read with an
+ * optional intron).  Lines of one name make one read; its names decide span-start ties against gene
+ * names (solve/solve.cpp:70-98).  `count` takes MRF_SINGLE only, as in the reference. */
+int lsq_reads_parse(const char *read_format, const char *path, lsq_events *e, int n_threads, lsq_reads **out);
 /* Wraps caller-made arrays as a read set without copying (the arrays must outlive it).
  * blk_off has n_reads+1 entries; blocks are 0-based half-open; chrom_id / strand_id index
  * lsq_events_chrom_id() / lsq_events_strand_id() dictionaries; line_no is the 1-based line

@@ -63,6 +63,7 @@ _sig("lsq_events_num_buckets", i64, vp)
 _sig("lsq_events_lds_table_bytes", i64, vp)
 _sig("lsq_events_set_shard", C.c_int, vp, u64, u64)
 _sig("lsq_mrf_parse", C.c_int, cs, cs, vp, C.c_int, P(vp))
+_sig("lsq_reads_parse", C.c_int, cs, cs, vp, C.c_int, P(vp))
 _sig("lsq_reads_wrap", C.c_int, u64, P(u64), P(u32), P(i32), P(i32), P(u16), P(u8), P(vp))
 _sig("lsq_reads_free", None, vp)
 _sig("lsq_reads_count", u64, vp)

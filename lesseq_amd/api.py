@@ -140,7 +140,7 @@ class Reads:
     @classmethod
     def from_mrf(cls, path, events, n_threads=0, read_format="MRF_SINGLE"):
         h = vp()
-        check(lib.lsq_mrf_parse(_b(read_format), _b(path), events.h, n_threads, C.byref(h)))
+        check(lib.lsq_reads_parse(_b(read_format), _b(path), events.h, n_threads, C.byref(h)))
         return cls(h)
 
     @classmethod

@@ -98,11 +98,15 @@ int count_formats_only(const char *iso_fmt, const char *iso_path, const char *g2
 	return LSQ_OK;
 }
 
-int precheck_reads_file(const char *fmt, const char *path) {
+bool named_read_format(const char *fmt) {       // the read formats only `solve` takes (solve/solve.cpp:413,487,552)
+	return strcmp(fmt, "UCSC_GFF") == 0 || strcmp(fmt, "UCSC_BED") == 0 || strcmp(fmt, "WORMBASE_GFF3") == 0;
+}
+
+int precheck_reads_file(const char *fmt, const char *path, bool solve) {
 	FILE *f = fopen(path, "rb");
 	if (!f) return fail(LSQ_E_IO, "cannot open reads file %s", path);
 	fclose(f);
-	if (strcmp(fmt, "MRF_SINGLE") != 0) return fail(LSQ_E_FORMAT, "Unknown file format error: %s", fmt);
+	if (strcmp(fmt, "MRF_SINGLE") != 0 && !(solve && named_read_format(fmt))) return fail(LSQ_E_FORMAT, "Unknown file format error: %s", fmt);
 	return LSQ_OK;
 }
 
@@ -202,7 +206,7 @@ int run_count_solve(bool solve, int argc, const char *const *argv, std::string &
 	logf(2, "Loading the reads from %d sampling method(s)", M);
 	for (int m = 0; m < M; ++m) {
 		// what the reference decides before it reads a line: the file opens (assert) and the format literal is known
-		st = precheck_reads_file(fmts[m], paths[m]);
+		st = precheck_reads_file(fmts[m], paths[m], solve);
 		if (st) { logf(0, "%s", lsq_last_error()); return status_to_exit(st); }
 		if (!F.c) {
 			int dev = 0;
@@ -211,12 +215,12 @@ int run_count_solve(bool solve, int argc, const char *const *argv, std::string &
 			if (!st) st = lsq_events_upload(F.c, F.e);
 			if (st) { logf(0, "%s", lsq_last_error()); return 3; }
 		}
-		// text -> HBM -> parsed and ingested there
-		st = lsq_reads_upload_mrf(F.c, m, fmts[m], paths[m]);
+		// MRF text -> HBM -> parsed and ingested there; the name-keyed formats are grouped by name on the host first
+		st = named_read_format(fmts[m]) ? LSQ_E_UNSUPPORTED : lsq_reads_upload_mrf(F.c, m, fmts[m], paths[m]);
 		if (st == LSQ_E_UNSUPPORTED) {
 			// a strand string beyond the device parser's 7 bytes: the host parser reads such files
 			lsq_reads *r = nullptr;
-			st = lsq_mrf_parse(fmts[m], paths[m], F.e, 0, &r);
+			st = lsq_reads_parse(fmts[m], paths[m], F.e, 0, &r);
 			if (!st) { F.r.push_back(r); st = lsq_reads_upload(F.c, m, r); lsq_reads_free(r); F.r.back() = nullptr; }
 		}
 		if (st == LSQ_E_PARSE) { logf(0, "%s", lsq_last_error()); logf(0, "Lexical_cast error when converting arguments to numeric values"); return status_to_exit(st); }

@@ -63,6 +63,10 @@ struct CountArgs {
 	const unsigned char *images;
 	const TieRec *ties;
 	const unsigned char *strand_rank;
+	// reads with their own names (solve's UCSC_GFF / UCSC_BED / WORMBASE_GFF3): name table of the method, and the
+	// gene names in device event order; null for MRF reads, whose name is "read-<line>"
+	const char *read_names; const unsigned long long *read_name_off;
+	const char *gene_names; const unsigned *gene_name_off;
 	unsigned n_buckets;
 	unsigned ablate;                   // developer switch (LSQ_ABLATE): 1 skip per-read work, 2 skip LDS atomics, 4 skip flush, 8 skip record look
 	unsigned tables_lds_bytes;         // LDS bytes reserved for the bucket image + histogram (16-byte multiple)
@@ -92,11 +96,22 @@ struct LdsView {
 // Span-start tie (count/count.cpp:64-85): the read starts exactly at the event's first base and
 // ends exactly at its last; it is a candidate unless (strand, name) orders it before the event.
 // "read-<line>" < gene name is std::string operator< on the reference's read names.
-__device__ __noinline__ bool tie_orders_read_first(const TieRec *ties, const unsigned char *strand_rank,
-                                                   unsigned ev_index, unsigned read_strand, unsigned line) {
-	const TieRec *t = ties + ev_index;
-	const unsigned rs = strand_rank[read_strand], gs = strand_rank[t->strand_id];
+__device__ __noinline__ bool tie_orders_read_first(const CountArgs &A, unsigned ev_index, unsigned read_strand, unsigned line) {
+	const TieRec *t = A.ties + ev_index;
+	const unsigned rs = A.strand_rank[read_strand], gs = A.strand_rank[t->strand_id];
 	if (rs != gs) return rs < gs;
+	if (A.read_name_off) {
+		// named reads: `line` indexes the method's name table; std::string operator< against the gene name
+		const unsigned long long r0 = A.read_name_off[line], r1 = A.read_name_off[line + 1];
+		const unsigned g0 = A.gene_name_off[ev_index], g1 = A.gene_name_off[ev_index + 1];
+		const unsigned long long rn = r1 - r0;
+		const unsigned gn = g1 - g0;
+		for (unsigned long long i = 0; i < rn && i < gn; ++i) {
+			const unsigned char a = (unsigned char)A.read_names[r0 + i], b = (unsigned char)A.gene_names[g0 + i];
+			if (a != b) return a < b;
+		}
+		return rn < gn;
+	}
 	const unsigned mode = t->tie_mode;
 	if (mode != 2) return mode == 1;
 	// compare the decimal digits of `line`, most significant first, with the name's tail
@@ -161,7 +176,7 @@ __device__ inline void process_read(const LdsView &L, const BucketDesc &d, const
 		if (p == e.gs) {
 			// reads ordered before the key (chrom, gene_start, gene_end, strand, name) are not candidates
 			if (q < e.ge) continue;
-			if (q == e.ge && tie_orders_read_first(A.ties, A.strand_rank, d.ev_base + i, strand_arr[slot], line_arr[slot])) continue;
+			if (q == e.ge && tie_orders_read_first(A, d.ev_base + i, strand_arr[slot], line_arr[slot])) continue;
 		}
 		Walk w;
 		const int2 *segs = L.segs + e.seg_off;
@@ -873,7 +888,7 @@ __device__ void eval_read_global(const CountArgs &A, const GlobalBucket &G, cons
 		bool cand = p <= ge;
 		if (cand && p == gs) {
 			if (q < ge) cand = false;
-			else if (q == ge && tie_orders_read_first(A.ties, A.strand_rank, d.ev_base + i, strand_id, line)) cand = false;
+			else if (q == ge && tie_orders_read_first(A, d.ev_base + i, strand_id, line)) cand = false;
 		}
 		if (cand) {
 			int2 segs[4] = {make_int2((int)w1.x, (int)w1.y), make_int2((int)w1.z, (int)w1.w), make_int2((int)w2.x, (int)w2.y), make_int2((int)w2.z, (int)w2.w)};
@@ -1599,6 +1614,9 @@ struct MethodReads {
 	DevBuf<uint32_t> p1_line, p2_line, pn_line, pn_blk_off, pn_nblk, pn_bucket;
 	DevBuf<unsigned long long> p1_off, p2_off, pn_off, pnb_off, slot_off;
 	double skew = 1.0;                      // reads of the fullest bucket / mean reads per bucket
+	bool named = false;                     // the reads carry their own names (the *_line arrays index name_off)
+	DevBuf<char> names;
+	DevBuf<unsigned long long> name_off;
 	DevBuf<unsigned> wg_first;             // lsq_wg_plan_kernel's table for `wg_grid` workgroups
 	unsigned long long wg_grid = 0;
 };
@@ -1616,7 +1634,8 @@ struct lsq_ctx {
 	DevBuf<BucketDesc> buckets;
 	DevBuf<uint8_t> images, strand_rank, dK;
 	DevBuf<TieRec> ties;
-	DevBuf<uint32_t> cls_base, iso_base, iters, em_order;
+	DevBuf<uint32_t> cls_base, iso_base, iters, em_order, gene_name_off;
+	DevBuf<char> gene_names;                // device event order
 	unsigned em_places = 0;
 	DevBuf<double> G, theta, logll;
 	DevBuf<uint8_t> flags;
@@ -1730,6 +1749,12 @@ int lsq_events_upload(lsq_ctx *c, lsq_events *E) {
 		}
 		c->em_places = (unsigned)order.size();
 		if ((rc = c->em_order.upload(order.data(), order.size(), c->stream))) return rc;
+		// gene names for span-start ties against named reads
+		std::string blob;
+		std::vector<uint32_t> goff(n_dev + 1, 0);
+		for (size_t d = 0; d < n_dev; ++d) { blob += E->ev[E->dev2out[d]].gname; goff[d + 1] = (uint32_t)blob.size(); }
+		if ((rc = c->gene_names.upload(blob.data(), blob.size(), c->stream))) return rc;
+		if ((rc = c->gene_name_off.upload(goff.data(), goff.size(), c->stream))) return rc;
 	}
 	// G = 1/ARS (common/read.h:331-340), device isoform order, per method
 	const size_t n_iso = E->n_iso_total, M = (size_t)E->n_methods;
@@ -1914,7 +1939,15 @@ int lsq_reads_upload(lsq_ctx *c, int method, const lsq_reads *R) {
 	IngestRaw Rw;
 	Rw.n_reads = n; Rw.blk_off = d_blk_off.p; Rw.line_no = d_line.p; Rw.blk_start = d_bs.p; Rw.blk_end = d_be.p;
 	Rw.blk_chrom = d_bc.p; Rw.blk_strand = d_bst.p;
-	return ingest_device(c, method, Rw, nblk);
+	if ((rc = ingest_device(c, method, Rw, nblk))) return rc;
+	MethodReads &mr = c->reads[method];
+	mr.named = R->named;
+	if (R->named) {
+		if ((rc = mr.names.upload(R->name_blob.data(), R->name_blob.size(), st))) return rc;
+		if ((rc = mr.name_off.upload((const unsigned long long *)R->name_off.data(), R->name_off.size(), st))) return rc;
+		HIP_TRY(hipStreamSynchronize(st));
+	}
+	return LSQ_OK;
 }
 
 int lsq_reads_upload_mrf(lsq_ctx *c, int method, const char *read_format, const char *path) {
@@ -1928,6 +1961,7 @@ int lsq_reads_upload_mrf(lsq_ctx *c, int method, const char *read_format, const 
 	IngestRaw Rw;
 	Rw.n_reads = P.n_reads; Rw.blk_off = P.blk_off.p; Rw.line_no = P.line_no.p; Rw.blk_start = P.bs.p; Rw.blk_end = P.be.p;
 	Rw.blk_chrom = P.bc.p; Rw.blk_strand = P.bst.p;
+	c->reads[method].named = false;
 	return ingest_device(c, method, Rw, P.n_blocks);
 }
 
@@ -2003,6 +2037,8 @@ static int run_count(lsq_ctx *c, bool all_reads) {
 		CountArgs A;
 		A.buckets = c->buckets.p; A.images = c->images.p; A.ties = c->ties.p; A.strand_rank = c->strand_rank.p;
 		A.wg_first = mr.wg_first.p;
+		A.read_names = mr.named ? mr.names.p : nullptr; A.read_name_off = mr.named ? mr.name_off.p : nullptr;
+		A.gene_names = c->gene_names.p; A.gene_name_off = c->gene_name_off.p;
 		A.n_buckets = (unsigned)E.buckets.size();
 		A.tables_lds_bytes = tables_bytes;
 		A.ablate = 0;

@@ -189,6 +189,11 @@ struct lsq_reads {
 	std::vector<int32_t> o_start, o_end;
 	std::vector<uint16_t> o_chrom;
 	std::vector<uint8_t> o_strand;
+	// reads that carry their own names (solve's UCSC_GFF / UCSC_BED / WORMBASE_GFF3 read formats): line_no
+	// then indexes this table instead of naming the read "read-<line_no>"
+	bool named = false;
+	std::string name_blob;
+	std::vector<uint64_t> name_off;                // n_reads + 1
 	void adopt();
 };
 

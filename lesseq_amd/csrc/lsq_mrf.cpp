@@ -10,7 +10,9 @@
 #include <cerrno>
 #include <cstdlib>
 #include <cstring>
+#include <sstream>
 #include <thread>
+#include <unordered_map>
 
 #include "lsq_internal.hpp"
 #include "lsq_mrf_line.hpp"
@@ -189,6 +191,181 @@ int lsq_mrf_parse(const char *read_format, const char *path, lsq_events *E, int 
 		}
 	}
 	if (data) munmap((void *)data, len);
+	R->adopt();
+	*out = R.release();
+	return LSQ_OK;
+}
+
+// solve's name-keyed read formats (solve/solve.cpp:413-428 UCSC_GFF, :487-551 UCSC_BED, :552-634
+// WORMBASE_GFF3).  Every accepted line adds its blocks to the read of its name, in file order; the
+// device ingest then merges them with add_interval and takes chromosome and strand from the last kept
+// block, which is the last accepted line.  UCSC_BED and WORMBASE_GFF3 accept or drop a line by its
+// whole span, so that test runs here against the covered regions; UCSC_GFF tests the block itself, as
+// the ingest kernel does anyway.
+int lsq_reads_parse(const char *read_format, const char *path, lsq_events *E, int n_threads, lsq_reads **out) {
+	if (!read_format || !path || !E || !out) return fail(LSQ_E_ARG, "null argument");
+	const std::string fmt = read_format;
+	if (fmt == "MRF_SINGLE") return lsq_mrf_parse(read_format, path, E, n_threads, out);
+	FILE *fp = fopen(path, "rb");
+	if (!fp) return fail(LSQ_E_IO, "cannot open reads file %s", path);
+	if (fmt != "UCSC_GFF" && fmt != "UCSC_BED" && fmt != "WORMBASE_GFF3") { fclose(fp); return fail(LSQ_E_FORMAT, "Unknown file format error: %s", read_format); }
+	std::string data;
+	{
+		char buf[1 << 16];
+		size_t n;
+		while ((n = fread(buf, 1, sizeof buf, fp)) > 0) data.append(buf, n);
+		fclose(fp);
+	}
+	struct Line { uint32_t read; int32_t s[2], e[2]; uint16_t chrom; uint8_t strand, n; };
+	std::vector<Line> accepted;
+	std::unordered_map<std::string, uint32_t> by_name;
+	std::vector<std::string> names;
+	const int64_t LIM = (int64_t)1 << 30;
+	auto chrom_of = [&](const std::string &c) -> int { int id = E->chroms.find(c); return (id < 0 || (size_t)id >= E->covered.size()) ? -1 : id; };
+	auto covered = [&](int chrom, int64_t s, int64_t e) -> bool {
+		if (!(s < e)) return true;                       // contains_interval of an empty interval (interval_list.hpp:396-422)
+		return chrom >= 0 && E->covered[chrom].contains(s, e);
+	};
+	auto strand_of = [&](const std::string &st, int &sid) -> bool { sid = E->strands.intern(st); return sid <= 255; };
+	auto push = [&](const std::string &name, int chrom, int sid, int nblk, const int64_t *bs, const int64_t *be) {
+		auto it = by_name.find(name);
+		uint32_t r;
+		if (it == by_name.end()) { r = (uint32_t)names.size(); by_name.emplace(name, r); names.push_back(name); } else r = it->second;
+		for (int k = 0; k < nblk; k += 2) {
+			Line l; l.read = r; l.strand = (uint8_t)sid; l.n = (uint8_t)std::min(2, nblk - k);
+			l.chrom = chrom < 0 ? NOCHROM : (uint16_t)chrom;
+			for (int q = 0; q < l.n; ++q) {
+				int64_t s = bs[k + q], e = be[k + q];
+				if (s <= -LIM || e >= LIM || s >= LIM || e <= -LIM) { l.chrom = NOCHROM; s = 0; e = 0; }
+				l.s[q] = (int32_t)s; l.e[q] = (int32_t)e;
+			}
+			accepted.push_back(l);
+		}
+		if (nblk == 0) { Line l; l.read = r; l.strand = (uint8_t)sid; l.n = 0; l.chrom = NOCHROM; l.s[0] = l.e[0] = l.s[1] = l.e[1] = 0; accepted.push_back(l); }
+	};
+	auto field = [](const std::string &ln, int k, size_t &b, size_t &e) -> bool {       // tab field k as a find('\t') chain sees it
+		size_t pos = 0;
+		for (int i = 0; i < k; ++i) { size_t t = ln.find('\t', pos); if (t == std::string::npos) return false; pos = t + 1; }
+		size_t t = ln.find('\t', pos);
+		b = pos; e = t == std::string::npos ? ln.size() : t;
+		return true;
+	};
+	auto cast_field = [&](const std::string &ln, int k, int64_t &v) -> bool {
+		size_t b, e;
+		if (!field(ln, k, b, e)) return false;
+		return mrf_cast_long(MrfView{ln.data() + b, e - b}, v);
+	};
+	size_t pos = 0, line_no = 0;
+	const size_t skip = fmt == "UCSC_GFF" ? 2 : (fmt == "UCSC_BED" ? 1 : 0);
+	int status = LSQ_OK;
+	std::string err;
+	while (pos < data.size() && status == LSQ_OK) {
+		size_t nl = data.find('\n', pos);
+		if (nl == std::string::npos) break;                  // an unterminated last line is never seen
+		const std::string ln(data, pos, nl - pos);
+		pos = nl + 1;
+		if (line_no++ < skip) continue;
+		int sid = 0;
+		if (fmt == "UCSC_GFF") {
+			std::istringstream iss(ln);
+			long start = 0, end = 0;
+			std::string rname, chr, tmp, strand;
+			iss >> chr >> tmp >> tmp >> start >> end >> tmp >> strand >> tmp >> rname;
+			if (iss.fail()) { status = LSQ_E_ARG; err = "line " + std::to_string(line_no) + " does not have the UCSC_GFF columns (the reference reads uninitialised coordinates here)"; break; }
+			const int chrom = chrom_of(chr);
+			if (!covered(chrom, (int64_t)start - 1, end)) continue;
+			if (!strand_of(strand, sid)) { status = LSQ_E_RANGE; err = "more than 256 distinct strand strings"; break; }
+			const int64_t bs[1] = {(int64_t)start - 1}, be[1] = {end};
+			push(rname, chrom, sid, 1, bs, be);
+		} else if (fmt == "UCSC_BED") {
+			int64_t start, end, nb;
+			size_t b, e;
+			if (!cast_field(ln, 1, start) || !cast_field(ln, 2, end)) { status = LSQ_E_PARSE; err = "#" + std::to_string(line_no) + ":" + ln; break; }
+			std::string chr = field(ln, 0, b, e) ? ln.substr(b, e - b) : std::string();
+			const int chrom = chrom_of(chr);
+			if (!covered(chrom, start, end)) continue;
+			if (!cast_field(ln, 9, nb)) { status = LSQ_E_PARSE; err = "#" + std::to_string(line_no) + ":" + ln; break; }
+			std::string rname = field(ln, 3, b, e) ? ln.substr(b, e - b) : std::string();
+			std::string strand = field(ln, 5, b, e) ? ln.substr(b, e - b) : std::string();
+			std::string sizes = field(ln, 10, b, e) ? ln.substr(b, e - b) : std::string();
+			std::string starts = field(ln, 11, b, e) ? ln.substr(b, e - b) : std::string();
+			if (!strand_of(strand, sid)) { status = LSQ_E_RANGE; err = "more than 256 distinct strand strings"; break; }
+			std::vector<int64_t> bs, be;
+			size_t ps = 0, pz = 0;
+			for (int64_t i = 0; i < nb; ++i) {
+				size_t qs = starts.find(',', ps), qz = sizes.find(',', pz);
+				if (qs == std::string::npos) qs = starts.size();
+				if (qz == std::string::npos) qz = sizes.size();
+				int64_t istart, isize;
+				if (ps > starts.size() || pz > sizes.size() || !mrf_cast_long(MrfView{starts.data() + ps, qs - ps}, istart) || !mrf_cast_long(MrfView{sizes.data() + pz, qz - pz}, isize)) {
+					status = LSQ_E_PARSE; err = "#" + std::to_string(line_no) + ":" + ln; break;
+				}
+				bs.push_back(start + istart); be.push_back(start + istart + isize);
+				ps = qs + 1; pz = qz + 1;
+			}
+			if (status != LSQ_OK) break;
+			push(rname, chrom, sid, (int)bs.size(), bs.data(), be.data());
+		} else {
+			int64_t start, end;
+			size_t b, e;
+			if (!cast_field(ln, 3, start) || !cast_field(ln, 4, end)) { status = LSQ_E_PARSE; err = "#" + std::to_string(line_no) + ":" + ln; break; }
+			std::string chr = "chr" + (field(ln, 0, b, e) ? ln.substr(b, e - b) : std::string());
+			std::string strand = field(ln, 6, b, e) ? ln.substr(b, e - b) : std::string();
+			std::string rinfo = field(ln, 8, b, e) ? ln.substr(b, e - b) : std::string();
+			std::string rname;
+			bool found_parent = false;
+			int64_t start2 = 0, end2 = 0;
+			size_t a0 = 0;
+			for (;;) {                                           // attributes closed by ';' only
+				size_t a1 = rinfo.find(';', a0);
+				if (a1 == std::string::npos) break;
+				const std::string at = rinfo.substr(a0, a1 - a0);
+				if (at.compare(0, 7, "Target=") == 0) { const std::string v = at.substr(7); rname = v.substr(0, v.find(' ')); }
+				else if (at.compare(0, 7, "Parent=") == 0) {
+					const std::string v = at.substr(7);
+					if (v.compare(0, 7, "intron_") == 0) {
+						found_parent = true;
+						size_t u0 = v.find('_', 7), u1 = u0 == std::string::npos ? u0 : v.find('_', u0 + 1);
+						size_t u2 = u1 == std::string::npos ? u1 : v.find('_', u1 + 1);
+						bool ok = u0 != std::string::npos && u1 != std::string::npos;
+						if (ok) {
+							const std::string t1 = v.substr(u0 + 1, u1 - u0 - 1), t2 = v.substr(u1 + 1, u2 == std::string::npos ? std::string::npos : u2 - u1 - 1);
+							ok = !t1.empty() && !t2.empty() && t1[0] != '-' && t2[0] != '-' && mrf_cast_long(MrfView{t1.data(), t1.size()}, start2) && mrf_cast_long(MrfView{t2.data(), t2.size()}, end2);
+						}
+						if (!ok) { status = LSQ_E_PARSE; err = "#" + std::to_string(line_no) + ":" + ln; break; }
+					}
+				}
+				a0 = a1 + 1;
+			}
+			if (status != LSQ_OK) break;
+			const int chrom = chrom_of(chr);
+			if (!covered(chrom, start - 1, end)) continue;
+			if (!strand_of(strand, sid)) { status = LSQ_E_RANGE; err = "more than 256 distinct strand strings"; break; }
+			if (!found_parent) { const int64_t bs[1] = {start - 1}, be[1] = {end}; push(rname, chrom, sid, 1, bs, be); }
+			else { const int64_t bs[2] = {start - 1, end2}, be[2] = {start2 - 1, end}; push(rname, chrom, sid, 2, bs, be); }
+		}
+	}
+	if (status != LSQ_OK) return fail(status, "%s", err.c_str());
+	// reads in order of first appearance; the blocks of a read in file order
+	std::unique_ptr<lsq_reads> R(new lsq_reads);
+	const size_t nr = names.size();
+	std::vector<uint64_t> cnt(nr + 1, 0);
+	for (const Line &l : accepted) cnt[l.read + 1] += l.n;
+	R->o_blk_off.assign(nr + 1, 0);
+	for (size_t r = 0; r < nr; ++r) R->o_blk_off[r + 1] = R->o_blk_off[r] + cnt[r + 1];
+	const uint64_t nb = R->o_blk_off[nr];
+	R->o_start.resize(nb); R->o_end.resize(nb); R->o_chrom.resize(nb); R->o_strand.resize(nb);
+	R->o_line_no.resize(nr);
+	std::vector<uint64_t> cur(R->o_blk_off.begin(), R->o_blk_off.end() - 1);
+	for (const Line &l : accepted)
+		for (int q = 0; q < l.n; ++q) {
+			const uint64_t w = cur[l.read]++;
+			R->o_start[w] = l.s[q]; R->o_end[w] = l.e[q]; R->o_chrom[w] = l.chrom; R->o_strand[w] = l.strand;
+		}
+	if (nr > 0xFFFFFFF0ull) return fail(LSQ_E_RANGE, "more than 2^32 read names");
+	R->named = true;
+	R->name_off.assign(nr + 1, 0);
+	for (size_t r = 0; r < nr; ++r) { R->o_line_no[r] = (uint32_t)r; R->name_blob += names[r]; R->name_off[r + 1] = R->name_blob.size(); }
 	R->adopt();
 	*out = R.release();
 	return LSQ_OK;

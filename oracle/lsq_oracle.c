@@ -264,6 +264,11 @@ static int lexical_cast_ulong(const char *s, unsigned long *out) {
 	*out = v;
 	return 1;
 }
+static int lexical_cast_ulong_n(const char *s, size_t n, unsigned long *out) {
+	char t[64]; if (n == 0 || n > 62) return 0;
+	memcpy(t, s, n); t[n] = 0;
+	return lexical_cast_ulong(t, out);
+}
 static int lexical_cast_double(const char *s, double *out) {
 	if (!*s || isspace((unsigned char)*s)) return 0;
 	char *end;
@@ -348,7 +353,8 @@ static int split_atol(const char *s, size_t n, long **out) {
 /* ------------------------------------------------------------------ reads */
 
 typedef struct {
-	unsigned long line_num;    /* name == "read-<line_num>" */
+	unsigned long line_num;    /* name == "read-<line_num>" when `name` is NULL */
+	char *name;                /* the formats only solve reads carry their own read names */
 	int chrom, strand;         /* ids into string tables (compared as strings) */
 	ilist il;
 	long start, end;
@@ -447,14 +453,152 @@ static int load_mrf(const text_t *t, chrom_regions *covered, strtab *chroms, str
 	return 0;
 }
 
+/* ------------------------------------------------------------------ solve's name-keyed read formats
+ * (solve.cpp:413-428 UCSC_GFF, :487-551 UCSC_BED, :552-634 WORMBASE_GFF3).  Every accepted line adds
+ * its intervals to the read of its name, in file order; chromosome and strand are those of the last
+ * accepted line.  Accepted lines are collected first, then grouped by name with a stable sort. */
+
+typedef struct { char *name; int chrom, strand; long s[2], e[2]; int n; size_t ord; } named_line;
+typedef struct { named_line *v; size_t n, cap; } named_vec;
+
+static void named_push(named_vec *nv, const char *name, size_t nn, int chrom, int strand, long s0, long e0, int two, long s1, long e1) {
+	if (nv->n == nv->cap) { nv->cap = nv->cap ? nv->cap * 2 : 1024; nv->v = (named_line *)xrealloc(nv->v, sizeof(named_line) * nv->cap); }
+	named_line *l = &nv->v[nv->n];
+	l->name = xstrndup(name, nn); l->chrom = chrom; l->strand = strand;
+	l->s[0] = s0; l->e[0] = e0; l->s[1] = s1; l->e[1] = e1; l->n = two ? 2 : 1; l->ord = nv->n;
+	nv->n++;
+}
+static int cmp_named(const void *pa, const void *pb) {
+	const named_line *a = (const named_line *)pa, *b = (const named_line *)pb;
+	int c = strcmp(a->name, b->name);
+	if (c) return c;
+	return a->ord < b->ord ? -1 : (a->ord > b->ord ? 1 : 0);
+}
+static void named_finish(named_vec *nv, readvec *out) {
+	qsort(nv->v, nv->n, sizeof(named_line), cmp_named);
+	size_t i = 0;
+	while (i < nv->n) {
+		size_t j = i;
+		read_t rd; memset(&rd, 0, sizeof rd);
+		rd.name = nv->v[i].name;
+		while (j < nv->n && strcmp(nv->v[j].name, rd.name) == 0) {
+			rd.chrom = nv->v[j].chrom; rd.strand = nv->v[j].strand;
+			for (int k = 0; k < nv->v[j].n; k++) lsqo_il_add(&rd.il, nv->v[j].s[k], nv->v[j].e[k]);
+			if (j > i) free(nv->v[j].name);
+			j++;
+		}
+		if (rd.il.n > 0) {
+			rd.start = rd.il.s[0]; rd.end = rd.il.e[rd.il.n - 1];
+			if (out->n == out->cap) { out->cap = out->cap ? out->cap * 2 : 1024; out->v = (read_t *)xrealloc(out->v, sizeof(read_t) * out->cap); }
+			out->v[out->n++] = rd;
+		} else il_free(&rd.il);        /* a read with no interval at all: undefined behaviour in the reference */
+		i = j;
+	}
+	free(nv->v);
+}
+
+/* tab fields: field k (0-based) of a line as the reference finds it with find('\t') chains */
+static int tab_field(const char *line, size_t n, int k, const char **f, size_t *fn) {
+	size_t pos = 0;
+	for (int i = 0; i < k; i++) {
+		const char *t = (const char *)memchr(line + pos, '\t', n - pos);
+		if (!t) return 0;
+		pos = (size_t)(t - line) + 1;
+	}
+	const char *t = (const char *)memchr(line + pos, '\t', n - pos);
+	*f = line + pos; *fn = t ? (size_t)(t - (line + pos)) : n - pos;
+	return 1;
+}
+
+/* returns 0 ok, 1 lexical_cast error */
+static int load_named_reads(const char *fmt, const text_t *t, chrom_regions *covered, strtab *chroms, strtab *strands, readvec *out) {
+	named_vec nv; memset(&nv, 0, sizeof nv);
+	size_t pos = 0; const char *line; size_t n;
+	if (strcmp(fmt, "UCSC_GFF") == 0) {
+		next_line(t, &pos, &line, &n); next_line(t, &pos, &line, &n);            /* two header lines */
+		while (next_line(t, &pos, &line, &n)) {
+			const char *tok[9]; size_t tn[9]; int nt = 0; size_t p = 0;
+			while (nt < 9 && next_tok(line, n, &p, &tok[nt], &tn[nt])) nt++;
+			long start = 0, end = 0;
+			if (nt < 9 || !stream_long(tok[3], tn[3], &start) || !stream_long(tok[4], tn[4], &end)) continue;   /* malformed: the reference reads garbage */
+			if (lsqo_il_contains(regions_get(covered, tok[0], tn[0]), start - 1, end))
+				named_push(&nv, tok[8], tn[8], strtab_id(chroms, tok[0], tn[0]), strtab_id(strands, tok[6], tn[6]), start - 1, end, 0, 0, 0);
+		}
+	} else if (strcmp(fmt, "UCSC_BED") == 0) {
+		next_line(t, &pos, &line, &n);                                            /* one header line */
+		while (next_line(t, &pos, &line, &n)) {
+			const char *f[12]; size_t fn[12];
+			for (int k = 0; k < 12; k++) if (!tab_field(line, n, k, &f[k], &fn[k])) { f[k] = ""; fn[k] = 0; }
+			long start, end, nb;
+			if (!lexical_cast_long(f[1], fn[1], &start) || !lexical_cast_long(f[2], fn[2], &end)) return 1;
+			char cbuf[512]; snprintf(cbuf, sizeof cbuf, "%.*s", (int)fn[0], f[0]);
+			if (!lsqo_il_contains(regions_get(covered, f[0], fn[0]), start, end)) continue;
+			if (!lexical_cast_long(f[9], fn[9], &nb)) return 1;
+			/* blockSizes (col 11) and blockStarts (col 12), comma separated, the first blockCount of them */
+			size_t ps = 0, pz = 0;
+			int chrom = strtab_id(chroms, f[0], fn[0]), strand = strtab_id(strands, f[5], fn[5]);
+			if (nb <= 0) named_push(&nv, f[3], fn[3], chrom, strand, 0, 0, 0, 0, 0);   /* a name with no interval */
+			for (long i = 0; i < nb; i++) {
+				size_t qs = ps; while (qs < fn[11] && f[11][qs] != ',') qs++;
+				size_t qz = pz; while (qz < fn[10] && f[10][qz] != ',') qz++;
+				long istart, isize;
+				if (!lexical_cast_long(f[11] + ps, qs - ps, &istart) || !lexical_cast_long(f[10] + pz, qz - pz, &isize)) return 1;
+				named_push(&nv, f[3], fn[3], chrom, strand, start + istart, start + istart + isize, 0, 0, 0);
+				ps = qs + 1; pz = qz + 1;
+			}
+		}
+	} else {   /* WORMBASE_GFF3 */
+		while (next_line(t, &pos, &line, &n)) {
+			const char *f[9]; size_t fn[9];
+			for (int k = 0; k < 9; k++) if (!tab_field(line, n, k, &f[k], &fn[k])) { f[k] = ""; fn[k] = 0; }
+			long start, end;
+			if (!lexical_cast_long(f[3], fn[3], &start) || !lexical_cast_long(f[4], fn[4], &end)) return 1;
+			char chr[512]; int cn = snprintf(chr, sizeof chr, "chr%.*s", (int)fn[0], f[0]);
+			/* attributes: only those closed by ';' are looked at */
+			const char *ri = f[8]; size_t rn = fn[8];
+			const char *rname = ""; size_t rnn = 0;
+			int found_parent = 0; unsigned long start2 = 0, end2 = 0;
+			size_t a0 = 0;
+			for (;;) {
+				size_t a1 = a0; while (a1 < rn && ri[a1] != ';') a1++;
+				if (a1 >= rn) break;
+				const char *at = ri + a0; size_t an = a1 - a0;
+				if (an >= 7 && memcmp(at, "Target=", 7) == 0) {
+					const char *v = at + 7; size_t vn = an - 7, sp = 0;
+					while (sp < vn && v[sp] != ' ') sp++;
+					rname = v; rnn = sp;
+				} else if (an >= 7 && memcmp(at, "Parent=", 7) == 0) {
+					const char *v = at + 7; size_t vn = an - 7;
+					if (vn >= 7 && memcmp(v, "intron_", 7) == 0) {
+						found_parent = 1;
+						size_t u0 = 7; while (u0 < vn && v[u0] != '_') u0++;          /* end of the intron's own name */
+						size_t u1 = u0 + 1; while (u1 < vn && v[u1] != '_') u1++;
+						size_t u2 = u1 + 1; while (u2 < vn && v[u2] != '_') u2++;
+						if (u0 >= vn || !lexical_cast_ulong_n(v + u0 + 1, u1 - u0 - 1, &start2)) return 1;
+						if (u1 >= vn || !lexical_cast_ulong_n(v + u1 + 1, (u2 < vn ? u2 : vn) - u1 - 1, &end2)) return 1;
+					}
+				}
+				a0 = a1 + 1;
+			}
+			if (lsqo_il_contains(regions_get(covered, chr, (size_t)cn), start - 1, end)) {
+				int chrom = strtab_id(chroms, chr, (size_t)cn), strand = strtab_id(strands, f[6], fn[6]);
+				if (!found_parent) named_push(&nv, rname, rnn, chrom, strand, start - 1, end, 0, 0, 0);
+				else named_push(&nv, rname, rnn, chrom, strand, start - 1, (long)start2 - 1, 1, (long)end2, end);
+			}
+		}
+	}
+	named_finish(&nv, out);
+	return 0;
+}
+
 /* ------------------------------------------------------------------ read index order (count.cpp:64-85) */
 
 static strtab *g_chroms, *g_strands;
 
-static int cmp_name_num(unsigned long a, unsigned long b) { /* "read-a" vs "read-b" as strings */
-	char x[32], y[32];
-	snprintf(x, sizeof x, "%lu", a); snprintf(y, sizeof y, "%lu", b);
-	return strcmp(x, y);
+static const char *read_name(const read_t *r, char *buf, size_t cap) {
+	if (r->name) return r->name;
+	snprintf(buf, cap, "read-%lu", r->line_num);
+	return buf;
 }
 static int cmp_read(const void *pa, const void *pb) {
 	const read_t *a = (const read_t *)pa, *b = (const read_t *)pb;
@@ -462,7 +606,8 @@ static int cmp_read(const void *pa, const void *pb) {
 	if (a->start != b->start) return a->start < b->start ? -1 : 1;
 	if (a->end != b->end) return a->end < b->end ? -1 : 1;
 	if (a->strand != b->strand) { int c = strcmp(g_strands->v[a->strand], g_strands->v[b->strand]); if (c) return c; }
-	return cmp_name_num(a->line_num, b->line_num);
+	char x[40], y[40];
+	return strcmp(read_name(a, x, sizeof x), read_name(b, y, sizeof y));
 }
 /* RinfopComp(read, gp): is read < (chrom, start, end, strand, name) ? */
 static int read_less_than_key(const read_t *a, const char *chrom, long start, long end, const char *strand, const char *name) {
@@ -472,8 +617,8 @@ static int read_less_than_key(const read_t *a, const char *chrom, long start, lo
 	if (a->end != end) return a->end < end;
 	c = strcmp(g_strands->v[a->strand], strand);
 	if (c) return c < 0;
-	char x[40]; snprintf(x, sizeof x, "read-%lu", a->line_num);
-	return strcmp(x, name) < 0;
+	char x[40];
+	return strcmp(read_name(a, x, sizeof x), name) < 0;
 }
 
 /* ------------------------------------------------------------------ Read_single::build (read.h:204-274) */
@@ -875,9 +1020,11 @@ static int run(const params_t *P, sink *out, exact_t *ex) {
 	g_chroms = &chroms; g_strands = &strands;
 	readvec *rv = (readvec *)calloc((size_t)P->M, sizeof(readvec));
 	for (int m = 0; m < P->M; m++) {
-		if (strcmp(P->read_formats[m], "MRF_SINGLE") != 0) { err_line("Unknown file format error"); return 1; }
 		if (!load_text(P->reads_paths[m], &txt)) { err_line("cannot open reads file"); return 134; }
-		int rc = load_mrf(&txt, &covered, &chroms, &strands, &rv[m]);
+		const char *rf = P->read_formats[m];
+		const int named = P->is_solve && (strcmp(rf, "UCSC_GFF") == 0 || strcmp(rf, "UCSC_BED") == 0 || strcmp(rf, "WORMBASE_GFF3") == 0);
+		if (strcmp(rf, "MRF_SINGLE") != 0 && !named) { err_line("Unknown file format error"); return 1; }
+		int rc = named ? load_named_reads(rf, &txt, &covered, &chroms, &strands, &rv[m]) : load_mrf(&txt, &covered, &chroms, &strands, &rv[m]);
 		free(txt.data);
 		if (rc) { err_line("Lexical_cast error when converting arguments to numeric values"); return 1; }
 		qsort(rv[m].v, rv[m].n, sizeof(read_t), cmp_read);

@@ -185,6 +185,20 @@ def main():
         return {"count": count, "solve": solve}
     case("formats", w, sp)
 
+    # the read formats only `solve` reads (solve/solve.cpp:413-428,487-634): reads keyed by name
+    def w(d):
+        return gi.write_readfmts(d)
+    def sp(info):
+        base = ["0", "rf", "./", "LH_GENE_TXT", "rf.interval", "UCSC_GENE2ISOFORM", "rf.map", "0", "1000"]
+        trb = str(info["total_read_bases"])
+        R = str(info["R"])
+        solve = [base + [fmt, "SHORT_READ", R, path, trb] for fmt, path in (("UCSC_GFF", "rf.gff"), ("UCSC_BED", "rf.bed"), ("WORMBASE_GFF3", "rf.gff3"), ("MRF_SINGLE", "rf.mrf"))]
+        solve.append(base + ["UCSC_GFF", "SHORT_READ", R, "rf.gff", trb, "UCSC_BED", "MEDIUM_READ", R, "rf.bed", trb])
+        solve.append(base[:7] + ["2", "9", "WORMBASE_GFF3", "MEDIUM_READ", R, "rf.gff3", trb])
+        count = [base + [fmt, "SHORT_READ", R, path] for fmt, path in (("UCSC_GFF", "rf.gff"), ("UCSC_BED", "rf.bed"), ("WORMBASE_GFF3", "rf.gff3"))]
+        return {"count": count, "solve": solve}
+    case("readfmts", w, sp)
+
     # 6-significant-digit formatting of counts >= 1e6 (input regenerated by the tests)
     def w(d):
         return gi.write_fmt1m(d)

@@ -538,3 +538,58 @@ def write_formats(d):
     _w(os.path.join(d, "f.worm.map"), "".join(worm_g2i))
     _w(os.path.join(d, "f.mrf"), "AlignmentBlocks\n" + "".join(mrf_line(*r) for r in reads))
     return {"total_read_bases": 1200 * R, "R": R}
+
+
+# ----------------------------------------------------------------------------- solve's other read formats
+
+def write_readfmts(d):
+    """One set of named reads in the three read formats only `solve` takes (solve/solve.cpp:413-428,
+    487-634): UCSC_GFF (a line per block, lines of a name make one read), UCSC_BED (a line per read,
+    kept or dropped as a whole by its span), WORMBASE_GFF3 (a line per read, an optional intron in
+    the Parent attribute).  Names decide span-start ties against gene names, so some reads cover an
+    event's span exactly and carry names below, equal to and above the gene's."""
+    rng = random.Random(43)
+    R = 50
+    chroms = ["chr1", "chr2"]
+    events = gen_events(rng, 25, R, chroms)
+    iv, mp = [], []
+    for e in events:
+        for k, form in enumerate(e["forms"]):
+            iname = "%s.%s" % (e["name"], "ab"[k])
+            iv.append(interval_line(iname, e["chrom"], e["strand"], form))
+            mp.append("%s\t%s\n" % (e["name"], iname))
+    raw = [r for r in gen_reads(rng, events, 900, R, chroms) if len(r[2]) <= 2]
+    reads = []           # (name, chrom, strand, blocks)
+    for i, (c, strand, blocks) in enumerate(raw):
+        reads.append(("r%04d" % i, c, strand, blocks))
+    for j, e in enumerate(events):          # span-start ties: exactly the event's span, one block
+        gs, ge = e["span"]
+        for nm, st in ((e["name"], e["strand"]), (e["name"] + "0", e["strand"]), ("!" + e["name"], e["strand"]), ("zz%d" % j, e["strand"]),
+                       ("!s%d" % j, "+" if e["strand"] == "-" else "-"), ("zs%d" % j, "+" if e["strand"] == "-" else "-")):
+            if rng.random() < 0.6:
+                reads.append((nm, e["chrom"], st, [(gs, ge)]))
+    for k in range(6):                      # two entries under one name: one read with the union of their blocks
+        a = reads[rng.randrange(200)]
+        reads.append((a[0], a[1], a[2], [(a[3][0][0] + 7, a[3][0][0] + 7 + R)]))
+    rng.shuffle(reads)
+    gff = ["track name=reads\n", "browser position chr1\n"]
+    bed = ["track name=reads\n"]
+    gff3 = []
+    for (nm, c, strand, blocks) in reads:
+        for (s, x) in blocks:
+            gff.append("%s\tdemo\tread\t%d\t%d\t.\t%s\t.\t%s\n" % (c, s + 1, x, strand, nm))
+        s0, e0 = blocks[0][0], blocks[-1][1]
+        sizes = ",".join(str(x - s) for s, x in blocks) + ","
+        starts = ",".join(str(s - s0) for s, _ in blocks) + ","
+        bed.append("%s\t%d\t%d\t%s\t0\t%s\t%d\t%d\t0\t%d\t%s\t%s\n" % (c, s0, e0, nm, strand, s0, e0, len(blocks), sizes, starts))
+        attr = "ID=m%s;Target=%s 1 %d +;" % (nm, nm, sum(x - s for s, x in blocks))
+        if len(blocks) == 2:
+            attr += "Parent=intron_X_%d_%d;" % (blocks[0][1] + 1, blocks[1][0])
+        gff3.append("%s\tdemo\tmatch\t%d\t%d\t.\t%s\t.\t%s\n" % (c[3:], s0 + 1, e0, strand, attr))
+    _w(os.path.join(d, "rf.interval"), "".join(iv))
+    _w(os.path.join(d, "rf.map"), "".join(mp))
+    _w(os.path.join(d, "rf.gff"), "".join(gff))
+    _w(os.path.join(d, "rf.bed"), "".join(bed))
+    _w(os.path.join(d, "rf.gff3"), "".join(gff3))
+    _w(os.path.join(d, "rf.mrf"), "AlignmentBlocks\n" + "".join(mrf_line(c, st, bl) for (_, c, st, bl) in reads))
+    return {"total_read_bases": len(reads) * R, "R": R}

@@ -40,7 +40,7 @@ def gpu_exact(argv, tool="solve"):
     ctx = L.Context(0)
     ctx.upload_events(ev)
     for m, g in enumerate(groups):
-        ctx.upload_reads(m, L.Reads.from_mrf(g[3], ev))
+        ctx.upload_reads(m, L.Reads.from_mrf(g[3], ev, read_format=g[0]))
     ctx.count()
     ctx.solve()
     cnt, bases = ctx.counts()
