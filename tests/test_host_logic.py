@@ -209,3 +209,27 @@ def test_synthetic_generator_is_deterministic(tmp_path):
     for ext in ("interval", "map", "mrf"):
         assert open(tmp_path / "a" / ("s." + ext)).read() == open(tmp_path / "b" / ("s." + ext)).read()
     assert len(open(tmp_path / "a" / "s.mrf").read().splitlines()) == 2001
+
+
+def test_named_read_formats_group_lines_by_name(tmp_path, monkeypatch):
+    """solve's UCSC_GFF / UCSC_BED / WORMBASE_GFF3 readers: the host parser keeps exactly the reads the
+    oracle loads (lines of one name make one read; BED and GFF3 lines stand or fall by their span)"""
+    c, d = load_case("readfmts", tmp_path)
+    monkeypatch.chdir(d)
+    a = L.Annotation("rf.interval", "rf.map", 0, 1000)
+    ev = L.Events(a, ("SHORT_READ",), (50,))
+    for idx, (fmt, path) in enumerate((("UCSC_GFF", "rf.gff"), ("UCSC_BED", "rf.bed"), ("WORMBASE_GFF3", "rf.gff3"))):
+        r = c["solve"][idx]
+        assert r["argv"][9] == fmt
+        rc, _, _ = ob.run("solve", r["argv"])
+        assert rc == 0
+        reads = L.Reads.from_mrf(path, ev, read_format=fmt)
+        assert len(reads) == ob.last_n_loaded[0] > 500
+        blk_off = reads.arrays()[0]
+        assert int(blk_off[-1]) == reads.num_blocks >= len(reads)
+    with pytest.raises(L.LsqError, match="Unknown file format"):
+        L.Reads.from_mrf("rf.bed", ev, read_format="UCSC_PSL")
+    # `count` knows MRF_SINGLE only
+    for r in c["count"]:
+        rc, text = L.cli_run("count", r["argv"])
+        assert rc == r["exit"] == 1 and text == ""
