@@ -429,6 +429,7 @@ struct Ring {
 	__device__ inline unsigned live() const { return tail - head; }
 	__device__ inline void push(bool want, unsigned lane, const uint4 e0, const uint4 e1) {
 		const unsigned long long m = __ballot(want);
+		if (!m) return;          // wave-uniform: the reads that need parking sit together in the start-ordered pools, most steps park nothing
 		const unsigned at = (tail + (unsigned)__popcll(m & ((1ull << lane) - 1ull))) % CAP;
 		if (want) {
 			if (NB == 1) q[at] = e0;
@@ -568,6 +569,7 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 							nA += a ? 1u : 0u; sA += a ? len : 0u;
 							nX += x ? 1u : 0u; sX += x ? len : 0u;
 							park[j] = in && !a && !x && !(A.ablate & 17u);
+							if ((A.ablate & 256u) && park[j]) atomicAdd(&A.dbg[5 + (m ? (info == CELL_INFO_SHARED ? 2 : 1) : 0)], 1ull);
 							pe0[j] = make_uint4((unsigned)ra, (unsigned)rb, m ? owner_word : PARK_EVENT_UNKNOWN, rel);
 							pe1[j] = make_uint4(0, 0, 0, 0);
 						}
@@ -2258,7 +2260,7 @@ int lsq_debug_counters(lsq_ctx *c, unsigned long long *out8) {
 	HIP_TRY(hipMemcpy(out8, c->dbg.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
 	std::vector<unsigned> h(c->exc_count.n);
 	HIP_TRY(hipMemcpy(h.data(), c->exc_count.p, h.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
-	out8[4] = h[0]; out8[5] = h[1];
+	out8[4] = h[0];
 	return LSQ_OK;
 }
 
