@@ -1144,6 +1144,16 @@ __device__ inline void em_pass_lean(const double (&kd)[SLOTS], const double (&gm
 		far = far || (on_t[t] && !(fabs(d[t]) < 0.03125));
 		if (on_t[t] && !(sm[t] > 0)) far = true;             // log of zero: the full routine gives the reference's -inf
 	}
+	// the numerators first: the next pass waits for them, and nothing in them waits for the logarithm
+	// or for the wave-wide vote below (an in-order wave stalls at that branch until the vote is in)
+#pragma unroll
+	for (int t = 0; t < SLOTS; ++t) {
+		const double kr = (on_t[t] && sm[t] > 0) ? kd[t] * r[t] : 0.0;
+#pragma unroll
+		for (int j = 0; j < KK; ++j) zz[j] += local[t][j] * kr;
+	}
+#pragma unroll
+	for (int j = 0; j < KK; ++j) z[j] = group_sum(zz[j]);
 #if defined(LSQ_EM_FORCE_SERIES)
 	const bool full = false;
 #elif defined(LSQ_EM_FORCE_FULL)
@@ -1168,13 +1178,8 @@ __device__ inline void em_pass_lean(const double (&kd)[SLOTS], const double (&gm
 		P.s[t] = safe[t]; P.r[t] = r[t]; P.lg[t] = lg;
 		const double term = kd[t] * lg;
 		l += on_t[t] ? term : 0.0;
-		const double kr = (on_t[t] && sm[t] > 0) ? kd[t] * r[t] : 0.0;
-#pragma unroll
-		for (int j = 0; j < KK; ++j) zz[j] += local[t][j] * kr;
 	}
 	ll = group_sum(l);
-#pragma unroll
-	for (int j = 0; j < KK; ++j) z[j] = group_sum(zz[j]);
 }
 
 // The whole EM of a wave whose events all fit SLOTS (method, class) pairs per lane and KK isoforms,
