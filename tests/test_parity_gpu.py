@@ -389,3 +389,23 @@ def test_long_introns_wide_bins_and_a_hot_spot(tmp_path):
     rc, text = L.cli_run("count", argv[:-1])
     rc2, ctext, _ = ob.run("count", argv[:-1])
     assert rc == rc2 == 0 and text == ctext
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_adversarial_inputs_many_seeds_vs_oracle(block, tmp_path):
+    """the generator behind the wild_* golden sets (overlapping isoform structures on a tiny range,
+    odd names and strands, shuffled blocks, ARS = 0) on seeds the reference never saw: the GPU path
+    against the oracle, exact integers, theta to 1e-6, and the printed count table"""
+    import golden_inputs as gi
+    for seed in range(200 + 12 * block, 200 + 12 * (block + 1)):
+        d = tmp_path / ("s%d" % seed)
+        d.mkdir()
+        info = gi.write_wild_case(str(d), "w", seed)
+        argv = ["0", "w", "./", "LH_GENE_TXT", str(d / "w.interval"), "UCSC_GENE2ISOFORM", str(d / "w.map"), "0", "1000",
+                "MRF_SINGLE", "SHORT_READ" if seed % 3 else "MEDIUM_READ", str(info["R"]), str(d / "w.mrf"), str(info["total_read_bases"])]
+        rc, otext, exact = ob.run("solve", argv)
+        assert rc == 0, seed
+        compare_exact(gpu_exact(argv), exact, "wild seed %d" % seed)
+        rc, text = L.cli_run("count", argv[:-1])
+        rc2, ctext, _ = ob.run("count", argv[:-1])
+        assert rc == rc2 == 0 and text == ctext, seed
