@@ -409,3 +409,19 @@ def test_adversarial_inputs_many_seeds_vs_oracle(block, tmp_path):
         rc, text = L.cli_run("count", argv[:-1])
         rc2, ctext, _ = ob.run("count", argv[:-1])
         assert rc == rc2 == 0 and text == ctext, seed
+
+
+@pytest.mark.parametrize("seed", range(300, 308))
+def test_event_shaped_inputs_more_seeds_vs_oracle(seed, tmp_path):
+    """the generator behind the events_s* golden sets (all eight event types, overlaps, 15 % off-target
+    reads, Zipf depth on even seeds) on seeds and read lengths the golden sets do not have"""
+    import golden_inputs as gi
+    R = [40, 60, 90, 120][seed % 4]
+    info = gi.write_events_case(str(tmp_path), "ev", seed=seed, n_events=60, n_reads=4000, R=R, n_chrom=2, zipf=(seed % 2 == 0))
+    argv = ["0", "ev", "./", "LH_GENE_TXT", str(tmp_path / "ev.interval"), "UCSC_GENE2ISOFORM", str(tmp_path / "ev.map"), "0", "1000",
+            "MRF_SINGLE", "SHORT_READ" if seed % 3 else "MEDIUM_READ", str(R), str(tmp_path / "ev.mrf"), str(info["total_read_bases"])]
+    rc, otext, exact = ob.run("solve", argv)
+    assert rc == 0
+    compare_exact(gpu_exact(argv), exact, "events seed %d" % seed)
+    rc, text = L.cli_run("solve", argv)
+    assert rc == 0 and ob.solve_text_close(text, otext)
