@@ -1126,7 +1126,7 @@ __device__ inline double log1p_small(double d) {
 
 template <int SLOTS, int KK>
 __device__ inline void em_pass_lean(const double (&kd)[SLOTS], const double (&gm)[SLOTS][KK], const double (&th)[KK],
-                                    const bool on, EmPairState<SLOTS> &P, double &ll, double (&z)[KK], unsigned *n_full = nullptr) {
+                                    const bool on, EmPairState<SLOTS> &P, double &ll, double (&z)[KK]) {
 	double l = 0, zz[KK];
 #pragma unroll
 	for (int j = 0; j < KK; ++j) zz[j] = 0;
@@ -1154,27 +1154,14 @@ __device__ inline void em_pass_lean(const double (&kd)[SLOTS], const double (&gm
 	}
 #pragma unroll
 	for (int j = 0; j < KK; ++j) z[j] = group_sum(zz[j]);
-#if defined(LSQ_EM_FORCE_SERIES)
-	const bool full = false;
-#elif defined(LSQ_EM_FORCE_FULL)
-	const bool full = true;
-#else
 	const bool full = __any(far);
-#endif
-#ifdef LSQ_EM_DEBUG
-	if (n_full && full) ++*n_full;
-#endif
 #pragma unroll
 	for (int t = 0; t < SLOTS; ++t) {
-#ifdef LSQ_EM_NOLOG      // developer probe: the pass without its logarithm
-		const double lg = sm[t];
-#else
 		double lg = P.lg[t] + log1p_small(d[t]);
 		if (full) {                                  // wave-uniform, taken a handful of times per event
 			asm volatile("" ::: "memory");           // keeps the compiler from flattening the branch into both computations
 			lg = fast_log(on_t[t] ? sm[t] : 1.0);
 		}
-#endif
 		P.s[t] = safe[t]; P.r[t] = r[t]; P.lg[t] = lg;
 		const double term = kd[t] * lg;
 		l += on_t[t] ? term : 0.0;
@@ -1209,18 +1196,11 @@ __device__ inline void em_lean(const EmArgs &A, const EmCache &C, const unsigned
 #pragma unroll
 	for (int j = 0; j < KK; ++j) c3[j] = z3[j] * inv_n;
 	em_pass_lean<SLOTS, KK>(kd, gm, c3, run, P, cll, cz3);
-#ifdef LSQ_EM_DEBUG
-	unsigned dbg_full = 0, dbg_pass = 0;
-#endif
 	while (__any(run)) {
 		double n3[KK], nll, nz3[KK];
 #pragma unroll
 		for (int j = 0; j < KK; ++j) n3[j] = cz3[j] * inv_n;
-#ifdef LSQ_EM_DEBUG
-		em_pass_lean<SLOTS, KK>(kd, gm, n3, run, P, nll, nz3, &dbg_full); ++dbg_pass;
-#else
 		em_pass_lean<SLOTS, KK>(kd, gm, n3, run, P, nll, nz3);         // speculative: theta(t+2)
-#endif
 		const unsigned cll_ex = (unsigned)((unsigned long long)__double_as_longlong(cll) >> 52) & 0x7FFu;
 		// read.h:659, floating abs; -inf, nan, zero keep the division's own answers
 		const double crit = (cll_ex - 1u < 0x7FEu) ? fabs(1.0 - ll * fast_recip(cll)) : fabs(1.0 - ll / cll);
@@ -1232,16 +1212,10 @@ __device__ inline void em_lean(const EmArgs &A, const EmCache &C, const unsigned
 		if (go && fabs(crit - 1E-6) < 1E-11) flag |= 1;
 		if (go && !(crit > 1E-6)) run = false;
 		else if (go && iters >= 1000000u) { flag |= 2; run = false; }
-#ifdef LSQ_EM_PROBE      // developer probe: event 0 runs a fixed number of passes (latency of a lone wave)
-		if (e == 0) run = iters < (unsigned)LSQ_EM_PROBE;
-#endif
 #pragma unroll
 		for (int j = 0; j < KK; ++j) { c3[j] = n3[j]; cz3[j] = nz3[j]; }
 		cll = nll;
 	}
-#ifdef LSQ_EM_DEBUG
-	if ((threadIdx.x & 63u) == 0 && dbg_pass > 100) printf("wave %u passes %u full %u\n", (blockIdx.x * blockDim.x + threadIdx.x) / 64u, dbg_pass, dbg_full);
-#endif
 	if (ev_ok && sub == 0) {
 #pragma unroll
 		for (int j = 0; j < KK; ++j) if (j < K) A.theta[ib + j] = t3[j];
@@ -1301,9 +1275,7 @@ __global__ void __launch_bounds__(256) lsq_em_kernel(EmArgs A) {
 	bool run = ev_ok && n_total > 0 && K > 1;
 	const bool any_reads = ev_ok && n_total > 0;
 	// every event of the wave fits the registers: a loop with nothing but the lean pass in it
-#ifndef LSQ_EM_NO_ONE_SLOT
 	if (__all(!ev_ok || (cached && K <= 2 && n_pairs <= EM_LANES))) { em_lean<1, 2>(A, C, e, sub, ev_ok, K, ib, inv_n, any_reads, run); return; }
-#endif
 	if (__all(!ev_ok || cached)) { em_lean<EM_CACHED_PAIRS, EM_CACHED_K>(A, C, e, sub, ev_ok, K, ib, inv_n, any_reads, run); return; }
 	if (cached) em_pass_cached(C, th, any_reads, ll, z);
 	else em_pass(A, cb, ib, K, nc, sub, any_reads, th, ll, z);
