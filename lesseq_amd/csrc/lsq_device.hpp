@@ -1,0 +1,118 @@
+// Shared by the HIP translation units of the device group (not part of the ABI): device buffers, the
+// per-read-file state, the context, and the entry points one unit offers the others.
+//   lsq_device.hip  context, event tables, result fetch         lsq_count.hip  count kernels
+//   lsq_ingest.hip  loader kernels (MRF parse, filter, pools)    lsq_em.hip     EM kernel
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <numeric>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "lsq_internal.hpp"
+
+using namespace lsq;
+
+#define HIP_TRY(expr)                                                                          \
+	do {                                                                                       \
+		hipError_t _e = (expr);                                                                \
+		if (_e != hipSuccess) return fail(LSQ_E_DEVICE, "%s: %s", #expr, hipGetErrorString(_e)); \
+	} while (0)
+
+
+constexpr int EM_LANES = 4;          // lanes that share one event in the EM kernel (and one place of its grid)
+
+namespace lsq {
+
+// A (read, event) pair the fast kernel does not settle itself: span-start ties that need the
+// strand/name order, two-block reads whose blocks touch, second looks that did not fit the LDS
+// queue.  pool 0 = one-block pool, 1 = two-block pool; scan: continue with the following events.
+struct ExcEntry {
+	unsigned long long slot;       // index into the pool
+	unsigned bucket;
+	unsigned ev_pool_scan;         // event index in the bucket | pool << 29 (0 one block, 1 two blocks, 2 n blocks) | scan << 31
+};
+
+template <class T>
+struct DevBuf {
+	T *p = nullptr;
+	size_t n = 0;
+	~DevBuf() { if (p) (void)hipFree(p); }
+	int alloc(size_t count) {
+		if (p) { (void)hipFree(p); p = nullptr; }
+		n = count;
+		HIP_TRY(hipMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T)));
+		return LSQ_OK;
+	}
+	int upload(const T *src, size_t count, hipStream_t st) {
+		int rc = alloc(count);
+		if (rc) return rc;
+		if (count) HIP_TRY(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, st));
+		return LSQ_OK;
+	}
+};
+
+template <class T>
+struct DevView { T *p = nullptr; size_t n = 0; };     // a slice of somebody else's allocation
+
+struct MethodReads {
+	bool present = false;
+	uint64_t n_retained = 0, n_retained_blocks = 0, total_slots = 0;
+	DevBuf<int32_t> p1, p2, pn_se;
+	DevBuf<uint8_t> p1_strand, p2_strand, pn_strand;
+	DevBuf<uint32_t> p1_line, p2_line, pn_line, pn_blk_off, pn_nblk, pn_bucket;
+	DevBuf<unsigned long long> p1_off, p2_off, pn_off, pnb_off, slot_off;
+	double skew = 1.0;                      // reads of the fullest bucket / mean reads per bucket
+	bool named = false;                     // the reads carry their own names (the *_line arrays index name_off)
+	DevBuf<char> names;
+	DevBuf<unsigned long long> name_off;
+	DevBuf<unsigned> wg_first;             // lsq_wg_plan_kernel's table for `wg_grid` workgroups
+	unsigned long long wg_grid = 0;
+};
+
+} // namespace lsq
+
+struct lsq_ctx {
+	int device = 0;
+	int n_cu = 256;
+	hipStream_t stream = nullptr;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+	hipEvent_t evf0[LSQ_MAX_METHODS] = {}, evf1[LSQ_MAX_METHODS] = {};   // around each method's lsq_count_fast_kernel launch
+	int fast_launched = 0;
+	lsq_events *E = nullptr;                // must outlive the uploads made from it (its strand dictionary grows with the reads)
+	DevBuf<BucketDesc> buckets;
+	DevBuf<uint8_t> images, strand_rank, dK;
+	DevBuf<TieRec> ties;
+	DevBuf<uint32_t> cls_base, iso_base, iters, em_order, gene_name_off;
+	DevBuf<char> gene_names;                // device event order
+	unsigned em_places = 0;
+	DevBuf<double> G, theta, logll;
+	DevBuf<uint8_t> flags;
+	DevBuf<unsigned long long> counters;   // cnt | bases | exc_count | dbg in one allocation: one memset per count
+	DevView<unsigned long long> cnt, bases, dbg;
+	DevBuf<ExcEntry> exc;                  // shared by the methods (launches are serialised on the stream)
+	DevView<unsigned> exc_count;           // per method: [2m] appended, [2m+1] overflow flag
+	DevBuf<unsigned> cov_off, cut_off;     // ingest tables: covered regions and bucket cuts per chromosome id
+	DevBuf<int> cov_s, cov_e, cut_lo, chrom_first_bucket;
+	DevBuf<unsigned> bin_base;             // per bucket: first of its bins among all bins (n_buckets + 1)
+	size_t n_fine = 0;
+	unsigned n_chrom_tables = 0;
+	bool redo_checked = true;
+	MethodReads reads[LSQ_MAX_METHODS];
+	bool counted = false, solved = false;
+	bool has_fast = false, has_generic = false;
+	float count_ms = 0, solve_ms = 0;
+	float mrf_h2d_ms = 0, mrf_parse_ms = 0;
+};
+
+namespace lsq {
+int upload_strand_ranks(lsq_ctx *c);                 // lsq_device.hip
+int run_count(lsq_ctx *c, bool all_reads);           // lsq_count.hip
+int ensure_counts_complete(lsq_ctx *c);              // lsq_count.hip: redo over every read when an exception list overflowed
+int run_solve(lsq_ctx *c);                           // lsq_em.hip
+} // namespace lsq

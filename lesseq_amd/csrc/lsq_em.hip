@@ -1,0 +1,369 @@
+// The batched EM of `solve` (common/read.h:592-660 on compatibility-class counts): kernel and launch.
+#include "lsq_device.hpp"
+
+namespace {
+
+// ---- EM: one event per lane (common/read.h:592-660 on compatibility classes) ----------------
+struct EmArgs {
+	unsigned n_events, n_methods, n_cls, n_iso;
+	unsigned n_places;                 // entries of `order`
+	const unsigned *order;             // device event per place of the EM grid
+	const unsigned char *K;
+	const unsigned *cls_base, *iso_base;
+	const unsigned long long *cnt;     // [method][n_cls]
+	const double *G;                   // [method][n_iso]
+	double *theta, *logll;
+	unsigned *iters;
+	unsigned char *flags;
+};
+
+// Four lanes per event: lane `sub` takes the (method, class) pairs sub, sub+4, ...; the four
+// partial sums meet by two xor-shuffles.  One pass per EM iteration gives, for the current theta,
+// the class mixtures s, the log-likelihood and the numerators of the next theta.  All four
+// lanes of an event hold the same theta and take the same decisions.
+
+// sum over the four lanes of an event (an aligned quad): two DPP quad permutes per 32-bit half,
+// plain VALU moves with no trip through the LDS crossbar
+template <int CTRL>
+__device__ inline double quad_perm_f64(double x) {
+	int lo = __double2loint(x), hi = __double2hiint(x);
+	lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+	hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+	return __hiloint2double(hi, lo);
+}
+__device__ inline double group_sum(double x) {
+	x += quad_perm_f64<0xB1>(x);      // quad_perm:[1,0,3,2]
+	x += quad_perm_f64<0x4E>(x);      // quad_perm:[2,3,0,1]
+	return x;
+}
+
+__device__ inline void em_pass(const EmArgs &A, unsigned cb, unsigned ib, int K, int nc, unsigned sub, bool on,
+                               const double *th, double &ll, double *z) {
+	double l = 0;
+	double zz[LSQ_MAX_ISOFORMS];
+#pragma unroll
+	for (int j = 0; j < LSQ_MAX_ISOFORMS; ++j) zz[j] = 0;
+	if (on) {
+		const int n_pairs = (int)A.n_methods * nc;
+		for (int q = (int)sub; q < n_pairs; q += EM_LANES) {
+			const int m = q / nc, c = q - m * nc + 1;
+			const unsigned long long k = A.cnt[(size_t)m * A.n_cls + cb + (unsigned)(c - 1)];
+			if (!k) continue;
+			const double *g = A.G + (size_t)m * A.n_iso + ib;
+			double s = 0;
+#pragma unroll
+			for (int j = 0; j < LSQ_MAX_ISOFORMS; ++j) if (j < K && (c >> j & 1)) s += th[j] * g[j];
+			const double kd = (double)k;
+			l += kd * log(s);
+			if (s > 0) {
+#pragma unroll
+				for (int j = 0; j < LSQ_MAX_ISOFORMS; ++j) if (j < K && (c >> j & 1)) {
+					const double local = th[j] * g[j];
+					if (local > 0) zz[j] += kd * (local / s);
+				}
+			}
+		}
+	}
+	ll = group_sum(l);
+#pragma unroll
+	for (int j = 0; j < LSQ_MAX_ISOFORMS; ++j) z[j] = group_sum(zz[j]);
+}
+
+// An event's (method, class) counts and G values in registers when there are at most two pairs
+// per lane and three isoforms (every LESSeq local event with up to two read files): the passes
+// then touch no memory, and the latency of one pass is what bounds the kernel (the slowest
+// event of the batch runs ~160 dependent passes).
+constexpr int EM_CACHED_PAIRS = 2, EM_CACHED_K = 3;
+struct EmCache {
+	double kd[EM_CACHED_PAIRS];
+	double g[EM_CACHED_PAIRS][EM_CACHED_K];
+	int cls[EM_CACHED_PAIRS];
+};
+
+// 1/s to ~1 ulp: hardware reciprocal estimate and two Newton steps -- about half the dependent
+// chain of an IEEE division (the result stays far inside the 1e-6 tolerance of the path)
+__device__ inline double fast_recip(double s) {
+	double r = __builtin_amdgcn_rcp(s);
+	r = fma(fma(-s, r, 1.0), r, r);
+	r = fma(fma(-s, r, 1.0), r, r);
+	return r;
+}
+
+// log(s) for normal positive s to about 1 ulp (everything else goes to the library): exponent and
+// mantissa m in [sqrt(1/2), sqrt(2)), log m = 2 atanh(z) with z = (m-1)/(m+1), |z| < 0.172, as an
+// odd series in z evaluated by Estrin's scheme -- a dependent chain of about 20 operations, a
+// third of the library routine's.  The stop rule compares log-likelihoods to 1e-6; events whose
+// criterion comes within 1e-11 of it are flagged whatever the logarithm used.
+__device__ inline double fast_log(double s) {
+	const unsigned long long bits = (unsigned long long)__double_as_longlong(s);
+	const unsigned ex = (unsigned)(bits >> 52);
+	if (ex - 1u >= 0x7FEu) return log(s);                       // zero, subnormal, negative, inf, nan
+	double m = __longlong_as_double((long long)((bits & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull));
+	int e = (int)ex - 1023;
+	if (m > 1.4142135623730951) { m *= 0.5; e += 1; }
+	const double f = m - 1.0;
+	const double z = f * fast_recip(2.0 + f);
+	const double w = z * z, w2 = w * w, w4 = w2 * w2, w8 = w4 * w4;
+	// 1/3 + w/5 + w^2/7 + ... + w^9/21
+	const double p01 = fma(w, 1.0 / 5.0, 1.0 / 3.0), p23 = fma(w, 1.0 / 9.0, 1.0 / 7.0), p45 = fma(w, 1.0 / 13.0, 1.0 / 11.0),
+	             p67 = fma(w, 1.0 / 17.0, 1.0 / 15.0), p89 = fma(w, 1.0 / 21.0, 1.0 / 19.0);
+	const double q0 = fma(w2, p23, p01), q1 = fma(w2, p67, p45);
+	const double poly = fma(w8, p89, fma(w4, q1, q0));
+	const double lm = fma(z * w, 2.0 * poly, 2.0 * z);
+	const double ed = (double)e;
+	return fma(ed, 0.69314718055994528623, fma(ed, 2.3190468138462995584e-17, lm));
+}
+
+__device__ inline void em_pass_cached(const EmCache &E, const double *th, bool on, double &ll, double *z) {
+	double l = 0, zz[EM_CACHED_K] = {0, 0, 0};
+#pragma unroll
+	for (int t = 0; t < EM_CACHED_PAIRS; ++t) {
+		const double kd = E.kd[t];
+		if (on && kd != 0) {
+			const int c = E.cls[t];
+			double s = 0;
+#pragma unroll
+			for (int j = 0; j < EM_CACHED_K; ++j) if (c >> j & 1) s += th[j] * E.g[t][j];
+			l += kd * fast_log(s);
+			if (s > 0) {
+				const double kr = kd * fast_recip(s);
+#pragma unroll
+				for (int j = 0; j < EM_CACHED_K; ++j) if (c >> j & 1) {
+					const double local = th[j] * E.g[t][j];
+					if (local > 0) zz[j] += local * kr;
+				}
+			}
+		}
+	}
+	ll = group_sum(l);
+#pragma unroll
+	for (int j = 0; j < EM_CACHED_K; ++j) z[j] = group_sum(zz[j]);
+}
+
+// The register-cached pass with the class masks folded into G (an isoform outside the class has
+// G = 0: its term adds an exact zero, so sums and their order are those of em_pass_cached).
+// What a pass leaves behind per pair for the next one: the mixture s, its reciprocal and its
+// logarithm.  Passes follow one another with small steps in s (that is what makes slow events
+// slow), so log s(t+1) = log s(t) + log1p(d) with d = (s(t+1) - s(t)) / s(t), and for |d| < 2^-5 a
+// twelve-term series gives log1p to 1e-19: a chain of six operations instead of the logarithm's twenty.
+// A wave takes the series only when every live pair of every lane is inside that range.
+template <int SLOTS>
+struct EmPairState { double s[SLOTS], r[SLOTS], lg[SLOTS]; };
+
+__device__ inline double log1p_small(double d) {
+	// d (1 - d/2 + d^2/3 - ... - d^11/12), |d| < 2^-5: the first term left out is below 1e-19
+	const double w = d * d, w2 = w * w, w4 = w2 * w2;
+	const double a0 = fma(d, -1.0 / 2.0, 1.0), a1 = fma(d, -1.0 / 4.0, 1.0 / 3.0), a2 = fma(d, -1.0 / 6.0, 1.0 / 5.0),
+	             a3 = fma(d, -1.0 / 8.0, 1.0 / 7.0), a4 = fma(d, -1.0 / 10.0, 1.0 / 9.0), a5 = fma(d, -1.0 / 12.0, 1.0 / 11.0);
+	const double b0 = fma(w, a1, a0), b1 = fma(w, a3, a2), b2 = fma(w, a5, a4);
+	return d * fma(w4, b2, fma(w2, b1, b0));
+}
+
+template <int SLOTS, int KK>
+__device__ inline void em_pass_lean(const double (&kd)[SLOTS], const double (&gm)[SLOTS][KK], const double (&th)[KK],
+                                    const bool on, EmPairState<SLOTS> &P, double &ll, double (&z)[KK]) {
+	double l = 0, zz[KK];
+#pragma unroll
+	for (int j = 0; j < KK; ++j) zz[j] = 0;
+	double local[SLOTS][KK], sm[SLOTS], safe[SLOTS], r[SLOTS], d[SLOTS];
+	bool on_t[SLOTS], far = false;
+#pragma unroll
+	for (int t = 0; t < SLOTS; ++t) {
+		sm[t] = 0;
+#pragma unroll
+		for (int j = 0; j < KK; ++j) { local[t][j] = th[j] * gm[t][j]; sm[t] += local[t][j]; }
+		on_t[t] = on && kd[t] != 0;
+		safe[t] = (on_t[t] && sm[t] > 0) ? sm[t] : 1.0;     // an empty pair slot must not send the wave down the library path
+		r[t] = fast_recip(safe[t]);
+		d[t] = (safe[t] - P.s[t]) * P.r[t];
+		far = far || (on_t[t] && !(fabs(d[t]) < 0.03125));
+		if (on_t[t] && !(sm[t] > 0)) far = true;             // log of zero: the full routine gives the reference's -inf
+	}
+	// the numerators first: the next pass waits for them, and nothing in them waits for the logarithm
+	// or for the wave-wide vote below (an in-order wave stalls at that branch until the vote is in)
+#pragma unroll
+	for (int t = 0; t < SLOTS; ++t) {
+		const double kr = (on_t[t] && sm[t] > 0) ? kd[t] * r[t] : 0.0;
+#pragma unroll
+		for (int j = 0; j < KK; ++j) zz[j] += local[t][j] * kr;
+	}
+#pragma unroll
+	for (int j = 0; j < KK; ++j) z[j] = group_sum(zz[j]);
+	const bool full = __any(far);
+#pragma unroll
+	for (int t = 0; t < SLOTS; ++t) {
+		double lg = P.lg[t] + log1p_small(d[t]);
+		if (full) {                                  // wave-uniform, taken a handful of times per event
+			asm volatile("" ::: "memory");           // keeps the compiler from flattening the branch into both computations
+			lg = fast_log(on_t[t] ? sm[t] : 1.0);
+		}
+		P.s[t] = safe[t]; P.r[t] = r[t]; P.lg[t] = lg;
+		const double term = kd[t] * lg;
+		l += on_t[t] ? term : 0.0;
+	}
+	ll = group_sum(l);
+}
+
+// The whole EM of a wave whose events all fit SLOTS (method, class) pairs per lane and KK isoforms,
+// in registers.  The pass for theta(t+2) starts from z(t+1) as soon as that exists, without waiting
+// for the stop test on ll(t+1): the test (a reciprocal, a compare, a ballot) runs beside the next
+// pass instead of between two passes.  One pass per event is thrown away.
+template <int SLOTS, int KK>
+__device__ inline void em_lean(const EmArgs &A, const EmCache &C, const unsigned e, const unsigned sub, const bool ev_ok, const int K, const unsigned ib,
+                               const double inv_n, const bool any_reads, bool run) {
+	double kd[SLOTS], gm[SLOTS][KK], t3[KK], z3[KK];
+#pragma unroll
+	for (int t = 0; t < SLOTS; ++t) {
+		kd[t] = C.kd[t];
+#pragma unroll
+		for (int j = 0; j < KK; ++j) gm[t][j] = (C.cls[t] >> j & 1) ? C.g[t][j] : 0.0;
+	}
+#pragma unroll
+	for (int j = 0; j < KK; ++j) t3[j] = (K == 1) ? 1.0 : 1.0 / (double)K;   // solve/solve.cpp:798-802, read.h:642
+	EmPairState<SLOTS> P;
+#pragma unroll
+	for (int t = 0; t < SLOTS; ++t) { P.s[t] = 1.0; P.r[t] = 1.0; P.lg[t] = 0.0; }
+	unsigned iters = 0;
+	unsigned char flag = 0;
+	double ll = 0;
+	em_pass_lean<SLOTS, KK>(kd, gm, t3, any_reads, P, ll, z3);
+	double c3[KK], cll, cz3[KK];           // candidate: theta(t+1), its log-likelihood and numerators
+#pragma unroll
+	for (int j = 0; j < KK; ++j) c3[j] = z3[j] * inv_n;
+	em_pass_lean<SLOTS, KK>(kd, gm, c3, run, P, cll, cz3);
+	while (__any(run)) {
+		double n3[KK], nll, nz3[KK];
+#pragma unroll
+		for (int j = 0; j < KK; ++j) n3[j] = cz3[j] * inv_n;
+		em_pass_lean<SLOTS, KK>(kd, gm, n3, run, P, nll, nz3);         // speculative: theta(t+2)
+		const unsigned cll_ex = (unsigned)((unsigned long long)__double_as_longlong(cll) >> 52) & 0x7FFu;
+		// read.h:659, floating abs; -inf, nan, zero keep the division's own answers
+		const double crit = (cll_ex - 1u < 0x7FEu) ? fabs(1.0 - ll * fast_recip(cll)) : fabs(1.0 - ll / cll);
+		const bool go = run;
+#pragma unroll
+		for (int j = 0; j < KK; ++j) { t3[j] = go ? c3[j] : t3[j]; z3[j] = go ? cz3[j] : z3[j]; }
+		ll = go ? cll : ll;
+		iters += go ? 1u : 0u;
+		if (go && fabs(crit - 1E-6) < 1E-11) flag |= 1;
+		if (go && !(crit > 1E-6)) run = false;
+		else if (go && iters >= 1000000u) { flag |= 2; run = false; }
+#pragma unroll
+		for (int j = 0; j < KK; ++j) { c3[j] = n3[j]; cz3[j] = nz3[j]; }
+		cll = nll;
+	}
+	if (ev_ok && sub == 0) {
+#pragma unroll
+		for (int j = 0; j < KK; ++j) if (j < K) A.theta[ib + j] = t3[j];
+		A.logll[e] = ll;
+		A.iters[e] = iters;
+		A.flags[e] = flag;
+	}
+}
+
+__global__ void __launch_bounds__(256) lsq_em_kernel(EmArgs A) {
+	const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
+	const unsigned place = gid / EM_LANES, sub = gid % EM_LANES;
+	// events in the order of A.order: the small ones (two isoforms, one pair per lane) first, then the
+	// rest, each group filling whole waves (0xFFFFFFFF = empty place)
+	const unsigned e = place < A.n_places ? A.order[place] : 0xFFFFFFFFu;
+	const bool ev_ok = e != 0xFFFFFFFFu;
+	const int K = ev_ok ? A.K[e] : 1;
+	const unsigned cb = ev_ok ? A.cls_base[e] : 0, ib = ev_ok ? A.iso_base[e] : 0;
+	const int nc = (1 << K) - 1;
+	const int n_pairs = (int)A.n_methods * nc;
+	const bool cached = K <= EM_CACHED_K && n_pairs <= EM_LANES * EM_CACHED_PAIRS;
+	double th[LSQ_MAX_ISOFORMS], z[LSQ_MAX_ISOFORMS];
+#pragma unroll
+	for (int j = 0; j < LSQ_MAX_ISOFORMS; ++j) z[j] = 0;
+	EmCache C;
+	double tot = 0;
+#pragma unroll
+	for (int t = 0; t < EM_CACHED_PAIRS; ++t) {
+		C.kd[t] = 0; C.cls[t] = 0;
+#pragma unroll
+		for (int j = 0; j < EM_CACHED_K; ++j) C.g[t][j] = 0;
+	}
+	if (ev_ok) {
+		for (int q = (int)sub; q < n_pairs; q += EM_LANES) {
+			const int m = q / nc, c = q - m * nc;
+			const double kd = (double)A.cnt[(size_t)m * A.n_cls + cb + (unsigned)c];      // exact: counts are far below 2^53
+			tot += kd;
+			const int t = (q - (int)sub) / EM_LANES;
+			if (cached && t < EM_CACHED_PAIRS) {
+#pragma unroll
+				for (int tt = 0; tt < EM_CACHED_PAIRS; ++tt) if (tt == t) {
+					C.kd[tt] = kd; C.cls[tt] = c + 1;
+#pragma unroll
+					for (int j = 0; j < EM_CACHED_K; ++j) C.g[tt][j] = j < K ? A.G[(size_t)m * A.n_iso + ib + j] : 0.0;
+				}
+			}
+		}
+	}
+	const double n_total = group_sum(tot);
+	const double inv_n = 1.0 / n_total;
+#pragma unroll
+	for (int j = 0; j < LSQ_MAX_ISOFORMS; ++j) th[j] = (K == 1) ? 1.0 : 1.0 / (double)K;   // solve/solve.cpp:798-802, read.h:642
+	unsigned iters = 0;
+	unsigned char flag = 0;
+	double ll = 0;
+	// no reads: theta stays 1/K, log-likelihood 0; one isoform: theta = 1 (solve/solve.cpp:798-802)
+	bool run = ev_ok && n_total > 0 && K > 1;
+	const bool any_reads = ev_ok && n_total > 0;
+	// every event of the wave fits the registers: a loop with nothing but the lean pass in it
+	if (__all(!ev_ok || (cached && K <= 2 && n_pairs <= EM_LANES))) { em_lean<1, 2>(A, C, e, sub, ev_ok, K, ib, inv_n, any_reads, run); return; }
+	if (__all(!ev_ok || cached)) { em_lean<EM_CACHED_PAIRS, EM_CACHED_K>(A, C, e, sub, ev_ok, K, ib, inv_n, any_reads, run); return; }
+	if (cached) em_pass_cached(C, th, any_reads, ll, z);
+	else em_pass(A, cb, ib, K, nc, sub, any_reads, th, ll, z);
+	while (__any(run)) {
+		// theta' = z(theta) / n; then one pass at theta' gives ll(theta') and z(theta')
+		double nth[LSQ_MAX_ISOFORMS], nll, nz[LSQ_MAX_ISOFORMS];
+#pragma unroll
+		for (int j = 0; j < LSQ_MAX_ISOFORMS; ++j) { nth[j] = cached ? z[j] * inv_n : z[j] / n_total; nz[j] = 0; }
+		if (cached) em_pass_cached(C, nth, run, nll, nz);
+		else em_pass(A, cb, ib, K, nc, sub, run, nth, nll, nz);
+		if (run) {
+			// read.h:659, floating abs; the quotient through the reciprocal when the passes are the
+			// register-cached ones (1 ulp, against a guard band of 1e-11 around the threshold)
+			const unsigned nll_ex = (unsigned)((unsigned long long)__double_as_longlong(nll) >> 52) & 0x7FFu;
+			const bool nll_normal = nll_ex - 1u < 0x7FEu;     // -inf, nan, zero keep the division's own answers
+			const double crit = (cached && nll_normal) ? fabs(1.0 - ll * fast_recip(nll)) : fabs(1.0 - ll / nll);
+#pragma unroll
+			for (int j = 0; j < LSQ_MAX_ISOFORMS; ++j) { th[j] = nth[j]; z[j] = nz[j]; }
+			ll = nll;
+			++iters;
+			if (fabs(crit - 1E-6) < 1E-11) flag |= 1;
+			if (!(crit > 1E-6)) run = false;
+			else if (iters >= 1000000u) { flag |= 2; run = false; }
+		}
+	}
+	if (ev_ok && sub == 0) {
+		for (int j = 0; j < K; ++j) A.theta[ib + j] = th[j];
+		A.logll[e] = ll;
+		A.iters[e] = iters;
+		A.flags[e] = flag;
+	}
+}
+
+} // namespace
+
+namespace lsq {
+
+int run_solve(lsq_ctx *c) {
+	const lsq_events &E = *c->E;
+	hipStream_t st = c->stream;
+	HIP_TRY(hipEventRecord(c->ev2, st));
+	const unsigned n_ev = (unsigned)E.dev2out.size();
+	if (n_ev) {
+		EmArgs A;
+		A.n_events = n_ev; A.n_methods = (unsigned)E.n_methods; A.n_cls = E.n_cls_total; A.n_iso = E.n_iso_total;
+		A.K = c->dK.p; A.cls_base = c->cls_base.p; A.iso_base = c->iso_base.p;
+		A.n_places = c->em_places; A.order = c->em_order.p;
+		A.cnt = c->cnt.p; A.G = c->G.p; A.theta = c->theta.p; A.logll = c->logll.p; A.iters = c->iters.p; A.flags = c->flags.p;
+		hipLaunchKernelGGL(lsq_em_kernel, dim3((c->em_places * EM_LANES + 255) / 256), dim3(256), 0, st, A);
+		HIP_TRY(hipGetLastError());
+	}
+	HIP_TRY(hipEventRecord(c->ev3, st));
+	return LSQ_OK;
+}
+
+} // namespace lsq

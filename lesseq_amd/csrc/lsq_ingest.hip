@@ -1,0 +1,460 @@
+// Loader kernels of the device group: MRF text parsed in HBM, the load-time containment filter, block
+// merge and the bucket / bin / pool layout (count/count.cpp:279-364), and the entry points around them.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include "lsq_device.hpp"
+#include "lsq_mrf_line.hpp"
+
+namespace {
+
+// =====================================================================================
+// Ingest on the device: from parsed blocks in file order to the bucketed, pooled arrays.
+//   classify: per read, the per-block containment filter against the covered regions of the
+//             block's own chromosome (count/count.cpp:319, interval_list.hpp:396-422), the
+//             interval_list merge of the kept blocks (:323, interval_list.hpp:462-503),
+//             chromosome/strand of the last kept block (:321-322), the bucket of the first
+//             merged base and the pool (1, 2, 3+ blocks); per (bucket, pool) counts
+//   scan    : exclusive prefix sums -> offsets per (bucket, bin) for the one- and two-block pools
+//             (bin = the bucket's coordinate bin of the read's first base, the one the count kernel
+//             looks up), per bucket for the n-block pool
+//   scatter : every retained read to its place: a counting sort, so the reads of a bin -- which
+//             mostly share a cell -- sit together and a wave of the count kernel sees one or two
+//             cells at a time (order inside a bin is whatever the atomics give; the count kernels
+//             only add integers, so results do not depend on it)
+// This replaces the reference's load-time filter and its read index (count/count.cpp:348-364).
+// =====================================================================================
+constexpr int INGEST_MAX_BLOCKS = 16;                  // merged blocks per read the device ingest handles
+constexpr unsigned INGEST_NO_KEY = 0xFFFFFFFFu;
+
+struct IngestTables {
+	const unsigned *cov_off;       // per chromosome id: range of its covered intervals
+	const int *cov_s, *cov_e;
+	const unsigned *cut_off;       // per chromosome id: range of its bucket cuts
+	const int *cut_lo;
+	const int *chrom_first_bucket;
+	const BucketDesc *buckets;
+	const unsigned *bin_base;      // per bucket: first of its bins in the fine counters (n_buckets + 1)
+	unsigned n_chrom;
+};
+
+struct IngestRaw {
+	unsigned long long n_reads;
+	const unsigned long long *blk_off;
+	const unsigned *line_no;
+	const int *blk_start, *blk_end;
+	const unsigned short *blk_chrom;
+	const unsigned char *blk_strand;
+};
+
+struct IngestWork {
+	unsigned *key;                 // per read: bucket * 4 + pool, or INGEST_NO_KEY
+	unsigned *fine;                // per read: bin_base[bucket] + bin of the first base
+	unsigned char *nb;             // per read: merged blocks
+	unsigned char *strand;         // per read: strand id of the last kept block
+	int *ms, *me;                  // merged blocks, at the read's original block offset
+	unsigned *cnt1, *cnt2;         // [n_fine]: one- / two-block reads per (bucket, bin)
+	unsigned *cntn, *cntnb;        // [n_buckets]: n-block reads, and their blocks
+	unsigned *cur1, *cur2, *curn, *curnb;   // scatter cursors, same shapes
+	unsigned long long *totals;    // [0] retained reads, [1] retained blocks, [2] error flag
+};
+
+// interval_list::add_interval on a small sorted array (see lsq::IntervalList::add)
+__device__ inline bool small_add_interval(int *s, int *e, int &n, int start, int end) {
+	if (!(start < end)) return true;
+	int ss = 0, se = 0, es = 0, ee = 0;
+	for (int i = 0; i < n; ++i) { ss += s[i] < start; se += e[i] < start; es += s[i] < end; ee += e[i] < end; }
+	const bool start_inside = (ss - se == 1), end_inside = (es - ee == 1);
+	// starts: erase [ss, es), insert `start` at ss unless start_inside; ends: erase [se, ee), insert `end` at se unless end_inside
+	const int ns = n - (es - ss) + (start_inside ? 0 : 1);
+	if (ns > INGEST_MAX_BLOCKS) return false;
+	int ts[INGEST_MAX_BLOCKS], te[INGEST_MAX_BLOCKS];
+	int k = 0;
+	for (int i = 0; i < ss; ++i) ts[k++] = s[i];
+	if (!start_inside) ts[k++] = start;
+	for (int i = es; i < n; ++i) ts[k++] = s[i];
+	k = 0;
+	for (int i = 0; i < se; ++i) te[k++] = e[i];
+	if (!end_inside) te[k++] = end;
+	for (int i = ee; i < n; ++i) te[k++] = e[i];
+	n = ns;
+	for (int i = 0; i < n; ++i) { s[i] = ts[i]; e[i] = te[i]; }
+	return true;
+}
+
+__device__ inline bool covered_contains(const IngestTables &T, unsigned chrom, int start, int end) {
+	if (!(start < end)) return true;
+	const unsigned lo0 = T.cov_off[chrom], hi0 = T.cov_off[chrom + 1];
+	unsigned lo = lo0, hi = hi0;                      // lower_bound(starts, start)
+	while (lo < hi) { const unsigned mid = (lo + hi) >> 1; if (T.cov_s[mid] < start) lo = mid + 1; else hi = mid; }
+	if (lo < hi0 && T.cov_s[lo] <= start && end <= T.cov_e[lo]) return true;
+	if (lo > lo0 && T.cov_s[lo - 1] <= start && end <= T.cov_e[lo - 1]) return true;
+	return false;
+}
+
+__global__ void __launch_bounds__(256) lsq_ingest_classify_kernel(IngestTables T, IngestRaw R, IngestWork W) {
+	const unsigned long long gsz = (unsigned long long)gridDim.x * blockDim.x;
+	unsigned long long kept_reads = 0, kept_blocks = 0;
+	for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < R.n_reads; i += gsz) {
+		const unsigned long long b0 = R.blk_off[i], b1 = R.blk_off[i + 1];
+		int s[INGEST_MAX_BLOCKS], e[INGEST_MAX_BLOCKS];
+		int n = 0, chrom = -1;
+		unsigned strand = 0;
+		bool any = false, ok = true;
+		for (unsigned long long j = b0; j < b1; ++j) {
+			const unsigned c = R.blk_chrom[j];
+			if (c >= T.n_chrom) continue;
+			const int bs = R.blk_start[j], be = R.blk_end[j];
+			if (!covered_contains(T, c, bs, be)) continue;
+			any = true; chrom = (int)c; strand = R.blk_strand[j];
+			ok = small_add_interval(s, e, n, bs, be) && ok;
+		}
+		unsigned key = INGEST_NO_KEY;
+		if (any && n > 0) {
+			++kept_reads; kept_blocks += (unsigned)n;
+			int tot = 0;
+			for (int q = 0; q < n; ++q) tot += e[q] - s[q];
+			if (!ok || tot >= (1 << 18)) atomicMax(&W.totals[2], 1ull);
+			// bucket of the first merged base
+			const int first = T.chrom_first_bucket[chrom];
+			if (first >= 0) {
+				const unsigned c0 = T.cut_off[chrom], c1 = T.cut_off[chrom + 1];
+				unsigned lo = c0, hi = c1;                  // upper_bound(cuts, p)
+				while (lo < hi) { const unsigned mid = (lo + hi) >> 1; if (T.cut_lo[mid] <= s[0]) lo = mid + 1; else hi = mid; }
+				if (lo > c0) {
+					const unsigned b = (unsigned)first + (lo - c0 - 1);
+					if (s[0] <= T.buckets[b].hi) {
+						const unsigned pool = n == 1 ? 0u : (n == 2 ? 1u : 2u);
+						key = b * 4u + pool;
+						const BucketDesc &d = T.buckets[b];
+						const int rel = s[0] - d.lo;
+						const unsigned bin = rel <= 0 ? 0u : min((unsigned)rel >> d.shift, d.n_bins - 1u);
+						const unsigned fine = T.bin_base[b] + bin;
+						W.fine[i] = fine;
+						if (pool == 0) atomicAdd(&W.cnt1[fine], 1u);
+						else if (pool == 1) atomicAdd(&W.cnt2[fine], 1u);
+						else { atomicAdd(&W.cntn[b], 1u); atomicAdd(&W.cntnb[b], (unsigned)n); }
+					}
+				}
+			}
+			for (int q = 0; q < n; ++q) { W.ms[b0 + q] = s[q]; W.me[b0 + q] = e[q]; }
+		}
+		W.key[i] = key;
+		W.nb[i] = (unsigned char)n;
+		W.strand[i] = (unsigned char)strand;
+	}
+	if (kept_reads) { atomicAdd(&W.totals[0], kept_reads); atomicAdd(&W.totals[1], kept_blocks); }
+}
+
+// one workgroup: out[i] = sum of in[0..i), out[n] = total
+__global__ void __launch_bounds__(1024) lsq_scan_u32_kernel(const unsigned *in, unsigned long long n, unsigned long long *out) {
+	__shared__ unsigned long long part[1024];
+	const unsigned tid = threadIdx.x;
+	const unsigned long long per = (n + 1023ull) / 1024ull;
+	const unsigned long long b0 = min(tid * per, n), b1 = min(b0 + per, n);
+	unsigned long long acc = 0;
+	for (unsigned long long b = b0; b < b1; ++b) acc += in[b];
+	part[tid] = acc;
+	__syncthreads();
+	if (tid == 0) { unsigned long long run = 0; for (unsigned t = 0; t < 1024; ++t) { const unsigned long long v = part[t]; part[t] = run; run += v; } }
+	__syncthreads();
+	unsigned long long run = part[tid];
+	for (unsigned long long b = b0; b < b1; ++b) { out[b] = run; run += in[b]; }
+	if (tid == 1023) out[n] = run;
+}
+
+// per-bucket pool offsets out of the per-bin ones
+__global__ void __launch_bounds__(256) lsq_ingest_offsets_kernel(const unsigned *bin_base, unsigned n_buckets, const unsigned long long *off1,
+                                                                 const unsigned long long *off2, const unsigned long long *pn_off,
+                                                                 unsigned long long *p1_off, unsigned long long *p2_off, unsigned long long *slot_off) {
+	const unsigned b = blockIdx.x * blockDim.x + threadIdx.x;
+	if (b > n_buckets) return;
+	const unsigned long long a1 = off1[bin_base[b]], a2 = off2[bin_base[b]];
+	p1_off[b] = a1; p2_off[b] = a2;
+	slot_off[b] = a1 + a2 + pn_off[b];
+}
+
+struct IngestOut {
+	int2 *p1; unsigned char *p1_strand; unsigned *p1_line;
+	int4 *p2; unsigned char *p2_strand; unsigned *p2_line;
+	unsigned *pn_blk_off, *pn_nblk, *pn_line, *pn_bucket; unsigned char *pn_strand; int2 *pn_se;
+	const unsigned long long *off1, *off2, *pn_off, *pnb_off;       // per (bucket, bin) / per bucket
+};
+
+__global__ void __launch_bounds__(256) lsq_ingest_scatter_kernel(IngestRaw R, IngestWork W, IngestOut O) {
+	const unsigned long long gsz = (unsigned long long)gridDim.x * blockDim.x;
+	for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < R.n_reads; i += gsz) {
+		const unsigned key = W.key[i];
+		if (key == INGEST_NO_KEY) continue;
+		const unsigned b = key >> 2, pool = key & 3u;
+		const unsigned long long b0 = R.blk_off[i];
+		if (pool == 0) {
+			const unsigned fine = W.fine[i];
+			const unsigned long long w = O.off1[fine] + atomicAdd(&W.cur1[fine], 1u);
+			O.p1[w] = make_int2(W.ms[b0], W.me[b0]);
+			O.p1_strand[w] = W.strand[i]; O.p1_line[w] = R.line_no[i];
+		} else if (pool == 1) {
+			const unsigned fine = W.fine[i];
+			const unsigned long long w = O.off2[fine] + atomicAdd(&W.cur2[fine], 1u);
+			O.p2[w] = make_int4(W.ms[b0], W.me[b0], W.ms[b0 + 1], W.me[b0 + 1]);
+			O.p2_strand[w] = W.strand[i]; O.p2_line[w] = R.line_no[i];
+		} else {
+			const unsigned n = W.nb[i];
+			const unsigned long long w = O.pn_off[b] + atomicAdd(&W.curn[b], 1u);
+			const unsigned long long bo = O.pnb_off[b] + atomicAdd(&W.curnb[b], n);
+			O.pn_blk_off[w] = (unsigned)bo; O.pn_nblk[w] = n; O.pn_bucket[w] = b;
+			O.pn_strand[w] = W.strand[i]; O.pn_line[w] = R.line_no[i];
+			for (unsigned q = 0; q < n; ++q) O.pn_se[bo + q] = make_int2(W.ms[b0 + q], W.me[b0 + q]);
+		}
+	}
+}
+
+// Orders the reads of every (bucket, bin) by their first base: a counting sort in LDS over the
+// bin's coordinates, one wave per bin (the scatter above left the bin's reads together, in the
+// order its atomics gave).  This is the device form of the reference's read index, a std::set
+// ordered by start (count/count.cpp:348-364): a wave of the count kernel then sees the reads of
+// one cell, then those of the next.  Bins wider than BINSORT_MAX_W coordinates are copied as they
+// are -- the order only matters for speed.
+constexpr unsigned BINSORT_MAX_W = 2048;
+template <class ReadT>
+__global__ void __launch_bounds__(256) lsq_ingest_binsort_kernel(const BucketDesc *buckets, const unsigned *bin_base, unsigned n_buckets, unsigned n_fine,
+                                                                 const unsigned long long *off, const ReadT *in, const unsigned char *in_strand,
+                                                                 const unsigned *in_line, ReadT *out, unsigned char *out_strand, unsigned *out_line) {
+	__shared__ unsigned cnt_all[4][BINSORT_MAX_W];
+	const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	unsigned *cnt = cnt_all[wave];
+	for (unsigned fine = blockIdx.x * 4u + wave; fine < n_fine; fine += gridDim.x * 4u) {
+		const unsigned long long o0 = off[fine], o1 = off[fine + 1];
+		if (o0 == o1) continue;
+		const unsigned n = (unsigned)(o1 - o0);
+		unsigned lo_b = 0, hi_b = n_buckets;                 // bucket of the bin: last b with bin_base[b] <= fine
+		while (hi_b - lo_b > 1) { const unsigned mid = (lo_b + hi_b) >> 1; if (bin_base[mid] <= fine) lo_b = mid; else hi_b = mid; }
+		const BucketDesc &d = buckets[lo_b];
+		const unsigned W = d.shift < 31u ? (1u << d.shift) : 0x80000000u;
+		if (W > BINSORT_MAX_W || n < 3) {
+			for (unsigned i = lane; i < n; i += 64u) { out[o0 + i] = in[o0 + i]; out_strand[o0 + i] = in_strand[o0 + i]; out_line[o0 + i] = in_line[o0 + i]; }
+			continue;
+		}
+		const int bin_lo = d.lo + (int)((fine - bin_base[lo_b]) << d.shift);
+		for (unsigned k = lane; k < W; k += 64u) cnt[k] = 0;
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+		for (unsigned i = lane; i < n; i += 64u) {
+			const int rel = in[o0 + i].x - bin_lo;       // the first and last bins of a bucket also hold what lies beyond them
+			atomicAdd(&cnt[(unsigned)max(0, min(rel, (int)W - 1))], 1u);
+		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+		// exclusive prefix over the W counters: W/64 consecutive ones per lane
+		const unsigned per = (W + 63u) / 64u, k0 = min(lane * per, W), k1 = min(k0 + per, W);
+		unsigned acc = 0;
+		for (unsigned k = k0; k < k1; ++k) acc += cnt[k];
+		unsigned inc = acc;
+		for (unsigned dd = 1; dd < 64; dd <<= 1) { const unsigned t = __shfl_up(inc, dd); if (lane >= dd) inc += t; }
+		unsigned run = inc - acc;
+		for (unsigned k = k0; k < k1; ++k) { const unsigned v = cnt[k]; cnt[k] = run; run += v; }
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+		for (unsigned i = lane; i < n; i += 64u) {
+			const ReadT r = in[o0 + i];
+			const int rel = r.x - bin_lo;
+			const unsigned pos = atomicAdd(&cnt[(unsigned)max(0, min(rel, (int)W - 1))], 1u);
+			out[o0 + pos] = r; out_strand[o0 + pos] = in_strand[o0 + i]; out_line[o0 + pos] = in_line[o0 + i];
+		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+	}
+}
+
+#include "lsq_mrf_device.hpp"
+
+// Runs the three ingest kernels over parsed blocks that are already on the device (file order).
+static int ingest_device(lsq_ctx *c, int method, const IngestRaw &Rw, uint64_t nblk) {
+	const lsq_events &E = *c->E;
+	MethodReads &mr = c->reads[method];
+	mr.present = false;
+	const unsigned B = (unsigned)E.buckets.size();
+	const uint64_t n = Rw.n_reads;
+	hipStream_t st = c->stream;
+	int rc;
+	DevBuf<int> d_ms, d_me;
+	DevBuf<unsigned char> d_nb, d_strand;
+	DevBuf<unsigned> d_key, d_fine;
+	DevBuf<unsigned> d_cnt;                      // cnt1 | cnt2 | cntn | cntnb, then the four cursor arrays
+	DevBuf<unsigned long long> d_off1, d_off2, d_totals;
+	const size_t F = c->n_fine;                  // bins of all buckets
+	const size_t n_cnt = 2 * F + 2 * (size_t)B;
+	if ((rc = d_ms.alloc(nblk)) || (rc = d_me.alloc(nblk)) || (rc = d_nb.alloc(n)) || (rc = d_strand.alloc(n)) || (rc = d_key.alloc(n)) || (rc = d_fine.alloc(n))) return rc;
+	if ((rc = d_cnt.alloc(2 * n_cnt)) || (rc = d_off1.alloc(F + 1)) || (rc = d_off2.alloc(F + 1)) || (rc = d_totals.alloc(4))) return rc;
+	HIP_TRY(hipMemsetAsync(d_cnt.p, 0, std::max<size_t>(2 * n_cnt, 1) * 4, st));
+	HIP_TRY(hipMemsetAsync(d_totals.p, 0, 4 * 8, st));
+	IngestTables T;
+	T.cov_off = c->cov_off.p; T.cov_s = c->cov_s.p; T.cov_e = c->cov_e.p;
+	T.cut_off = c->cut_off.p; T.cut_lo = c->cut_lo.p; T.chrom_first_bucket = c->chrom_first_bucket.p;
+	T.buckets = c->buckets.p; T.bin_base = c->bin_base.p; T.n_chrom = c->n_chrom_tables;
+	IngestWork W;
+	W.key = d_key.p; W.fine = d_fine.p; W.nb = d_nb.p; W.strand = d_strand.p; W.ms = d_ms.p; W.me = d_me.p;
+	W.cnt1 = d_cnt.p; W.cnt2 = W.cnt1 + F; W.cntn = W.cnt2 + F; W.cntnb = W.cntn + B;
+	W.cur1 = d_cnt.p + n_cnt; W.cur2 = W.cur1 + F; W.curn = W.cur2 + F; W.curnb = W.curn + B;
+	W.totals = d_totals.p;
+	const unsigned igrid = (unsigned)std::min<unsigned long long>((n + 255) / 256 + 1, (unsigned long long)c->n_cu * 16);
+	if (n) {
+		hipLaunchKernelGGL(lsq_ingest_classify_kernel, dim3(igrid), dim3(256), 0, st, T, Rw, W);
+		HIP_TRY(hipGetLastError());
+	}
+	if ((rc = mr.p1_off.alloc(B + 1)) || (rc = mr.p2_off.alloc(B + 1)) || (rc = mr.pn_off.alloc(B + 1)) || (rc = mr.pnb_off.alloc(B + 1)) || (rc = mr.slot_off.alloc(B + 1))) return rc;
+	hipLaunchKernelGGL(lsq_scan_u32_kernel, dim3(1), dim3(1024), 0, st, W.cnt1, (unsigned long long)F, d_off1.p);
+	hipLaunchKernelGGL(lsq_scan_u32_kernel, dim3(1), dim3(1024), 0, st, W.cnt2, (unsigned long long)F, d_off2.p);
+	hipLaunchKernelGGL(lsq_scan_u32_kernel, dim3(1), dim3(1024), 0, st, W.cntn, (unsigned long long)B, mr.pn_off.p);
+	hipLaunchKernelGGL(lsq_scan_u32_kernel, dim3(1), dim3(1024), 0, st, W.cntnb, (unsigned long long)B, mr.pnb_off.p);
+	hipLaunchKernelGGL(lsq_ingest_offsets_kernel, dim3(B / 256 + 1), dim3(256), 0, st, c->bin_base.p, B, d_off1.p, d_off2.p, mr.pn_off.p,
+	                   mr.p1_off.p, mr.p2_off.p, mr.slot_off.p);
+	HIP_TRY(hipGetLastError());
+	unsigned long long tot[4] = {0, 0, 0, 0}, sums[4] = {0, 0, 0, 0};
+	HIP_TRY(hipMemcpyAsync(tot, d_totals.p, 4 * 8, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(&sums[0], mr.p1_off.p + B, 8, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(&sums[1], mr.p2_off.p + B, 8, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(&sums[2], mr.pn_off.p + B, 8, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(&sums[3], mr.pnb_off.p + B, 8, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	if (tot[2]) return fail(LSQ_E_RANGE, "a read covers 2^18 or more bases or keeps more than %d separate blocks: outside the device tables' range", INGEST_MAX_BLOCKS);
+	if (sums[3] > 0xFFFFFFF0ull) return fail(LSQ_E_RANGE, "too many blocks in multi-block reads");
+	if (n > 0xFFFFFFF0ull) return fail(LSQ_E_RANGE, "more than 2^32 reads in one file");
+	const size_t n1 = (size_t)sums[0], n2 = (size_t)sums[1], nn = (size_t)sums[2], nnb = (size_t)sums[3];
+	if ((rc = mr.p1.alloc(2 * n1)) || (rc = mr.p1_strand.alloc(n1)) || (rc = mr.p1_line.alloc(n1))) return rc;
+	if ((rc = mr.p2.alloc(4 * n2)) || (rc = mr.p2_strand.alloc(n2)) || (rc = mr.p2_line.alloc(n2))) return rc;
+	if ((rc = mr.pn_se.alloc(2 * nnb)) || (rc = mr.pn_blk_off.alloc(nn)) || (rc = mr.pn_nblk.alloc(nn)) || (rc = mr.pn_strand.alloc(nn)) ||
+	    (rc = mr.pn_line.alloc(nn)) || (rc = mr.pn_bucket.alloc(nn))) return rc;
+	if (n) {
+		// the scatter fills temporaries; the per-bin sort writes the pools
+		DevBuf<int32_t> t_p1, t_p2;
+		DevBuf<uint8_t> t_p1_strand, t_p2_strand;
+		DevBuf<uint32_t> t_p1_line, t_p2_line;
+		if ((rc = t_p1.alloc(2 * n1)) || (rc = t_p1_strand.alloc(n1)) || (rc = t_p1_line.alloc(n1))) return rc;
+		if ((rc = t_p2.alloc(4 * n2)) || (rc = t_p2_strand.alloc(n2)) || (rc = t_p2_line.alloc(n2))) return rc;
+		IngestOut O;
+		O.p1 = reinterpret_cast<int2 *>(t_p1.p); O.p1_strand = t_p1_strand.p; O.p1_line = t_p1_line.p;
+		O.p2 = reinterpret_cast<int4 *>(t_p2.p); O.p2_strand = t_p2_strand.p; O.p2_line = t_p2_line.p;
+		O.pn_blk_off = mr.pn_blk_off.p; O.pn_nblk = mr.pn_nblk.p; O.pn_line = mr.pn_line.p; O.pn_bucket = mr.pn_bucket.p;
+		O.pn_strand = mr.pn_strand.p; O.pn_se = reinterpret_cast<int2 *>(mr.pn_se.p);
+		O.off1 = d_off1.p; O.off2 = d_off2.p; O.pn_off = mr.pn_off.p; O.pnb_off = mr.pnb_off.p;
+		hipLaunchKernelGGL(lsq_ingest_scatter_kernel, dim3(igrid), dim3(256), 0, st, Rw, W, O);
+		HIP_TRY(hipGetLastError());
+		const unsigned sgrid = (unsigned)std::min<size_t>(F / 4 + 1, (size_t)c->n_cu * 32);
+		if (n1) hipLaunchKernelGGL(lsq_ingest_binsort_kernel<int2>, dim3(sgrid), dim3(256), 0, st, c->buckets.p, c->bin_base.p, B, (unsigned)F, d_off1.p,
+		                           reinterpret_cast<const int2 *>(t_p1.p), t_p1_strand.p, t_p1_line.p, reinterpret_cast<int2 *>(mr.p1.p), mr.p1_strand.p, mr.p1_line.p);
+		if (n2) hipLaunchKernelGGL(lsq_ingest_binsort_kernel<int4>, dim3(sgrid), dim3(256), 0, st, c->buckets.p, c->bin_base.p, B, (unsigned)F, d_off2.p,
+		                           reinterpret_cast<const int4 *>(t_p2.p), t_p2_strand.p, t_p2_line.p, reinterpret_cast<int4 *>(mr.p2.p), mr.p2_strand.p, mr.p2_line.p);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipStreamSynchronize(st));            // the temporaries go out of scope here
+	}
+	{
+		// exception list: a quarter of the one- and two-block reads, at least 64 Ki entries
+		const size_t want = std::max<size_t>(65536, (n1 + n2) / 4);
+		if (c->exc.n < want && (rc = c->exc.alloc(want))) return rc;
+	}
+	if ((rc = upload_strand_ranks(c))) return rc;      // the reads may have introduced new strand strings
+	HIP_TRY(hipStreamSynchronize(st));
+	mr.n_retained = tot[0];
+	mr.n_retained_blocks = tot[1];
+	mr.total_slots = n1 + n2 + nn;
+	mr.wg_grid = 0;
+	{
+		// how unevenly the reads fall on the buckets: with hot genes the reads that need the general walk
+		// fill whole workgroup shares, and smaller shares (more workgroups) even the load out
+		std::vector<unsigned long long> so(B + 1, 0);
+		HIP_TRY(hipMemcpy(so.data(), mr.slot_off.p, (B + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+		unsigned long long mx = 0;
+		for (unsigned b = 0; b < B; ++b) mx = std::max(mx, so[b + 1] - so[b]);
+		mr.skew = (B && mr.total_slots) ? (double)mx * (double)B / (double)mr.total_slots : 1.0;
+	}
+	mr.present = true;
+	c->counted = c->solved = false;
+	return LSQ_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int lsq_reads_upload(lsq_ctx *c, int method, const lsq_reads *R) {
+	if (!c || !R) return fail(LSQ_E_ARG, "null argument");
+	if (!c->E) return fail(LSQ_E_STATE, "lsq_events_upload must come first");
+	if (method < 0 || method >= c->E->n_methods) return fail(LSQ_E_ARG, "method %d out of range", method);
+	HIP_TRY(hipSetDevice(c->device));
+	const uint64_t n = R->n_reads, nblk = R->n_blocks;
+	hipStream_t st = c->stream;
+	int rc;
+	// the parsed blocks, file order
+	DevBuf<unsigned long long> d_blk_off;
+	DevBuf<unsigned> d_line;
+	DevBuf<int> d_bs, d_be;
+	DevBuf<unsigned short> d_bc;
+	DevBuf<unsigned char> d_bst;
+	const unsigned long long zero_off = 0;
+	if ((rc = d_blk_off.upload(n ? (const unsigned long long *)R->blk_off : &zero_off, n + 1, st))) return rc;
+	if ((rc = d_line.upload(R->line_no, n, st))) return rc;
+	if ((rc = d_bs.upload(R->blk_start, nblk, st))) return rc;
+	if ((rc = d_be.upload(R->blk_end, nblk, st))) return rc;
+	if ((rc = d_bc.upload(R->blk_chrom, nblk, st))) return rc;
+	if ((rc = d_bst.upload(R->blk_strand, nblk, st))) return rc;
+	IngestRaw Rw;
+	Rw.n_reads = n; Rw.blk_off = d_blk_off.p; Rw.line_no = d_line.p; Rw.blk_start = d_bs.p; Rw.blk_end = d_be.p;
+	Rw.blk_chrom = d_bc.p; Rw.blk_strand = d_bst.p;
+	if ((rc = ingest_device(c, method, Rw, nblk))) return rc;
+	MethodReads &mr = c->reads[method];
+	mr.named = R->named;
+	if (R->named) {
+		if ((rc = mr.names.upload(R->name_blob.data(), R->name_blob.size(), st))) return rc;
+		if ((rc = mr.name_off.upload((const unsigned long long *)R->name_off.data(), R->name_off.size(), st))) return rc;
+		HIP_TRY(hipStreamSynchronize(st));
+	}
+	return LSQ_OK;
+}
+
+int lsq_reads_upload_mrf(lsq_ctx *c, int method, const char *read_format, const char *path) {
+	if (!c) return fail(LSQ_E_ARG, "null argument");
+	if (!c->E) return fail(LSQ_E_STATE, "lsq_events_upload must come first");
+	if (method < 0 || method >= c->E->n_methods) return fail(LSQ_E_ARG, "method %d out of range", method);
+	HIP_TRY(hipSetDevice(c->device));
+	DevParsed P;
+	int rc = device_parse_mrf(c, read_format, path, P, &c->mrf_h2d_ms, &c->mrf_parse_ms);
+	if (rc) return rc;
+	IngestRaw Rw;
+	Rw.n_reads = P.n_reads; Rw.blk_off = P.blk_off.p; Rw.line_no = P.line_no.p; Rw.blk_start = P.bs.p; Rw.blk_end = P.be.p;
+	Rw.blk_chrom = P.bc.p; Rw.blk_strand = P.bst.p;
+	c->reads[method].named = false;
+	return ingest_device(c, method, Rw, P.n_blocks);
+}
+
+int lsq_mrf_parse_device(lsq_ctx *c, const char *read_format, const char *path, lsq_reads **out) {
+	if (!c || !out) return fail(LSQ_E_ARG, "null argument");
+	HIP_TRY(hipSetDevice(c->device));
+	DevParsed P;
+	int rc = device_parse_mrf(c, read_format, path, P, &c->mrf_h2d_ms, &c->mrf_parse_ms);
+	if (rc) return rc;
+	std::unique_ptr<lsq_reads> R(new lsq_reads);
+	R->o_blk_off.resize(P.n_reads + 1); R->o_line_no.resize(P.n_reads);
+	R->o_start.resize(P.n_blocks); R->o_end.resize(P.n_blocks); R->o_chrom.resize(P.n_blocks); R->o_strand.resize(P.n_blocks);
+	HIP_TRY(hipMemcpy(R->o_blk_off.data(), P.blk_off.p, (P.n_reads + 1) * 8, hipMemcpyDeviceToHost));
+	if (P.n_reads) HIP_TRY(hipMemcpy(R->o_line_no.data(), P.line_no.p, P.n_reads * 4, hipMemcpyDeviceToHost));
+	if (P.n_blocks) {
+		HIP_TRY(hipMemcpy(R->o_start.data(), P.bs.p, P.n_blocks * 4, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(R->o_end.data(), P.be.p, P.n_blocks * 4, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(R->o_chrom.data(), P.bc.p, P.n_blocks * 2, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(R->o_strand.data(), P.bst.p, P.n_blocks, hipMemcpyDeviceToHost));
+	}
+	R->adopt();
+	*out = R.release();
+	return LSQ_OK;
+}
+
+int lsq_last_mrf_timing(lsq_ctx *c, float *h2d_ms, float *parse_ms) {
+	if (!c) return fail(LSQ_E_ARG, "null context");
+	if (h2d_ms) *h2d_ms = c->mrf_h2d_ms;
+	if (parse_ms) *parse_ms = c->mrf_parse_ms;
+	return LSQ_OK;
+}
+
+uint64_t lsq_reads_retained(const lsq_ctx *c, int method) { return (c && method >= 0 && method < LSQ_MAX_METHODS) ? c->reads[method].n_retained : 0; }
+uint64_t lsq_reads_retained_blocks(const lsq_ctx *c, int method) { return (c && method >= 0 && method < LSQ_MAX_METHODS) ? c->reads[method].n_retained_blocks : 0; }
+
+} // extern "C"

@@ -1,4 +1,4 @@
-// MRF_SINGLE parsed on the device (included by lsq_device.hip; not a public header).
+// MRF_SINGLE parsed on the device (included by lsq_ingest.hip; not a public header).
 //
 // The text goes to HBM as it is.  Newlines are found 16 bytes per lane, their ordinals by a
 // two-level prefix sum; one lane then owns one line and runs the shared splitter

@@ -1,5 +1,5 @@
 // The MRF_SINGLE line splitter, shared by the host parser (lsq_mrf.cpp) and the device parser
-// (lsq_device.hip): one source for the reference's field arithmetic (count/count.cpp:297-326).
+// (lsq_ingest.hip): one source for the reference's field arithmetic (count/count.cpp:297-326).
 //
 // The reference walks a line with std::string::find / substr.  Two of its habits matter for
 // odd lines and are kept: `npos + 1 == 0` (a search that starts "after" a colon that was not
