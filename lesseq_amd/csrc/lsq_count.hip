@@ -976,7 +976,7 @@ int run_count(lsq_ctx *c, bool all_reads) {
 			HIP_TRY(hipGetLastError());
 			mr.wg_grid = grid;
 		}
-		CountArgs A;
+		CountArgs A{};
 		A.buckets = c->buckets.p; A.images = c->images.p; A.ties = c->ties.p; A.strand_rank = c->strand_rank.p;
 		A.wg_first = mr.wg_first.p;
 		A.read_names = mr.named ? mr.names.p : nullptr; A.read_name_off = mr.named ? mr.name_off.p : nullptr;

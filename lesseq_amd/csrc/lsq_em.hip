@@ -354,7 +354,7 @@ int run_solve(lsq_ctx *c) {
 	HIP_TRY(hipEventRecord(c->ev2, st));
 	const unsigned n_ev = (unsigned)E.dev2out.size();
 	if (n_ev) {
-		EmArgs A;
+		EmArgs A{};
 		A.n_events = n_ev; A.n_methods = (unsigned)E.n_methods; A.n_cls = E.n_cls_total; A.n_iso = E.n_iso_total;
 		A.K = c->dK.p; A.cls_base = c->cls_base.p; A.iso_base = c->iso_base.p;
 		A.n_places = c->em_places; A.order = c->em_order.p;

@@ -286,11 +286,11 @@ static int ingest_device(lsq_ctx *c, int method, const IngestRaw &Rw, uint64_t n
 	if ((rc = d_cnt.alloc(2 * n_cnt)) || (rc = d_off1.alloc(F + 1)) || (rc = d_off2.alloc(F + 1)) || (rc = d_totals.alloc(4))) return rc;
 	HIP_TRY(hipMemsetAsync(d_cnt.p, 0, std::max<size_t>(2 * n_cnt, 1) * 4, st));
 	HIP_TRY(hipMemsetAsync(d_totals.p, 0, 4 * 8, st));
-	IngestTables T;
+	IngestTables T{};
 	T.cov_off = c->cov_off.p; T.cov_s = c->cov_s.p; T.cov_e = c->cov_e.p;
 	T.cut_off = c->cut_off.p; T.cut_lo = c->cut_lo.p; T.chrom_first_bucket = c->chrom_first_bucket.p;
 	T.buckets = c->buckets.p; T.bin_base = c->bin_base.p; T.n_chrom = c->n_chrom_tables;
-	IngestWork W;
+	IngestWork W{};
 	W.key = d_key.p; W.fine = d_fine.p; W.nb = d_nb.p; W.strand = d_strand.p; W.ms = d_ms.p; W.me = d_me.p;
 	W.cnt1 = d_cnt.p; W.cnt2 = W.cnt1 + F; W.cntn = W.cnt2 + F; W.cntnb = W.cntn + B;
 	W.cur1 = d_cnt.p + n_cnt; W.cur2 = W.cur1 + F; W.curn = W.cur2 + F; W.curnb = W.curn + B;
@@ -330,7 +330,7 @@ static int ingest_device(lsq_ctx *c, int method, const IngestRaw &Rw, uint64_t n
 		DevBuf<uint32_t> t_p1_line, t_p2_line;
 		if ((rc = t_p1.alloc(2 * n1)) || (rc = t_p1_strand.alloc(n1)) || (rc = t_p1_line.alloc(n1))) return rc;
 		if ((rc = t_p2.alloc(4 * n2)) || (rc = t_p2_strand.alloc(n2)) || (rc = t_p2_line.alloc(n2))) return rc;
-		IngestOut O;
+		IngestOut O{};
 		O.p1 = reinterpret_cast<int2 *>(t_p1.p); O.p1_strand = t_p1_strand.p; O.p1_line = t_p1_line.p;
 		O.p2 = reinterpret_cast<int4 *>(t_p2.p); O.p2_strand = t_p2_strand.p; O.p2_line = t_p2_line.p;
 		O.pn_blk_off = mr.pn_blk_off.p; O.pn_nblk = mr.pn_nblk.p; O.pn_line = mr.pn_line.p; O.pn_bucket = mr.pn_bucket.p;
@@ -396,7 +396,7 @@ int lsq_reads_upload(lsq_ctx *c, int method, const lsq_reads *R) {
 	if ((rc = d_be.upload(R->blk_end, nblk, st))) return rc;
 	if ((rc = d_bc.upload(R->blk_chrom, nblk, st))) return rc;
 	if ((rc = d_bst.upload(R->blk_strand, nblk, st))) return rc;
-	IngestRaw Rw;
+	IngestRaw Rw{};
 	Rw.n_reads = n; Rw.blk_off = d_blk_off.p; Rw.line_no = d_line.p; Rw.blk_start = d_bs.p; Rw.blk_end = d_be.p;
 	Rw.blk_chrom = d_bc.p; Rw.blk_strand = d_bst.p;
 	if ((rc = ingest_device(c, method, Rw, nblk))) return rc;
@@ -418,7 +418,7 @@ int lsq_reads_upload_mrf(lsq_ctx *c, int method, const char *read_format, const 
 	DevParsed P;
 	int rc = device_parse_mrf(c, read_format, path, P, &c->mrf_h2d_ms, &c->mrf_parse_ms);
 	if (rc) return rc;
-	IngestRaw Rw;
+	IngestRaw Rw{};
 	Rw.n_reads = P.n_reads; Rw.blk_off = P.blk_off.p; Rw.line_no = P.line_no.p; Rw.blk_start = P.bs.p; Rw.blk_end = P.be.p;
 	Rw.blk_chrom = P.bc.p; Rw.blk_strand = P.bst.p;
 	c->reads[method].named = false;

@@ -323,9 +323,9 @@ static int device_parse_mrf(lsq_ctx *c, const char *read_format, const char *pat
 	    (rc = d_names.upload(h_names.data(), h_names.size(), st)) || (rc = d_strand.upload(h_strand.data(), 256, st))) return rc;
 	if ((rc = out.blk_off.alloc(n_reads + 1)) || (rc = out.line_no.alloc(n_reads)) || (rc = out.bs.alloc(n_blocks)) || (rc = out.be.alloc(n_blocks)) ||
 	    (rc = out.bc.alloc(n_blocks)) || (rc = out.bst.alloc(n_blocks))) return rc;
-	MrfDict D;
+	MrfDict D{};
 	D.chrom_hash = d_hash.p; D.chrom_id = d_id.p; D.name_off = d_off.p; D.names = d_names.p; D.mask = (unsigned)(tab - 1); D.strand_tab = d_strand.p;
-	MrfOut O;
+	MrfOut O{};
 	O.blk_off = out.blk_off.p; O.line_no = out.line_no.p; O.blk_start = out.bs.p; O.blk_end = out.be.p; O.blk_chrom = out.bc.p; O.blk_strand = out.bst.p;
 	hipLaunchKernelGGL(lsq_mrf_write_kernel, dim3((unsigned)n_wg), dim3(256), 0, st, d_text.p, d_nl_pos.p, n_lines, d_line_nb.p,
 	                   d_rd_base.p, d_bk_base.p, D, O, d_err.p);
