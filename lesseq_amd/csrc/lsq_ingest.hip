@@ -5,6 +5,8 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <thread>
+
 #include "lsq_device.hpp"
 #include "lsq_mrf_line.hpp"
 

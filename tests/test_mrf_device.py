@@ -165,7 +165,7 @@ def test_files_without_data_lines(text, tmp_path):
     ctx.close()
 
 
-def test_two_million_lines_tile_boundaries_and_results(tmp_path):
+def test_two_million_lines_tile_boundaries_and_results(tmp_path, monkeypatch):
     spec = L.SynthSpec(21, 3000, 2_000_000, 100, 6, L.EVENT_TYPES, False, 0.10)
     L.synth_write(spec, str(tmp_path), "s")
     ev, ctx = setup(str(tmp_path / "s.interval"), str(tmp_path / "s.map"), 100)
@@ -184,5 +184,9 @@ def test_two_million_lines_tile_boundaries_and_results(tmp_path):
     assert np.array_equal(s1[0], s2[0]) and np.array_equal(s1[1], s2[1], equal_nan=True)
     t = ctx.mrf_timing()
     assert t["parse_ms"] > 0
+    # the copy path of gigabyte files (two pinned buffers filled by host threads), forced on this 65 MB one
+    monkeypatch.setenv("LSQ_PINNED_COPY_MIN", "1")
+    parsed_equal(ev, host, ctx.parse_mrf_device(mrf))
+    monkeypatch.delenv("LSQ_PINNED_COPY_MIN")
     print("device parse of %d MB: h2d %.1f ms, kernels %.1f ms" % (os.path.getsize(mrf) >> 20, t["h2d_ms"], t["parse_ms"]))
     ctx.close()
