@@ -151,6 +151,23 @@ void split_atol(const std::string &s, std::vector<int64_t> &out) {
 	}
 }
 
+// the tokens `iss >> a >> b ...` would extract from a line: maximal runs of non-space characters
+// (isspace of the "C" locale), at most `max_tok` of them
+size_t split_ws(const std::string &line, std::string *tok, size_t max_tok) {
+	size_t n = 0, i = 0;
+	const size_t len = line.size();
+	while (n < max_tok) {
+		while (i < len && isspace((unsigned char)line[i])) ++i;
+		if (i >= len) break;
+		size_t j = i;
+		while (j < len && !isspace((unsigned char)line[j])) ++j;
+		tok[n++].assign(line, i, j - i);
+		i = j;
+	}
+	for (size_t k = n; k < max_tok; ++k) tok[k].clear();
+	return n;
+}
+
 // `while (getline(ifs, line) && !ifs.eof())`: only newline-terminated lines are seen
 bool read_lines(const char *path, std::vector<std::string> &lines) {
 	FILE *f = fopen(path, "rb");
@@ -209,13 +226,13 @@ int lsq_annotation_load(const char *isoform_format, const char *isoforms_path,
 		// LH_GENE_TXT: name chrom strand txStart txEnd exonCount exonStarts exonEnds (count/count.cpp:142-171);
 		// UCSC_GENE_TXT has cdsStart cdsEnd between txEnd and exonCount (jsc/bioinfo/gene_anno.hpp:59-101)
 		const bool ucsc = ifmt == "UCSC_GENE_TXT";
+		std::string tok[10];
 		for (const std::string &line : lines) {
-			std::istringstream iss(line);
 			std::unique_ptr<IsoRec> r(new IsoRec);
-			std::string t_s, t_e, t_n, starts, ends, cds_s, cds_e;
-			iss >> r->name >> r->chrom >> r->strand >> t_s >> t_e;
-			if (ucsc) iss >> cds_s >> cds_e;
-			iss >> t_n >> starts >> ends;
+			split_ws(line, tok, ucsc ? 10 : 8);
+			const size_t o = ucsc ? 2 : 0;
+			r->name = tok[0]; r->chrom = tok[1]; r->strand = tok[2];
+			const std::string &t_s = tok[3], &t_e = tok[4], &cds_s = tok[5], &cds_e = tok[6], &t_n = tok[5 + o], &starts = tok[6 + o], &ends = tok[7 + o];
 			int64_t cnt = 0, ignore = 0;
 			if (strict_long(t_s, r->txStart) && strict_long(t_e, r->txEnd) && (!ucsc || (strict_long(cds_s, ignore) && strict_long(cds_e, ignore))) &&
 			    strict_long(t_n, cnt) && cnt >= 0) {
@@ -288,10 +305,10 @@ int lsq_annotation_load(const char *isoform_format, const char *isoforms_path,
 	const std::string gfmt = g2i_format;
 	if (gfmt != "UCSC_GENE2ISOFORM" && gfmt != "WORMBASE_GENE2ISOFORMS") return fail(LSQ_E_FORMAT, "Unknown file format error: %s", g2i_format);
 	std::map<std::string, std::vector<const IsoRec *>> genes;   // std::map: bytewise key order == std::set<string>
+	std::string gtok[2];
 	for (const std::string &line : lines) {
-		std::istringstream iss(line);
-		std::string g, names;
-		iss >> g >> names;
+		split_ws(line, gtok, 2);
+		const std::string &g = gtok[0], &names = gtok[1];
 		// UCSC_GENE2ISOFORM: gene isoform; WORMBASE_GENE2ISOFORMS: gene iso1;iso2;... (solve/solve.cpp:310-329)
 		std::vector<std::string> inames;
 		if (gfmt == "UCSC_GENE2ISOFORM") inames.push_back(names);

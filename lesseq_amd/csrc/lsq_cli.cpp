@@ -5,6 +5,8 @@
 #include <cerrno>
 #include <cstdarg>
 #include <cstdlib>
+#include <chrono>
+#include <thread>
 #include <cstring>
 #include <ctime>
 #include <string>
@@ -152,7 +154,20 @@ int run_classify(int argc, const char *const *argv) {
 	return 0;
 }
 
+// developer aid: LSQ_CLI_TIMING=1 prints the seconds each phase took on stderr
+struct PhaseTimer {
+	bool on = getenv("LSQ_CLI_TIMING") != nullptr;
+	std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+	void mark(const char *what) {
+		if (!on) return;
+		const auto n = std::chrono::steady_clock::now();
+		fprintf(stderr, "[timing] %-28s %.3f s\n", what, std::chrono::duration<double>(n - t).count());
+		t = n;
+	}
+};
+
 int run_count_solve(bool solve, int argc, const char *const *argv, std::string &out) {
+	PhaseTimer T;
 	const int per = solve ? 5 : 4;
 	auto usage = [&] {
 		logf(0, "Usage:\n%s\n\tlog_level(0,1,2,...) proj_name out_prefix\n\tisoform_format isoforms_path g2i_format g2i_path gene_begin_idx gene_end_idx\n  (read_format read_type expected_read_length reads_path%s)+",
@@ -181,6 +196,19 @@ int run_count_solve(bool solve, int argc, const char *const *argv, std::string &
 	const int M = (int)paths.size();
 	if (M > LSQ_MAX_METHODS) { logf(0, "more than %d read files", LSQ_MAX_METHODS); return 2; }
 	Freer F;
+	// the device context (HIP start-up, a tenth of a second or more) is created on a second thread while
+	// this one reads the annotation; its status is looked at only where the reference would be past
+	// every check it makes before the reads
+	int ctx_status = LSQ_OK;
+	std::string ctx_error;
+	lsq_ctx *ctx_bg = nullptr;
+	std::thread ctx_thread([&] {
+		int dev = 0;
+		if (const char *e = getenv("LSQ_DEVICE")) dev = atoi(e);
+		ctx_status = lsq_ctx_create(dev, &ctx_bg);
+		if (ctx_status) ctx_error = lsq_last_error();          // the message lives in that thread
+	});
+	struct Joiner { std::thread &t; lsq_ctx *&c; lsq_ctx *&owner; ~Joiner() { if (t.joinable()) t.join(); if (c && !owner) lsq_ctx_destroy(c); } } joiner{ctx_thread, ctx_bg, F.c};
 	logf(2, "Loading isoforms...");
 	int st = solve ? LSQ_OK : count_formats_only(argv[4], argv[5], argv[6], argv[7]);
 	if (!st) st = lsq_annotation_load(argv[4], argv[5], argv[6], argv[7], gb, ge, &F.a);
@@ -188,6 +216,7 @@ int run_count_solve(bool solve, int argc, const char *const *argv, std::string &
 	logf(2, "Loaded %lld isoforms", (long long)lsq_annotation_num_isoforms_loaded(F.a));
 	logf(2, "Loaded %lld genes", (long long)lsq_annotation_num_genes_loaded(F.a));
 	logf(2, "Selected %lld gene(s)", (long long)lsq_annotation_num_genes(F.a));
+	T.mark("annotation load");
 	// An unknown read type is only noticed inside the per-gene loop of the reference
 	// (count/count.cpp:417-419), i.e. after every read file was loaded and only when at least one
 	// gene is selected; keep that precedence.
@@ -203,17 +232,20 @@ int run_count_solve(bool solve, int argc, const char *const *argv, std::string &
 	if (st) { logf(0, "%s", lsq_last_error()); return status_to_exit(st); }
 	const int64_t n_ev = lsq_events_count(F.e);
 	logf(2, "Built isoform structures for the %lld selected gene(s)", (long long)n_ev);
+	T.mark("event compile + device plan");
 	logf(2, "Loading the reads from %d sampling method(s)", M);
 	for (int m = 0; m < M; ++m) {
 		// what the reference decides before it reads a line: the file opens (assert) and the format literal is known
 		st = precheck_reads_file(fmts[m], paths[m], solve);
 		if (st) { logf(0, "%s", lsq_last_error()); return status_to_exit(st); }
 		if (!F.c) {
-			int dev = 0;
-			if (const char *e = getenv("LSQ_DEVICE")) dev = atoi(e);
-			st = lsq_ctx_create(dev, &F.c);
-			if (!st) st = lsq_events_upload(F.c, F.e);
+			if (ctx_thread.joinable()) ctx_thread.join();
+			T.mark("wait for the device context");
+			if (ctx_status) { logf(0, "%s", ctx_error.c_str()); return 3; }
+			F.c = ctx_bg;
+			st = lsq_events_upload(F.c, F.e);
 			if (st) { logf(0, "%s", lsq_last_error()); return 3; }
+			T.mark("event tables upload");
 		}
 		// MRF text -> HBM -> parsed and ingested there; the name-keyed formats are grouped by name on the host first
 		st = named_read_format(fmts[m]) ? LSQ_E_UNSUPPORTED : lsq_reads_upload_mrf(F.c, m, fmts[m], paths[m]);
@@ -226,6 +258,8 @@ int run_count_solve(bool solve, int argc, const char *const *argv, std::string &
 		if (st == LSQ_E_PARSE) { logf(0, "%s", lsq_last_error()); logf(0, "Lexical_cast error when converting arguments to numeric values"); return status_to_exit(st); }
 		if (st) { logf(0, "%s", lsq_last_error()); return st == LSQ_E_DEVICE ? 3 : (st == LSQ_E_IO || st == LSQ_E_FORMAT ? status_to_exit(st) : 2); }
 		logf(2, "Sampling method #%d: loaded %llu reads associated with the selected gene regions", m, (unsigned long long)lsq_reads_retained(F.c, m));
+		T.mark("reads: copy, parse, ingest");
+		if (T.on) { float h2d = 0, parse = 0; lsq_last_mrf_timing(F.c, &h2d, &parse); fprintf(stderr, "[timing]   of which text copy %.3f s, parse kernels %.3f s\n", h2d * 1e-3, parse * 1e-3); }
 	}
 	if (bad_type && n_ev > 0) { logf(0, "Unknown read type error: %s", bad_type_name.c_str()); return 1; }
 	logf(2, "Processing reads info for genes");
@@ -236,6 +270,7 @@ int run_count_solve(bool solve, int argc, const char *const *argv, std::string &
 	std::vector<uint64_t> cnt(std::max<size_t>((size_t)M * n_cls, 1)), bases(std::max<size_t>((size_t)M * n_cls, 1));
 	st = lsq_results_counts(F.c, cnt.data(), bases.data());
 	if (st) { logf(0, "%s", lsq_last_error()); return 3; }
+	T.mark("count + solve + fetch");
 	char *text = nullptr;
 	if (!solve) {
 		st = lsq_format_count(F.e, M, cnt.data(), &text);
@@ -251,6 +286,7 @@ int run_count_solve(bool solve, int argc, const char *const *argv, std::string &
 	if (st || !text) { logf(0, "%s", lsq_last_error()); return 2; }
 	out.assign(text);
 	free(text);
+	T.mark("format rows");
 	logf(2, "Processed %lld genes... Done", (long long)n_ev);
 	return 0;
 }

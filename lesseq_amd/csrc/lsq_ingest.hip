@@ -5,12 +5,28 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
+#include <chrono>
+#include <thread>
+
 #include <thread>
 
 #include "lsq_device.hpp"
 #include "lsq_mrf_line.hpp"
 
 namespace {
+
+// developer aid: LSQ_CLI_TIMING=1 prints host-side seconds of the loader's steps on stderr
+struct HostStopwatch {
+	bool on = getenv("LSQ_CLI_TIMING") != nullptr;
+	std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+	void mark(const char *what) {
+		if (!on) return;
+		const auto n = std::chrono::steady_clock::now();
+		fprintf(stderr, "[timing]     %-32s %.3f s\n", what, std::chrono::duration<double>(n - t).count());
+		t = n;
+	}
+};
 
 // =====================================================================================
 // Ingest on the device: from parsed blocks in file order to the bucketed, pooled arrays.
@@ -270,6 +286,7 @@ __global__ void __launch_bounds__(256) lsq_ingest_binsort_kernel(const BucketDes
 
 // Runs the three ingest kernels over parsed blocks that are already on the device (file order).
 static int ingest_device(lsq_ctx *c, int method, const IngestRaw &Rw, uint64_t nblk) {
+	HostStopwatch SW;
 	const lsq_events &E = *c->E;
 	MethodReads &mr = c->reads[method];
 	mr.present = false;
@@ -310,6 +327,7 @@ static int ingest_device(lsq_ctx *c, int method, const IngestRaw &Rw, uint64_t n
 	hipLaunchKernelGGL(lsq_ingest_offsets_kernel, dim3(B / 256 + 1), dim3(256), 0, st, c->bin_base.p, B, d_off1.p, d_off2.p, mr.pn_off.p,
 	                   mr.p1_off.p, mr.p2_off.p, mr.slot_off.p);
 	HIP_TRY(hipGetLastError());
+	SW.mark("ingest: allocs + classify launch");
 	unsigned long long tot[4] = {0, 0, 0, 0}, sums[4] = {0, 0, 0, 0};
 	HIP_TRY(hipMemcpyAsync(tot, d_totals.p, 4 * 8, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(&sums[0], mr.p1_off.p + B, 8, hipMemcpyDeviceToHost, st));
@@ -317,6 +335,7 @@ static int ingest_device(lsq_ctx *c, int method, const IngestRaw &Rw, uint64_t n
 	HIP_TRY(hipMemcpyAsync(&sums[2], mr.pn_off.p + B, 8, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(&sums[3], mr.pnb_off.p + B, 8, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
+	SW.mark("ingest: classify + scans done");
 	if (tot[2]) return fail(LSQ_E_RANGE, "a read covers 2^18 or more bases or keeps more than %d separate blocks: outside the device tables' range", INGEST_MAX_BLOCKS);
 	if (sums[3] > 0xFFFFFFF0ull) return fail(LSQ_E_RANGE, "too many blocks in multi-block reads");
 	if (n > 0xFFFFFFF0ull) return fail(LSQ_E_RANGE, "more than 2^32 reads in one file");
@@ -347,14 +366,18 @@ static int ingest_device(lsq_ctx *c, int method, const IngestRaw &Rw, uint64_t n
 		                           reinterpret_cast<const int4 *>(t_p2.p), t_p2_strand.p, t_p2_line.p, reinterpret_cast<int4 *>(mr.p2.p), mr.p2_strand.p, mr.p2_line.p);
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(hipStreamSynchronize(st));            // the temporaries go out of scope here
+		SW.mark("ingest: scatter + bin sort done");
 	}
+	SW.mark("ingest: pool temporaries freed");
 	{
 		// exception list: a quarter of the one- and two-block reads, at least 64 Ki entries
 		const size_t want = std::max<size_t>(65536, (n1 + n2) / 4);
 		if (c->exc.n < want && (rc = c->exc.alloc(want))) return rc;
 	}
+	SW.mark("ingest: exception list alloc");
 	if ((rc = upload_strand_ranks(c))) return rc;      // the reads may have introduced new strand strings
 	HIP_TRY(hipStreamSynchronize(st));
+	SW.mark("ingest: strand ranks");
 	mr.n_retained = tot[0];
 	mr.n_retained_blocks = tot[1];
 	mr.total_slots = n1 + n2 + nn;
@@ -363,13 +386,15 @@ static int ingest_device(lsq_ctx *c, int method, const IngestRaw &Rw, uint64_t n
 		// how unevenly the reads fall on the buckets: with hot genes the reads that need the general walk
 		// fill whole workgroup shares, and smaller shares (more workgroups) even the load out
 		std::vector<unsigned long long> so(B + 1, 0);
-		HIP_TRY(hipMemcpy(so.data(), mr.slot_off.p, (B + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpyAsync(so.data(), mr.slot_off.p, (B + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
 		unsigned long long mx = 0;
 		for (unsigned b = 0; b < B; ++b) mx = std::max(mx, so[b + 1] - so[b]);
 		mr.skew = (B && mr.total_slots) ? (double)mx * (double)B / (double)mr.total_slots : 1.0;
 	}
 	mr.present = true;
 	c->counted = c->solved = false;
+	SW.mark("ingest: skew, strand ranks");
 	return LSQ_OK;
 }
 
@@ -417,8 +442,10 @@ int lsq_reads_upload_mrf(lsq_ctx *c, int method, const char *read_format, const 
 	if (!c->E) return fail(LSQ_E_STATE, "lsq_events_upload must come first");
 	if (method < 0 || method >= c->E->n_methods) return fail(LSQ_E_ARG, "method %d out of range", method);
 	HIP_TRY(hipSetDevice(c->device));
+	HostStopwatch SW;
 	DevParsed P;
 	int rc = device_parse_mrf(c, read_format, path, P, &c->mrf_h2d_ms, &c->mrf_parse_ms);
+	SW.mark("parse: all (incl. unmap, frees)");
 	if (rc) return rc;
 	IngestRaw Rw{};
 	Rw.n_reads = P.n_reads; Rw.blk_off = P.blk_off.p; Rw.line_no = P.line_no.p; Rw.blk_start = P.bs.p; Rw.blk_end = P.be.p;

@@ -205,20 +205,24 @@ static int device_parse_mrf(lsq_ctx *c, const char *read_format, const char *pat
 	if (!read_format || !path) return fail(LSQ_E_ARG, "null argument");
 	if (!c->E) return fail(LSQ_E_STATE, "lsq_events_upload must come first");
 	lsq_events &E = *c->E;
+	HostStopwatch SW;
 	int fd = open(path, O_RDONLY);
 	if (fd < 0) return fail(LSQ_E_IO, "cannot open reads file %s", path);
 	if (strcmp(read_format, "MRF_SINGLE") != 0) { close(fd); return fail(LSQ_E_FORMAT, "Unknown file format error: %s", read_format); }
 	struct stat sb;
 	if (fstat(fd, &sb) != 0) { close(fd); return fail(LSQ_E_IO, "cannot stat %s", path); }
+	// Small files are mapped and copied as they are (the runtime stages pageable memory through its own
+	// pinned buffers on one thread: 18 GB/s measured).  Files of a gigabyte and more are never mapped:
+	// a few worker threads pread() them, a slice at a time, into two pinned 32 MiB buffers of ours while
+	// the DMA engine drains the other buffer (38 GB/s, and no page-table build-up and tear-down for
+	// gigabytes of mapping).
+	const unsigned long long len = (unsigned long long)sb.st_size;
+	const size_t SLICE = 32ull << 20;
+	unsigned long long pinned_min = 1ull << 30;           // below a gigabyte allocating the pinned buffers costs more than they save
+	if (const char *e = getenv("LSQ_PINNED_COPY_MIN")) { const long long v = atoll(e); if (v >= 0) pinned_min = (unsigned long long)v; }   // tests
+	bool pinned = len >= pinned_min && len >= 2 * SLICE;
+	struct FdCloser { int fd; ~FdCloser() { if (fd >= 0) close(fd); } } fdc{fd};
 	MappedFile mf;
-	mf.len = (size_t)sb.st_size;
-	if (mf.len) {
-		void *m = mmap(nullptr, mf.len, PROT_READ, MAP_PRIVATE, fd, 0);
-		if (m == MAP_FAILED) { close(fd); mf.len = 0; return fail(LSQ_E_IO, "cannot map %s", path); }
-		mf.data = (const char *)m;
-		madvise(m, mf.len, MADV_SEQUENTIAL);
-	}
-	close(fd);
 	hipStream_t st = c->stream;
 	int rc;
 	const unsigned long long zero_off = 0;
@@ -232,56 +236,71 @@ static int device_parse_mrf(lsq_ctx *c, const char *read_format, const char *pat
 	};
 	if (h2d_ms) *h2d_ms = 0;
 	if (parse_ms) *parse_ms = 0;
-	if (mf.len == 0) return empty_result();
+	if (len == 0) return empty_result();
 
-	const unsigned long long len = mf.len;
 	DevBuf<unsigned char> d_text;
 	if ((rc = d_text.alloc(len + 16))) return rc;
 	HIP_TRY(hipEventRecord(c->ev0, st));
 	{
-		// The mapping is pageable memory: copied as it is, the runtime stages it through small pinned
-		// buffers on one thread (18 GB/s measured).  Files of a gigabyte and more instead go through two
-		// pinned 32 MiB buffers of our own, filled by host threads (page faults and memcpy in parallel)
-		// while the DMA engine drains the other buffer.
-		const size_t SLICE = 32ull << 20;
-		const int T = std::max(1, std::min(16, host_threads(0)));
 		unsigned char *pin[2] = {nullptr, nullptr};
-		hipEvent_t done[2] = {nullptr, nullptr};
-		unsigned long long pinned_min = 1ull << 30;           // below a gigabyte allocating the pinned buffers costs more than they save
-		if (const char *e = getenv("LSQ_PINNED_COPY_MIN")) { const long long v = atoll(e); if (v >= 0) pinned_min = (unsigned long long)v; }   // tests
-		bool pinned = len >= pinned_min && len >= 2 * SLICE;
+		hipEvent_t drained[2] = {nullptr, nullptr};
 		if (pinned) {
 			pinned = hipHostMalloc((void **)&pin[0], SLICE, hipHostMallocDefault) == hipSuccess &&
 			         hipHostMalloc((void **)&pin[1], SLICE, hipHostMallocDefault) == hipSuccess &&
-			         hipEventCreateWithFlags(&done[0], hipEventDisableTiming) == hipSuccess &&
-			         hipEventCreateWithFlags(&done[1], hipEventDisableTiming) == hipSuccess;
+			         hipEventCreateWithFlags(&drained[0], hipEventDisableTiming) == hipSuccess &&
+			         hipEventCreateWithFlags(&drained[1], hipEventDisableTiming) == hipSuccess;
 			(void)hipGetLastError();
 		}
 		int rc_copy = LSQ_OK;
 		if (pinned) {
-			int k = 0;
-			for (size_t off = 0; off < len && rc_copy == LSQ_OK; off += SLICE, k ^= 1) {
-				const size_t nby = std::min<size_t>(SLICE, len - off);
-				if (off >= 2 * SLICE && hipEventSynchronize(done[k]) != hipSuccess) { rc_copy = fail(LSQ_E_DEVICE, "hipEventSynchronize failed in the text copy"); break; }
-				std::vector<std::thread> th;
-				for (int t = 0; t < T; ++t) th.emplace_back([&, t] {
-					const size_t a = nby * (size_t)t / (size_t)T, b = nby * (size_t)(t + 1) / (size_t)T;
-					memcpy(pin[k] + a, mf.data + off + a, b - a);
-				});
-				for (auto &x : th) x.join();
-				if (hipMemcpyAsync(d_text.p + off, pin[k], nby, hipMemcpyHostToDevice, st) != hipSuccess || hipEventRecord(done[k], st) != hipSuccess)
+			const int T = std::max(1, std::min(16, host_threads(0)));
+			const long n_slices = (long)((len + SLICE - 1) / SLICE);
+			std::atomic<long> go{-1}, filled{0};
+			std::atomic<int> io_error{0};
+			std::vector<std::thread> workers;
+			for (int t = 0; t < T; ++t) workers.emplace_back([&, t] {
+				for (long sl = 0; sl < n_slices; ++sl) {
+					while (go.load(std::memory_order_acquire) < sl) std::this_thread::yield();
+					const size_t off = (size_t)sl * SLICE, nby = std::min<size_t>(SLICE, len - off);
+					size_t a = nby * (size_t)t / (size_t)T;
+					const size_t b = nby * (size_t)(t + 1) / (size_t)T;
+					while (a < b) {
+						const ssize_t got = pread(fd, pin[sl & 1] + a, b - a, (off_t)(off + a));
+						if (got <= 0) { io_error.store(1); break; }
+						a += (size_t)got;
+					}
+					filled.fetch_add(1, std::memory_order_release);
+				}
+			});
+			for (long sl = 0; sl < n_slices; ++sl) {
+				const int k = (int)(sl & 1);
+				if (sl >= 2 && rc_copy == LSQ_OK && hipEventSynchronize(drained[k]) != hipSuccess) rc_copy = fail(LSQ_E_DEVICE, "hipEventSynchronize failed in the text copy");
+				go.store(sl, std::memory_order_release);
+				while (filled.load(std::memory_order_acquire) < (long)T * (sl + 1)) std::this_thread::yield();
+				const size_t off = (size_t)sl * SLICE, nby = std::min<size_t>(SLICE, len - off);
+				if (rc_copy == LSQ_OK && (hipMemcpyAsync(d_text.p + off, pin[k], nby, hipMemcpyHostToDevice, st) != hipSuccess || hipEventRecord(drained[k], st) != hipSuccess))
 					rc_copy = fail(LSQ_E_DEVICE, "hipMemcpyAsync failed in the text copy");
 			}
+			for (auto &w : workers) w.join();
 			if (hipStreamSynchronize(st) != hipSuccess && rc_copy == LSQ_OK) rc_copy = fail(LSQ_E_DEVICE, "text copy failed");
+			if (io_error.load() && rc_copy == LSQ_OK) rc_copy = fail(LSQ_E_IO, "cannot read %s", path);
 		} else {
-			for (size_t off = 0; off < len && rc_copy == LSQ_OK; off += SLICE) {
-				const size_t nby = std::min<size_t>(SLICE, len - off);
-				if (hipMemcpyAsync(d_text.p + off, mf.data + off, nby, hipMemcpyHostToDevice, st) != hipSuccess) rc_copy = fail(LSQ_E_DEVICE, "hipMemcpyAsync failed in the text copy");
+			void *m = mmap(nullptr, (size_t)len, PROT_READ, MAP_PRIVATE, fd, 0);
+			if (m == MAP_FAILED) rc_copy = fail(LSQ_E_IO, "cannot map %s", path);
+			else {
+				mf.data = (const char *)m; mf.len = (size_t)len;
+				madvise(m, mf.len, MADV_SEQUENTIAL);
+				for (size_t off = 0; off < len && rc_copy == LSQ_OK; off += SLICE) {
+					const size_t nby = std::min<size_t>(SLICE, len - off);
+					if (hipMemcpyAsync(d_text.p + off, mf.data + off, nby, hipMemcpyHostToDevice, st) != hipSuccess) rc_copy = fail(LSQ_E_DEVICE, "hipMemcpyAsync failed in the text copy");
+				}
+				if (hipStreamSynchronize(st) != hipSuccess && rc_copy == LSQ_OK) rc_copy = fail(LSQ_E_DEVICE, "text copy failed");
 			}
 		}
-		for (int q = 0; q < 2; ++q) { if (pin[q]) (void)hipHostFree(pin[q]); if (done[q]) (void)hipEventDestroy(done[q]); }
+		for (int q = 0; q < 2; ++q) { if (pin[q]) (void)hipHostFree(pin[q]); if (drained[q]) (void)hipEventDestroy(drained[q]); }
 		if (rc_copy) return rc_copy;
 	}
+	SW.mark("parse: open, map, text copy");
 	HIP_TRY(hipEventRecord(c->ev1, st));
 	const unsigned long long n_tiles = (len + MRF_TILE - 1) / MRF_TILE;
 	if (n_tiles > 0x7FFFFFFFull) return fail(LSQ_E_RANGE, "reads file larger than 8 TiB");
@@ -323,7 +342,13 @@ static int device_parse_mrf(lsq_ctx *c, const char *read_format, const char *pat
 	if (err[0] != MRF_NO_ERR) {
 		unsigned long long ab[2];
 		HIP_TRY(hipMemcpy(ab, d_nl_pos.p + (err[0] - 1), 16, hipMemcpyDeviceToHost));
-		const std::string text(mf.data + ab[0] + 1, (size_t)(ab[1] - ab[0] - 1));
+		std::string text((size_t)(ab[1] - ab[0] - 1), '\0');
+		size_t got_all = 0;
+		while (got_all < text.size()) {
+			const ssize_t got = pread(fd, &text[got_all], text.size() - got_all, (off_t)(ab[0] + 1 + got_all));
+			if (got <= 0) break;
+			got_all += (size_t)got;
+		}
 		return fail(LSQ_E_PARSE, "#%llu:%s", err[0], text.c_str());
 	}
 	// dictionaries
@@ -369,6 +394,7 @@ static int device_parse_mrf(lsq_ctx *c, const char *read_format, const char *pat
 	HIP_TRY(hipMemcpyAsync(err, d_err.p, sizeof(err), hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(h_strand.data(), d_strand.p, 256 * 8, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
+	SW.mark("parse: kernels");
 	if (h2d_ms) (void)hipEventElapsedTime(h2d_ms, c->ev0, c->ev1);
 	if (parse_ms) (void)hipEventElapsedTime(parse_ms, c->ev1, c->ev2);
 	if (err[1]) return fail(LSQ_E_UNSUPPORTED, "a strand string longer than 7 bytes: outside the device parser's range (lsq_mrf_parse handles it)");
