@@ -170,6 +170,14 @@ int lsq_reads_upload(lsq_ctx *c, int method, const lsq_reads *r);
  * the first failing line in lsq_last_error(), LSQ_E_IO); LSQ_E_UNSUPPORTED when the file holds a
  * strand string longer than 7 bytes (lsq_mrf_parse + lsq_reads_upload take those). */
 int lsq_reads_upload_mrf(lsq_ctx *c, int method, const char *read_format, const char *path);
+/* The same in two steps, for callers that want the copy under way before the event tables exist (the
+ * executables start it on a second thread while the annotation is still being read):
+ * lsq_text_stage copies the file's bytes to HBM and needs only the context; lsq_reads_upload_text
+ * parses and ingests them (status as lsq_reads_upload_mrf).  The text may be freed afterwards. */
+typedef struct lsq_text lsq_text;
+int lsq_text_stage(lsq_ctx *c, const char *path, lsq_text **out);
+void lsq_text_free(lsq_text *t);
+int lsq_reads_upload_text(lsq_ctx *c, int method, const char *read_format, lsq_text *t);
 /* The device parser's blocks copied back to the host (same arrays lsq_mrf_parse makes; for tools
  * and tests).  Needs lsq_events_upload first. */
 int lsq_mrf_parse_device(lsq_ctx *c, const char *read_format, const char *path, lsq_reads **out);

@@ -79,6 +79,9 @@ _sig("lsq_reads_upload", C.c_int, vp, C.c_int, vp)
 _sig("lsq_reads_arrays", C.c_int, vp, P(vp), P(vp), P(vp), P(vp), P(vp), P(vp))
 _sig("lsq_events_strand_name", cs, vp, C.c_int)
 _sig("lsq_reads_upload_mrf", C.c_int, vp, C.c_int, cs, cs)
+_sig("lsq_text_stage", C.c_int, vp, cs, P(vp))
+_sig("lsq_text_free", None, vp)
+_sig("lsq_reads_upload_text", C.c_int, vp, C.c_int, cs, vp)
 _sig("lsq_mrf_parse_device", C.c_int, vp, cs, cs, P(vp))
 _sig("lsq_last_mrf_timing", C.c_int, vp, P(C.c_float), P(C.c_float))
 _sig("lsq_reads_retained", u64, vp, C.c_int)

@@ -202,13 +202,21 @@ int run_count_solve(bool solve, int argc, const char *const *argv, std::string &
 	int ctx_status = LSQ_OK;
 	std::string ctx_error;
 	lsq_ctx *ctx_bg = nullptr;
+	// ... and the same thread goes on to copy the MRF text of every read file to HBM (that needs no event
+	// table); a file that does not open or is not MRF_SINGLE is left to the main thread, which reports it
+	std::vector<lsq_text *> texts((size_t)M, nullptr);
 	std::thread ctx_thread([&] {
 		int dev = 0;
 		if (const char *e = getenv("LSQ_DEVICE")) dev = atoi(e);
 		ctx_status = lsq_ctx_create(dev, &ctx_bg);
-		if (ctx_status) ctx_error = lsq_last_error();          // the message lives in that thread
+		if (ctx_status) { ctx_error = lsq_last_error(); return; }          // the message lives in that thread
+		for (int m = 0; m < M; ++m)
+			if (strcmp(fmts[m], "MRF_SINGLE") == 0 && lsq_text_stage(ctx_bg, paths[m], &texts[(size_t)m]) != LSQ_OK) texts[(size_t)m] = nullptr;
 	});
-	struct Joiner { std::thread &t; lsq_ctx *&c; lsq_ctx *&owner; ~Joiner() { if (t.joinable()) t.join(); if (c && !owner) lsq_ctx_destroy(c); } } joiner{ctx_thread, ctx_bg, F.c};
+	struct Joiner {
+		std::thread &t; lsq_ctx *&c; lsq_ctx *&owner; std::vector<lsq_text *> &tx;
+		~Joiner() { if (t.joinable()) t.join(); for (auto *x : tx) lsq_text_free(x); if (c && !owner) lsq_ctx_destroy(c); }
+	} joiner{ctx_thread, ctx_bg, F.c, texts};
 	logf(2, "Loading isoforms...");
 	int st = solve ? LSQ_OK : count_formats_only(argv[4], argv[5], argv[6], argv[7]);
 	if (!st) st = lsq_annotation_load(argv[4], argv[5], argv[6], argv[7], gb, ge, &F.a);
@@ -248,7 +256,10 @@ int run_count_solve(bool solve, int argc, const char *const *argv, std::string &
 			T.mark("event tables upload");
 		}
 		// MRF text -> HBM -> parsed and ingested there; the name-keyed formats are grouped by name on the host first
-		st = named_read_format(fmts[m]) ? LSQ_E_UNSUPPORTED : lsq_reads_upload_mrf(F.c, m, fmts[m], paths[m]);
+		if (texts[(size_t)m]) {
+			st = lsq_reads_upload_text(F.c, m, fmts[m], texts[(size_t)m]);
+			lsq_text_free(texts[(size_t)m]); texts[(size_t)m] = nullptr;
+		} else st = named_read_format(fmts[m]) ? LSQ_E_UNSUPPORTED : lsq_reads_upload_mrf(F.c, m, fmts[m], paths[m]);
 		if (st == LSQ_E_UNSUPPORTED) {
 			// a strand string beyond the device parser's 7 bytes: the host parser reads such files
 			lsq_reads *r = nullptr;

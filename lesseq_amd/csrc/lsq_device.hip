@@ -39,6 +39,7 @@ int lsq_ctx_create(int device_id, lsq_ctx **out) {
 	HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 	HIP_TRY(hipEventCreate(&c->ev0)); HIP_TRY(hipEventCreate(&c->ev1));
 	HIP_TRY(hipEventCreate(&c->ev2)); HIP_TRY(hipEventCreate(&c->ev3));
+	HIP_TRY(hipEventCreate(&c->evt0)); HIP_TRY(hipEventCreate(&c->evt1));
 	for (int m = 0; m < LSQ_MAX_METHODS; ++m) { HIP_TRY(hipEventCreate(&c->evf0[m])); HIP_TRY(hipEventCreate(&c->evf1[m])); }
 	*out = c.release();
 	return LSQ_OK;
@@ -52,6 +53,8 @@ void lsq_ctx_destroy(lsq_ctx *c) {
 	if (c->ev1) (void)hipEventDestroy(c->ev1);
 	if (c->ev2) (void)hipEventDestroy(c->ev2);
 	if (c->ev3) (void)hipEventDestroy(c->ev3);
+	if (c->evt0) (void)hipEventDestroy(c->evt0);
+	if (c->evt1) (void)hipEventDestroy(c->evt1);
 	for (int m = 0; m < LSQ_MAX_METHODS; ++m) { if (c->evf0[m]) (void)hipEventDestroy(c->evf0[m]); if (c->evf1[m]) (void)hipEventDestroy(c->evf1[m]); }
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;

@@ -82,6 +82,7 @@ struct lsq_ctx {
 	int n_cu = 256;
 	hipStream_t stream = nullptr;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+	hipEvent_t evt0 = nullptr, evt1 = nullptr;      // around a text copy (lsq_text_stage may run beside other host work)
 	hipEvent_t evf0[LSQ_MAX_METHODS] = {}, evf1[LSQ_MAX_METHODS] = {};   // around each method's lsq_count_fast_kernel launch
 	int fast_launched = 0;
 	lsq_events *E = nullptr;                // must outlive the uploads made from it (its strand dictionary grows with the reads)
@@ -108,6 +109,15 @@ struct lsq_ctx {
 	bool has_fast = false, has_generic = false;
 	float count_ms = 0, solve_ms = 0;
 	float mrf_h2d_ms = 0, mrf_parse_ms = 0;
+};
+
+// MRF text of one file in HBM (lsq_text_stage).  Staging needs no event tables: the executables start it
+// on a second thread while the first is still reading the annotation.
+struct lsq_text {
+	std::string path;
+	unsigned long long len = 0;
+	lsq::DevBuf<unsigned char> d_text;
+	float h2d_ms = 0;
 };
 
 namespace lsq {

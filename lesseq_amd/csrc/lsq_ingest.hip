@@ -454,6 +454,32 @@ int lsq_reads_upload_mrf(lsq_ctx *c, int method, const char *read_format, const 
 	return ingest_device(c, method, Rw, P.n_blocks);
 }
 
+int lsq_text_stage(lsq_ctx *c, const char *path, lsq_text **out) {
+	if (!c || !path || !out) return fail(LSQ_E_ARG, "null argument");
+	HIP_TRY(hipSetDevice(c->device));
+	std::unique_ptr<lsq_text> T(new lsq_text);
+	int rc = stage_text_file(c, path, *T);
+	if (rc) return rc;
+	*out = T.release();
+	return LSQ_OK;
+}
+void lsq_text_free(lsq_text *t) { delete t; }
+
+int lsq_reads_upload_text(lsq_ctx *c, int method, const char *read_format, lsq_text *t) {
+	if (!c || !t) return fail(LSQ_E_ARG, "null argument");
+	if (!c->E) return fail(LSQ_E_STATE, "lsq_events_upload must come first");
+	if (method < 0 || method >= c->E->n_methods) return fail(LSQ_E_ARG, "method %d out of range", method);
+	HIP_TRY(hipSetDevice(c->device));
+	DevParsed P;
+	int rc = parse_staged_text(c, read_format, *t, P, &c->mrf_h2d_ms, &c->mrf_parse_ms);
+	if (rc) return rc;
+	IngestRaw Rw{};
+	Rw.n_reads = P.n_reads; Rw.blk_off = P.blk_off.p; Rw.line_no = P.line_no.p; Rw.blk_start = P.bs.p; Rw.blk_end = P.be.p;
+	Rw.blk_chrom = P.bc.p; Rw.blk_strand = P.bst.p;
+	c->reads[method].named = false;
+	return ingest_device(c, method, Rw, P.n_blocks);
+}
+
 int lsq_mrf_parse_device(lsq_ctx *c, const char *read_format, const char *path, lsq_reads **out) {
 	if (!c || !out) return fail(LSQ_E_ARG, "null argument");
 	HIP_TRY(hipSetDevice(c->device));

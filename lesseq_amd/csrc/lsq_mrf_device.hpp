@@ -199,16 +199,10 @@ struct MappedFile {
 	~MappedFile() { if (data) munmap((void *)data, len); }
 };
 
-// Parses the file on the device.  The events' strand dictionary grows by the strand strings the
-// file introduces (as it does under lsq_mrf_parse).
-static int device_parse_mrf(lsq_ctx *c, const char *read_format, const char *path, DevParsed &out, float *h2d_ms, float *parse_ms) {
-	if (!read_format || !path) return fail(LSQ_E_ARG, "null argument");
-	if (!c->E) return fail(LSQ_E_STATE, "lsq_events_upload must come first");
-	lsq_events &E = *c->E;
+static int stage_text_file(lsq_ctx *c, const char *path, lsq_text &T) {
 	HostStopwatch SW;
 	int fd = open(path, O_RDONLY);
 	if (fd < 0) return fail(LSQ_E_IO, "cannot open reads file %s", path);
-	if (strcmp(read_format, "MRF_SINGLE") != 0) { close(fd); return fail(LSQ_E_FORMAT, "Unknown file format error: %s", read_format); }
 	struct stat sb;
 	if (fstat(fd, &sb) != 0) { close(fd); return fail(LSQ_E_IO, "cannot stat %s", path); }
 	// Small files are mapped and copied as they are (the runtime stages pageable memory through its own
@@ -225,22 +219,11 @@ static int device_parse_mrf(lsq_ctx *c, const char *read_format, const char *pat
 	MappedFile mf;
 	hipStream_t st = c->stream;
 	int rc;
-	const unsigned long long zero_off = 0;
-	out.n_reads = out.n_blocks = 0;
-	auto empty_result = [&]() -> int {
-		int r2;
-		if ((r2 = out.blk_off.upload(&zero_off, 1, st)) || (r2 = out.line_no.alloc(0)) || (r2 = out.bs.alloc(0)) || (r2 = out.be.alloc(0)) ||
-		    (r2 = out.bc.alloc(0)) || (r2 = out.bst.alloc(0))) return r2;
-		HIP_TRY(hipStreamSynchronize(st));
-		return LSQ_OK;
-	};
-	if (h2d_ms) *h2d_ms = 0;
-	if (parse_ms) *parse_ms = 0;
-	if (len == 0) return empty_result();
-
-	DevBuf<unsigned char> d_text;
+	T.path = path; T.len = len; T.h2d_ms = 0;
+	if (len == 0) return LSQ_OK;
+	DevBuf<unsigned char> &d_text = T.d_text;
 	if ((rc = d_text.alloc(len + 16))) return rc;
-	HIP_TRY(hipEventRecord(c->ev0, st));
+	HIP_TRY(hipEventRecord(c->evt0, st));
 	{
 		unsigned char *pin[2] = {nullptr, nullptr};
 		hipEvent_t drained[2] = {nullptr, nullptr};
@@ -300,7 +283,37 @@ static int device_parse_mrf(lsq_ctx *c, const char *read_format, const char *pat
 		for (int q = 0; q < 2; ++q) { if (pin[q]) (void)hipHostFree(pin[q]); if (drained[q]) (void)hipEventDestroy(drained[q]); }
 		if (rc_copy) return rc_copy;
 	}
-	SW.mark("parse: open, map, text copy");
+	HIP_TRY(hipEventRecord(c->evt1, st));
+	HIP_TRY(hipEventSynchronize(c->evt1));
+	(void)hipEventElapsedTime(&T.h2d_ms, c->evt0, c->evt1);
+	SW.mark("text: open and copy to HBM");
+	return LSQ_OK;
+}
+
+// Parses staged text on the device.  The events' strand dictionary grows by the strand strings the
+// file introduces (as it does under lsq_mrf_parse).
+static int parse_staged_text(lsq_ctx *c, const char *read_format, lsq_text &T, DevParsed &out, float *h2d_ms, float *parse_ms) {
+	if (!read_format) return fail(LSQ_E_ARG, "null argument");
+	if (!c->E) return fail(LSQ_E_STATE, "lsq_events_upload must come first");
+	if (strcmp(read_format, "MRF_SINGLE") != 0) return fail(LSQ_E_FORMAT, "Unknown file format error: %s", read_format);
+	lsq_events &E = *c->E;
+	HostStopwatch SW;
+	hipStream_t st = c->stream;
+	int rc;
+	const unsigned long long len = T.len;
+	DevBuf<unsigned char> &d_text = T.d_text;
+	const unsigned long long zero_off = 0;
+	out.n_reads = out.n_blocks = 0;
+	auto empty_result = [&]() -> int {
+		int r2;
+		if ((r2 = out.blk_off.upload(&zero_off, 1, st)) || (r2 = out.line_no.alloc(0)) || (r2 = out.bs.alloc(0)) || (r2 = out.be.alloc(0)) ||
+		    (r2 = out.bc.alloc(0)) || (r2 = out.bst.alloc(0))) return r2;
+		HIP_TRY(hipStreamSynchronize(st));
+		return LSQ_OK;
+	};
+	if (h2d_ms) *h2d_ms = T.h2d_ms;
+	if (parse_ms) *parse_ms = 0;
+	if (len == 0) return empty_result();
 	HIP_TRY(hipEventRecord(c->ev1, st));
 	const unsigned long long n_tiles = (len + MRF_TILE - 1) / MRF_TILE;
 	if (n_tiles > 0x7FFFFFFFull) return fail(LSQ_E_RANGE, "reads file larger than 8 TiB");
@@ -344,11 +357,13 @@ static int device_parse_mrf(lsq_ctx *c, const char *read_format, const char *pat
 		HIP_TRY(hipMemcpy(ab, d_nl_pos.p + (err[0] - 1), 16, hipMemcpyDeviceToHost));
 		std::string text((size_t)(ab[1] - ab[0] - 1), '\0');
 		size_t got_all = 0;
-		while (got_all < text.size()) {
+		const int fd = open(T.path.c_str(), O_RDONLY);
+		while (fd >= 0 && got_all < text.size()) {
 			const ssize_t got = pread(fd, &text[got_all], text.size() - got_all, (off_t)(ab[0] + 1 + got_all));
 			if (got <= 0) break;
 			got_all += (size_t)got;
 		}
+		if (fd >= 0) close(fd);
 		return fail(LSQ_E_PARSE, "#%llu:%s", err[0], text.c_str());
 	}
 	// dictionaries
@@ -395,7 +410,6 @@ static int device_parse_mrf(lsq_ctx *c, const char *read_format, const char *pat
 	HIP_TRY(hipMemcpyAsync(h_strand.data(), d_strand.p, 256 * 8, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	SW.mark("parse: kernels");
-	if (h2d_ms) (void)hipEventElapsedTime(h2d_ms, c->ev0, c->ev1);
 	if (parse_ms) (void)hipEventElapsedTime(parse_ms, c->ev1, c->ev2);
 	if (err[1]) return fail(LSQ_E_UNSUPPORTED, "a strand string longer than 7 bytes: outside the device parser's range (lsq_mrf_parse handles it)");
 	if (err[2]) return fail(LSQ_E_RANGE, "more than 256 distinct strand strings");
@@ -408,4 +422,20 @@ static int device_parse_mrf(lsq_ctx *c, const char *read_format, const char *pat
 	}
 	out.n_reads = n_reads; out.n_blocks = n_blocks;
 	return LSQ_OK;
+}
+
+// open -> format literal -> copy -> parse: the order in which the reference meets a bad file or literal
+static int device_parse_mrf(lsq_ctx *c, const char *read_format, const char *path, DevParsed &out, float *h2d_ms, float *parse_ms) {
+	if (!read_format || !path) return fail(LSQ_E_ARG, "null argument");
+	if (!c->E) return fail(LSQ_E_STATE, "lsq_events_upload must come first");
+	{
+		FILE *f = fopen(path, "rb");
+		if (!f) return fail(LSQ_E_IO, "cannot open reads file %s", path);
+		fclose(f);
+	}
+	if (strcmp(read_format, "MRF_SINGLE") != 0) return fail(LSQ_E_FORMAT, "Unknown file format error: %s", read_format);
+	lsq_text T;
+	int rc = stage_text_file(c, path, T);
+	if (rc) return rc;
+	return parse_staged_text(c, read_format, T, out, h2d_ms, parse_ms);
 }
