@@ -178,6 +178,14 @@ typedef struct lsq_text lsq_text;
 int lsq_text_stage(lsq_ctx *c, const char *path, lsq_text **out);
 void lsq_text_free(lsq_text *t);
 int lsq_reads_upload_text(lsq_ctx *c, int method, const char *read_format, lsq_text *t);
+/* A slice of a file for one of several processes that share it (lesseq_amd/dist.py::run_read_sharded):
+ * the bytes [byte_begin, byte_end), which must start on a line boundary; lsq_text_lines counts its
+ * newlines (so that every process can work out the file-wide number of its first line: read names are
+ * "read-<line>", count/count.cpp:293-295); lsq_reads_upload_text_at parses it with has_header = 1 only
+ * for the slice that holds the file's first line, first_line = the number of its first data line. */
+int lsq_text_stage_range(lsq_ctx *c, const char *path, uint64_t byte_begin, uint64_t byte_end, lsq_text **out);
+int lsq_text_lines(lsq_ctx *c, lsq_text *t, uint64_t *n_newlines);
+int lsq_reads_upload_text_at(lsq_ctx *c, int method, const char *read_format, lsq_text *t, int has_header, uint64_t first_line);
 /* The device parser's blocks copied back to the host (same arrays lsq_mrf_parse makes; for tools
  * and tests).  Needs lsq_events_upload first. */
 int lsq_mrf_parse_device(lsq_ctx *c, const char *read_format, const char *path, lsq_reads **out);
@@ -207,6 +215,9 @@ int lsq_solve(lsq_ctx *c);
 int64_t lsq_results_num_classes(const lsq_ctx *c);
 int lsq_results_class_offsets(const lsq_ctx *c, uint64_t *class_off /* n_events+1 */);
 int lsq_results_counts(lsq_ctx *c, uint64_t *class_count, uint64_t *class_bases);
+/* The inverse: class counts and matched bases in that layout become the context's counts (e.g. the
+ * sums over several processes that each counted a slice of the reads); lsq_solve then runs on them. */
+int lsq_results_set_counts(lsq_ctx *c, const uint64_t *class_count, const uint64_t *class_bases);
 int lsq_results_solve(lsq_ctx *c, double *theta, double *logll, uint32_t *em_iters, uint8_t *em_flags);
 
 /* Copies the raw device-order results into caller-provided DEVICE buffers (e.g. tensors of a

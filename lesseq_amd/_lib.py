@@ -80,6 +80,10 @@ _sig("lsq_reads_arrays", C.c_int, vp, P(vp), P(vp), P(vp), P(vp), P(vp), P(vp))
 _sig("lsq_events_strand_name", cs, vp, C.c_int)
 _sig("lsq_reads_upload_mrf", C.c_int, vp, C.c_int, cs, cs)
 _sig("lsq_text_stage", C.c_int, vp, cs, P(vp))
+_sig("lsq_text_stage_range", C.c_int, vp, cs, u64, u64, P(vp))
+_sig("lsq_text_lines", C.c_int, vp, vp, P(u64))
+_sig("lsq_reads_upload_text_at", C.c_int, vp, C.c_int, cs, vp, C.c_int, u64)
+_sig("lsq_results_set_counts", C.c_int, vp, P(u64), P(u64))
 _sig("lsq_text_free", None, vp)
 _sig("lsq_reads_upload_text", C.c_int, vp, C.c_int, cs, vp)
 _sig("lsq_mrf_parse_device", C.c_int, vp, cs, cs, P(vp))

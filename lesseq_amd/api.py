@@ -273,6 +273,30 @@ class Context:
         check(lib.lsq_results_counts(self.h, _ptr(cnt, u64), _ptr(bases, u64)))
         return cnt[:M, :n], bases[:M, :n]
 
+    def set_counts(self, cnt, bases):
+        """the inverse of counts(): arrays of shape [n_methods, n_classes] become the context's counts"""
+        cnt = np.ascontiguousarray(cnt, np.uint64)
+        bases = np.ascontiguousarray(bases, np.uint64)
+        check(lib.lsq_results_set_counts(self.h, _ptr(cnt, u64), _ptr(bases, u64)))
+
+    def stage_text(self, path, byte_begin=0, byte_end=2 ** 64 - 1):
+        """bytes [byte_begin, byte_end) of an MRF file copied to HBM; returns an opaque handle"""
+        h = vp()
+        check(lib.lsq_text_stage_range(self.h, _b(path), byte_begin, byte_end, C.byref(h)))
+        return h
+
+    def text_lines(self, text):
+        n = u64()
+        check(lib.lsq_text_lines(self.h, text, C.byref(n)))
+        return n.value
+
+    def upload_reads_text(self, method, text, has_header=True, first_line=1, read_format="MRF_SINGLE", free=True):
+        try:
+            check(lib.lsq_reads_upload_text_at(self.h, method, _b(read_format), text, 1 if has_header else 0, first_line))
+        finally:
+            if free:
+                lib.lsq_text_free(text)
+
     def solution(self):
         """(theta[n_isoforms], logll[n_events], iters, flags), output order"""
         ne, ni = len(self.events), self.events.total_isoforms

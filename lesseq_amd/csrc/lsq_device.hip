@@ -221,6 +221,35 @@ int lsq_results_counts(lsq_ctx *c, uint64_t *class_count, uint64_t *class_bases)
 	return LSQ_OK;
 }
 
+// The inverse of lsq_results_counts: class counts and matched bases (output order, as that call returns
+// them) become the context's counts -- e.g. the sums over several processes that each counted a slice
+// of the reads (lesseq_amd/dist.py::run_read_sharded); lsq_solve then runs on them.
+int lsq_results_set_counts(lsq_ctx *c, const uint64_t *class_count, const uint64_t *class_bases) {
+	if (!c || !class_count || !class_bases) return fail(LSQ_E_ARG, "null argument");
+	if (!c->E) return fail(LSQ_E_STATE, "lsq_events_upload must come first");
+	HIP_TRY(hipSetDevice(c->device));
+	const lsq_events &E = *c->E;
+	const size_t n_cls = E.n_cls_total, n_out = (size_t)E.class_off.back(), M = (size_t)E.n_methods;
+	std::vector<unsigned long long> hc(std::max<size_t>(M * n_cls, 1), 0), hb(std::max<size_t>(M * n_cls, 1), 0);
+	for (size_t d = 0; d < E.dev2out.size(); ++d) {
+		const size_t o = (size_t)E.dev2out[d];
+		const size_t nc = (1u << E.ev[o].K) - 1u;
+		for (size_t m = 0; m < M; ++m)
+			for (size_t k = 0; k < nc; ++k) {
+				hc[m * n_cls + E.dev_cls_base[d] + k] = class_count[m * n_out + E.class_off[o] + k];
+				hb[m * n_cls + E.dev_cls_base[d] + k] = class_bases[m * n_out + E.class_off[o] + k];
+			}
+	}
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	if (M * n_cls) {
+		HIP_TRY(hipMemcpyAsync(c->cnt.p, hc.data(), M * n_cls * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(hipMemcpyAsync(c->bases.p, hb.data(), M * n_cls * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));
+	}
+	c->counted = true; c->solved = false; c->redo_checked = true;
+	return LSQ_OK;
+}
+
 int lsq_results_solve(lsq_ctx *c, double *theta, double *logll, uint32_t *em_iters, uint8_t *em_flags) {
 	if (!c || !theta || !logll) return fail(LSQ_E_ARG, "null argument");
 	if (!c->solved) return fail(LSQ_E_STATE, "lsq_solve must come first");

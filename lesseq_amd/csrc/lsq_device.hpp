@@ -115,9 +115,12 @@ struct lsq_ctx {
 // on a second thread while the first is still reading the annotation.
 struct lsq_text {
 	std::string path;
-	unsigned long long len = 0;
+	unsigned long long offset = 0, len = 0;        // the bytes [offset, offset + len) of the file
 	lsq::DevBuf<unsigned char> d_text;
 	float h2d_ms = 0;
+	bool scanned = false;                           // newline positions found (lsq_text_lines or the parse)
+	unsigned long long n_nl = 0;
+	lsq::DevBuf<unsigned long long> d_nl_pos;
 };
 
 namespace lsq {

@@ -454,24 +454,38 @@ int lsq_reads_upload_mrf(lsq_ctx *c, int method, const char *read_format, const 
 	return ingest_device(c, method, Rw, P.n_blocks);
 }
 
-int lsq_text_stage(lsq_ctx *c, const char *path, lsq_text **out) {
+int lsq_text_stage_range(lsq_ctx *c, const char *path, uint64_t byte_begin, uint64_t byte_end, lsq_text **out) {
 	if (!c || !path || !out) return fail(LSQ_E_ARG, "null argument");
 	HIP_TRY(hipSetDevice(c->device));
 	std::unique_ptr<lsq_text> T(new lsq_text);
-	int rc = stage_text_file(c, path, *T);
+	int rc = stage_text_file(c, path, byte_begin, byte_end, *T);
 	if (rc) return rc;
 	*out = T.release();
+	return LSQ_OK;
+}
+int lsq_text_stage(lsq_ctx *c, const char *path, lsq_text **out) { return lsq_text_stage_range(c, path, 0, ~0ull, out); }
+
+int lsq_text_lines(lsq_ctx *c, lsq_text *t, uint64_t *n_newlines) {
+	if (!c || !t || !n_newlines) return fail(LSQ_E_ARG, "null argument");
+	HIP_TRY(hipSetDevice(c->device));
+	int rc = scan_newlines(c, *t);
+	if (rc) return rc;
+	*n_newlines = t->n_nl;
 	return LSQ_OK;
 }
 void lsq_text_free(lsq_text *t) { delete t; }
 
 int lsq_reads_upload_text(lsq_ctx *c, int method, const char *read_format, lsq_text *t) {
+	return lsq_reads_upload_text_at(c, method, read_format, t, 1, 1);
+}
+
+int lsq_reads_upload_text_at(lsq_ctx *c, int method, const char *read_format, lsq_text *t, int has_header, uint64_t first_line) {
 	if (!c || !t) return fail(LSQ_E_ARG, "null argument");
 	if (!c->E) return fail(LSQ_E_STATE, "lsq_events_upload must come first");
 	if (method < 0 || method >= c->E->n_methods) return fail(LSQ_E_ARG, "method %d out of range", method);
 	HIP_TRY(hipSetDevice(c->device));
 	DevParsed P;
-	int rc = parse_staged_text(c, read_format, *t, P, &c->mrf_h2d_ms, &c->mrf_parse_ms);
+	int rc = parse_staged_text(c, read_format, *t, has_header ? 1u : 0u, first_line, P, &c->mrf_h2d_ms, &c->mrf_parse_ms);
 	if (rc) return rc;
 	IngestRaw Rw{};
 	Rw.n_reads = P.n_reads; Rw.blk_off = P.blk_off.p; Rw.line_no = P.line_no.p; Rw.blk_start = P.bs.p; Rw.blk_end = P.be.p;

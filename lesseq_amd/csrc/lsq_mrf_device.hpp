@@ -82,20 +82,24 @@ __global__ void __launch_bounds__(256) lsq_mrf_newline_pos_kernel(const unsigned
 	while (bits) { const unsigned j = (unsigned)__ffs((int)bits) - 1u; bits &= bits - 1u; nl_pos[w++] = at + j; }
 }
 
-__device__ inline lsq::MrfView mrf_data_line(const unsigned char *text, const unsigned long long *nl_pos, unsigned long long L) {
-	const unsigned long long a = nl_pos[L - 1] + 1, b = nl_pos[L];
+// data line i (0-based) of the text: with a header the bytes between newlines i and i+1, without one (a
+// slice of a file that starts on a line boundary) those between newlines i-1 and i
+__device__ inline lsq::MrfView mrf_data_line(const unsigned char *text, const unsigned long long *nl_pos, unsigned long long i, unsigned has_header) {
+	const unsigned long long e = i + has_header;
+	const unsigned long long a = e == 0 ? 0ull : nl_pos[e - 1] + 1, b = nl_pos[e];
 	return lsq::MrfView{reinterpret_cast<const char *>(text) + a, (size_t)(b - a)};
 }
 
 // pass 1: blocks per data line (0 for skipped lines), first failing line, per-workgroup sums
 __global__ void __launch_bounds__(256) lsq_mrf_count_kernel(const unsigned char *text, const unsigned long long *nl_pos, unsigned long long n_lines,
+                                                            unsigned has_header, unsigned long long first_line,
                                                             unsigned *line_nb, unsigned *wg_reads, unsigned *wg_blocks, unsigned long long *err) {
 	__shared__ unsigned lds4[4];
 	const unsigned long long i = (unsigned long long)blockIdx.x * 256ull + threadIdx.x;
 	unsigned nb = 0;
 	if (i < n_lines) {
-		const unsigned long long L = i + 1;
-		const lsq::MrfView line = mrf_data_line(text, nl_pos, L);
+		const unsigned long long L = first_line + i;          // the line's number in the whole file (read name "read-<L>")
+		const lsq::MrfView line = mrf_data_line(text, nl_pos, i, has_header);
 		if (!lsq::mrf_line_is_skipped(line)) {
 			const bool ok = lsq::mrf_split_line(line, [&](lsq::MrfView, lsq::MrfView, int64_t, int64_t) { ++nb; });
 			if (!ok) { atomicMin(&err[0], L); nb = 0; }
@@ -157,7 +161,7 @@ struct MrfOut {
 
 // pass 2: every read's blocks to their place
 __global__ void __launch_bounds__(256) lsq_mrf_write_kernel(const unsigned char *text, const unsigned long long *nl_pos, unsigned long long n_lines,
-                                                            const unsigned *line_nb, const unsigned long long *rd_base, const unsigned long long *bk_base,
+                                                            unsigned has_header, unsigned long long first_line, const unsigned *line_nb, const unsigned long long *rd_base, const unsigned long long *bk_base,
                                                             MrfDict D, MrfOut O, unsigned long long *err) {
 	__shared__ unsigned lds4[4];
 	const unsigned long long i = (unsigned long long)blockIdx.x * 256ull + threadIdx.x;
@@ -167,8 +171,8 @@ __global__ void __launch_bounds__(256) lsq_mrf_write_kernel(const unsigned char 
 	const unsigned long long o = bk_base[blockIdx.x] + mrf_block_excl_scan(nb, lds4, tb);
 	if (i + 1 == n_lines) O.blk_off[r + (nb ? 1u : 0u)] = o + nb;
 	if (!nb) return;
-	const unsigned long long L = i + 1;
-	const lsq::MrfView line = mrf_data_line(text, nl_pos, L);
+	const unsigned long long L = first_line + i;
+	const lsq::MrfView line = mrf_data_line(text, nl_pos, i, has_header);
 	O.blk_off[r] = o;
 	O.line_no[r] = (unsigned)L;
 	unsigned long long w = o;
@@ -199,7 +203,7 @@ struct MappedFile {
 	~MappedFile() { if (data) munmap((void *)data, len); }
 };
 
-static int stage_text_file(lsq_ctx *c, const char *path, lsq_text &T) {
+static int stage_text_file(lsq_ctx *c, const char *path, unsigned long long byte_begin, unsigned long long byte_end, lsq_text &T) {
 	HostStopwatch SW;
 	int fd = open(path, O_RDONLY);
 	if (fd < 0) return fail(LSQ_E_IO, "cannot open reads file %s", path);
@@ -210,7 +214,10 @@ static int stage_text_file(lsq_ctx *c, const char *path, lsq_text &T) {
 	// a few worker threads pread() them, a slice at a time, into two pinned 32 MiB buffers of ours while
 	// the DMA engine drains the other buffer (38 GB/s, and no page-table build-up and tear-down for
 	// gigabytes of mapping).
-	const unsigned long long len = (unsigned long long)sb.st_size;
+	const unsigned long long file_len = (unsigned long long)sb.st_size;
+	byte_end = std::min(byte_end, file_len);
+	byte_begin = std::min(byte_begin, byte_end);
+	const unsigned long long len = byte_end - byte_begin;          // the bytes [byte_begin, byte_end) of the file
 	const size_t SLICE = 32ull << 20;
 	unsigned long long pinned_min = 1ull << 30;           // below a gigabyte allocating the pinned buffers costs more than they save
 	if (const char *e = getenv("LSQ_PINNED_COPY_MIN")) { const long long v = atoll(e); if (v >= 0) pinned_min = (unsigned long long)v; }   // tests
@@ -219,7 +226,7 @@ static int stage_text_file(lsq_ctx *c, const char *path, lsq_text &T) {
 	MappedFile mf;
 	hipStream_t st = c->stream;
 	int rc;
-	T.path = path; T.len = len; T.h2d_ms = 0;
+	T.path = path; T.len = len; T.offset = byte_begin; T.h2d_ms = 0;
 	if (len == 0) return LSQ_OK;
 	DevBuf<unsigned char> &d_text = T.d_text;
 	if ((rc = d_text.alloc(len + 16))) return rc;
@@ -248,7 +255,7 @@ static int stage_text_file(lsq_ctx *c, const char *path, lsq_text &T) {
 					size_t a = nby * (size_t)t / (size_t)T;
 					const size_t b = nby * (size_t)(t + 1) / (size_t)T;
 					while (a < b) {
-						const ssize_t got = pread(fd, pin[sl & 1] + a, b - a, (off_t)(off + a));
+						const ssize_t got = pread(fd, pin[sl & 1] + a, b - a, (off_t)(byte_begin + off + a));
 						if (got <= 0) { io_error.store(1); break; }
 						a += (size_t)got;
 					}
@@ -268,14 +275,14 @@ static int stage_text_file(lsq_ctx *c, const char *path, lsq_text &T) {
 			if (hipStreamSynchronize(st) != hipSuccess && rc_copy == LSQ_OK) rc_copy = fail(LSQ_E_DEVICE, "text copy failed");
 			if (io_error.load() && rc_copy == LSQ_OK) rc_copy = fail(LSQ_E_IO, "cannot read %s", path);
 		} else {
-			void *m = mmap(nullptr, (size_t)len, PROT_READ, MAP_PRIVATE, fd, 0);
+			void *m = mmap(nullptr, (size_t)file_len, PROT_READ, MAP_PRIVATE, fd, 0);
 			if (m == MAP_FAILED) rc_copy = fail(LSQ_E_IO, "cannot map %s", path);
 			else {
-				mf.data = (const char *)m; mf.len = (size_t)len;
+				mf.data = (const char *)m; mf.len = (size_t)file_len;
 				madvise(m, mf.len, MADV_SEQUENTIAL);
 				for (size_t off = 0; off < len && rc_copy == LSQ_OK; off += SLICE) {
 					const size_t nby = std::min<size_t>(SLICE, len - off);
-					if (hipMemcpyAsync(d_text.p + off, mf.data + off, nby, hipMemcpyHostToDevice, st) != hipSuccess) rc_copy = fail(LSQ_E_DEVICE, "hipMemcpyAsync failed in the text copy");
+					if (hipMemcpyAsync(d_text.p + off, mf.data + byte_begin + off, nby, hipMemcpyHostToDevice, st) != hipSuccess) rc_copy = fail(LSQ_E_DEVICE, "hipMemcpyAsync failed in the text copy");
 				}
 				if (hipStreamSynchronize(st) != hipSuccess && rc_copy == LSQ_OK) rc_copy = fail(LSQ_E_DEVICE, "text copy failed");
 			}
@@ -292,7 +299,37 @@ static int stage_text_file(lsq_ctx *c, const char *path, lsq_text &T) {
 
 // Parses staged text on the device.  The events' strand dictionary grows by the strand strings the
 // file introduces (as it does under lsq_mrf_parse).
-static int parse_staged_text(lsq_ctx *c, const char *read_format, lsq_text &T, DevParsed &out, float *h2d_ms, float *parse_ms) {
+// newline positions of a staged text (kept with it): lsq_text_lines runs this ahead of the parse
+static int scan_newlines(lsq_ctx *c, lsq_text &T) {
+	if (T.scanned) return LSQ_OK;
+	hipStream_t st = c->stream;
+	int rc;
+	const unsigned long long len = T.len;
+	T.n_nl = 0;
+	if (len) {
+		const unsigned long long n_tiles = (len + MRF_TILE - 1) / MRF_TILE;
+		if (n_tiles > 0x7FFFFFFFull) return fail(LSQ_E_RANGE, "reads file larger than 8 TiB");
+		DevBuf<unsigned> d_tile_cnt;
+		DevBuf<unsigned long long> d_tile_base;
+		if ((rc = d_tile_cnt.alloc(n_tiles)) || (rc = d_tile_base.alloc(n_tiles + 1))) return rc;
+		hipLaunchKernelGGL(lsq_mrf_newline_count_kernel, dim3((unsigned)n_tiles), dim3(256), 0, st, T.d_text.p, len, d_tile_cnt.p);
+		HIP_TRY(hipGetLastError());
+		hipLaunchKernelGGL(lsq_scan_u32_kernel, dim3(1), dim3(1024), 0, st, d_tile_cnt.p, n_tiles, d_tile_base.p);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipMemcpyAsync(&T.n_nl, d_tile_base.p + n_tiles, 8, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
+		if ((rc = T.d_nl_pos.alloc(T.n_nl))) return rc;
+		if (T.n_nl) {
+			hipLaunchKernelGGL(lsq_mrf_newline_pos_kernel, dim3((unsigned)n_tiles), dim3(256), 0, st, T.d_text.p, len, d_tile_base.p, T.d_nl_pos.p);
+			HIP_TRY(hipGetLastError());
+			HIP_TRY(hipStreamSynchronize(st));
+		}
+	}
+	T.scanned = true;
+	return LSQ_OK;
+}
+
+static int parse_staged_text(lsq_ctx *c, const char *read_format, lsq_text &T, unsigned has_header, unsigned long long first_line, DevParsed &out, float *h2d_ms, float *parse_ms) {
 	if (!read_format) return fail(LSQ_E_ARG, "null argument");
 	if (!c->E) return fail(LSQ_E_STATE, "lsq_events_upload must come first");
 	if (strcmp(read_format, "MRF_SINGLE") != 0) return fail(LSQ_E_FORMAT, "Unknown file format error: %s", read_format);
@@ -315,25 +352,12 @@ static int parse_staged_text(lsq_ctx *c, const char *read_format, lsq_text &T, D
 	if (parse_ms) *parse_ms = 0;
 	if (len == 0) return empty_result();
 	HIP_TRY(hipEventRecord(c->ev1, st));
-	const unsigned long long n_tiles = (len + MRF_TILE - 1) / MRF_TILE;
-	if (n_tiles > 0x7FFFFFFFull) return fail(LSQ_E_RANGE, "reads file larger than 8 TiB");
-	DevBuf<unsigned> d_tile_cnt;
-	DevBuf<unsigned long long> d_tile_base;
-	if ((rc = d_tile_cnt.alloc(n_tiles)) || (rc = d_tile_base.alloc(n_tiles + 1))) return rc;
-	hipLaunchKernelGGL(lsq_mrf_newline_count_kernel, dim3((unsigned)n_tiles), dim3(256), 0, st, d_text.p, len, d_tile_cnt.p);
-	HIP_TRY(hipGetLastError());
-	hipLaunchKernelGGL(lsq_scan_u32_kernel, dim3(1), dim3(1024), 0, st, d_tile_cnt.p, n_tiles, d_tile_base.p);
-	HIP_TRY(hipGetLastError());
-	unsigned long long n_nl = 0;
-	HIP_TRY(hipMemcpyAsync(&n_nl, d_tile_base.p + n_tiles, 8, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipStreamSynchronize(st));
-	if (n_nl < 2) return empty_result();               // header only (or no terminated line at all)
-	const unsigned long long n_lines = n_nl - 1;
-	if (n_lines > 0xFFFFFFFFull) return fail(LSQ_E_RANGE, "more than 2^32 lines");
-	DevBuf<unsigned long long> d_nl_pos;
-	if ((rc = d_nl_pos.alloc(n_nl))) return rc;
-	hipLaunchKernelGGL(lsq_mrf_newline_pos_kernel, dim3((unsigned)n_tiles), dim3(256), 0, st, d_text.p, len, d_tile_base.p, d_nl_pos.p);
-	HIP_TRY(hipGetLastError());
+	if ((rc = scan_newlines(c, T))) return rc;
+	const unsigned long long n_nl = T.n_nl;
+	if (n_nl < 1 + has_header) return empty_result();   // header only (or no terminated line at all)
+	const unsigned long long n_lines = n_nl - has_header;
+	if (first_line + n_lines > 0xFFFFFFFFull) return fail(LSQ_E_RANGE, "more than 2^32 lines");
+	DevBuf<unsigned long long> &d_nl_pos = T.d_nl_pos;
 	const unsigned long long n_wg = (n_lines + 255) / 256;
 	DevBuf<unsigned> d_line_nb, d_wg_reads, d_wg_blocks;
 	DevBuf<unsigned long long> d_rd_base, d_bk_base, d_err;
@@ -341,7 +365,7 @@ static int parse_staged_text(lsq_ctx *c, const char *read_format, lsq_text &T, D
 	    (rc = d_rd_base.alloc(n_wg + 1)) || (rc = d_bk_base.alloc(n_wg + 1)) || (rc = d_err.alloc(4))) return rc;
 	unsigned long long err[4] = {MRF_NO_ERR, 0, 0, 0};
 	HIP_TRY(hipMemcpyAsync(d_err.p, err, sizeof(err), hipMemcpyHostToDevice, st));
-	hipLaunchKernelGGL(lsq_mrf_count_kernel, dim3((unsigned)n_wg), dim3(256), 0, st, d_text.p, d_nl_pos.p, n_lines,
+	hipLaunchKernelGGL(lsq_mrf_count_kernel, dim3((unsigned)n_wg), dim3(256), 0, st, d_text.p, d_nl_pos.p, n_lines, has_header, first_line,
 	                   d_line_nb.p, d_wg_reads.p, d_wg_blocks.p, d_err.p);
 	HIP_TRY(hipGetLastError());
 	hipLaunchKernelGGL(lsq_scan_u32_kernel, dim3(1), dim3(1024), 0, st, d_wg_reads.p, n_wg, d_rd_base.p);
@@ -353,13 +377,15 @@ static int parse_staged_text(lsq_ctx *c, const char *read_format, lsq_text &T, D
 	HIP_TRY(hipMemcpyAsync(&n_blocks, d_bk_base.p + n_wg, 8, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	if (err[0] != MRF_NO_ERR) {
-		unsigned long long ab[2];
-		HIP_TRY(hipMemcpy(ab, d_nl_pos.p + (err[0] - 1), 16, hipMemcpyDeviceToHost));
+		const unsigned long long ei = err[0] - first_line + has_header;      // newline that ends the failing line
+		unsigned long long ab[2] = {~0ull, 0};                                  // ab[0] + 1 = first byte of the line
+		if (ei > 0) HIP_TRY(hipMemcpy(&ab[0], d_nl_pos.p + (ei - 1), 8, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(&ab[1], d_nl_pos.p + ei, 8, hipMemcpyDeviceToHost));
 		std::string text((size_t)(ab[1] - ab[0] - 1), '\0');
 		size_t got_all = 0;
 		const int fd = open(T.path.c_str(), O_RDONLY);
 		while (fd >= 0 && got_all < text.size()) {
-			const ssize_t got = pread(fd, &text[got_all], text.size() - got_all, (off_t)(ab[0] + 1 + got_all));
+			const ssize_t got = pread(fd, &text[got_all], text.size() - got_all, (off_t)(T.offset + ab[0] + 1 + got_all));
 			if (got <= 0) break;
 			got_all += (size_t)got;
 		}
@@ -402,7 +428,7 @@ static int parse_staged_text(lsq_ctx *c, const char *read_format, lsq_text &T, D
 	D.chrom_hash = d_hash.p; D.chrom_id = d_id.p; D.name_off = d_off.p; D.names = d_names.p; D.mask = (unsigned)(tab - 1); D.strand_tab = d_strand.p;
 	MrfOut O{};
 	O.blk_off = out.blk_off.p; O.line_no = out.line_no.p; O.blk_start = out.bs.p; O.blk_end = out.be.p; O.blk_chrom = out.bc.p; O.blk_strand = out.bst.p;
-	hipLaunchKernelGGL(lsq_mrf_write_kernel, dim3((unsigned)n_wg), dim3(256), 0, st, d_text.p, d_nl_pos.p, n_lines, d_line_nb.p,
+	hipLaunchKernelGGL(lsq_mrf_write_kernel, dim3((unsigned)n_wg), dim3(256), 0, st, d_text.p, d_nl_pos.p, n_lines, has_header, first_line, d_line_nb.p,
 	                   d_rd_base.p, d_bk_base.p, D, O, d_err.p);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(c->ev2, st));
@@ -435,7 +461,7 @@ static int device_parse_mrf(lsq_ctx *c, const char *read_format, const char *pat
 	}
 	if (strcmp(read_format, "MRF_SINGLE") != 0) return fail(LSQ_E_FORMAT, "Unknown file format error: %s", read_format);
 	lsq_text T;
-	int rc = stage_text_file(c, path, T);
+	int rc = stage_text_file(c, path, 0, ~0ull, T);
 	if (rc) return rc;
-	return parse_staged_text(c, read_format, T, out, h2d_ms, parse_ms);
+	return parse_staged_text(c, read_format, T, 1u, 1ull, out, h2d_ms, parse_ms);
 }

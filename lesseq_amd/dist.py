@@ -1,4 +1,5 @@
-"""Multi-GPU driver for the count + solve path: one process per GPU, events sharded by index.
+"""Multi-GPU drivers for the count + solve path: one process per GPU.  run_sharded shards the events by
+index (below); run_read_sharded, at the end of the file, shards the reads of one job.
 
 Events are independent (the reference already scales out by running disjoint
 gene_begin_idx..gene_end_idx slices, count/count.cpp:204-215).  Here every rank loads the whole
@@ -85,3 +86,77 @@ def run_sharded(tool, argv, rank, world, device_index=0, group=None, comm_device
     if tool == "count":
         return api.format_count(ev, parts[0])
     return api.format_solve(ev, parts[0], parts[1], parts[2], parts[3], a["total_read_bases"])
+
+
+# ----------------------------------------------------------------------------------------------
+# Read-sharded run of ONE job: every rank takes a slice of every MRF file against all events.
+# The class histograms of the slices add up (integer sums, exact), so one all-reduce of the counts
+# and matched bases gives every rank the whole job's counts; the EM then runs on them.  Unlike the
+# event-sharded run each rank parses and filters only its share of the text.  Read names are
+# "read-<line number>" (count/count.cpp:293-295) and decide span-start ties, so every rank needs the
+# file-wide number of its first line: the newline counts of the slices are exchanged first.
+
+def slice_bounds(path, world, window=1 << 16):
+    """byte cuts [b_0 = 0, ..., b_world = size]: the nominal cut size*r/world moved forward to the
+    start of the next line (every rank computes the same cuts from the file alone)"""
+    import os
+    size = os.path.getsize(path)
+    cuts = [0]
+    with open(path, "rb") as f:
+        for r in range(1, world):
+            pos = max(size * r // world, cuts[-1])
+            cut = size
+            f.seek(pos)
+            while pos < size:
+                buf = f.read(window)
+                if not buf:
+                    break
+                k = buf.find(b"\n")
+                if k >= 0:
+                    cut = pos + k + 1
+                    break
+                pos += len(buf)
+            cuts.append(min(cut, size))
+    cuts.append(size)
+    return cuts
+
+
+def run_read_sharded(tool, argv, rank, world, device_index=0, group=None, comm_device=None):
+    """count / solve of one job over `world` ranks, reads sharded.  Returns the table text (the same
+    on every rank, byte-identical to the single-process run)."""
+    import torch
+    import torch.distributed as dist
+    a = parse_cli(tool, argv)
+    ann = api.Annotation(a["isoforms"], a["g2i"], a["begin"], a["end"])
+    ev = api.Events(ann, a["read_types"], a["read_lengths"])
+    ctx = api.Context(device_index)
+    ctx.upload_events(ev)
+    texts = []
+    for path in a["read_paths"]:
+        cuts = slice_bounds(path, world)
+        texts.append(ctx.stage_text(path, cuts[rank], cuts[rank + 1]))
+    # file-wide line numbers: a data line's number is the count of newlines before it
+    mine = torch.tensor([ctx.text_lines(t) for t in texts], dtype=torch.int64)
+    if comm_device is not None:
+        mine = mine.to(comm_device)
+    if world > 1:
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine, group=group)
+    else:
+        every = [mine]
+    for m, t in enumerate(texts):
+        before = sum(int(every[r][m].item()) for r in range(rank))
+        ctx.upload_reads_text(m, t, has_header=(rank == 0), first_line=(1 if rank == 0 else before))
+    ctx.count()
+    cnt, bases = ctx.counts()
+    if world > 1:
+        cnt, bases = combine([cnt, bases], group, comm_device)
+        ctx.set_counts(cnt, bases)
+    if tool == "count":
+        text = api.format_count(ev, cnt)
+    else:
+        ctx.solve()
+        theta, ll, iters, flags = ctx.solution()
+        text = api.format_solve(ev, cnt, bases, theta, ll, a["total_read_bases"])
+    ctx.close()
+    return text

@@ -122,3 +122,56 @@ def test_two_ranks_sharded_run_equals_single_process(tmp_path):
     for rank, c, s in res:
         assert c == single_count
         assert s == single_solve
+
+
+def test_slice_bounds_cut_on_line_starts(tmp_path):
+    p = tmp_path / "t.mrf"
+    body = b"AlignmentBlocks\n" + b"".join(b"chr1:+:%d:%d:1:50\n" % (i * 7 + 1, i * 7 + 50) for i in range(5000)) + b"tail without newline"
+    p.write_bytes(body)
+    for world in (1, 2, 3, 8, 64):
+        cuts = ld.slice_bounds(str(p), world)
+        assert len(cuts) == world + 1 and cuts[0] == 0 and cuts[-1] == len(body)
+        assert cuts == sorted(cuts)
+        assert all(c == len(body) or body[c - 1:c] == b"\n" for c in cuts[1:-1])
+    tiny = tmp_path / "tiny.mrf"
+    tiny.write_bytes(b"x\n")
+    assert ld.slice_bounds(str(tiny), 4) == [0, 2, 2, 2, 2]
+
+
+def _gpu_read_worker(rank, world, port, argv_count, argv_solve, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        c = ld.run_read_sharded("count", argv_count, rank, world, device_index=0)
+        s = ld.run_read_sharded("solve", argv_solve, rank, world, device_index=0)
+        q.put((rank, c, s))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_three_ranks_read_sharded_run_equals_single_process(tmp_path):
+    """three ranks each parse a third of the MRF text (file-wide line numbers from the exchanged newline
+    counts: the adversarial reads of the generator include span-start ties decided by the read name),
+    count it against all events, and all-reduce the class histograms: byte-identical tables"""
+    spec = L.SynthSpec(37, 300, 90000, 100, 3, L.EVENT_TYPES)
+    L.synth_write(spec, str(tmp_path), "d")
+    base = ["0", "d", "./", "LH_GENE_TXT", str(tmp_path / "d.interval"), "UCSC_GENE2ISOFORM", str(tmp_path / "d.map"),
+            "0", "100000000", "MRF_SINGLE", "SHORT_READ", "100", str(tmp_path / "d.mrf")]
+    rc, single_count = L.cli_run("count", base)
+    rc2, single_solve = L.cli_run("solve", base + ["9000000"])
+    assert rc == rc2 == 0
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_gpu_read_worker, args=(r, 3, port, base, base + ["9000000"], q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, c, s in res:
+        assert c == single_count
+        assert s == single_solve
