@@ -160,3 +160,38 @@ def run_read_sharded(tool, argv, rank, world, device_index=0, group=None, comm_d
         text = api.format_solve(ev, cnt, bases, theta, ll, a["total_read_bases"])
     ctx.close()
     return text
+
+
+def main(args=None):
+    """python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 -m lesseq_amd.dist
+           [--shard reads|events] count|solve <the reference's argv>
+    One process per GPU (LOCAL_RANK picks it), RCCL for the exchange; rank 0 prints the table."""
+    import argparse
+    import os
+    import sys
+    import torch
+    import torch.distributed as dist
+    ap = argparse.ArgumentParser(prog="lesseq_amd.dist")
+    ap.add_argument("--shard", choices=("reads", "events"), default="reads")
+    ap.add_argument("tool", choices=("count", "solve"))
+    ap.add_argument("argv", nargs=argparse.REMAINDER)
+    a = ap.parse_args(args)
+    rank, world, local = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    argv = a.argv                     # the reference's arguments, without the program name
+    dev = None
+    if world > 1:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        dist.init_process_group("nccl", device_id=dev)
+    try:
+        run = run_read_sharded if a.shard == "reads" else run_sharded
+        text = run(a.tool, argv, rank, world, device_index=local, comm_device=dev)
+        if rank == 0:
+            sys.stdout.write(text)
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
