@@ -367,6 +367,9 @@ __device__ inline bool fast_trip(const FastCtx &C, const int4 v, const int total
 // Each wave streams its own part of the workgroup's range straight from HBM into registers
 // (next words in flight while the current ones are processed) and owns its parking area: no
 // workgroup barrier inside the stream, a slow wave never holds up the others.
+#ifndef LSQ_STREAM_WORDS_P2
+#define LSQ_STREAM_WORDS_P2 2
+#endif
 #ifndef LSQ_STREAM_WORDS
 #define LSQ_STREAM_WORDS 2
 #endif
@@ -433,7 +436,13 @@ __device__ inline void walk_parked(const FastCtx &C, Ring<NB> &R, const bool to_
 			const unsigned first = reinterpret_cast<const unsigned *>(C.bins)[4u * bin] >> 16;
 			if (i == PARK_EVENT_UNKNOWN) { i = first; e0.z = first; }
 		}
-		else { rd = make_int4((int)e0.x, (int)e0.y, (int)e0.z, (int)e0.w); i = e1.x; rel = e1.y; }
+		else {
+			rd = make_int4((int)e0.x, (int)e0.y, (int)e0.z, (int)e0.w); i = e1.x; rel = e1.y;
+			const int brel = rd.x - C.lo;
+			const unsigned bin = brel <= 0 ? 0u : min((unsigned)brel >> C.shift, C.n_bins - 1u);
+			const unsigned first = reinterpret_cast<const unsigned *>(C.bins)[4u * bin] >> 16;
+			if (i == PARK_EVENT_UNKNOWN) { i = first; e1.x = first; }
+		}
 		const int total = NB == 1 ? rd.y - rd.x : (rd.y - rd.x) + (rd.w - rd.z);
 		const bool more = fast_trip<NB>(C, rd, total, rel, i, on) && !one_event && !(C.ablate & 64u);
 		wave_sync_lds();
@@ -449,7 +458,9 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
                                         const CountArgs &A, uint4 *queue, const uint4 *src_generic,
                                         const unsigned long long g0, const unsigned long long g1) {
 	constexpr int NB = RPW == 2 ? 1 : 2;
-	constexpr unsigned TILE = 64u * STREAM_WORDS;        // words per wave step
+	// words per lane in flight, and looked up together: two-block reads take the whole step as one group
+	constexpr int SW = RPW == 2 ? STREAM_WORDS : LSQ_STREAM_WORDS_P2, GW = RPW == 2 ? GROUP_WORDS : SW;
+	constexpr unsigned TILE = 64u * SW;        // words per wave step
 	C.pool = RPW == 2 ? 0u : 1u;
 	C.slot0 = g0;
 	global_words src = (global_words)src_generic;       // kernel-argument memory: global address space
@@ -462,11 +473,11 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 	const unsigned ww0 = min(wave * TILE, n_words), ww1 = n_words;                   // relative to w0
 	const unsigned first_rel = (unsigned)(g0 - w0 * RPW);                            // 0 or 1: reads of word w0 before the range
 	const unsigned n_rel = (unsigned)(g1 - g0);
-	uint4 nxt[STREAM_WORDS];
-	auto fetch_into = [&](uint4 (&dst)[STREAM_WORDS], unsigned wt) {
+	uint4 nxt[SW];
+	auto fetch_into = [&](uint4 (&dst)[SW], unsigned wt) {
 #pragma unroll
-		for (int k = 0; k < STREAM_WORDS; ++k) {
-			const unsigned w = wt + lane * (unsigned)STREAM_WORDS + (unsigned)k;      // a lane's words are neighbours in the pool
+		for (int k = 0; k < SW; ++k) {
+			const unsigned w = wt + lane * (unsigned)SW + (unsigned)k;      // a lane's words are neighbours in the pool
 			u32x4 t = {0u, 0u, 0u, 0u};
 			if (w < ww1) t = src[w0 + w];
 			dst[k] = make_uint4(t.x, t.y, t.z, t.w);
@@ -485,25 +496,25 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 	R.q = queue;
 	if (ww0 < ww1) fetch(ww0);
 	for (unsigned wt = ww0; wt < ww1; wt += WAVES * TILE) {
-		uint4 cur[STREAM_WORDS];
+		uint4 cur[SW];
 #pragma unroll
-		for (int k = 0; k < STREAM_WORDS; ++k) cur[k] = nxt[k];
+		for (int k = 0; k < SW; ++k) cur[k] = nxt[k];
 		if (wt + WAVES * TILE < ww1) fetch(wt + WAVES * TILE);
 #pragma unroll
-		for (int k0 = 0; k0 < STREAM_WORDS; k0 += GROUP_WORDS) {
+		for (int k0 = 0; k0 < SW; k0 += GW) {
 		if (A.ablate & 512u) {      // developer switch: stream only
 #pragma unroll
-			for (int kg = 0; kg < GROUP_WORDS; ++kg) asm volatile("" ::"v"(cur[k0 + kg].x), "v"(cur[k0 + kg].y), "v"(cur[k0 + kg].z), "v"(cur[k0 + kg].w));
+			for (int kg = 0; kg < GW; ++kg) asm volatile("" ::"v"(cur[k0 + kg].x), "v"(cur[k0 + kg].y), "v"(cur[k0 + kg].z), "v"(cur[k0 + kg].w));
 			continue;
 		}
 		// the reads of a group are looked up first (independent chains), parking comes after
-		constexpr int N_READS = GROUP_WORDS * RPW;
+		constexpr int N_READS = GW * RPW;
 		bool park[N_READS];
 		uint4 pe0[N_READS], pe1[N_READS];
 #pragma unroll
-		for (int kg = 0; kg < GROUP_WORDS; ++kg) {
+		for (int kg = 0; kg < GW; ++kg) {
 			const int k = k0 + kg;
-			const unsigned w = wt + lane * (unsigned)STREAM_WORDS + (unsigned)k;           // word, relative to w0
+			const unsigned w = wt + lane * (unsigned)SW + (unsigned)k;           // word, relative to w0
 			if (RPW == 2) {
 				// One look at the tables per lane and group: the lane's reads are neighbours in the
 				// start-ordered pool, so the cell of the first one is the cell of (nearly) all of
@@ -527,7 +538,7 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 						for (int j = 0; j < N_READS; ++j) {
 							const int kk = k0 + j / 2;
 							const int ra = (j & 1) ? (int)cur[kk].z : (int)cur[kk].x, rb = (j & 1) ? (int)cur[kk].w : (int)cur[kk].y;
-							const unsigned wj = wt + lane * (unsigned)STREAM_WORDS + (unsigned)kk;
+							const unsigned wj = wt + lane * (unsigned)SW + (unsigned)kk;
 							const unsigned rel = wj * 2u + (unsigned)(j & 1) - first_rel;      // position in the range (wraps above n_rel when outside)
 							const bool in = decltype(whole_step)::value || (wj < ww1 && rel < n_rel);
 							const bool m = in && (unsigned)(ra - lo) < width;
@@ -551,34 +562,57 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 						if (nX && sb != CELL_NONE) atomicAdd(&C.hist[sb], ((unsigned long long)nX << 40) | sX);
 					} else asm volatile("" ::"v"(nA), "v"(sA), "v"(nX), "v"(sX));
 				}
-			} else {
-				const uint4 u = cur[k];
+			} else if (kg == 0) {
+				// Two-block reads, a lane's two neighbours at a time.  The ingest groups the reads of a bin
+				// by their junction (end of block 1, start of block 2), so the second read almost always
+				// crosses the junction of the first: the first is looked up in full -- block 1 must run to the
+				// end of one segment, block 2 start on the first base of a later segment of the same event
+				// and end inside it -- and the second only has to lie inside the same two cells.  The lane
+				// adds its one or two reads with one LDS atomic; a second read with another junction is parked.
+				const uint4 u = cur[k0];
 				const int4 rd = make_int4((int)u.x, (int)u.y, (int)u.z, (int)u.w);
-				const unsigned rel = w - first_rel;
-				const bool in = w < ww1 && rel < n_rel;
+				const unsigned w0i = wt + lane * (unsigned)SW + (unsigned)k0;
+				const unsigned rel = w0i - first_rel;
+				const bool in = w0i < ww1 && rel < n_rel;
 				unsigned c1, c2, evf, evf2;
 				locate(rd.x, c1, evf);
 				locate(rd.z, c2, evf2);
-				// the usual junction read: block 1 runs to the end of one segment, block 2 starts on the
-				// first base of a later segment of the same event and ends inside it
 				const uint4 cw1 = cells[min(c1, n_cells - 1u)], cw2 = cells[min(c2, n_cells - 1u)];
 				const unsigned i1 = cell_info[min(c1, n_cells - 1u)], i2 = cell_info[min(c2, n_cells - 1u)];
-				const bool hit = in && c1 < n_cells && c2 < n_cells && i1 != CELL_INFO_SHARED && i2 != CELL_INFO_SHARED &&
-				                 (int)cw1.x <= rd.x && rd.y == (int)cw1.y && (i1 & 2u) &&          // block 1 ends on its segment's end
-				                 rd.z == (int)cw2.x && (i2 & 1u) && rd.w <= (int)cw2.y &&          // block 2 starts on its segment's start
-				                 (i1 >> 8) == (i2 >> 8) && ((i2 >> 2) & 0x3Fu) > ((i1 >> 2) & 0x3Fu) && !(A.ablate & 8u);
-				if (!(A.ablate & 1u)) {
-					const unsigned ev = hit ? i1 >> 8 : 0u;
-					const uint4 w0r = C.recs[3u * ev];
-					const unsigned long long tbl = ((unsigned long long)w0r.w << 32) | w0r.z;
-					const unsigned mask = (1u << ((i1 >> 2) & 0x3u)) | (1u << ((i2 >> 2) & 0x3u));
-					const unsigned cls = (unsigned)(tbl >> (4u * mask)) & 0xFu;
-					if (hit && cls != 0) atomicAdd(&C.hist[(w0r.y & 0xFFFFu) + cls - 1u], (1ull << 40) | (unsigned long long)(unsigned)((rd.y - rd.x) + (rd.w - rd.z)));
-				}
-				park[kg] = in && !hit && !(A.ablate & 17u);
-				pe0[kg] = u;
+				const bool junction = c1 < n_cells && c2 < n_cells && i1 != CELL_INFO_SHARED && i2 != CELL_INFO_SHARED &&
+				                      rd.y == (int)cw1.y && (i1 & 2u) &&          // block 1 ends on its segment's end
+				                      rd.z == (int)cw2.x && (i2 & 1u) &&          // block 2 starts on its segment's start
+				                      (i1 >> 8) == (i2 >> 8) && ((i2 >> 2) & 0x3Fu) > ((i1 >> 2) & 0x3Fu) && !(A.ablate & 8u);
+				const bool hit = in && junction && (int)cw1.x <= rd.x && rd.w <= (int)cw2.y;
+				const unsigned ev = junction ? i1 >> 8 : 0u;
+				const uint4 w0r = C.recs[3u * ev];
+				const unsigned long long tbl = ((unsigned long long)w0r.w << 32) | w0r.z;
+				const unsigned mask = (1u << ((i1 >> 2) & 0x3u)) | (1u << ((i2 >> 2) & 0x3u));
+				const unsigned cls = (unsigned)(tbl >> (4u * mask)) & 0xFu;
+				unsigned n_add = hit ? 1u : 0u, s_add = hit ? (unsigned)((rd.y - rd.x) + (rd.w - rd.z)) : 0u;
+				park[0] = in && !hit && !(A.ablate & 17u);
+				pe0[0] = u;
 				const bool owned1 = c1 < n_cells && i1 != CELL_INFO_SHARED && (int)cw1.x <= rd.x && rd.x < (int)cw1.y;
-				pe1[kg] = make_uint4(owned1 ? ((i1 >> 8) | PARK_ONE_EVENT) : evf, rel, 0u, 0u);
+				pe1[0] = make_uint4(owned1 ? ((i1 >> 8) | PARK_ONE_EVENT) : evf, rel, 0u, 0u);
+#pragma unroll
+				for (int j = 1; j < N_READS; ++j) {
+					const uint4 v = cur[k0 + j];
+					const int4 r2 = make_int4((int)v.x, (int)v.y, (int)v.z, (int)v.w);
+					const unsigned wj = wt + lane * (unsigned)SW + (unsigned)(k0 + j);
+					const unsigned rel2 = wj - first_rel;
+					const bool in2 = wj < ww1 && rel2 < n_rel;
+					// same junction: block 1 ends and block 2 starts where the first read's do; then only the outer ends matter
+					const bool same = in2 && junction && r2.y == rd.y && r2.z == rd.z;
+					const bool hit2 = same && (int)cw1.x <= r2.x && r2.x < r2.y && r2.w <= (int)cw2.y;
+					n_add += hit2 ? 1u : 0u;
+					s_add += hit2 ? (unsigned)((r2.y - r2.x) + (r2.w - r2.z)) : 0u;
+					park[j] = in2 && !hit2 && !(A.ablate & 17u);
+					pe0[j] = v;
+					// a read of the same junction that starts left of the cell, or overshoots: same owner, one look; anything else scans
+					pe1[j] = make_uint4(same && (int)cw1.x <= r2.x && r2.x < (int)cw1.y ? ((i1 >> 8) | PARK_ONE_EVENT) : PARK_EVENT_UNKNOWN, rel2, 0u, 0u);
+				}
+				if (!(A.ablate & 1u)) { if (n_add && cls != 0) atomicAdd(&C.hist[(w0r.y & 0xFFFFu) + cls - 1u], ((unsigned long long)n_add << 40) | s_add); }
+				else asm volatile("" ::"v"(n_add), "v"(s_add));
 			}
 		}
 #pragma unroll

@@ -229,13 +229,24 @@ __global__ void __launch_bounds__(256) lsq_ingest_scatter_kernel(IngestRaw R, In
 	}
 }
 
-// Orders the reads of every (bucket, bin) by their first base: a counting sort in LDS over the
-// bin's coordinates, one wave per bin (the scatter above left the bin's reads together, in the
+// Orders the reads of every (bucket, bin): one-block reads by their first base, two-block reads by
+// their junction (end of block 1, start of block 2 -- the count kernel decides a lane's second read
+// against the junction of its first); a counting sort in LDS over the
+// bin's coordinates (or, for junctions, a hash of the pair: only "equal keys sit together" matters), one wave per bin (the scatter above left the bin's reads together, in the
 // order its atomics gave).  This is the device form of the reference's read index, a std::set
 // ordered by start (count/count.cpp:348-364): a wave of the count kernel then sees the reads of
 // one cell, then those of the next.  Bins wider than BINSORT_MAX_W coordinates are copied as they
 // are -- the order only matters for speed.
 constexpr unsigned BINSORT_MAX_W = 2048;
+__device__ inline unsigned binsort_key(const int2 r, int bin_lo, unsigned W) {
+	const int rel = r.x - bin_lo;                    // the first and last bins of a bucket also hold what lies beyond them
+	return (unsigned)max(0, min(rel, (int)W - 1));
+}
+__device__ inline unsigned binsort_key(const int4 r, int bin_lo, unsigned W) {
+	(void)bin_lo;
+	return (((unsigned)r.y * 2654435761u) ^ ((unsigned)r.z * 2246822519u)) >> 21 & (W - 1u);      // W is a power of two
+}
+
 template <class ReadT>
 __global__ void __launch_bounds__(256) lsq_ingest_binsort_kernel(const BucketDesc *buckets, const unsigned *bin_base, unsigned n_buckets, unsigned n_fine,
                                                                  const unsigned long long *off, const ReadT *in, const unsigned char *in_strand,
@@ -258,10 +269,7 @@ __global__ void __launch_bounds__(256) lsq_ingest_binsort_kernel(const BucketDes
 		const int bin_lo = d.lo + (int)((fine - bin_base[lo_b]) << d.shift);
 		for (unsigned k = lane; k < W; k += 64u) cnt[k] = 0;
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-		for (unsigned i = lane; i < n; i += 64u) {
-			const int rel = in[o0 + i].x - bin_lo;       // the first and last bins of a bucket also hold what lies beyond them
-			atomicAdd(&cnt[(unsigned)max(0, min(rel, (int)W - 1))], 1u);
-		}
+		for (unsigned i = lane; i < n; i += 64u) atomicAdd(&cnt[binsort_key(in[o0 + i], bin_lo, W)], 1u);
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
 		// exclusive prefix over the W counters: W/64 consecutive ones per lane
 		const unsigned per = (W + 63u) / 64u, k0 = min(lane * per, W), k1 = min(k0 + per, W);
@@ -274,8 +282,7 @@ __global__ void __launch_bounds__(256) lsq_ingest_binsort_kernel(const BucketDes
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
 		for (unsigned i = lane; i < n; i += 64u) {
 			const ReadT r = in[o0 + i];
-			const int rel = r.x - bin_lo;
-			const unsigned pos = atomicAdd(&cnt[(unsigned)max(0, min(rel, (int)W - 1))], 1u);
+			const unsigned pos = atomicAdd(&cnt[binsort_key(r, bin_lo, W)], 1u);
 			out[o0 + pos] = r; out_strand[o0 + pos] = in_strand[o0 + i]; out_line[o0 + pos] = in_line[o0 + i];
 		}
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
