@@ -147,7 +147,12 @@ typedef struct lsq_ctx lsq_ctx;
 
 int lsq_ctx_create(int device_id, lsq_ctx **out);
 void lsq_ctx_destroy(lsq_ctx *c);
-/* HIP stream the context launches on (hipStream_t as void*), for callers timing with events */
+/* The context works on two HIP streams of its own: uploads, ingest and the count kernels on one
+ * (returned here as hipStream_t in a void*, for callers timing with events), the EM and the
+ * hand-off of results (lsq_results_copy_device) on a second one, ordered after the count they
+ * belong to.  lsq_count / lsq_solve / lsq_results_copy_device only submit work; a following
+ * lsq_count runs beside the tail of the previous lsq_solve (the counters exist twice).
+ * lsq_ctx_synchronize waits for both streams; the host-side result getters do so themselves. */
 void *lsq_ctx_stream(lsq_ctx *c);
 int lsq_ctx_synchronize(lsq_ctx *c);
 
@@ -228,8 +233,13 @@ int lsq_results_solve(lsq_ctx *c, double *theta, double *logll, uint32_t *em_ite
 int lsq_results_copy_device(lsq_ctx *c, void *d_class_count, void *d_theta, void *d_logll);
 int lsq_results_device_order(const lsq_ctx *c, int32_t *dev2out /* n_events */);
 
-/* Device timing of the last lsq_count / lsq_solve (ms, from HIP events on the context
- * stream) and the count kernel's launch geometry; for bench.py. */
+/* Device timing, for bench.py and the developer tools.  Off by default: the event records between
+ * the kernels of a step hold the queue up (measured: 0.343 -> 0.317 ms per count+solve step on the
+ * 100 M-read workload without them).  lsq_set_timing(ctx, 1) makes the following lsq_count /
+ * lsq_solve calls record HIP events on the context stream around their launches; the getters
+ * return LSQ_E_STATE for a call that ran without. */
+int lsq_set_timing(lsq_ctx *c, int on);
+/* Duration of the last lsq_count / lsq_solve (ms), kernels only. */
 int lsq_last_timing(lsq_ctx *c, float *count_ms, float *solve_ms);
 /* Duration of the last lsq_count's lsq_count_fast_kernel launches alone (summed over read files),
  * from HIP events recorded immediately around each launch. */

@@ -245,6 +245,10 @@ class Context:
     def stream(self):
         return lib.lsq_ctx_stream(self.h)
 
+    def set_timing(self, on=True):
+        """HIP events around the kernels of the following count()/solve() calls (off by default: they cost queue time)"""
+        check(lib.lsq_set_timing(self.h, 1 if on else 0))
+
     def timing(self):
         a, b = C.c_float(), C.c_float()
         check(lib.lsq_last_timing(self.h, C.byref(a), C.byref(b)))

@@ -922,6 +922,7 @@ __device__ inline unsigned first_event_for(const GlobalBucket &G, int p) {
 
 __global__ void __launch_bounds__(256) lsq_count_cleanup_kernel(CountArgs A, unsigned long long n_p1, unsigned long long n_p2,
                                                                 unsigned long long n_pn, int all_reads) {
+	__builtin_amdgcn_s_setprio(3);          // runs beside the next count's streaming kernel: short, and the EM waits for it
 	const unsigned long long gtid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
 	const unsigned long long gsz = (unsigned long long)gridDim.x * blockDim.x;
 	// ---- exception list
@@ -978,9 +979,20 @@ int run_count(lsq_ctx *c, bool all_reads) {
 	const size_t n_cls = E.n_cls_total;
 	const int M = E.n_methods;
 	hipStream_t st = c->stream;
-	HIP_TRY(hipMemsetAsync(c->counters.p, 0, c->counters.n * sizeof(unsigned long long), st));
+	hipStream_t st_em = c->stream_em;
+	// This count writes the counter set the solve before last read; the previous count had it
+	// zeroed on the result stream, behind those readers, and recorded ev_mark after that.  Now the
+	// same for the next count: zero the set the latest solve reads, behind it.
+	const int set = c->flip ^ 1, other = c->flip;
+	if (c->mark_recorded) HIP_TRY(hipStreamWaitEvent(st, c->ev_mark, 0));
+	HIP_TRY(hipMemsetAsync(c->counters.p + (size_t)other * c->counters_per_set, 0, c->counters_per_set * sizeof(unsigned long long), st_em));
+	HIP_TRY(hipEventRecord(c->ev_mark, st_em));
+	c->mark_recorded = true;
+	select_counter_set(c, set);
 	c->fast_launched = 0;
-	HIP_TRY(hipEventRecord(c->ev0, st));      // ev0..ev1 brackets the count kernel launches only
+	struct Cleanup { CountArgs A; unsigned long long n_p1, n_p2, n_pn; unsigned grid; };
+	std::vector<Cleanup> cleanups;
+	if (c->time_events) HIP_TRY(hipEventRecord(c->ev0, st));      // ev0..ev1 brackets the count kernel launches only
 	const unsigned generic_tables_bytes = (std::max<unsigned>(E.max_lds_bytes, 16) + 15u) & ~15u;
 	const unsigned tables_bytes = generic_tables_bytes + VISIT_LDS_BYTES;            // fast kernel: + the visit record
 	const unsigned lds_bytes = tables_bytes + WAVES * WAVE_QUEUE_WORDS * 16;
@@ -1026,7 +1038,7 @@ int run_count(lsq_ctx *c, bool all_reads) {
 		A.p1_off = mr.p1_off.p; A.p2_off = mr.p2_off.p; A.pn_off = mr.pn_off.p; A.slot_off = mr.slot_off.p;
 		A.total_slots = mr.total_slots;
 		A.cnt = c->cnt.p + (size_t)m * n_cls; A.bases = c->bases.p + (size_t)m * n_cls;
-		A.exc = c->exc.p; A.exc_count = c->exc_count.p + 2 * m; A.exc_cap = (unsigned)c->exc.n;
+		A.exc = mr.exc.p + (size_t)set * mr.exc_cap; A.exc_count = c->exc_count.p + 2 * m; A.exc_cap = (unsigned)mr.exc_cap;
 		A.dbg = c->dbg.p;
 		const unsigned long long n_p1 = mr.p1.n / 2, n_p2 = mr.p2.n / 4, n_pn = mr.pn_strand.n;
 		// pool-n workers: one workgroup per CU at most, one lane per read and pass
@@ -1035,23 +1047,30 @@ int run_count(lsq_ctx *c, bool all_reads) {
 		A.n_workers = (unsigned)std::min<unsigned long long>((n_pn + COUNT_BLOCK - 1) / COUNT_BLOCK, (unsigned long long)c->n_cu * workers_per_cu);
 		if (c->has_fast) {
 			if (!all_reads) {
-				HIP_TRY(hipEventRecord(c->evf0[m], st));
+				if (c->time_events) HIP_TRY(hipEventRecord(c->evf0[m], st));
 				hipLaunchKernelGGL(lsq_count_fast_kernel, dim3((unsigned)grid + A.n_workers), dim3(COUNT_BLOCK), lds_bytes, st, A);
 				HIP_TRY(hipGetLastError());
-				HIP_TRY(hipEventRecord(c->evf1[m], st));
+				if (c->time_events) HIP_TRY(hipEventRecord(c->evf1[m], st));
 				c->fast_launched |= 1 << m;
 			}
 			const unsigned long long work = all_reads ? std::max<unsigned long long>(n_pn, 64ull * E.buckets.size()) : 4096ull;
 			const unsigned cgrid = (unsigned)std::min<unsigned long long>((work + 255) / 256, (unsigned long long)c->n_cu * 32);
-			hipLaunchKernelGGL(lsq_count_cleanup_kernel, dim3(std::max(cgrid, 1u)), dim3(256), 0, st, A, n_p1, n_p2, n_pn, all_reads ? 1 : 0);
-			HIP_TRY(hipGetLastError());
+			cleanups.push_back({A, n_p1, n_p2, n_pn, std::max(cgrid, 1u)});
 		}
 		if (c->has_generic) {
 			hipLaunchKernelGGL(lsq_count_generic_kernel, dim3((unsigned)grid), dim3(COUNT_BLOCK), generic_tables_bytes, st, A);
 			HIP_TRY(hipGetLastError());
 		}
 	}
-	HIP_TRY(hipEventRecord(c->ev1, st));
+	if (c->time_events) HIP_TRY(hipEventRecord(c->ev1, st));
+	c->count_timed = c->time_events;
+	// the exception pass, and everything that reads the counts, on the result stream behind the streaming kernels
+	HIP_TRY(hipEventRecord(c->ev_counted, st));
+	HIP_TRY(hipStreamWaitEvent(st_em, c->ev_counted, 0));
+	for (const Cleanup &u : cleanups) {
+		hipLaunchKernelGGL(lsq_count_cleanup_kernel, dim3(u.grid), dim3(256), 0, st_em, u.A, u.n_p1, u.n_p2, u.n_pn, all_reads ? 1 : 0);
+		HIP_TRY(hipGetLastError());
+	}
 	return LSQ_OK;
 }
 
@@ -1059,7 +1078,7 @@ int run_count(lsq_ctx *c, bool all_reads) {
 // (and a solve based on them) are redone with the cleanup kernel over every read.
 int ensure_counts_complete(lsq_ctx *c) {
 	if (c->redo_checked || !c->counted) return LSQ_OK;
-	HIP_TRY(hipStreamSynchronize(c->stream));
+	{ int rc = sync_all(c); if (rc) return rc; }
 	std::vector<unsigned> h(c->exc_count.n, 0);
 	HIP_TRY(hipMemcpy(h.data(), c->exc_count.p, h.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
 	bool overflow = false;
@@ -1069,7 +1088,8 @@ int ensure_counts_complete(lsq_ctx *c) {
 		int rc = run_count(c, true);
 		if (rc) return rc;
 		if (c->solved) { rc = run_solve(c); if (rc) return rc; }
-		HIP_TRY(hipStreamSynchronize(c->stream));
+		rc = sync_all(c);
+		if (rc) return rc;
 	}
 	return LSQ_OK;
 }
@@ -1081,7 +1101,7 @@ extern "C" {
 // developer aid (not in the header): counters filled when LSQ_ABLATE & 256
 int lsq_debug_counters(lsq_ctx *c, unsigned long long *out8) {
 	HIP_TRY(hipSetDevice(c->device));
-	HIP_TRY(hipStreamSynchronize(c->stream));
+	{ int rc = sync_all(c); if (rc) return rc; }
 	HIP_TRY(hipMemcpy(out8, c->dbg.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
 	std::vector<unsigned> h(c->exc_count.n);
 	HIP_TRY(hipMemcpy(h.data(), c->exc_count.p, h.size() * sizeof(unsigned), hipMemcpyDeviceToHost));

@@ -18,6 +18,22 @@ int upload_strand_ranks(lsq_ctx *c) {
 	return LSQ_OK;
 }
 
+int sync_all(lsq_ctx *c) {
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream_em));
+	return LSQ_OK;
+}
+
+void select_counter_set(lsq_ctx *c, int set) {
+	unsigned long long *base = c->counters.p + (size_t)set * c->counters_per_set;
+	const size_t per = c->cnt.n;
+	c->flip = set;
+	c->cnt.p = base;
+	c->bases.p = base + per;
+	c->exc_count.p = reinterpret_cast<unsigned *>(base + 2 * per);
+	c->dbg.p = base + 2 * per + LSQ_MAX_METHODS;
+}
+
 } // namespace lsq
 
 extern "C" {
@@ -37,6 +53,9 @@ int lsq_ctx_create(int device_id, lsq_ctx **out) {
 	c->device = device_id;
 	c->n_cu = prop.multiProcessorCount;
 	HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+	HIP_TRY(hipStreamCreateWithFlags(&c->stream_em, hipStreamNonBlocking));      // (a higher stream priority changed nothing measurable)
+	HIP_TRY(hipEventCreateWithFlags(&c->ev_counted, hipEventDisableTiming));
+	HIP_TRY(hipEventCreateWithFlags(&c->ev_mark, hipEventDisableTiming));
 	HIP_TRY(hipEventCreate(&c->ev0)); HIP_TRY(hipEventCreate(&c->ev1));
 	HIP_TRY(hipEventCreate(&c->ev2)); HIP_TRY(hipEventCreate(&c->ev3));
 	HIP_TRY(hipEventCreate(&c->evt0)); HIP_TRY(hipEventCreate(&c->evt1));
@@ -49,6 +68,9 @@ void lsq_ctx_destroy(lsq_ctx *c) {
 	if (!c) return;
 	(void)hipSetDevice(c->device);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
+	if (c->stream_em) (void)hipStreamSynchronize(c->stream_em);
+	if (c->ev_counted) (void)hipEventDestroy(c->ev_counted);
+	if (c->ev_mark) (void)hipEventDestroy(c->ev_mark);
 	if (c->ev0) (void)hipEventDestroy(c->ev0);
 	if (c->ev1) (void)hipEventDestroy(c->ev1);
 	if (c->ev2) (void)hipEventDestroy(c->ev2);
@@ -57,6 +79,7 @@ void lsq_ctx_destroy(lsq_ctx *c) {
 	if (c->evt1) (void)hipEventDestroy(c->evt1);
 	for (int m = 0; m < LSQ_MAX_METHODS; ++m) { if (c->evf0[m]) (void)hipEventDestroy(c->evf0[m]); if (c->evf1[m]) (void)hipEventDestroy(c->evf1[m]); }
 	if (c->stream) (void)hipStreamDestroy(c->stream);
+	if (c->stream_em) (void)hipStreamDestroy(c->stream_em);
 	delete c;
 }
 
@@ -64,13 +87,13 @@ void *lsq_ctx_stream(lsq_ctx *c) { return c ? (void *)c->stream : nullptr; }
 int lsq_ctx_synchronize(lsq_ctx *c) {
 	if (!c) return fail(LSQ_E_ARG, "null context");
 	HIP_TRY(hipSetDevice(c->device));
-	HIP_TRY(hipStreamSynchronize(c->stream));
-	return LSQ_OK;
+	return sync_all(c);
 }
 
 int lsq_events_upload(lsq_ctx *c, lsq_events *E) {
 	if (!c || !E) return fail(LSQ_E_ARG, "null argument");
 	HIP_TRY(hipSetDevice(c->device));
+	{ int rc = sync_all(c); if (rc) return rc; }        // the buffers below may still be read by a solve in flight
 	if (E->max_lds_bytes > 160 * 1024) return fail(LSQ_E_UNSUPPORTED, "bucket tables exceed the CU's LDS");
 	c->E = E;
 	c->counted = c->solved = false;
@@ -97,6 +120,7 @@ int lsq_events_upload(lsq_ctx *c, lsq_events *E) {
 				if (small == (pass == 0)) order.push_back((uint32_t)d);
 			}
 			while (order.size() % (64 / EM_LANES)) order.push_back(0xFFFFFFFFu);
+			if (pass == 0) c->em_small_places = (unsigned)order.size();
 		}
 		c->em_places = (unsigned)order.size();
 		if ((rc = c->em_order.upload(order.data(), order.size(), c->stream))) return rc;
@@ -122,11 +146,12 @@ int lsq_events_upload(lsq_ctx *c, lsq_events *E) {
 	const size_t n_cls = E->n_cls_total, n_ev = E->dev2out.size();
 	{
 		const size_t per = std::max<size_t>(M, 1) * n_cls;
-		if ((rc = c->counters.alloc(2 * per + LSQ_MAX_METHODS + 8))) return rc;
-		c->cnt.p = c->counters.p; c->cnt.n = per;
-		c->bases.p = c->counters.p + per; c->bases.n = per;
-		c->exc_count.p = reinterpret_cast<unsigned *>(c->counters.p + 2 * per); c->exc_count.n = 2 * LSQ_MAX_METHODS;
-		c->dbg.p = c->counters.p + 2 * per + LSQ_MAX_METHODS; c->dbg.n = 8;
+		c->counters_per_set = 2 * per + LSQ_MAX_METHODS + 8;
+		if ((rc = c->counters.alloc(2 * c->counters_per_set))) return rc;
+		c->cnt.n = per; c->bases.n = per; c->exc_count.n = 2 * LSQ_MAX_METHODS; c->dbg.n = 8;
+		c->mark_recorded = false;
+		select_counter_set(c, 0);
+		HIP_TRY(hipMemsetAsync(c->counters.p, 0, c->counters.n * sizeof(unsigned long long), c->stream));      // both sets start out zero
 	}
 	if ((rc = c->theta.alloc(n_iso))) return rc;
 	if ((rc = c->logll.alloc(n_ev))) return rc;
@@ -202,7 +227,7 @@ int lsq_results_counts(lsq_ctx *c, uint64_t *class_count, uint64_t *class_bases)
 	// hold every selected event's classes (output order), zero outside the shard
 	const size_t n_cls = E.n_cls_total, n_out = (size_t)E.class_off.back(), M = (size_t)E.n_methods;
 	std::vector<unsigned long long> hc(std::max<size_t>(M * n_cls, 1)), hb(std::max<size_t>(M * n_cls, 1));
-	HIP_TRY(hipStreamSynchronize(c->stream));
+	{ int rc = sync_all(c); if (rc) return rc; }
 	if (M * n_cls) {
 		HIP_TRY(hipMemcpy(hc.data(), c->cnt.p, M * n_cls * sizeof(unsigned long long), hipMemcpyDeviceToHost));
 		HIP_TRY(hipMemcpy(hb.data(), c->bases.p, M * n_cls * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -240,7 +265,7 @@ int lsq_results_set_counts(lsq_ctx *c, const uint64_t *class_count, const uint64
 				hb[m * n_cls + E.dev_cls_base[d] + k] = class_bases[m * n_out + E.class_off[o] + k];
 			}
 	}
-	HIP_TRY(hipStreamSynchronize(c->stream));
+	{ int rc = sync_all(c); if (rc) return rc; }
 	if (M * n_cls) {
 		HIP_TRY(hipMemcpyAsync(c->cnt.p, hc.data(), M * n_cls * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
 		HIP_TRY(hipMemcpyAsync(c->bases.p, hb.data(), M * n_cls * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
@@ -260,7 +285,7 @@ int lsq_results_solve(lsq_ctx *c, double *theta, double *logll, uint32_t *em_ite
 	std::vector<double> ht(std::max<size_t>(n_iso, 1)), hl(std::max<size_t>(n_ev, 1));
 	std::vector<uint32_t> hi(std::max<size_t>(n_ev, 1));
 	std::vector<uint8_t> hf(std::max<size_t>(n_ev, 1));
-	HIP_TRY(hipStreamSynchronize(c->stream));
+	{ int rc = sync_all(c); if (rc) return rc; }
 	if (n_ev) {
 		HIP_TRY(hipMemcpy(ht.data(), c->theta.p, n_iso * sizeof(double), hipMemcpyDeviceToHost));
 		HIP_TRY(hipMemcpy(hl.data(), c->logll.p, n_ev * sizeof(double), hipMemcpyDeviceToHost));
@@ -310,7 +335,7 @@ int lsq_results_copy_device(lsq_ctx *c, void *d_class_count, void *d_theta, void
 	const size_t n0 = d_class_count ? M * n_cls : 0, n1 = d_theta ? (size_t)E.n_iso_total : 0, n2 = d_logll ? E.dev2out.size() : 0;
 	if (n0 + n1 + n2) {
 		const unsigned grid = (unsigned)std::min<size_t>((n0 + n1 + n2 + 255) / 256, (size_t)c->n_cu * 8);
-		hipLaunchKernelGGL(lsq_copy_results_kernel, dim3(grid), dim3(256), 0, c->stream, (unsigned long long *)d_class_count, c->cnt.p, n0,
+		hipLaunchKernelGGL(lsq_copy_results_kernel, dim3(grid), dim3(256), 0, c->stream_em, (unsigned long long *)d_class_count, c->cnt.p, n0,
 		                   (unsigned long long *)d_theta, (const unsigned long long *)c->theta.p, n1, (unsigned long long *)d_logll, (const unsigned long long *)c->logll.p, n2);
 		HIP_TRY(hipGetLastError());
 	}
@@ -323,10 +348,17 @@ int lsq_results_device_order(const lsq_ctx *c, int32_t *dev2out) {
 	return LSQ_OK;
 }
 
+int lsq_set_timing(lsq_ctx *c, int on) {
+	if (!c) return fail(LSQ_E_ARG, "null context");
+	c->time_events = on != 0;
+	return LSQ_OK;
+}
+
 int lsq_last_fast_kernel_ms(lsq_ctx *c, float *ms) {
 	if (!c || !ms) return fail(LSQ_E_ARG, "null argument");
+	if (!c->counted || !c->count_timed) return fail(LSQ_E_STATE, "the last lsq_count ran without timing (lsq_set_timing)");
 	HIP_TRY(hipSetDevice(c->device));
-	HIP_TRY(hipStreamSynchronize(c->stream));
+	{ int rc = sync_all(c); if (rc) return rc; }
 	*ms = 0;
 	for (int m = 0; m < LSQ_MAX_METHODS; ++m) if (c->fast_launched >> m & 1) { float t = 0; HIP_TRY(hipEventElapsedTime(&t, c->evf0[m], c->evf1[m])); *ms += t; }
 	return LSQ_OK;
@@ -335,7 +367,9 @@ int lsq_last_fast_kernel_ms(lsq_ctx *c, float *ms) {
 int lsq_last_timing(lsq_ctx *c, float *count_ms, float *solve_ms) {
 	if (!c) return fail(LSQ_E_ARG, "null context");
 	HIP_TRY(hipSetDevice(c->device));
-	HIP_TRY(hipStreamSynchronize(c->stream));
+	{ int rc = sync_all(c); if (rc) return rc; }
+	if ((count_ms && c->counted && !c->count_timed) || (solve_ms && c->solved && !c->solve_timed))
+		return fail(LSQ_E_STATE, "the last lsq_count / lsq_solve ran without timing (lsq_set_timing)");
 	if (count_ms) { *count_ms = 0; if (c->counted) HIP_TRY(hipEventElapsedTime(count_ms, c->ev0, c->ev1)); }
 	if (solve_ms) { *solve_ms = 0; if (c->solved) HIP_TRY(hipEventElapsedTime(solve_ms, c->ev2, c->ev3)); }
 	return LSQ_OK;

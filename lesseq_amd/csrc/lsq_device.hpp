@@ -61,6 +61,8 @@ template <class T>
 struct DevView { T *p = nullptr; size_t n = 0; };     // a slice of somebody else's allocation
 
 struct MethodReads {
+	DevBuf<ExcEntry> exc;                  // exception lists: two halves of exc_cap entries, one per counter set
+	size_t exc_cap = 0;
 	bool present = false;
 	uint64_t n_retained = 0, n_retained_blocks = 0, total_slots = 0;
 	DevBuf<int32_t> p1, p2, pn_se;
@@ -80,11 +82,25 @@ struct MethodReads {
 struct lsq_ctx {
 	int device = 0;
 	int n_cu = 256;
-	hipStream_t stream = nullptr;
+	hipStream_t stream = nullptr;           // uploads, ingest and the count kernels
+	// The EM and the hand-off of results run on a stream of their own: the EM ends in a long tail
+	// of a few slow events on an otherwise idle device, and the next lsq_count may run beside it.
+	// So do the zeroing of the counters and the exception pass of a count (lsq_count_cleanup_kernel).
+	// For that the counters and the exception lists exist twice (a count writes the set the solve
+	// before last read); ev_counted: end of the latest count's streaming kernels; ev_mark: recorded
+	// on the result stream when a count is submitted, behind the zeroing of the set the NEXT count
+	// writes -- that count waits for it, i.e. for the readers of its set and not for the EM in between.
+	hipStream_t stream_em = nullptr;
+	hipEvent_t ev_counted = nullptr, ev_mark = nullptr;
+	bool mark_recorded = false;
+	int flip = 0;                           // counter set of the latest count
+	size_t counters_per_set = 0;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
 	hipEvent_t evt0 = nullptr, evt1 = nullptr;      // around a text copy (lsq_text_stage may run beside other host work)
 	hipEvent_t evf0[LSQ_MAX_METHODS] = {}, evf1[LSQ_MAX_METHODS] = {};   // around each method's lsq_count_fast_kernel launch
 	int fast_launched = 0;
+	bool time_events = false;               // lsq_set_timing: event records around the kernels cost ~4 us each in the queue
+	bool count_timed = false, solve_timed = false;      // the last lsq_count / lsq_solve ran with them
 	lsq_events *E = nullptr;                // must outlive the uploads made from it (its strand dictionary grows with the reads)
 	DevBuf<BucketDesc> buckets;
 	DevBuf<uint8_t> images, strand_rank, dK;
@@ -92,11 +108,11 @@ struct lsq_ctx {
 	DevBuf<uint32_t> cls_base, iso_base, iters, em_order, gene_name_off;
 	DevBuf<char> gene_names;                // device event order
 	unsigned em_places = 0;
+	unsigned em_small_places = 0;           // the first of them: events of the lean EM kernel
 	DevBuf<double> G, theta, logll;
 	DevBuf<uint8_t> flags;
-	DevBuf<unsigned long long> counters;   // cnt | bases | exc_count | dbg in one allocation: one memset per count
+	DevBuf<unsigned long long> counters;   // two sets of cnt | bases | exc_count | dbg (one memset per count); the views below are the latest count's
 	DevView<unsigned long long> cnt, bases, dbg;
-	DevBuf<ExcEntry> exc;                  // shared by the methods (launches are serialised on the stream)
 	DevView<unsigned> exc_count;           // per method: [2m] appended, [2m+1] overflow flag
 	DevBuf<unsigned> cov_off, cut_off;     // ingest tables: covered regions and bucket cuts per chromosome id
 	DevBuf<int> cov_s, cov_e, cut_lo, chrom_first_bucket;
@@ -127,5 +143,7 @@ namespace lsq {
 int upload_strand_ranks(lsq_ctx *c);                 // lsq_device.hip
 int run_count(lsq_ctx *c, bool all_reads);           // lsq_count.hip
 int ensure_counts_complete(lsq_ctx *c);              // lsq_count.hip: redo over every read when an exception list overflowed
-int run_solve(lsq_ctx *c);                           // lsq_em.hip
+int run_solve(lsq_ctx *c);
+int sync_all(lsq_ctx *c);                 // both streams
+void select_counter_set(lsq_ctx *c, int set);                           // lsq_em.hip
 } // namespace lsq

@@ -379,7 +379,10 @@ static int ingest_device(lsq_ctx *c, int method, const IngestRaw &Rw, uint64_t n
 	{
 		// exception list: a quarter of the one- and two-block reads, at least 64 Ki entries
 		const size_t want = std::max<size_t>(65536, (n1 + n2) / 4);
-		if (c->exc.n < want && (rc = c->exc.alloc(want))) return rc;
+		if (mr.exc_cap < want) {
+			if ((rc = mr.exc.alloc(2 * want))) return rc;
+			mr.exc_cap = want;
+		}
 	}
 	SW.mark("ingest: exception list alloc");
 	if ((rc = upload_strand_ranks(c))) return rc;      // the reads may have introduced new strand strings

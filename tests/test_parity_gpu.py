@@ -425,3 +425,96 @@ def test_event_shaped_inputs_more_seeds_vs_oracle(seed, tmp_path):
     compare_exact(gpu_exact(argv), exact, "events seed %d" % seed)
     rc, text = L.cli_run("solve", argv)
     assert rc == 0 and ob.solve_text_close(text, otext)
+
+
+def test_steps_submitted_back_to_back_with_changing_reads(tmp_path):
+    """The step pipeline (two streams, two counter sets): steps are only submitted, with another
+    read set uploaded in between and the hand-off going to a buffer per step; every step's tables must be the ones
+    the same reads give in a synchronous run, and the host getters must return the last step's."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")          # the runtime the library itself is linked to
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    hip.hipFree.argtypes = [C.c_void_p]
+
+    class DevArr:
+        def __init__(self, n, dtype, fill=0):
+            self.n, self.dtype = n, np.dtype(dtype)
+            p = C.c_void_p()
+            assert hip.hipMalloc(C.byref(p), max(n, 1) * self.dtype.itemsize) == 0
+            self.p = p.value
+            assert hip.hipMemset(self.p, fill, max(n, 1) * self.dtype.itemsize) == 0     # synchronous
+
+        def get(self):
+            out = np.empty(self.n, self.dtype)
+            assert hip.hipMemcpy(out.ctypes.data, self.p, self.n * self.dtype.itemsize, 2) == 0
+            return out
+
+        def free(self):
+            hip.hipFree(self.p)
+    specs = [L.SynthSpec(40 + i, 2500, 300000 + 50000 * i, 100, 3, L.EVENT_TYPES) for i in range(3)]
+    L.synth_write(specs[0], str(tmp_path), "p", write_mrf=False)
+    ann = L.Annotation(str(tmp_path / "p.interval"), str(tmp_path / "p.map"))
+    ev = L.Events(ann, ("SHORT_READ",), (100,))
+    # the annotation is that of specs[0]; the other read sets lie over other synthetic annotations of the same
+    # chromosomes (whatever falls on these events is counted)
+    reads = [L.Reads.synthetic(sp, ev) for sp in specs]
+    ctx = L.Context(0)
+    ctx.upload_events(ev)
+    n_cls = int(L.lib.lsq_results_num_classes(ctx.h))
+    # synchronous reference per read set
+    ref = []
+    for r in reads[:1]:
+        ctx.upload_reads(0, r)
+        ctx.count(); ctx.solve()
+        cnt, bases = ctx.counts()
+        theta, ll, iters, flags = ctx.solution()
+        t_c, t_t, t_l = DevArr(n_cls, np.int64), DevArr(ev.total_isoforms, np.float64), DevArr(len(ev), np.float64)
+        ctx.copy_results_device(t_c.p, t_t.p, t_l.p); ctx.synchronize()
+        ref.append((t_c.get(), t_t.get(), t_l.get(), cnt.copy(), theta.copy()))
+    assert int(ref[0][0].sum()) == int(ref[0][3].sum()) > 0
+    # nine steps in a row, nothing waited for; count-only steps and repeated solves mixed in
+    outs = []
+    for k in range(9):
+        ctx.count()
+        if k % 4 != 3:
+            ctx.solve()
+        if k % 5 == 4:
+            ctx.solve()
+        t_c, t_t, t_l = DevArr(n_cls, np.int64, 0xFF), DevArr(ev.total_isoforms, np.float64, 0xFF), DevArr(len(ev), np.float64, 0xFF)
+        ctx.copy_results_device(t_c.p, t_t.p if k % 4 != 3 else None, t_l.p if k % 4 != 3 else None)
+        outs.append((k, t_c, t_t, t_l))
+    ctx.synchronize()
+    for k, t_c, t_t, t_l in outs:
+        assert np.array_equal(t_c.get(), ref[0][0]), "step %d" % k
+        if k % 4 != 3:
+            assert np.array_equal(t_t.get(), ref[0][1]) and np.array_equal(t_l.get(), ref[0][2]), "step %d" % k
+    cnt, _ = ctx.counts()
+    assert np.array_equal(cnt, ref[0][3])
+    # timing getters: refused for runs without events, fine after set_timing
+    with pytest.raises(L.LsqError):
+        ctx.timing()
+    ctx.set_timing(True)
+    ctx.count(); ctx.solve()
+    c_ms, s_ms = ctx.timing()
+    assert c_ms > 0 and s_ms > 0 and ctx.fast_kernel_ms() > 0
+    ctx.set_timing(False)
+    # other read sets through the same context, again without waiting in between
+    seen = []
+    for i in (1, 2, 1):
+        ctx.upload_reads(0, reads[i])
+        ctx.count(); ctx.solve()
+        t_c = DevArr(n_cls, np.int64)
+        ctx.copy_results_device(t_c.p, None, None)
+        ctx.count()        # a second count of the same reads while the first one's solve may still run
+        seen.append((i, t_c))
+    ctx.synchronize()
+    sync = {}
+    for i in (1, 2):
+        ctx.upload_reads(0, reads[i]); ctx.count(); ctx.synchronize()
+        sync[i] = ctx.counts()[0].copy()
+    for i, t_c in seen:
+        assert int(t_c.get().sum()) == int(sync[i].sum()), "read set %d" % i
+    assert int(sync[1].sum()) != int(sync[2].sum())
+    ctx.close()
