@@ -8,6 +8,7 @@ struct EmArgs {
 	unsigned n_events, n_methods, n_cls, n_iso;
 	unsigned n_places;                 // entries of `order` this launch covers: [place0, n_places)
 	unsigned place0;
+	unsigned max_iters;                // read.h has no cap; 1000000 flags the event (developer switch LSQ_EM_CAP lowers it for timing experiments)
 	const unsigned *order;             // device event per place of the EM grid
 	const unsigned char *K;
 	const unsigned *cls_base, *iso_base;
@@ -247,7 +248,7 @@ __device__ inline void em_lean(const EmArgs &A, const EmCache &C, const unsigned
 		iters += go ? 1u : 0u;
 		if (go && fabs(crit - 1E-6) < 1E-11) flag |= 1;
 		if (go && !(crit > 1E-6)) run = false;
-		else if (go && iters >= 1000000u) { flag |= 2; run = false; }
+		else if (go && iters >= A.max_iters) { flag |= 2; run = false; }
 #pragma unroll
 		for (int j = 0; j < KK; ++j) { c3[j] = n3[j]; cz3[j] = nz3[j]; }
 		cll = nll;
@@ -344,7 +345,7 @@ __global__ void __launch_bounds__(256) lsq_em_kernel(EmArgs A) {
 			++iters;
 			if (fabs(crit - 1E-6) < 1E-11) flag |= 1;
 			if (!(crit > 1E-6)) run = false;
-			else if (iters >= 1000000u) { flag |= 2; run = false; }
+			else if (iters >= A.max_iters) { flag |= 2; run = false; }
 		}
 	}
 	if (ev_ok && sub == 0) {
@@ -369,6 +370,8 @@ int run_solve(lsq_ctx *c) {
 		A.n_events = n_ev; A.n_methods = (unsigned)E.n_methods; A.n_cls = E.n_cls_total; A.n_iso = E.n_iso_total;
 		A.K = c->dK.p; A.cls_base = c->cls_base.p; A.iso_base = c->iso_base.p;
 		A.order = c->em_order.p;
+		A.max_iters = 1000000u;
+		if (const char *e = getenv("LSQ_EM_CAP")) { const int v = atoi(e); if (v > 0) A.max_iters = (unsigned)v; }
 		A.cnt = c->cnt.p; A.G = c->G.p; A.theta = c->theta.p; A.logll = c->logll.p; A.iters = c->iters.p; A.flags = c->flags.p;
 		// one wave per workgroup: beside a streaming kernel that fills the device, a wave that is done gives its
 		// registers back without waiting for three others (measured 0.259 -> 0.254 ms per pipelined step)
