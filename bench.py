@@ -42,6 +42,9 @@ WORKLOADS = {
     # one GPU's share of configs[4] (1 B reads / 200 k events over 8 GPUs), skewed read depth (hot genes)
     "c5s": dict(n_events=25_000, n_reads=125_000_000, R=100, n_chrom=24, types=None, seed=5, zipf=True,
                 desc="one eighth of BASELINE configs[4]: 125M synthetic 100bp reads over 25k mixed events, Zipf read depth (hot genes), 24 chromosomes"),
+    # all of configs[4] on ONE GPU (a size check: ~25 GB of parsed reads on the host, ~10 GB of pools in HBM)
+    "c5": dict(n_events=200_000, n_reads=1_000_000_000, R=100, n_chrom=24, types=None, seed=5, zipf=True,
+               desc="BASELINE configs[4] whole: 1B synthetic 100bp reads over 200k mixed events, Zipf read depth (hot genes), 24 chromosomes"),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 measured copy rate
 

@@ -348,6 +348,17 @@ int lsq_results_device_order(const lsq_ctx *c, int32_t *dev2out) {
 	return LSQ_OK;
 }
 
+// developer aid (not in the header): another placement of the events in the EM grid (experiments on wave make-up)
+int lsq_debug_set_em_order(lsq_ctx *c, const uint32_t *order, unsigned n_small_places, unsigned n_places) {
+	HIP_TRY(hipSetDevice(c->device));
+	{ int rc = sync_all(c); if (rc) return rc; }
+	int rc = c->em_order.upload(order, n_places, c->stream);
+	if (rc) return rc;
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	c->em_small_places = n_small_places; c->em_places = n_places;
+	return LSQ_OK;
+}
+
 int lsq_set_timing(lsq_ctx *c, int on) {
 	if (!c) return fail(LSQ_E_ARG, "null context");
 	c->time_events = on != 0;

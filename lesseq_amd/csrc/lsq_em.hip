@@ -148,7 +148,9 @@ __device__ inline void em_pass_cached(const EmCache &E, const double *th, bool o
 // logarithm.  Passes follow one another with small steps in s (that is what makes slow events
 // slow), so log s(t+1) = log s(t) + log1p(d) with d = (s(t+1) - s(t)) / s(t), and for |d| < 2^-5 a
 // twelve-term series gives log1p to 1e-19: a chain of six operations instead of the logarithm's twenty.
-// A wave takes the series only when every live pair of every lane is inside that range.
+// A wave skips the full routine when every live pair of every lane is inside that range; when it
+// does not, only the pairs outside it take the routine's value, so an event's numbers do not depend
+// on the events it shares a wave with.
 template <int SLOTS>
 struct EmPairState { double s[SLOTS], r[SLOTS], lg[SLOTS]; };
 
@@ -168,7 +170,7 @@ __device__ inline void em_pass_lean(const double (&kd)[SLOTS], const double (&gm
 #pragma unroll
 	for (int j = 0; j < KK; ++j) zz[j] = 0;
 	double local[SLOTS][KK], sm[SLOTS], safe[SLOTS], r[SLOTS], d[SLOTS];
-	bool on_t[SLOTS], far = false;
+	bool on_t[SLOTS], far_t[SLOTS], far = false;
 #pragma unroll
 	for (int t = 0; t < SLOTS; ++t) {
 		sm[t] = 0;
@@ -178,8 +180,9 @@ __device__ inline void em_pass_lean(const double (&kd)[SLOTS], const double (&gm
 		safe[t] = (on_t[t] && sm[t] > 0) ? sm[t] : 1.0;     // an empty pair slot must not send the wave down the library path
 		r[t] = fast_recip(safe[t]);
 		d[t] = (safe[t] - P.s[t]) * P.r[t];
-		far = far || (on_t[t] && !(fabs(d[t]) < 0.03125));
-		if (on_t[t] && !(sm[t] > 0)) far = true;             // log of zero: the full routine gives the reference's -inf
+		// outside the series' range, or log of zero (the full routine gives the reference's -inf)
+		far_t[t] = on_t[t] && (!(fabs(d[t]) < 0.03125) || !(sm[t] > 0));
+		far = far || far_t[t];
 	}
 	// the numerators first: the next pass waits for them, and nothing in them waits for the logarithm
 	// or for the wave-wide vote below (an in-order wave stalls at that branch until the vote is in)
@@ -197,7 +200,10 @@ __device__ inline void em_pass_lean(const double (&kd)[SLOTS], const double (&gm
 		double lg = P.lg[t] + log1p_small(d[t]);
 		if (full) {                                  // wave-uniform, taken a handful of times per event
 			asm volatile("" ::: "memory");           // keeps the compiler from flattening the branch into both computations
-			lg = fast_log(on_t[t] ? sm[t] : 1.0);
+			// only the pairs that are out of range themselves take the value: what an event computes does not
+			// depend on the events it shares a wave with
+			const double fl = fast_log(on_t[t] ? sm[t] : 1.0);
+			lg = far_t[t] ? fl : lg;
 		}
 		P.s[t] = safe[t]; P.r[t] = r[t]; P.lg[t] = lg;
 		const double term = kd[t] * lg;
@@ -382,6 +388,7 @@ int run_solve(lsq_ctx *c) {
 			HIP_TRY(hipGetLastError());
 		}
 		if (c->em_places > c->em_small_places) {
+			A.order = c->em_order.p;
 			A.place0 = c->em_small_places; A.n_places = c->em_places;
 			hipLaunchKernelGGL(lsq_em_kernel<false>, dim3(((c->em_places - c->em_small_places) * EM_LANES + 255) / 256), dim3(256), 0, st, A);
 			HIP_TRY(hipGetLastError());

@@ -518,3 +518,34 @@ def test_steps_submitted_back_to_back_with_changing_reads(tmp_path):
         assert int(t_c.get().sum()) == int(sync[i].sum()), "read set %d" % i
     assert int(sync[1].sum()) != int(sync[2].sum())
     ctx.close()
+
+
+def test_em_numbers_do_not_depend_on_which_events_share_a_wave(tmp_path):
+    """theta, log-likelihood and iteration counts of an event are functions of its own counts: any placement of the
+    events in the EM grid (16 per wave) gives bit-identical numbers"""
+    import ctypes as C
+    spec = L.SynthSpec(77, 4000, 600000, 100, 4, L.EVENT_TYPES)
+    L.synth_write(spec, str(tmp_path), "w", write_mrf=False)
+    ann = L.Annotation(str(tmp_path / "w.interval"), str(tmp_path / "w.map"))
+    ev = L.Events(ann, ("SHORT_READ",), (100,))
+    ctx = L.Context(0)
+    ctx.upload_events(ev)
+    ctx.upload_reads(0, L.Reads.synthetic(spec, ev))
+    ctx.count(); ctx.solve()
+    ref = [x.copy() for x in ctx.solution()]
+    assert ref[2].max() > 20              # some slow events among fast ones
+    n = len(ev)
+    L.lib.lsq_debug_set_em_order.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint]
+    rng = np.random.default_rng(5)
+    for trial in range(3):
+        order = rng.permutation(n).astype(np.uint32)
+        if trial == 2:                    # and with holes in the grid
+            holes = np.full(n // 3, 0xFFFFFFFF, np.uint32)
+            order = rng.permutation(np.concatenate([order, holes]))
+        order = np.concatenate([order, np.full((-len(order)) % 16, 0xFFFFFFFF, np.uint32)])
+        assert L.lib.lsq_debug_set_em_order(ctx.h, order.ctypes.data, len(order), len(order)) == 0
+        ctx.solve()
+        got = ctx.solution()
+        for a, b, what in zip(ref, got, ("theta", "logll", "iters", "flags")):
+            assert np.array_equal(a, b, equal_nan=True), "%s differs with placement %d" % (what, trial)
+    ctx.close()

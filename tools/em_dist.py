@@ -28,3 +28,15 @@ Ks = np.array([ev.K(int(i)) for i in d2o])
 for k in sorted(set(Ks.tolist())):
     sel = it_dev[Ks == k]
     print("K=%d events=%d iters mean %.1f p99 %d max %d; top5 %s" % (k, len(sel), sel.mean(), np.percentile(sel, 99), sel.max(), np.sort(sel)[-5:]))
+# features for a predictor of the iteration count (class counts in device order)
+cnt, bases = ctx.counts()
+off = ev.class_offsets()
+cc = np.zeros((n, 3), np.int64)
+for d in range(n):
+    o = int(d2o[d])
+    k = ev.K(o)
+    c = cnt[0, off[o]:off[o] + (1 << k) - 1]
+    cc[d, :min(3, len(c))] = c[:3]
+os.makedirs("gpurun_out", exist_ok=True)
+np.savez_compressed("gpurun_out/em_features.npz", iters=it_dev, cc=cc, K=Ks, theta0=np.array([theta[ev.iso_offsets()[int(o)]] if hasattr(ev, "iso_offsets") else 0.0 for o in d2o]))
+

@@ -31,6 +31,19 @@ def step():
     ctx.count()
     if mode != "nosolve": ctx.solve()
     if mode != "nocopy": ctx.copy_results_device(t_cnt.data_ptr(), t_theta.data_ptr() if mode != "nosolve" else None, t_ll.data_ptr() if mode != "nosolve" else None)
+if os.environ.get("SB_SORT_EM"):
+    # experiment: events placed in the EM grid by their iteration count of a first run (a perfect predictor)
+    import ctypes as C, numpy as np
+    ctx.count(); ctx.solve()
+    theta, ll, iters, flags = ctx.solution()
+    d2o = ctx.device_order()
+    it_dev = iters[d2o]
+    order = np.argsort(it_dev, kind="stable").astype(np.uint32)
+    if os.environ["SB_SORT_EM"] == "rev": order = order[::-1].copy()
+    pad = (-len(order)) % 16
+    order = np.concatenate([order, np.full(pad, 0xFFFFFFFF, np.uint32)])
+    L.lib.lsq_debug_set_em_order.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint]
+    assert L.lib.lsq_debug_set_em_order(ctx.h, order.ctypes.data, len(order), len(order)) == 0
 for rep in range(4):
     for _ in range(5): step()
     ctx.synchronize()
