@@ -1008,7 +1008,7 @@ int run_count(lsq_ctx *c, bool all_reads) {
 	{
 		int nb = 0;
 		HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)lsq_count_fast_kernel, (int)COUNT_BLOCK, (size_t)lds_bytes));
-		if (nb >= 1 && !getenv("LSQ_NO_OCC_QUERY")) per_cu = std::min(per_cu, (unsigned)nb);
+		if (nb >= 1) per_cu = std::min(per_cu, (unsigned)nb);
 	}
 	int mult_env = 0;
 	if (const char *e = getenv("LSQ_GRID_MULT")) { int v = atoi(e); if (v >= 1 && v <= 64) mult_env = v; }
