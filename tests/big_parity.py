@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One-off large parity check on the GPU box: the executables' tables against the oracle's on a
 C3-shaped input (mixed events, 24 chromosomes) too large for the test suite.
-python tools/big_parity.py [n_reads] [n_events] [zipf]"""
+python tests/big_parity.py [n_reads] [n_events] [zipf]"""
 import os
 import sys
 import tempfile

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""One-off randomized parity campaign on the GPU box (not collected by pytest): the generators behind the
+wild_* and events_s* golden sets on seed ranges of any length, HIP path against the oracle -- exact integers,
+theta to 1e-6, printed count tables byte for byte.
+python tests/fuzz_campaign.py [first_seed] [n_seeds]"""
+import os
+import sys
+import tempfile
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, ".."))
+sys.path.insert(0, HERE)
+import lesseq_amd as L  # noqa: E402
+import oracle_binding as ob  # noqa: E402
+import golden_inputs as gi  # noqa: E402
+from test_parity_gpu import gpu_exact, compare_exact  # noqa: E402
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+t0 = time.time()
+bad, flagged, refused = [], 0, 0
+for seed in range(first, first + n):
+    d = tempfile.mkdtemp(prefix="lsq_fuzz_%d_" % seed, dir="/tmp")
+    try:
+        if seed % 2:
+            info = gi.write_wild_case(d, "w", seed)
+            R = info["R"]
+        else:
+            R = [36, 50, 75, 100, 150][seed % 5]
+            info = gi.write_events_case(d, "w", seed=seed, n_events=40 + seed % 50, n_reads=3000 + 37 * (seed % 100), R=R, n_chrom=1 + seed % 3,
+                                        zipf=(seed % 4 == 0))
+        argv = ["0", "w", "./", "LH_GENE_TXT", d + "/w.interval", "UCSC_GENE2ISOFORM", d + "/w.map", "0", "100000",
+                "MRF_SINGLE", "SHORT_READ" if seed % 3 else "MEDIUM_READ", str(R), d + "/w.mrf", str(info["total_read_bases"])]
+        rc, otext, exact = ob.run("solve", argv)
+        if rc != 0:                      # an input the reference itself refuses (assert / exit 1): the library must refuse it too
+            rc_lib, _ = L.cli_run("solve", argv)
+            assert rc_lib != 0, "oracle rc %d but the library ran" % rc
+            refused += 1
+            continue
+        flagged += compare_exact(gpu_exact(argv), exact, "seed %d" % seed)
+        rc, text = L.cli_run("count", argv[:-1])
+        rc2, ctext, _ = ob.run("count", argv[:-1])
+        assert rc == rc2 == 0 and text == ctext, "count table differs"
+    except AssertionError as e:
+        bad.append((seed, str(e)[:200]))
+    finally:
+        for f in os.listdir(d):
+            os.unlink(os.path.join(d, f))
+        os.rmdir(d)
+    if (seed - first) % 50 == 49:
+        print("  ... %d seeds, %d failures, %.0f s" % (seed - first + 1, len(bad), time.time() - t0), flush=True)
+print("seeds %d..%d: %d failures, %d inputs refused by both, %d events flagged by the EM guard band, %.0f s" % (first, first + n - 1, len(bad), refused, flagged, time.time() - t0))
+for b in bad[:20]:
+    print("  FAIL seed %d: %s" % b)
+sys.exit(1 if bad else 0)
