@@ -513,8 +513,6 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 		uint4 pe0[N_READS], pe1[N_READS];
 #pragma unroll
 		for (int kg = 0; kg < GW; ++kg) {
-			const int k = k0 + kg;
-			const unsigned w = wt + lane * (unsigned)SW + (unsigned)k;           // word, relative to w0
 			if (RPW == 2) {
 				// One look at the tables per lane and group: the lane's reads are neighbours in the
 				// start-ordered pool, so the cell of the first one is the cell of (nearly) all of
