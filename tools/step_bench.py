@@ -49,8 +49,9 @@ for rep in range(4):
     ctx.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps): step()
+    t_sub = time.perf_counter() - t0
     ctx.synchronize()
-    print("%s steps=%d ms_per_step=%.4f  checksum=%d" % (wl, steps, (time.perf_counter() - t0) * 1e3 / steps, int(t_cnt.sum().item())))
+    print("%s steps=%d ms_per_step=%.4f (host submission %.4f)  checksum=%d" % (wl, steps, (time.perf_counter() - t0) * 1e3 / steps, t_sub * 1e3 / steps, int(t_cnt.sum().item())))
 
 ctx.set_timing(True)
 piped, alone = [], []
