@@ -1004,9 +1004,12 @@ int run_count(lsq_ctx *c, bool all_reads) {
 	// resident workgroups per CU as the runtime sees them (registers, LDS, wave slots): the grid is a whole number of rounds
 	unsigned per_cu = std::max(1u, std::min(2048u / COUNT_BLOCK, (160u * 1024u) / lds_bytes));
 	{
-		int nb = 0;
-		HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)lsq_count_fast_kernel, (int)COUNT_BLOCK, (size_t)lds_bytes));
-		if (nb >= 1) per_cu = std::min(per_cu, (unsigned)nb);
+		if (c->occ_lds_bytes != lds_bytes) {             // asked once per table size
+			int nb = 0;
+			HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)lsq_count_fast_kernel, (int)COUNT_BLOCK, (size_t)lds_bytes));
+			c->occ_lds_bytes = lds_bytes; c->occ_blocks = nb;
+		}
+		if (c->occ_blocks >= 1) per_cu = std::min(per_cu, (unsigned)c->occ_blocks);
 	}
 	int mult_env = 0;
 	if (const char *e = getenv("LSQ_GRID_MULT")) { int v = atoi(e); if (v >= 1 && v <= 64) mult_env = v; }

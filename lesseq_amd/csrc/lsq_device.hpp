@@ -99,6 +99,7 @@ struct lsq_ctx {
 	hipEvent_t evt0 = nullptr, evt1 = nullptr;      // around a text copy (lsq_text_stage may run beside other host work)
 	hipEvent_t evf0[LSQ_MAX_METHODS] = {}, evf1[LSQ_MAX_METHODS] = {};   // around each method's lsq_count_fast_kernel launch
 	int fast_launched = 0;
+	unsigned occ_lds_bytes = 0; int occ_blocks = 0;      // the runtime's occupancy answer for the fast kernel at that LDS size
 	bool time_events = false;               // lsq_set_timing: event records around the kernels cost ~4 us each in the queue
 	bool count_timed = false, solve_timed = false;      // the last lsq_count / lsq_solve ran with them
 	lsq_events *E = nullptr;                // must outlive the uploads made from it (its strand dictionary grows with the reads)
