@@ -1,0 +1,33 @@
+/* lesseq_hip_dev.h -- developer entry points of liblesseq_hip.so, beside the product ABI of
+ * lesseq_hip.h.  Nothing here replaces anything in the reference; the tools under tools/ and a
+ * few tests use them to look inside a run (tools/kbench.py, tools/step_bench.py,
+ * tests/test_parity_gpu.py).  They may change without notice. */
+#ifndef LESSEQ_HIP_DEV_H
+#define LESSEQ_HIP_DEV_H
+
+#include <stdint.h>
+#include "lesseq_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Counters the count kernels fill when LSQ_ABLATE has bit 256 set: [0] parked one-block reads,
+ * [1] parked two-block reads, [2] walk steps, [3] walk lanes, [4] exception-list entries,
+ * [5..7] reasons for parking one-block reads. */
+int lsq_debug_counters(lsq_ctx *c, unsigned long long *out8);
+
+/* The combined slot offsets of a method's buckets (n_buckets + 1 values): the work partition of
+ * the count kernels. */
+int lsq_debug_slot_offsets(lsq_ctx *c, int method, unsigned long long *out, unsigned long long n);
+
+/* Another placement of the events in the EM grid (sixteen per wave; 0xFFFFFFFF = empty place):
+ * the first n_small_places entries go to the lean kernel and must be events with at most two
+ * isoforms and one (method, class) pair per lane.  Results do not depend on the placement
+ * (tests/test_parity_gpu.py::test_em_numbers_do_not_depend_on_which_events_share_a_wave). */
+int lsq_debug_set_em_order(lsq_ctx *c, const uint32_t *order, unsigned n_small_places, unsigned n_places);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1107,7 +1107,7 @@ int ensure_counts_complete(lsq_ctx *c) {
 
 extern "C" {
 
-// developer aid (not in the header): counters filled when LSQ_ABLATE & 256
+// developer aid (include/lesseq_hip_dev.h): counters filled when LSQ_ABLATE & 256
 int lsq_debug_counters(lsq_ctx *c, unsigned long long *out8) {
 	HIP_TRY(hipSetDevice(c->device));
 	{ int rc = sync_all(c); if (rc) return rc; }
@@ -1118,7 +1118,7 @@ int lsq_debug_counters(lsq_ctx *c, unsigned long long *out8) {
 	return LSQ_OK;
 }
 
-// developer aid (not in the header): per-bucket slot offsets of a method (n_buckets + 1 values)
+// developer aid (include/lesseq_hip_dev.h): per-bucket slot offsets of a method (n_buckets + 1 values)
 int lsq_debug_slot_offsets(lsq_ctx *c, int method, unsigned long long *out, unsigned long long n) {
 	HIP_TRY(hipSetDevice(c->device));
 	HIP_TRY(hipStreamSynchronize(c->stream));

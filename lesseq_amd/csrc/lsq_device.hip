@@ -348,7 +348,7 @@ int lsq_results_device_order(const lsq_ctx *c, int32_t *dev2out) {
 	return LSQ_OK;
 }
 
-// developer aid (not in the header): another placement of the events in the EM grid (experiments on wave make-up)
+// developer aid (include/lesseq_hip_dev.h): another placement of the events in the EM grid (experiments on wave make-up)
 int lsq_debug_set_em_order(lsq_ctx *c, const uint32_t *order, unsigned n_small_places, unsigned n_places) {
 	HIP_TRY(hipSetDevice(c->device));
 	{ int rc = sync_all(c); if (rc) return rc; }

@@ -14,9 +14,12 @@ from test_oracle_golden import GOLD, CASES, load_case
 
 
 def test_library_exports_every_declared_symbol():
-    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "lesseq_hip.h")).read()
-    names = set(re.findall(r"\b(lsq_[a-z0-9_]+)\s*\(", hdr))
-    assert len(names) > 40
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    names = set()
+    for h in sorted(os.listdir(inc)):
+        if h.endswith(".h"):
+            names |= set(re.findall(r"\b(lsq_[a-z0-9_]+)\s*\(", open(os.path.join(inc, h)).read()))
+    assert len(names) > 40 and "lsq_debug_counters" in names
     for n in sorted(names):
         assert hasattr(L.lib, n), "missing export " + n
     assert L.lib.lsq_abi_version() == 1
