@@ -549,3 +549,24 @@ def test_em_numbers_do_not_depend_on_which_events_share_a_wave(tmp_path):
         for a, b, what in zip(ref, got, ("theta", "logll", "iters", "flags")):
             assert np.array_equal(a, b, equal_nan=True), "%s differs with placement %d" % (what, trial)
     ctx.close()
+
+
+@pytest.mark.parametrize("name", ["toy", "multi_method", "events_s1", "readfmts", "formats"])
+def test_example_host_prints_the_reference_solve_table(name, tmp_path, monkeypatch):
+    """examples/solve_host.c (plain C against include/lesseq_hip.h, the binding INTEGRATION.md describes) through the
+    fine-grained entry points: its table is the reference's golden solve table"""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lesseq_amd", "bin", "solve_host")
+    assert os.path.exists(exe), "lesseq_amd/bin/solve_host is built by lesseq_amd/csrc/Makefile"
+    c, d = load_case(name, tmp_path)
+    monkeypatch.chdir(d)
+    n = 0
+    for tool, r in runs(c):
+        if tool != "solve" or r["exit"] != 0:
+            continue
+        a = r["argv"]                      # [log, proj, prefix, iso_fmt, iso, g2i_fmt, g2i, begin, end, groups...]
+        p = subprocess.run([exe] + a[3:], capture_output=True, text=True, timeout=120)
+        assert p.returncode == 0, (name, a, p.stderr)
+        assert ob.solve_text_close(p.stdout, open(os.path.join(d, r["stdout"])).read()), (name, a)
+        n += 1
+    assert n >= 1
