@@ -225,6 +225,19 @@ int lsq_results_counts(lsq_ctx *c, uint64_t *class_count, uint64_t *class_bases)
 int lsq_results_set_counts(lsq_ctx *c, const uint64_t *class_count, const uint64_t *class_bases);
 int lsq_results_solve(lsq_ctx *c, double *theta, double *logll, uint32_t *em_iters, uint8_t *em_flags);
 
+/* Optional: the expected Fisher information of theta_1..theta_{K-1} per read at the solved theta,
+ * and the two variance estimates made from it -- common/fim.h:115-158,320-367 (bruteforce_fim / ofim:
+ * the sum over every accessible read start of every isoform), :58-93 (estimate_mle_variance_by_diag,
+ * _by_inv) with common/linalg.h:28-71's inverse.  PARITY UNPINNED: the reference never includes these
+ * headers, no reference binary prints these numbers; the tests check the HIP path against the oracle's
+ * restatement of the headers.  One matrix per event and read file, (K-1) x (K-1), row-major; events
+ * in output order at lsq_results_fim_offsets (n_events + 1 values; K = 1: empty matrix, variances 0).
+ * Call after lsq_solve.  fim: [method][lsq_results_fim_size], variances: [method][n_events]. */
+int lsq_fim(lsq_ctx *c);
+int64_t lsq_results_fim_size(const lsq_ctx *c);
+int lsq_results_fim_offsets(const lsq_ctx *c, uint64_t *fim_off /* n_events+1 */);
+int lsq_results_fim(lsq_ctx *c, double *fim, double *var_by_diag, double *var_by_inverse);
+
 /* Copies the raw device-order results into caller-provided DEVICE buffers (e.g. tensors of a
  * framework that will run a collective on them), asynchronously on the context stream:
  * d_class_count [n_methods * n_classes] uint64, d_theta [n_isoforms] f64, d_logll [n_events]

@@ -98,6 +98,10 @@ _sig("lsq_results_counts", C.c_int, vp, P(u64), P(u64))
 _sig("lsq_results_solve", C.c_int, vp, P(C.c_double), P(C.c_double), P(u32), P(u8))
 _sig("lsq_results_copy_device", C.c_int, vp, vp, vp, vp)
 _sig("lsq_results_device_order", C.c_int, vp, P(i32))
+_sig("lsq_fim", C.c_int, vp)
+_sig("lsq_results_fim_size", C.c_int64, vp)
+_sig("lsq_results_fim_offsets", C.c_int, vp, P(C.c_uint64))
+_sig("lsq_results_fim", C.c_int, vp, P(C.c_double), P(C.c_double), P(C.c_double))
 _sig("lsq_set_timing", C.c_int, vp, C.c_int)
 _sig("lsq_last_fast_kernel_ms", C.c_int, vp, P(C.c_float))
 _sig("lsq_last_timing", C.c_int, vp, P(C.c_float), P(C.c_float))

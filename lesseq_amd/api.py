@@ -311,6 +311,21 @@ class Context:
         check(lib.lsq_results_solve(self.h, _ptr(theta, C.c_double), _ptr(ll, C.c_double), _ptr(it, u32), _ptr(fl, u8)))
         return theta[:ni], ll[:ne], it[:ne], fl[:ne]
 
+    def fim(self):
+        """after solve(): (offsets[n_events+1], fim[n_methods, size], var_by_diag[n_methods, n_events], var_by_inverse[...]) --
+        the expected Fisher information per read of theta_1..theta_{K-1} at the solved theta and fim.h's two variance
+        estimates (parity unpinned: dead code in the reference)"""
+        check(lib.lsq_fim(self.h))
+        ne, M = len(self.events), self.events.n_methods
+        off = np.zeros(ne + 1, np.uint64)
+        check(lib.lsq_results_fim_offsets(self.h, _ptr(off, C.c_uint64)))
+        size = int(off[ne])
+        f = np.zeros(max(M * size, 1), np.float64)
+        vd = np.zeros(max(M * ne, 1), np.float64)
+        vi = np.zeros(max(M * ne, 1), np.float64)
+        check(lib.lsq_results_fim(self.h, _ptr(f, C.c_double), _ptr(vd, C.c_double), _ptr(vi, C.c_double)))
+        return off, f[:M * size].reshape(M, size), vd[:M * ne].reshape(M, ne), vi[:M * ne].reshape(M, ne)
+
 
 class SynthSpec:
     def __init__(self, seed, n_events, n_reads, read_length=100, n_chrom=1, event_types=EVENT_TYPES, zipf=False, overlap_frac=0.10, first_read=0):

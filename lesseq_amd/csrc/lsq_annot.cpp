@@ -373,6 +373,54 @@ static uint64_t ars_total(const std::vector<uint64_t> &seg_len, uint64_t R, bool
 	return total;
 }
 
+// fim.h:115-158 sums over every accessible read start a of every isoform k the read generated there
+// (read.h:276-329: the isoform's segments from the one that holds the start to the one that holds the
+// last base).  The generated read, hence its compatibility class, only changes where the start crosses
+// a segment boundary or the end does, so the starts are counted in runs.  Accessible starts
+// (accessible_read_starts.h:48-89,221-274, :131-182): in isoform coordinates segment i contributes the
+// starts [c_{i-1}, c_{i-1} + a_i) with a_i = l_i (MEDIUM) or l_i + 1 (SHORT -- the last of them is the
+// first base of the next segment, which that segment contributes again: the reference counts it twice),
+// and the segment where less than a read is left contributes max(l + 1 - (c + R - L), 0).
+static void fim_start_classes(const lsq::Event &e, int k, uint64_t R, bool short_read, uint32_t *counts /* n_cls */) {
+	std::vector<int> seg;                       // the isoform's segments, ascending
+	for (int n = 0; n < e.N; ++n) if (e.iso_mask[k] >> n & 1) seg.push_back(n);
+	const int n = (int)seg.size();
+	std::vector<uint64_t> cum(n);               // cumulative segment lengths
+	uint64_t L = 0;
+	for (int i = 0; i < n; ++i) { L += (uint64_t)(e.seg_e[seg[i]] - e.seg_s[seg[i]]); cum[i] = L; }
+	auto class_of = [&](int se, int ee) {       // read.h:44-79 on the run of segments seg[se..ee]
+		uint64_t mask = 0;
+		for (int i = se; i <= ee; ++i) mask |= 1ull << seg[i];
+		const int hi = 63 - __builtin_clzll(mask), lo = __builtin_ctzll(mask);
+		const uint64_t span = (hi == 63 ? ~0ull : ((2ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
+		unsigned cls = 0;
+		for (int j = 0; j < e.K; ++j) if ((mask & ~e.iso_mask[j]) == 0 && (e.iso_mask[j] & span) == mask) cls |= 1u << j;
+		return cls;
+	};
+	uint64_t before = 0;
+	for (int i = 0; i < n; ++i) {
+		const uint64_t l = cum[i] - before;
+		uint64_t a;                               // accessible starts this segment contributes
+		bool last = false;
+		if (cum[i] + R > L) { const int64_t v = (int64_t)l + 1 - (int64_t)(cum[i] + R - L); a = (uint64_t)std::max<int64_t>(v, 0); last = true; }
+		else a = short_read ? l + 1 : l;
+		uint64_t s = before;                      // isoform coordinate of the start
+		const uint64_t s_end = before + a;
+		while (s < s_end) {
+			int se = 0; while (se < n && !(cum[se] > s)) ++se;            // upper_bound(start)
+			int ee = 0; while (ee < n && cum[ee] < s + R) ++ee;          // lower_bound(start + R)
+			if (se >= n || ee >= n) break;                               // (cannot happen: s + R <= L by construction)
+			// the run ends where the start leaves segment se or the end leaves segment ee
+			const uint64_t nxt = std::min(std::min(cum[se], cum[ee] - R + 1), s_end);
+			const unsigned cls = class_of(se, ee);
+			if (cls) counts[cls - 1] += (uint32_t)(nxt - s);
+			s = nxt;
+		}
+		before = cum[i];
+		if (last) break;
+	}
+}
+
 static const int64_t COORD_LIMIT = (int64_t)1 << 30;
 
 // Budget for one bucket's event tables in LDS (records + segments + isoform masks + class
@@ -719,6 +767,12 @@ int compile_events(const lsq_annotation *a, int n_methods, const char *const *re
 			e.iso_mask.push_back(mask);
 			e.iso_len.push_back(len);
 			for (int m = 0; m < n_methods; ++m) e.ars[m].push_back(ars_total(seg_len, E->read_lengths[m], is_short[m]));
+		}
+		if (e.K <= LSQ_MAX_ISOFORMS) {
+			const size_t n_cls = ((size_t)1 << e.K) - 1;
+			e.fim_starts.assign(n_methods, std::vector<uint32_t>((size_t)e.K * n_cls, 0u));
+			for (int m = 0; m < n_methods; ++m)
+				for (int k = 0; k < e.K; ++k) fim_start_classes(e, k, E->read_lengths[m], is_short[m], e.fim_starts[m].data() + (size_t)k * n_cls);
 		}
 		// "read-<n>" < gname ? (count/count.cpp:71, std::string operator<)
 		static const char pfx[] = "read-";

@@ -150,6 +150,7 @@ int lsq_events_upload(lsq_ctx *c, lsq_events *E) {
 		if ((rc = c->counters.alloc(2 * c->counters_per_set))) return rc;
 		c->cnt.n = per; c->bases.n = per; c->exc_count.n = 2 * LSQ_MAX_METHODS; c->dbg.n = 8;
 		c->mark_recorded = false;
+		c->fim_uploaded = false; c->fim_done = false;
 		select_counter_set(c, 0);
 		HIP_TRY(hipMemsetAsync(c->counters.p, 0, c->counters.n * sizeof(unsigned long long), c->stream));      // both sets start out zero
 	}
@@ -206,6 +207,90 @@ int lsq_solve(lsq_ctx *c) {
 	int rc = run_solve(c);
 	if (rc) return rc;
 	c->solved = true;
+	c->fim_done = false;
+	return LSQ_OK;
+}
+
+// fim.h / linalg.h (parity unpinned, see lsq_em.hip): needs lsq_solve's theta
+int lsq_fim(lsq_ctx *c) {
+	if (!c) return fail(LSQ_E_ARG, "null context");
+	if (!c->solved) return fail(LSQ_E_STATE, "lsq_solve must come first");
+	HIP_TRY(hipSetDevice(c->device));
+	const lsq_events &E = *c->E;
+	const size_t n_ev = E.dev2out.size(), M = (size_t)E.n_methods;
+	if (!c->fim_uploaded) {
+		std::vector<uint32_t> sb(n_ev + 1, 0), mb(n_ev + 1, 0);
+		for (size_t d = 0; d < n_ev; ++d) {
+			const lsq::Event &e = E.ev[(size_t)E.dev2out[d]];
+			if (e.K > LSQ_MAX_ISOFORMS || e.fim_starts.empty()) return fail(LSQ_E_UNSUPPORTED, "lsq_fim: event %s has more than %d isoforms", e.gname.c_str(), LSQ_MAX_ISOFORMS);
+			sb[d + 1] = sb[d] + (uint32_t)((size_t)e.K * (((size_t)1 << e.K) - 1));
+			mb[d + 1] = mb[d] + (uint32_t)((e.K - 1) * (e.K - 1));
+		}
+		c->fim_starts_total = sb[n_ev]; c->fim_mat_total = mb[n_ev];
+		std::vector<uint32_t> st(std::max<size_t>(M * c->fim_starts_total, 1), 0);
+		for (size_t m = 0; m < M; ++m)
+			for (size_t d = 0; d < n_ev; ++d) {
+				const lsq::Event &e = E.ev[(size_t)E.dev2out[d]];
+				std::copy(e.fim_starts[m].begin(), e.fim_starts[m].end(), st.begin() + (ptrdiff_t)(m * c->fim_starts_total + sb[d]));
+			}
+		int rc;
+		if ((rc = c->fim_start_base.upload(sb.data(), sb.size(), c->stream))) return rc;
+		if ((rc = c->fim_mat_base.upload(mb.data(), mb.size(), c->stream))) return rc;
+		if ((rc = c->fim_starts.upload(st.data(), st.size(), c->stream))) return rc;
+		if ((rc = c->fim.alloc(std::max<size_t>(M * c->fim_mat_total, 1)))) return rc;
+		if ((rc = c->fim_var.alloc(std::max<size_t>(M * n_ev * 2, 1)))) return rc;
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		c->fim_uploaded = true;
+	}
+	int rc = run_fim(c);
+	if (rc) return rc;
+	c->fim_done = true;
+	return LSQ_OK;
+}
+
+int64_t lsq_results_fim_size(const lsq_ctx *c) {
+	if (!c || !c->E) return 0;
+	int64_t n = 0;
+	for (const lsq::Event &e : c->E->ev) n += (int64_t)(e.K - 1) * (e.K - 1);
+	return n;
+}
+
+int lsq_results_fim_offsets(const lsq_ctx *c, uint64_t *fim_off) {
+	if (!c || !c->E || !fim_off) return fail(LSQ_E_ARG, "null argument");
+	uint64_t n = 0;
+	for (size_t o = 0; o < c->E->ev.size(); ++o) { fim_off[o] = n; n += (uint64_t)(c->E->ev[o].K - 1) * (uint64_t)(c->E->ev[o].K - 1); }
+	fim_off[c->E->ev.size()] = n;
+	return LSQ_OK;
+}
+
+int lsq_results_fim(lsq_ctx *c, double *fim, double *var_by_diag, double *var_by_inverse) {
+	if (!c || !fim || !var_by_diag || !var_by_inverse) return fail(LSQ_E_ARG, "null argument");
+	if (!c->fim_done || !c->solved) return fail(LSQ_E_STATE, "lsq_fim must come first");
+	HIP_TRY(hipSetDevice(c->device));
+	{ int rc = sync_all(c); if (rc) return rc; }
+	const lsq_events &E = *c->E;
+	const size_t n_ev = E.dev2out.size(), n_out = E.ev.size(), M = (size_t)E.n_methods;
+	std::vector<double> hf(std::max<size_t>(M * c->fim_mat_total, 1)), hv(std::max<size_t>(M * n_ev * 2, 1));
+	std::vector<uint32_t> mb(n_ev + 1, 0);
+	if (n_ev) {
+		HIP_TRY(hipMemcpy(hf.data(), c->fim.p, hf.size() * sizeof(double), hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(hv.data(), c->fim_var.p, hv.size() * sizeof(double), hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(mb.data(), c->fim_mat_base.p, mb.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+	}
+	std::vector<uint64_t> off(n_out + 1);
+	lsq_results_fim_offsets(c, off.data());
+	const size_t total = (size_t)off[n_out];
+	for (size_t i = 0; i < M * total; ++i) fim[i] = 0.0;
+	for (size_t i = 0; i < M * n_out; ++i) { var_by_diag[i] = 0.0; var_by_inverse[i] = 0.0; }       // events outside the shard: zeros
+	for (size_t d = 0; d < n_ev; ++d) {
+		const size_t o = (size_t)E.dev2out[d];
+		const size_t nn = (size_t)(E.ev[o].K - 1) * (size_t)(E.ev[o].K - 1);
+		for (size_t m = 0; m < M; ++m) {
+			for (size_t i = 0; i < nn; ++i) fim[m * total + off[o] + i] = hf[m * c->fim_mat_total + mb[d] + i];
+			var_by_diag[m * n_out + o] = hv[(m * n_ev + d) * 2];
+			var_by_inverse[m * n_out + o] = hv[(m * n_ev + d) * 2 + 1];
+		}
+	}
 	return LSQ_OK;
 }
 

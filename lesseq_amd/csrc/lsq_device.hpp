@@ -111,6 +111,12 @@ struct lsq_ctx {
 	unsigned em_places = 0;
 	unsigned em_small_places = 0;           // the first of them: events of the lean EM kernel
 	DevBuf<double> G, theta, logll;
+	// lsq_fim (fim.h / linalg.h): per device event the offset of its accessible-start class counts and of its
+	// (K-1) x (K-1) matrix; counts per method; results
+	DevBuf<uint32_t> fim_start_base, fim_mat_base, fim_starts;
+	DevBuf<double> fim, fim_var;
+	size_t fim_starts_total = 0, fim_mat_total = 0;
+	bool fim_uploaded = false, fim_done = false;
 	DevBuf<uint8_t> flags;
 	DevBuf<unsigned long long> counters;   // two sets of cnt | bases | exc_count | dbg (one memset per count); the views below are the latest count's
 	DevView<unsigned long long> cnt, bases, dbg;
@@ -145,6 +151,7 @@ int upload_strand_ranks(lsq_ctx *c);                 // lsq_device.hip
 int run_count(lsq_ctx *c, bool all_reads);           // lsq_count.hip
 int ensure_counts_complete(lsq_ctx *c);              // lsq_count.hip: redo over every read when an exception list overflowed
 int run_solve(lsq_ctx *c);
+int run_fim(lsq_ctx *c);
 int sync_all(lsq_ctx *c);                 // both streams
 void select_counter_set(lsq_ctx *c, int set);                           // lsq_em.hip
 } // namespace lsq

@@ -362,9 +362,103 @@ __global__ void __launch_bounds__(256) lsq_em_kernel(EmArgs A) {
 	}
 }
 
+// ---- expected Fisher information and the variance estimates made from it (fim.h, linalg.h) ------------
+// PARITY UNPINNED: no translation unit of the reference includes these headers.  fim.h:115-158 sums, over
+// every isoform k with theta_k != 0 and every accessible read start of it, theta_k G_k times the
+// observed information of the read generated there (fim.h:320-367):
+//   (dG_p - dG_K)(dG_q - dG_K) / (sum_j theta_j dG_j)^2,   dG_j = G_j if the read is compatible with j, else 0.
+// That term depends on the read only through its compatibility class, so the sum runs over classes with
+// the number of starts per (isoform, class) counted on the host (lsq_annot.cpp: fim_start_classes).
+// The matrix is (K-1) x (K-1) with K <= 6: one lane per (event, method), nothing here is a dense
+// contraction worth a matrix core.  Variances: fim.h:64-72 (reciprocals of the diagonal) and :74-93 through
+// linalg.h:28-71's inverse (GSL's LU with partial pivoting, then the identity's columns).
+struct FimArgs {
+	unsigned n_events, n_methods, n_iso;
+	const unsigned char *K;
+	const unsigned *iso_base, *start_base, *mat_base;
+	const unsigned *starts;            // [method][starts_total]
+	size_t starts_total, mat_total;
+	const double *theta, *G;           // G: [method][n_iso]
+	double *fim;                       // [method][mat_total]
+	double *var;                       // [method][n_events][2]: by the diagonal, by the inverse
+};
+
+__global__ void __launch_bounds__(64) lsq_fim_kernel(FimArgs A) {
+	const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= A.n_events * A.n_methods) return;
+	const unsigned e = t / A.n_methods, m = t % A.n_methods;
+	const int K = A.K[e], D = K - 1;
+	const unsigned n_cls = (1u << K) - 1u;
+	double th[LSQ_MAX_ISOFORMS], g[LSQ_MAX_ISOFORMS], I[(LSQ_MAX_ISOFORMS - 1) * (LSQ_MAX_ISOFORMS - 1)];
+	for (int j = 0; j < K; ++j) { th[j] = A.theta[A.iso_base[e] + j]; g[j] = A.G[(size_t)m * A.n_iso + A.iso_base[e] + j]; }
+	for (int i = 0; i < D * D; ++i) I[i] = 0;
+	const unsigned *st = A.starts + (size_t)m * A.starts_total + A.start_base[e];
+	for (int k = 0; k < K; ++k) {
+		if (th[k] == 0) continue;
+		for (unsigned c = 1; c <= n_cls; ++c) {
+			const unsigned a = st[(unsigned)k * n_cls + c - 1];
+			if (!a) continue;
+			double s = 0;
+			for (int j = 0; j < K; ++j) if ((c >> j & 1u) && g[j] > 0 && th[j] > 0) s += th[j] * g[j];
+			const double vK = (c >> (K - 1) & 1u) ? g[K - 1] : 0.0;
+			const double w = (double)a * (th[k] * g[k]) / (s * s);
+			for (int p = 0; p < D; ++p) {
+				const double dp = ((c >> p & 1u) ? g[p] : 0.0) - vK;
+				for (int q = 0; q < D; ++q) I[p * D + q] += w * dp * (((c >> q & 1u) ? g[q] : 0.0) - vK);
+			}
+		}
+	}
+	double *out = A.fim + (size_t)m * A.mat_total + A.mat_base[e];
+	for (int i = 0; i < D * D; ++i) out[i] = I[i];
+	double by_diag = 0;
+	for (int p = 0; p < D; ++p) by_diag += 1.0 / I[p * D + p];
+	// LU with partial pivoting, rows swapped in place (gsl_linalg_LU_decomp), then P e_col through L and U
+	double by_inv = 0;
+	if (D > 0) {
+		int perm[LSQ_MAX_ISOFORMS - 1];
+		for (int i = 0; i < D; ++i) perm[i] = i;
+		for (int j = 0; j < D - 1; ++j) {
+			double amax = fabs(I[j * D + j]); int ip = j;
+			for (int i = j + 1; i < D; ++i) { const double a = fabs(I[i * D + j]); if (a > amax) { amax = a; ip = i; } }
+			if (ip != j) { for (int col = 0; col < D; ++col) { const double x = I[j * D + col]; I[j * D + col] = I[ip * D + col]; I[ip * D + col] = x; } const int x = perm[j]; perm[j] = perm[ip]; perm[ip] = x; }
+			const double ajj = I[j * D + j];
+			if (ajj != 0.0)
+				for (int i = j + 1; i < D; ++i) {
+					const double aij = I[i * D + j] / ajj;
+					I[i * D + j] = aij;
+					for (int col = j + 1; col < D; ++col) I[i * D + col] -= aij * I[j * D + col];
+				}
+		}
+		for (int col = 0; col < D; ++col) {
+			double x[LSQ_MAX_ISOFORMS - 1];
+			for (int i = 0; i < D; ++i) x[i] = perm[i] == col ? 1.0 : 0.0;
+			for (int i = 1; i < D; ++i) for (int cc = 0; cc < i; ++cc) x[i] -= I[i * D + cc] * x[cc];
+			for (int i = D - 1; i >= 0; --i) { for (int cc = i + 1; cc < D; ++cc) x[i] -= I[i * D + cc] * x[cc]; x[i] /= I[i * D + i]; }
+			for (int i = 0; i < D; ++i) { by_inv += x[i]; if (i == col) by_inv += x[i]; }     // sum of all entries plus the trace
+		}
+	}
+	double *v = A.var + ((size_t)m * A.n_events + e) * 2;
+	v[0] = by_diag; v[1] = by_inv;
+}
+
 } // namespace
 
 namespace lsq {
+
+int run_fim(lsq_ctx *c) {
+	const lsq_events &E = *c->E;
+	const unsigned n_ev = (unsigned)E.dev2out.size();
+	if (!n_ev) return LSQ_OK;
+	FimArgs A{};
+	A.n_events = n_ev; A.n_methods = (unsigned)E.n_methods; A.n_iso = E.n_iso_total;
+	A.K = c->dK.p; A.iso_base = c->iso_base.p; A.start_base = c->fim_start_base.p; A.mat_base = c->fim_mat_base.p;
+	A.starts = c->fim_starts.p; A.starts_total = c->fim_starts_total; A.mat_total = c->fim_mat_total;
+	A.theta = c->theta.p; A.G = c->G.p; A.fim = c->fim.p; A.var = c->fim_var.p;
+	const unsigned n = n_ev * (unsigned)E.n_methods;
+	hipLaunchKernelGGL(lsq_fim_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream_em, A);      // behind the solve
+	HIP_TRY(hipGetLastError());
+	return LSQ_OK;
+}
 
 int run_solve(lsq_ctx *c) {
 	const lsq_events &E = *c->E;

@@ -49,6 +49,9 @@ struct Event {
 	std::vector<uint64_t> iso_len;                 // total segment length per isoform
 	int64_t gene_start = 0, gene_end = 0;          // first start / last end of the merged exon list
 	std::vector<std::vector<uint64_t>> ars;        // [method][iso]
+	// [method][iso * n_cls + (class - 1)]: how many of the isoform's accessible read starts give a read of that
+	// compatibility class (fim.h's sum over generated reads, grouped; lsq_fim)
+	std::vector<std::vector<uint32_t>> fim_starts;
 	// name tie-break against "read-<n>" (count/count.cpp:71): 0 never less, 1 always less,
 	// 2 compare the decimal digits of n with `tail`
 	int tie_mode = 0;

@@ -25,6 +25,12 @@
  *   common/splicing_graph.h:318-361  isoform x segment array, lengths
  *   jdu_source_collection/jsc/util/interval_list.hpp:348-357,396-422,462-503
  *
+ *   common/fim.h:58-93,115-158,320-367, common/linalg.h:28-71 (with LSQO_FIM in the
+ *       environment only)  expected Fisher information and the variance estimates -- PARITY
+ *       UNPINNED: the reference never includes these headers, no binary prints these numbers,
+ *       and linalg.h's inverse is GSL 1.12's LU (un-vendored blob), restated from its
+ *       published algorithm
+ *
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off; x86-64 SSE2 doubles as the
  * reference's g++ -O2 build).
  */
@@ -798,6 +804,132 @@ typedef struct {
 	double *total_read_bases;
 } params_t;
 
+
+/* ------------------------------------------------------------------ FIM (fim.h, linalg.h)
+ * PARITY UNPINNED: no translation unit of the reference includes fim.h, no binary produces
+ * these numbers; what follows restates the header's arithmetic for the HIP path to be checked
+ * against (the expected Fisher information of theta_1..theta_{K-1} per read, and the two
+ * variance estimates made from it). */
+
+/* per-exon ARS lengths of one isoform (accessible_read_starts.h:48-89 MEDIUM, :221-274 SHORT with
+ * min_partial_exon_size = 0): in every exon the accessible starts are one interval [0, len) --
+ * SHORT: [0,max(l-R+1,0)) and [max(l-R,0),l+1) merge to [0,l+1) -- so only the lengths are kept;
+ * cum[] = iso_ARS_total_lengths */
+static void fim_ars_lengths(const gene_t *g, int k, unsigned long R, int short_read, unsigned long *cum) {
+	const int n = g->iso_n[k];
+	unsigned long total = 0, iso_length = 0, iso_total = 0;
+	for (int i = 0; i < n; i++) iso_total += g->exon_len[g->iso_idx[k][i]];
+	int i = 0;
+	for (; i < n; i++) {
+		const unsigned long l = g->exon_len[g->iso_idx[k][i]];
+		iso_length += l;
+		if (iso_length + R > iso_total) {
+			long v = (long)l + 1 - (long)(iso_length + R - iso_total);
+			total += (unsigned long)(v > 0 ? v : 0);
+			cum[i] = total;
+			for (int j = i + 1; j < n; j++) cum[j] = total;
+			return;
+		}
+		total += short_read ? l + 1 : l;          /* (an exon of length 0 cannot exist: segments are non-empty) */
+		cum[i] = total;
+	}
+}
+
+/* accessible_read_starts.h:131-182 with one interval [0, len) per exon */
+static unsigned long fim_ars_to_iso_start(const gene_t *g, int k, const unsigned long *ars_cum, unsigned long a) {
+	const int n = g->iso_n[k];
+	int e = 0;
+	while (e < n && !(ars_cum[e] > a)) e++;                    /* upper_bound */
+	unsigned long ars_before = e > 0 ? ars_cum[e - 1] : 0, exon_before = 0;
+	for (int i = 0; i < e; i++) exon_before += g->exon_len[g->iso_idx[k][i]];
+	return exon_before + (a - ars_before);
+}
+
+/* read.h:276-329 generate_read with a fixed start: the isoform's exons from the one that holds
+ * the start to the one that holds the last base */
+static void fim_generate_read(const gene_t *g, int k, unsigned long read_start, unsigned long R, int *idx, int *nidx) {
+	const int n = g->iso_n[k];
+	unsigned long cum[64]; unsigned long t = 0;
+	for (int i = 0; i < n; i++) { t += g->exon_len[g->iso_idx[k][i]]; cum[i] = t; }
+	const unsigned long read_end = read_start + R;
+	int se = 0; while (se < n && !(cum[se] > read_start)) se++;     /* upper_bound(read_start) */
+	int ee = 0; while (ee < n && cum[ee] < read_end) ee++;         /* lower_bound(read_end) */
+	*nidx = 0;
+	if (se >= n || ee >= n) return;                               /* the reference asserts */
+	for (int i = se; i <= ee; i++) idx[(*nidx)++] = g->iso_idx[k][i];
+}
+
+/* fim.h:320-367 ofim + :115-158 bruteforce_fim.  I is (K-1) x (K-1), row-major. */
+static void fim_bruteforce(const gene_t *g, const double *theta, const double *G, unsigned long R, int short_read, double *I) {
+	const int K = g->K, D = K - 1;
+	for (int i = 0; i < D * D; i++) I[i] = 0;
+	for (int k = 0; k < K; k++) {
+		if (theta[k] == 0) continue;
+		unsigned long ars_cum[64];
+		fim_ars_lengths(g, k, R, short_read, ars_cum);
+		const unsigned long ars_total = ars_cum[g->iso_n[k] - 1];
+		for (unsigned long a = 0; a < ars_total; a++) {
+			int idx[64], nidx;
+			fim_generate_read(g, k, fim_ars_to_iso_start(g, k, ars_cum, a), R, idx, &nidx);
+			if (nidx == 0) continue;
+			const double log_scaler = log(G[k]) + log(theta[k]);
+			double v[16];
+			for (int j = 0; j < K; j++) v[j] = lsqo_connected_compat(idx, nidx, g->iso_idx[j], g->iso_n[j]) >= 0 ? G[j] : 0.0;
+			double sum = 0;
+			for (int j = 0; j < K; j++) if (v[j] > 0 && theta[j] > 0) sum += theta[j] * v[j];
+			const double log_prod = log(sum) + log(sum);
+			for (int p = 0; p < D; p++)
+				for (int q = 0; q < D; q++) {
+					double m = (v[p] - v[K - 1]) * (v[q] - v[K - 1]);
+					if (m != 0) {
+						const int sign = m > 0 ? 1 : -1;
+						if (m < 0) m = -m;
+						m = log(m) - log_prod;
+						I[p * D + q] += sign > 0 ? exp(m + log_scaler) : -exp(m + log_scaler);
+					}
+				}
+		}
+	}
+}
+
+/* fim.h:64-72 */
+static double fim_var_by_diag(const double *I, int D) {
+	double sum = 0;
+	for (int p = 0; p < D; p++) sum += 1.0 / I[p * D + p];
+	return sum;
+}
+
+/* linalg.h:28-71: gsl_linalg_LU_decomp + gsl_linalg_LU_invert (GSL 1.12: Gaussian elimination with
+ * partial pivoting, then the columns of the identity solved one by one), and fim.h:74-93 */
+static double fim_var_by_inv(const double *I, int D) {
+	double A[25], inv[25]; int perm[5];
+	if (D == 0) return 0;
+	for (int i = 0; i < D * D; i++) A[i] = I[i];
+	for (int i = 0; i < D; i++) perm[i] = i;
+	for (int j = 0; j < D - 1; j++) {
+		double amax = fabs(A[j * D + j]); int ip = j;
+		for (int i = j + 1; i < D; i++) { const double a = fabs(A[i * D + j]); if (a > amax) { amax = a; ip = i; } }
+		if (ip != j) { for (int c = 0; c < D; c++) { const double t = A[j * D + c]; A[j * D + c] = A[ip * D + c]; A[ip * D + c] = t; } const int t = perm[j]; perm[j] = perm[ip]; perm[ip] = t; }
+		const double ajj = A[j * D + j];
+		if (ajj != 0.0)
+			for (int i = j + 1; i < D; i++) {
+				const double aij = A[i * D + j] / ajj;
+				A[i * D + j] = aij;
+				for (int c = j + 1; c < D; c++) A[i * D + c] -= aij * A[j * D + c];
+			}
+	}
+	for (int col = 0; col < D; col++) {
+		double x[5];
+		for (int i = 0; i < D; i++) x[i] = perm[i] == col ? 1.0 : 0.0;        /* P e_col */
+		for (int i = 1; i < D; i++) for (int c = 0; c < i; c++) x[i] -= A[i * D + c] * x[c];          /* L y = b (unit diagonal) */
+		for (int i = D - 1; i >= 0; i--) { for (int c = i + 1; c < D; c++) x[i] -= A[i * D + c] * x[c]; x[i] /= A[i * D + i]; }   /* U x = y */
+		for (int i = 0; i < D; i++) inv[i * D + col] = x[i];
+	}
+	double sum = 0;
+	for (int p = 0; p < D; p++) { for (int q = 0; q < D; q++) sum += inv[p * D + q]; sum += inv[p * D + p]; }
+	return sum;
+}
+
 /* optional exact side-output for tests: per (gene, method) supports and bases, per
  * (gene, iso) counts, theta, EM iterations -- filled when non-NULL */
 typedef struct {
@@ -811,6 +943,8 @@ typedef struct {
 	double *logll;
 	unsigned long *iters;
 	unsigned long n_loaded[16];
+	double **fim;                 /* [gene][M * (K-1)^2], filled when the environment has LSQO_FIM (parity unpinned) */
+	double **fim_var;             /* [gene][M * 2]: by_diag, by_inv */
 } exact_t;
 
 static void err_line(const char *msg) { fprintf(stderr, "[oracle ERROR] %s\n", msg); }
@@ -1040,6 +1174,8 @@ static int run(const params_t *P, sink *out, exact_t *ex) {
 		ex->theta = (double **)calloc((size_t)nsel + 1, sizeof(void *));
 		ex->logll = (double *)calloc((size_t)nsel + 1, sizeof(double));
 		ex->iters = (unsigned long *)calloc((size_t)nsel + 1, sizeof(unsigned long));
+		ex->fim = (double **)calloc((size_t)nsel + 1, sizeof(void *));
+		ex->fim_var = (double **)calloc((size_t)nsel + 1, sizeof(void *));
 	}
 	/* ---- per gene (count.cpp:369-497 / solve.cpp:668-852) */
 	for (int gi = 0; gi < nsel; gi++) {
@@ -1154,6 +1290,22 @@ static int run(const params_t *P, sink *out, exact_t *ex) {
 				else sink_str(out, "\t0\n");
 			}
 			if (ex) { for (int k = 0; k < K; k++) ex->theta[gi][k] = theta[k]; ex->logll[gi] = logll; ex->iters[gi] = iters; }
+			if (ex && getenv("LSQO_FIM") && K >= 1 && K <= 6) {
+				const int D = K - 1;
+				ex->fim[gi] = (double *)calloc((size_t)P->M * (size_t)(D * D) + 1, sizeof(double));
+				ex->fim_var[gi] = (double *)calloc((size_t)P->M * 2 + 1, sizeof(double));
+				for (int m = 0; m < P->M; m++) {
+					const int short_read = strcmp(P->read_types[m], "MEDIUM_READ") != 0;
+					double G[8];
+					for (int k = 0; k < K; k++) {
+						const unsigned long ars = lsqo_ars_total(g->exon_len, g->iso_idx[k], g->iso_n[k], P->exp_len[m], short_read);
+						G[k] = ars == 0 ? 0.0 : 1.0 / (double)ars;
+					}
+					fim_bruteforce(g, theta, G, P->exp_len[m], short_read, ex->fim[gi] + (size_t)m * (size_t)(D * D));
+					ex->fim_var[gi][2 * m] = fim_var_by_diag(ex->fim[gi] + (size_t)m * (size_t)(D * D), D);
+					ex->fim_var[gi][2 * m + 1] = fim_var_by_inv(ex->fim[gi] + (size_t)m * (size_t)(D * D), D);
+				}
+			}
 			free(theta); free(rpkm);
 		}
 		for (int m = 0; m < nmat; m++) free(mats[m].g);
@@ -1228,6 +1380,9 @@ double lsqo_exact_theta(const exact_t *e, int g, int k) { return e->theta[g][k];
 double lsqo_exact_logll(const exact_t *e, int g) { return e->logll[g]; }
 unsigned long lsqo_exact_iters(const exact_t *e, int g) { return e->iters[g]; }
 unsigned long lsqo_exact_n_loaded(const exact_t *e, int m) { return e->n_loaded[m]; }
+int lsqo_exact_has_fim(const exact_t *e, int g) { return e->fim && e->fim[g] != NULL; }
+double lsqo_exact_fim(const exact_t *e, int g, int m, int p, int q) { const int D = e->K[g] - 1; return e->fim[g][(size_t)m * (size_t)(D * D) + (size_t)(p * D + q)]; }
+double lsqo_exact_fim_var(const exact_t *e, int g, int m, int which) { return e->fim_var[g][2 * m + which]; }
 
 /* fine-grained helpers for unit parity tests */
 int lsqo_segments(const long *starts, const long *ends, int n, long *out_s, long *out_e, int cap) {

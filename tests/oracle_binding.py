@@ -22,6 +22,9 @@ for name, res, args in [
     ("lsqo_exact_logll", C.c_double, [C.c_void_p, C.c_int]),
     ("lsqo_exact_iters", C.c_ulong, [C.c_void_p, C.c_int]),
     ("lsqo_exact_n_loaded", C.c_ulong, [C.c_void_p, C.c_int]),
+    ("lsqo_exact_has_fim", C.c_int, [C.c_void_p, C.c_int]),
+    ("lsqo_exact_fim", C.c_double, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    ("lsqo_exact_fim_var", C.c_double, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
 ]:
     f = getattr(_o, name)
     f.restype = res
@@ -66,6 +69,10 @@ def run(tool, argv, n_methods=None):
                 "logll": _o.lsqo_exact_logll(ex, g) if is_solve else None,
                 "iters": _o.lsqo_exact_iters(ex, g) if is_solve else None,
             })
+            if is_solve and _o.lsqo_exact_has_fim(ex, g):      # LSQO_FIM in the environment (parity unpinned, fim.h)
+                D = K - 1
+                exact[-1]["fim"] = [[[_o.lsqo_exact_fim(ex, g, m, p, q) for q in range(D)] for p in range(D)] for m in range(M)]
+                exact[-1]["fim_var"] = [(_o.lsqo_exact_fim_var(ex, g, m, 0), _o.lsqo_exact_fim_var(ex, g, m, 1)) for m in range(M)]
     return rc, out, exact
 
 

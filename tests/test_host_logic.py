@@ -7,6 +7,7 @@ import re
 
 import pytest
 
+import numpy as np
 import lesseq_amd as L
 import oracle_binding as ob
 from test_oracle_golden import GOLD, CASES, load_case
@@ -236,3 +237,66 @@ def test_named_read_formats_group_lines_by_name(tmp_path, monkeypatch):
     for r in c["count"]:
         rc, text = L.cli_run("count", r["argv"])
         assert rc == r["exit"] == 1 and text == ""
+
+
+def test_oracle_fisher_information_against_a_direct_derivation(tmp_path, monkeypatch):
+    """fim.h restated in the oracle (parity unpinned) checked against the textbook form on the toy inputs: for K = 2,
+    I = sum over isoforms k and their accessible starts of theta_k G_k (dG_1 - dG_2)^2 / (sum_j theta_j dG_j)^2 with the
+    reads enumerated here position by position from the segment lengths (SHORT reads: a segment offers its length + 1
+    starts, the one past its end being the next segment's first)"""
+    monkeypatch.setenv("LSQO_FIM", "1")
+    c, d = load_case("toy", tmp_path)
+    monkeypatch.chdir(d)
+    r = [x for x in c["runs"] if x["tool"] == "solve" and x["exit"] == 0][0] if "runs" in c else None
+    if r is None:
+        from test_parity_gpu import runs
+        r = [x for t, x in runs(c) if t == "solve" and x["exit"] == 0][0]
+    argv = r["argv"]
+    rc, _, exact = ob.run("solve", argv)
+    assert rc == 0 and all("fim" in g for g in exact)
+    R = int(argv[11])
+    iso = parse_interval(argv[4])
+    g2i = {}
+    for line in open(argv[6]).read().split("\n")[:-1]:
+        g, i = line.split()
+        g2i.setdefault(g, []).append(i)
+    for g in exact:
+        if g["K"] != 2:
+            continue
+        forms = [iso[n] for n in g2i[g["gname"]]]
+        segs = ob.segments([x for f in forms for x in f])
+        member = [[any(s >= a and e <= b for a, b in f) for (s, e) in segs] for f in forms]
+        lens = [e - s for s, e in segs]
+        th = g["theta"]
+        reads = []           # (isoform, tuple of segment indices)
+        G = []
+        for k in range(2):
+            mine = [n for n in range(len(segs)) if member[k][n]]
+            L = sum(lens[n] for n in mine)
+            starts = []
+            cum = 0
+            for i, n in enumerate(mine):
+                cum += lens[n]
+                if cum + R > L:
+                    starts += [cum - lens[n] + o for o in range(max(lens[n] + 1 - (cum + R - L), 0))]
+                    break
+                starts += [cum - lens[n] + o for o in range(lens[n] + 1)]
+            G.append(1.0 / len(starts) if starts else 0.0)
+            ends = np.cumsum([lens[n] for n in mine])
+            for s0 in starts:
+                se = int(np.searchsorted(ends, s0, side="right"))
+                ee = int(np.searchsorted(ends, s0 + R, side="left"))
+                reads.append((k, tuple(mine[se:ee + 1])))
+        info = 0.0
+        for k, run in reads:
+            comp = []
+            for j in range(2):
+                mine = [n for n in range(len(segs)) if member[j][n]]
+                comp.append(any(tuple(mine[a:a + len(run)]) == run for a in range(len(mine))))
+            dG = [G[j] if comp[j] else 0.0 for j in range(2)]
+            s_ = sum(th[j] * dG[j] for j in range(2) if dG[j] > 0 and th[j] > 0)
+            if th[k] != 0:
+                info += th[k] * G[k] * (dG[0] - dG[1]) ** 2 / s_ ** 2
+        assert abs(info - g["fim"][0][0][0]) <= 1e-9 * abs(info), (g["gname"], info, g["fim"])
+        assert abs(g["fim_var"][0][0] - 1.0 / info) <= 1e-9 / info
+        assert abs(g["fim_var"][0][1] - 2.0 / info) <= 1e-9 / info       # fim.h:74-93: all entries of the inverse plus its trace

@@ -31,7 +31,7 @@ def test_cli_matches_reference_golden(name, tmp_path, monkeypatch):
             assert ob.solve_text_close(text, exp), (name, r["argv"], text, exp)
 
 
-def gpu_exact(argv, tool="solve"):
+def gpu_exact(argv, tool="solve", want_fim=False):
     """runs the library pipeline step by step; returns per-gene dicts like the oracle's exact output"""
     per = 5 if tool == "solve" else 4
     groups = [argv[9 + i * per: 9 + (i + 1) * per] for i in range((len(argv) - 9) // per)]
@@ -61,6 +61,12 @@ def gpu_exact(argv, tool="solve"):
             "iters": int(iters[i]), "flags": int(flags[i]),
         })
         io += K
+    if want_fim:
+        foff, fim, vd, vi = ctx.fim()
+        for i, g in enumerate(out):
+            D = g["K"] - 1
+            g["fim"] = [fim[m, int(foff[i]):int(foff[i + 1])].reshape(D, D).tolist() for m in range(len(groups))]
+            g["fim_var"] = [(float(vd[m, i]), float(vi[m, i])) for m in range(len(groups))]
     ctx.close()
     return out
 
@@ -570,3 +576,39 @@ def test_example_host_prints_the_reference_solve_table(name, tmp_path, monkeypat
         assert ob.solve_text_close(p.stdout, open(os.path.join(d, r["stdout"])).read()), (name, a)
         n += 1
     assert n >= 1
+
+
+@pytest.mark.parametrize("name", ["toy", "events_s1", "events_s2", "multi_method", "wild_s11", "wild_s12", "wild_s13", "quirks"])
+def test_fisher_information_and_variances_vs_oracle(name, tmp_path, monkeypatch):
+    """lsq_fim (fim.h / linalg.h -- dead code in the reference, parity unpinned): the HIP path's class-grouped sum
+    against the oracle's restatement of bruteforce_fim / ofim / the two variance estimates, on the golden inputs'
+    solve runs: matrices to 1e-9 relative, variances likewise where the matrix is well conditioned"""
+    monkeypatch.setenv("LSQO_FIM", "1")
+    c, d = load_case(name, tmp_path)
+    monkeypatch.chdir(d)
+    checked = 0
+    for tool, r in runs(c):
+        if tool != "solve" or r["exit"] != 0:
+            continue
+        rc, _, exact = ob.run("solve", r["argv"])
+        assert rc == 0
+        got = gpu_exact(r["argv"], want_fim=True)
+        assert len(got) == len(exact)
+        for g, e in zip(got, exact):
+            assert g["gname"] == e["gname"] and g["K"] == e["K"]
+            if g["K"] > 6 or "fim" not in e:
+                continue
+            if any(abs(a - b) > 1e-9 * max(abs(a), abs(b)) for a, b in zip(g["theta"], e["theta"])):
+                continue                  # (an event whose EM was flagged: another theta, another matrix)
+            for m in range(len(e["fim"])):
+                A, B = np.array(g["fim"][m], float).reshape(-1), np.array(e["fim"][m], float).reshape(-1)
+                scale = max(np.abs(B).max(), 1e-300) if B.size else 1.0
+                assert np.all(np.abs(A - B) <= 1e-9 * scale), (name, g["gname"], m, A, B)
+                for w in (0, 1):
+                    a, b = g["fim_var"][m][w], e["fim_var"][m][w]
+                    if np.isfinite(b) and abs(b) < 1e12:
+                        assert abs(a - b) <= 1e-7 * max(abs(b), 1e-300), (name, g["gname"], m, w, a, b)
+                    else:
+                        assert not np.isfinite(a) or abs(a) >= 1e11 or (not np.isfinite(b)), (name, g["gname"], m, w, a, b)
+                checked += 1
+    assert checked >= 1
