@@ -174,6 +174,11 @@ int run_count_solve(bool solve, int argc, const char *const *argv, std::string &
 		     solve ? "solve" : "count", solve ? " total_read_bases" : "");
 		return 1;
 	};
+	// Extension (not in the reference, whose fim.h is dead code): `solve ... --fim` after the last read file
+	// appends, behind the table, one `#fim` line per event and read file with fim.h's two variance estimates and the
+	// expected Fisher information matrix (lsq_fim; parity unpinned).  The table itself does not change.
+	bool want_fim = false;
+	if (solve && argc > 15 && strcmp(argv[argc - 1], "--fim") == 0) { want_fim = true; --argc; }
 	if (argc < (solve ? 15 : 14)) return usage();
 	long lvl;
 	if (!cast_long(argv[1], lvl)) return EXIT_ABORT;      // lexical_cast outside the try block (count/count.cpp:99)
@@ -297,6 +302,24 @@ int run_count_solve(bool solve, int argc, const char *const *argv, std::string &
 	if (st || !text) { logf(0, "%s", lsq_last_error()); return 2; }
 	out.assign(text);
 	free(text);
+	if (want_fim) {
+		if (lsq_fim(F.c)) { logf(0, "%s", lsq_last_error()); return 3; }
+		std::vector<uint64_t> off((size_t)n_ev + 1);
+		lsq_results_fim_offsets(F.c, off.data());
+		const size_t total = (size_t)off[(size_t)n_ev];
+		std::vector<double> fim(std::max<size_t>((size_t)M * total, 1)), vd(std::max<size_t>((size_t)M * (size_t)n_ev, 1)), vi(vd.size());
+		if (lsq_results_fim(F.c, fim.data(), vd.data(), vi.data())) { logf(0, "%s", lsq_last_error()); return 3; }
+		char buf[64];
+		auto num = [&](double v) { snprintf(buf, sizeof buf, "%.17g", v); out += buf; };
+		for (int64_t i = 0; i < n_ev; ++i)
+			for (int m = 0; m < M; ++m) {
+				out += "#fim\t"; out += lsq_events_gene_name(F.e, i); out += "\t";
+				snprintf(buf, sizeof buf, "%d", m); out += buf; out += "\t";
+				num(vd[(size_t)m * (size_t)n_ev + (size_t)i]); out += "\t"; num(vi[(size_t)m * (size_t)n_ev + (size_t)i]);
+				for (uint64_t q = off[(size_t)i]; q < off[(size_t)i + 1]; ++q) { out += "\t"; num(fim[(size_t)m * total + (size_t)q]); }
+				out += "\n";
+			}
+	}
 	T.mark("format rows");
 	logf(2, "Processed %lld genes... Done", (long long)n_ev);
 	return 0;

@@ -20,6 +20,8 @@ first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 t0 = time.time()
 bad, flagged, refused = [], 0, 0
+FIM = os.environ.get("LSQO_FIM") is not None      # also lsq_fim against the oracle's fim.h restatement
+fim_checked = 0
 for seed in range(first, first + n):
     d = tempfile.mkdtemp(prefix="lsq_fuzz_%d_" % seed, dir="/tmp")
     try:
@@ -43,7 +45,18 @@ for seed in range(first, first + n):
             assert rc_lib != 0, "oracle rc %d but the library ran" % rc
             refused += 1
             continue
-        flagged += compare_exact(gpu_exact(argv), exact, "seed %d" % seed)
+        got = gpu_exact(argv, want_fim=FIM)
+        flagged += compare_exact(got, exact, "seed %d" % seed)
+        if FIM:
+            import numpy as np
+            for g, e in zip(got, exact):
+                if "fim" not in e or any(abs(a - b) > 1e-9 * max(abs(a), abs(b)) for a, b in zip(g["theta"], e["theta"])):
+                    continue
+                for m in range(len(e["fim"])):
+                    A, B = np.array(g["fim"][m], float).reshape(-1), np.array(e["fim"][m], float).reshape(-1)
+                    scale = max(np.abs(B).max(), 1e-300) if B.size else 1.0
+                    assert np.all(np.abs(A - B) <= 1e-9 * scale), "fim %s method %d" % (g["gname"], m)
+                    fim_checked += 1
         cargv = argv[:9] + [x for g in range((len(argv) - 9) // 5) for x in argv[9 + 5 * g:9 + 5 * g + 4]]     # count takes no total_read_bases
         rc, text = L.cli_run("count", cargv)
         rc2, ctext, _ = ob.run("count", cargv)
@@ -57,6 +70,8 @@ for seed in range(first, first + n):
     if (seed - first) % 50 == 49:
         print("  ... %d seeds, %d failures, %.0f s" % (seed - first + 1, len(bad), time.time() - t0), flush=True)
 print("seeds %d..%d: %d failures, %d inputs refused by both, %d events flagged by the EM guard band, %.0f s" % (first, first + n - 1, len(bad), refused, flagged, time.time() - t0))
+if FIM:
+    print("fisher information matrices compared: %d" % fim_checked)
 for b in bad[:20]:
     print("  FAIL seed %d: %s" % b)
 sys.exit(1 if bad else 0)

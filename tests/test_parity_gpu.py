@@ -612,3 +612,32 @@ def test_fisher_information_and_variances_vs_oracle(name, tmp_path, monkeypatch)
                         assert not np.isfinite(a) or abs(a) >= 1e11 or (not np.isfinite(b)), (name, g["gname"], m, w, a, b)
                 checked += 1
     assert checked >= 1
+
+
+def test_solve_fim_extension_keeps_the_table_and_appends_the_matrices(tmp_path, monkeypatch):
+    """`solve ... --fim` (an extension: the reference's fim.h is dead code): the table is the one without the flag, the
+    `#fim` lines behind it carry what lsq_results_fim returns; `count` does not know the flag"""
+    monkeypatch.setenv("LSQO_FIM", "1")
+    c, d = load_case("multi_method", tmp_path)
+    monkeypatch.chdir(d)
+    r = [x for t, x in runs(c) if t == "solve" and x["exit"] == 0][0]
+    rc0, plain = L.cli_run("solve", r["argv"])
+    rc1, with_fim = L.cli_run("solve", r["argv"] + ["--fim"])
+    assert rc0 == rc1 == 0 and with_fim.startswith(plain)
+    extra = with_fim[len(plain):].split("\n")[:-1]
+    rc, _, exact = ob.run("solve", r["argv"])
+    M = len(exact[0]["supports"])
+    assert len(extra) == len(exact) * M and all(x.startswith("#fim\t") for x in extra)
+    by_gene = {g["gname"]: g for g in exact}
+    for line in extra:
+        t = line.split("\t")
+        g, m = by_gene[t[1]], int(t[2])
+        D = g["K"] - 1
+        vals = [float(x) for x in t[3:]]
+        assert len(vals) == 2 + D * D
+        ref = [g["fim_var"][m][0], g["fim_var"][m][1]] + [x for row in g["fim"][m] for x in row]
+        for a, b in zip(vals, ref):
+            if np.isfinite(b) and abs(b) < 1e12:
+                assert abs(a - b) <= 1e-7 * max(abs(b), 1e-300), (line, ref)
+    rc, text = L.cli_run("count", [x for i, x in enumerate(r["argv"]) if i < 9 or (i - 9) % 5 != 4] + ["--fim"])
+    assert rc == 1                      # the reference's usage error: an incomplete read group
