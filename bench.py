@@ -214,6 +214,11 @@ def main():
         if world == 1 and os.path.exists(tpath):
             traffic = json.load(open(tpath)).get("count_fast_kernel_hbm_bytes_per_launch")
             traffic_src = "profiles/r01_traffic_%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; 2 x FETCH_SIZE + WRITE_SIZE)" % a.workload
+        # what a plain streaming read of the same number of bytes reaches on this device (state both ceilings)
+        import ctypes as C
+        L.lib.lsq_debug_stream_read_rate.argtypes = [C.c_void_p, C.c_ulonglong, C.POINTER(C.c_double)]
+        rate = C.c_double(0.0)
+        plain_read = rate.value if L.lib.lsq_debug_stream_read_rate(ctx.h, int(max(alg_bytes, 1 << 26)), C.byref(rate)) == 0 else None
         out = {
             "metric": "MRF reads/sec through count+solve",
             "value": total_retained * a.steps / elapsed,
@@ -246,6 +251,7 @@ def main():
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 # the same kernel on an otherwise idle device (steps synchronised one by one, no EM beside it)
                 "frac_alone": alg_bytes / (float(np.mean(alone_fast_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "plain_read_GBps_this_device": plain_read, "frac_of_plain_read": (achieved / plain_read if plain_read else None),
                 "traffic": traffic,
                 "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": alg_bytes,

@@ -27,6 +27,10 @@ int lsq_debug_slot_offsets(lsq_ctx *c, int method, unsigned long long *out, unsi
  * (tests/test_parity_gpu.py::test_em_numbers_do_not_depend_on_which_events_share_a_wave). */
 int lsq_debug_set_em_order(lsq_ctx *c, const uint32_t *order, unsigned n_small_places, unsigned n_places);
 
+/* The rate a plain streaming read of `bytes` of device memory reaches on this device, in GB/s (best launch over
+ * eight grid / unroll combinations): the practical ceiling bench.py reports beside the nominal HBM peak. */
+int lsq_debug_stream_read_rate(lsq_ctx *c, unsigned long long bytes, double *gb_per_s);
+
 #ifdef __cplusplus
 }
 #endif

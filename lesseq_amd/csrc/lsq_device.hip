@@ -433,6 +433,60 @@ int lsq_results_device_order(const lsq_ctx *c, int32_t *dev2out) {
 	return LSQ_OK;
 }
 
+extern "C++" {
+namespace {
+// plain streaming read: every lane 16 bytes per load, UNROLL loads in flight, grid-stride
+template <int UNROLL>
+__global__ void __launch_bounds__(256) lsq_read_rate_kernel(const uint4 *src, size_t n_words, unsigned *sink) {
+	const size_t gsz = (size_t)gridDim.x * blockDim.x;
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	unsigned acc = 0;
+	for (; i + (UNROLL - 1) * gsz < n_words; i += UNROLL * gsz) {
+		uint4 v[UNROLL];
+#pragma unroll
+		for (int k = 0; k < UNROLL; ++k) v[k] = src[i + k * gsz];
+#pragma unroll
+		for (int k = 0; k < UNROLL; ++k) acc ^= v[k].x ^ v[k].y ^ v[k].z ^ v[k].w;
+	}
+	for (; i < n_words; i += gsz) { const uint4 v = src[i]; acc ^= v.x ^ v.y ^ v.z ^ v.w; }
+	if (acc == 0x12345678u) *sink = acc;
+}
+} // namespace
+} // extern "C++"
+
+// developer aid (include/lesseq_hip_dev.h): what a plain read of `bytes` of HBM reaches on this device (GB/s, best launch over
+// eight grid / unroll combinations) -- the practical ceiling bench.py prints beside the 8 TB/s peak
+int lsq_debug_stream_read_rate(lsq_ctx *c, unsigned long long bytes, double *gb_per_s) {
+	if (!c || !gb_per_s || bytes < (1ull << 20)) return fail(LSQ_E_ARG, "bad argument");
+	HIP_TRY(hipSetDevice(c->device));
+	{ int rc = sync_all(c); if (rc) return rc; }
+	lsq::DevBuf<uint4> buf;
+	lsq::DevBuf<unsigned> sink;
+	const size_t n_words = (size_t)(bytes / 16);
+	int rc;
+	if ((rc = buf.alloc(n_words)) || (rc = sink.alloc(1))) return rc;
+	HIP_TRY(hipMemsetAsync(buf.p, 1, n_words * 16, c->stream));
+	hipEvent_t a, b;
+	HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
+	float best = 1e30f;
+	for (int cfg = 0; cfg < 8; ++cfg) {                 // workgroups per CU x loads in flight: the best combination counts
+		const unsigned grid = (unsigned)c->n_cu * (4u << (cfg & 3));
+		for (int it = 0; it < 6; ++it) {
+			HIP_TRY(hipEventRecord(a, c->stream));
+			if (cfg < 4) hipLaunchKernelGGL(lsq_read_rate_kernel<4>, dim3(grid), dim3(256), 0, c->stream, buf.p, n_words, sink.p);
+			else hipLaunchKernelGGL(lsq_read_rate_kernel<8>, dim3(grid), dim3(256), 0, c->stream, buf.p, n_words, sink.p);
+			HIP_TRY(hipEventRecord(b, c->stream));
+			HIP_TRY(hipEventSynchronize(b));
+			float ms = 0;
+			HIP_TRY(hipEventElapsedTime(&ms, a, b));
+			if (it >= 1) best = std::min(best, ms);
+		}
+	}
+	(void)hipEventDestroy(a); (void)hipEventDestroy(b);
+	*gb_per_s = (double)(n_words * 16) / ((double)best * 1e-3) / 1e9;
+	return LSQ_OK;
+}
+
 // developer aid (include/lesseq_hip_dev.h): another placement of the events in the EM grid (experiments on wave make-up)
 int lsq_debug_set_em_order(lsq_ctx *c, const uint32_t *order, unsigned n_small_places, unsigned n_places) {
 	HIP_TRY(hipSetDevice(c->device));
