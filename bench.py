@@ -276,6 +276,26 @@ def main():
                 "sample": "first %d MRF reads of the same stream (%d retained) over the same %d events; oracle count+solve "
                           "from MRF text incl. parse, filter and index, single thread, %.1f s" % (ns, ob.last_n_loaded[0], W["n_events"], dt),
             }
+            # the reference's own scale-out on the host's cores: one process per slice of the sorted gene list
+            # (gene_begin_idx..gene_end_idx, count/count.cpp:204-215), each reading the whole file; wall-clock of the slowest
+            import subprocess
+            P = max(1, min(os.cpu_count() or 1, 16))
+            child = ("import sys,time; sys.path.insert(0, %r); import oracle_binding as ob; a = sys.argv[1:]; t0 = time.perf_counter(); "
+                     "rc, _, _ = ob.run('solve', a); print(rc, time.perf_counter() - t0)") % os.path.join(ROOT, "tests")
+            t0 = time.perf_counter()
+            procs = []
+            for p_ in range(P):
+                av = list(argv)
+                av[7], av[8] = str(W["n_events"] * p_ // P), str(W["n_events"] * (p_ + 1) // P)
+                procs.append(subprocess.Popen([sys.executable, "-c", child] + av, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True))
+            outs = [q.communicate()[0].split() for q in procs]
+            dt_all = time.perf_counter() - t0
+            if all(len(o) == 2 and o[0] == "0" for o in outs):
+                out["cpu_baseline"]["all_cores"] = {
+                    "value": ob.last_n_loaded[0] / dt_all, "unit": "reads/s", "cores": P,
+                    "how": "%d oracle processes over disjoint gene_begin_idx..gene_end_idx slices of the same sample (each parses the whole "
+                           "file, as the reference's own scale-out does), wall-clock %.1f s" % (P, dt_all),
+                }
         print(json.dumps(out))
     ctx.close()
     if world > 1:
