@@ -237,6 +237,12 @@ def test_empty_and_degenerate_inputs(tmp_path, monkeypatch):
         rc, text = L.cli_run("solve", argv + ["1000"])
         orc, otext, _ = ob.run("solve", argv + ["1000"])
         assert rc == orc and ob.solve_text_close(text, otext), (lo, hi, mrf)
+        # the --fim extension on the same degenerate inputs: the table, then one finite-or-inf line per event and read file
+        rc2, text2 = L.cli_run("solve", argv + ["1000", "--fim"])
+        assert rc2 == rc and text2.startswith(text)
+        n_rows = len([x for x in text.split("\n") if x])
+        extra = [x for x in text2[len(text):].split("\n") if x]
+        assert all(x.startswith("#fim\t") for x in extra) and len(extra) * 2 == n_rows      # the toy events have two isoforms each
 
 
 def _random_gene_set(rng, n_genes, max_exons, max_iso, chroms=("c1", "c2"), spacing=4000):
