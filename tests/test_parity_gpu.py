@@ -647,3 +647,72 @@ def test_solve_fim_extension_keeps_the_table_and_appends_the_matrices(tmp_path, 
                 assert abs(a - b) <= 1e-7 * max(abs(b), 1e-300), (line, ref)
     rc, text = L.cli_run("count", [x for i, x in enumerate(r["argv"]) if i < 9 or (i - 9) % 5 != 4] + ["--fim"])
     assert rc == 1                      # the reference's usage error: an incomplete read group
+
+
+def test_redo_pass_over_every_read_gives_the_same_tables(tmp_path, monkeypatch):
+    """when the exception list overflows the counts are redone by the cleanup kernel over every read (checked at
+    result fetch); LSQ_FORCE_REDO takes that path without an overflow: same integers, same theta, also when further
+    steps were submitted behind the one that is fetched"""
+    spec = L.SynthSpec(91, 3000, 400000, 100, 3, L.EVENT_TYPES)
+    L.synth_write(spec, str(tmp_path), "r", write_mrf=False)
+    ann = L.Annotation(str(tmp_path / "r.interval"), str(tmp_path / "r.map"))
+    ev = L.Events(ann, ("SHORT_READ",), (100,))
+    ctx = L.Context(0)
+    ctx.upload_events(ev)
+    ctx.upload_reads(0, L.Reads.synthetic(spec, ev))
+    ctx.count(); ctx.solve()
+    cnt0, bases0 = [x.copy() for x in ctx.counts()]
+    sol0 = [x.copy() for x in ctx.solution()]
+    monkeypatch.setenv("LSQ_FORCE_REDO", "1")
+    for steps in (1, 3):
+        for _ in range(steps):
+            ctx.count(); ctx.solve()
+        cnt1, bases1 = ctx.counts()
+        sol1 = ctx.solution()
+        assert np.array_equal(cnt0, cnt1) and np.array_equal(bases0, bases1)
+        assert np.array_equal(sol0[0], sol1[0]) and np.array_equal(sol0[1], sol1[1], equal_nan=True) and np.array_equal(sol0[2], sol1[2])
+    ctx.close()
+
+
+def test_exception_list_overflow_is_noticed_and_redone(tmp_path, monkeypatch):
+    """an exception list that is too small (LSQ_EXC_CAP = 1, a developer switch) overflows on an input full of reads
+    that cover an event's span exactly (the strand/name order decides, count/count.cpp:64-85); the fetch notices the
+    flag and redoes the pass over every read: the oracle's tables still come out"""
+    import ctypes as C
+    import golden_inputs as gi
+    info = gi.write_events_case(str(tmp_path), "x", seed=77, n_events=40, n_reads=3000, R=60, n_chrom=2)
+    lines = open(tmp_path / "x.mrf").read().split("\n")
+    extra = []
+    for e in info["events"]:
+        gs = min(f[0][0] for f in e["forms"]); ge = max(f[-1][1] for f in e["forms"])
+        for strand in ("+", "-", e["strand"]):
+            extra.append("%s:%s:%d:%d:1:%d" % (e["chrom"], strand, gs + 1, ge, ge - gs))
+    with open(tmp_path / "x.mrf", "w") as f:
+        f.write("\n".join(lines[:-1] + extra) + "\n")
+    argv = ["0", "x", "./", "LH_GENE_TXT", str(tmp_path / "x.interval"), "UCSC_GENE2ISOFORM", str(tmp_path / "x.map"), "0", "1000",
+            "MRF_SINGLE", "SHORT_READ", "60", str(tmp_path / "x.mrf")]
+    orc, otext, _ = ob.run("count", argv)
+    orc2, otext2, _ = ob.run("solve", argv + ["200000"])
+    assert orc == 0 and orc2 == 0
+    for cap in ("1", "7", None):
+        if cap is None:
+            monkeypatch.delenv("LSQ_EXC_CAP")
+        else:
+            monkeypatch.setenv("LSQ_EXC_CAP", cap)
+        rc, text = L.cli_run("count", argv)
+        assert rc == 0 and text == otext, cap
+        rc, text = L.cli_run("solve", argv + ["200000"])
+        assert rc == 0 and ob.solve_text_close(text, otext2), cap
+    # the input does raise more exceptions than such a list holds
+    monkeypatch.setenv("LSQ_EXC_CAP", "7")
+    ann = L.Annotation(argv[4], argv[6], 0, 1000)
+    ev = L.Events(ann, ("SHORT_READ",), (60,))
+    ctx = L.Context(0)
+    ctx.upload_events(ev)
+    ctx.upload_reads(0, L.Reads.from_mrf(argv[12], ev))
+    ctx.count()
+    buf = (C.c_ulonglong * 8)()
+    L.lib.lsq_debug_counters.argtypes = [C.c_void_p, C.c_void_p]
+    assert L.lib.lsq_debug_counters(ctx.h, buf) == 0
+    assert buf[4] > 7, int(buf[4])
+    ctx.close()
