@@ -214,9 +214,13 @@ int lsq_solve(lsq_ctx *c);
  * class_off[ev] + c - 1 where class_off is the exclusive prefix sum of (2^K - 1).
  *   class_count[m * n_classes + slot], class_bases[...]: uint64
  *   theta[iso_off[ev] + j], logll[ev], em_iters[ev], em_flags[ev]
- * em_flags bit 0: the stop criterion |1 - old_ll/ll| came within 1e-11 (relative 1e-5) of
- * the 1e-6 threshold at some iteration, so a different summation order could stop one
- * iteration earlier or later. */
+ * em_flags bit 0: the stop criterion |1 - old_ll/ll| came within the guard band (1e-11 unless
+ * lsq_set_em_guard_band changed it) of the 1e-6 threshold at some iteration, so the kernel's sums over
+ * compatibility classes could stop an iteration apart from the reference's sums over reads.  Such an event
+ * is solved again in the reference's own order -- its valid reads in index order (count/count.cpp:64-85),
+ * per-read sums as common/read.h:592-660 forms them, IEEE fp64, libm's log, on the host -- by
+ * lsq_solve_finalize, which lsq_results_solve runs first; bit 2 (value 4) marks an event whose numbers
+ * come from that replay.  bit 1: the iteration cap was reached. */
 int64_t lsq_results_num_classes(const lsq_ctx *c);
 int lsq_results_class_offsets(const lsq_ctx *c, uint64_t *class_off /* n_events+1 */);
 int lsq_results_counts(lsq_ctx *c, uint64_t *class_count, uint64_t *class_bases);
@@ -224,6 +228,16 @@ int lsq_results_counts(lsq_ctx *c, uint64_t *class_count, uint64_t *class_bases)
  * sums over several processes that each counted a slice of the reads); lsq_solve then runs on them. */
 int lsq_results_set_counts(lsq_ctx *c, const uint64_t *class_count, const uint64_t *class_bases);
 int lsq_results_solve(lsq_ctx *c, double *theta, double *logll, uint32_t *em_iters, uint8_t *em_flags);
+/* The exact-order replay on its own, for callers that take the results through lsq_results_copy_device:
+ * waits for the latest lsq_solve, redoes every flagged event as described above and writes theta, logll,
+ * iteration count and flag bit 2 back to the device arrays; *n_replayed (may be NULL) = events redone.
+ * Events of counts that came from lsq_results_set_counts are left as they are (the reads behind such sums
+ * are not all on this device).  common/read.h:592-660, solve/solve.cpp:720-748,767-806. */
+int lsq_solve_finalize(lsq_ctx *c, uint32_t *n_replayed);
+/* Width of the band around the 1e-6 stop threshold (common/read.h:659) inside which an event is flagged
+ * and replayed; default 1e-11, i.e. ~100x the difference between the two summation orders.  A wider band
+ * replays more events (1.0: every event with an EM loop), never changes which result is right. */
+int lsq_set_em_guard_band(lsq_ctx *c, double band);
 
 /* Optional: the expected Fisher information of theta_1..theta_{K-1} per read at the solved theta,
  * and the two variance estimates made from it -- common/fim.h:115-158,320-367 (bruteforce_fim / ofim:

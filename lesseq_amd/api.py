@@ -238,6 +238,16 @@ class Context:
     def solve(self):
         check(lib.lsq_solve(self.h))
 
+    def set_em_guard_band(self, band):
+        """events whose EM stop test comes within `band` of its threshold are replayed in the reference's per-read order"""
+        check(lib.lsq_set_em_guard_band(self.h, float(band)))
+
+    def solve_finalize(self):
+        """the exact-order replay of flagged events on its own; returns how many were redone"""
+        n = u32()
+        check(lib.lsq_solve_finalize(self.h, C.byref(n)))
+        return n.value
+
     def synchronize(self):
         check(lib.lsq_ctx_synchronize(self.h))
 

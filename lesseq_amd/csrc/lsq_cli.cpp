@@ -296,7 +296,8 @@ int run_count_solve(bool solve, int argc, const char *const *argv, std::string &
 		st = lsq_results_solve(F.c, theta.data(), ll.data(), nullptr, flags.data());
 		if (st) { logf(0, "%s", lsq_last_error()); return 3; }
 		for (int64_t i = 0; i < n_ev; ++i)
-			if (flags[i] & 1) logf(1, "gene %s: EM stop criterion within 1e-11 of its threshold; a per-read summation order could stop one iteration apart", lsq_events_gene_name(F.e, i));
+			if (flags[i] & 4) logf(3, "gene %s: EM stop criterion within the guard band of its threshold; solved again in per-read summation order", lsq_events_gene_name(F.e, i));
+			else if (flags[i] & 1) logf(1, "gene %s: EM stop criterion within the guard band of its threshold and no exact-order replay was possible", lsq_events_gene_name(F.e, i));
 		st = lsq_format_solve(F.e, M, cnt.data(), bases.data(), theta.data(), ll.data(), trb.data(), &text);
 	}
 	if (st || !text) { logf(0, "%s", lsq_last_error()); return 2; }

@@ -197,6 +197,7 @@ int lsq_count(lsq_ctx *c) {
 	c->counted = true;
 	c->solved = false;
 	c->redo_checked = false;
+	c->counts_external = false;
 	return LSQ_OK;
 }
 
@@ -357,6 +358,7 @@ int lsq_results_set_counts(lsq_ctx *c, const uint64_t *class_count, const uint64
 		HIP_TRY(hipStreamSynchronize(c->stream));
 	}
 	c->counted = true; c->solved = false; c->redo_checked = true;
+	c->counts_external = true;
 	return LSQ_OK;
 }
 
@@ -365,6 +367,7 @@ int lsq_results_solve(lsq_ctx *c, double *theta, double *logll, uint32_t *em_ite
 	if (!c->solved) return fail(LSQ_E_STATE, "lsq_solve must come first");
 	HIP_TRY(hipSetDevice(c->device));
 	{ int rc = ensure_counts_complete(c); if (rc) return rc; }
+	{ int rc = replay_flagged(c, nullptr); if (rc) return rc; }      // guard-band events: the reference's per-read summation order
 	const lsq_events &E = *c->E;
 	const size_t n_ev = E.dev2out.size(), n_iso = E.n_iso_total;
 	std::vector<double> ht(std::max<size_t>(n_iso, 1)), hl(std::max<size_t>(n_ev, 1));

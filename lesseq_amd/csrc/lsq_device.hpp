@@ -129,6 +129,8 @@ struct lsq_ctx {
 	bool redo_checked = true;
 	MethodReads reads[LSQ_MAX_METHODS];
 	bool counted = false, solved = false;
+	bool counts_external = false;           // lsq_results_set_counts: the counts are sums the reads here do not explain
+	double em_band = 1E-11;                 // lsq_set_em_guard_band: events whose stop test comes this close to its threshold are replayed
 	bool has_fast = false, has_generic = false;
 	float count_ms = 0, solve_ms = 0;
 	float mrf_h2d_ms = 0, mrf_parse_ms = 0;
@@ -153,5 +155,6 @@ int ensure_counts_complete(lsq_ctx *c);              // lsq_count.hip: redo over
 int run_solve(lsq_ctx *c);
 int run_fim(lsq_ctx *c);
 int sync_all(lsq_ctx *c);                 // both streams
+int replay_flagged(lsq_ctx *c, unsigned *n_done);    // lsq_replay.hip: the EM of guard-band events in the reference's per-read order
 void select_counter_set(lsq_ctx *c, int set);                           // lsq_em.hip
 } // namespace lsq

@@ -8,6 +8,7 @@ struct EmArgs {
 	unsigned n_events, n_methods, n_cls, n_iso;
 	unsigned n_places;                 // entries of `order` this launch covers: [place0, n_places)
 	unsigned place0;
+	double band;                       // guard band around the 1e-6 stop threshold (lsq_set_em_guard_band)
 	unsigned max_iters;                // read.h has no cap; 1000000 flags the event (developer switch LSQ_EM_CAP lowers it for timing experiments)
 	const unsigned *order;             // device event per place of the EM grid
 	const unsigned char *K;
@@ -252,7 +253,7 @@ __device__ inline void em_lean(const EmArgs &A, const EmCache &C, const unsigned
 		for (int j = 0; j < KK; ++j) { t3[j] = go ? c3[j] : t3[j]; z3[j] = go ? cz3[j] : z3[j]; }
 		ll = go ? cll : ll;
 		iters += go ? 1u : 0u;
-		if (go && fabs(crit - 1E-6) < 1E-11) flag |= 1;
+		if (go && fabs(crit - 1E-6) < A.band) flag |= 1;
 		if (go && !(crit > 1E-6)) run = false;
 		else if (go && iters >= A.max_iters) { flag |= 2; run = false; }
 #pragma unroll
@@ -349,7 +350,7 @@ __global__ void __launch_bounds__(256) lsq_em_kernel(EmArgs A) {
 			for (int j = 0; j < LSQ_MAX_ISOFORMS; ++j) { th[j] = nth[j]; z[j] = nz[j]; }
 			ll = nll;
 			++iters;
-			if (fabs(crit - 1E-6) < 1E-11) flag |= 1;
+			if (fabs(crit - 1E-6) < A.band) flag |= 1;
 			if (!(crit > 1E-6)) run = false;
 			else if (iters >= A.max_iters) { flag |= 2; run = false; }
 		}
@@ -471,6 +472,7 @@ int run_solve(lsq_ctx *c) {
 		A.K = c->dK.p; A.cls_base = c->cls_base.p; A.iso_base = c->iso_base.p;
 		A.order = c->em_order.p;
 		A.max_iters = 1000000u;
+		A.band = c->em_band;
 		if (const char *e = getenv("LSQ_EM_CAP")) { const int v = atoi(e); if (v > 0) A.max_iters = (unsigned)v; }
 		A.cnt = c->cnt.p; A.G = c->G.p; A.theta = c->theta.p; A.logll = c->logll.p; A.iters = c->iters.p; A.flags = c->flags.p;
 		// one wave per workgroup: beside a streaming kernel that fills the device, a wave that is done gives its

@@ -1,0 +1,313 @@
+// Exact-order replay of the EM for events whose stop test came within the guard band.
+//
+// lsq_em_kernel sums over compatibility classes; the reference sums over reads, one after the other, in the
+// order of its read index (count/count.cpp:64-85: start, end, strand, name; solve/solve.cpp:720-748 fills
+// valid_rnames in that order, :767-793 builds one row per valid read, common/read.h:592-636 adds the rows in
+// turn).  The two differ by ~1e-13 relative, which matters only when |1 - old_ll/ll| lands within that of the
+// 1e-6 threshold (read.h:659): then the iteration count can differ and theta moves far more than 1e-6.  The
+// kernel flags such events (em_flags bit 0; the band is lsq_set_em_guard_band, 1e-11 by default) and this unit
+// redoes them: the reads of the event's bucket come back from HBM, each is evaluated against the event
+// (candidate window, Read::build, contiguous-run compatibility, 0.98 rule), the valid ones are put in index
+// order and the EM runs over that sequence with the reference's own loops, on the host, in IEEE fp64 with
+// libm's log -- the operations of read.h:592-660 in the same order, so the result is the reference's.
+// Flagged events are rare (3 of 200 000 on the skewed 1 B-read workload), so this is not a throughput path.
+#include "lsq_device.hpp"
+
+namespace {
+
+struct HostRead {
+	int start, end;            // first merged start, last merged end
+	unsigned line;             // MRF line number, or index into the method's name table
+	unsigned char strand;
+	unsigned char cls;         // compatibility class (bit j: isoform j), 0 = not valid for this event
+};
+
+// Read_single::build against one event's ascending segments (common/read.h:204-274), as lsq_count.hip's Walk
+struct HostWalk {
+	long long pos = 0; int it = 0; bool found = false; uint64_t mask = 0; long long matched = 0;
+	bool block(const lsq::Event &e, long long a, long long b) {
+		while (it < e.N) {
+			const long long sx = e.seg_s[(size_t)it], sy = e.seg_e[(size_t)it];
+			if (!(sx < b)) break;
+			pos = std::max(pos, sx);
+			if (a >= pos && a < sy) {
+				if (found && a > pos) break;
+				found = true;
+				mask |= 1ull << it;
+				pos = std::min(sy, b);
+				matched += pos - a;
+				if (b < sy) { a = b; break; }
+				a = (b == sy) ? b : sy;
+			} else if (pos > sx && pos < sy) {
+				break;
+			}
+			++it;
+		}
+		return a == b;
+	}
+};
+
+// class of a read given by its merged blocks; 0 when it is no candidate of the event or not valid
+unsigned eval_read(const lsq::Event &e, const int2 *blk, int nblk, bool read_orders_first) {
+	const long long p = blk[0].x, q = blk[nblk - 1].y;
+	if (p < e.gene_start || p > e.gene_end) return 0;
+	// count/count.cpp:429-432: lower_bound on (chrom, gene_start, gene_end, strand, name)
+	if (p == e.gene_start && (q < e.gene_end || (q == e.gene_end && read_orders_first))) return 0;
+	HostWalk w;
+	long long total = 0;
+	for (int k = 0; k < nblk; ++k) total += (long long)blk[k].y - blk[k].x;
+	for (int k = 0; k < nblk; ++k) if (!w.block(e, blk[k].x, blk[k].y)) break;
+	if (!w.mask) return 0;
+	if (!(50ll * w.matched > 49ll * total)) return 0;        // (double)matched / total > 0.98, count.cpp:441
+	const int hi = 63 - __builtin_clzll(w.mask), lo = __builtin_ctzll(w.mask);
+	const uint64_t span = (hi == 63 ? ~0ull : ((2ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
+	unsigned cls = 0;
+	for (int j = 0; j < e.K; ++j) {
+		const uint64_t iso = e.iso_mask[(size_t)j];
+		if ((w.mask & ~iso) == 0 && (iso & span) == w.mask) cls |= 1u << j;       // read.h:44-79
+	}
+	return cls;
+}
+
+template <class T>
+int fetch(std::vector<T> &dst, const T *src, size_t first, size_t count) {
+	dst.resize(count);
+	if (count) HIP_TRY(hipMemcpy(dst.data(), src + first, count * sizeof(T), hipMemcpyDeviceToHost));
+	return LSQ_OK;
+}
+
+// common/read.h:638-660 over per-read rows that are given as a class sequence per read file
+struct ExactEm {
+	int K = 0;
+	std::vector<std::vector<double>> G;               // [method][K]
+	std::vector<std::vector<unsigned char>> seq;      // [method] classes of the valid reads, index order
+	double row(size_t m, unsigned c, int k) const { return (c >> k & 1u) ? G[m][(size_t)k] : 0.0; }
+	double log_likelihood(const std::vector<double> &th) const {            // read.h:620-636
+		double ll = 0;
+		std::vector<double> lg(1u << K);
+		for (size_t m = 0; m < seq.size(); ++m) {
+			if (seq[m].empty()) continue;
+			for (unsigned c = 1; c < (1u << K); ++c) {
+				double s = 0;
+				for (int k = 0; k < K; ++k) s += th[(size_t)k] * row(m, c, k);
+				lg[c] = std::log(s);
+			}
+			for (unsigned char c : seq[m]) ll += lg[c];
+		}
+		return ll;
+	}
+	void step(const std::vector<double> &old_th, std::vector<double> &new_th) const {      // read.h:592-618
+		std::vector<double> z(1u << K);
+		for (int k = 0; k < K; ++k) {
+			double sum_zeta = 0, num_total_reads = 0;
+			for (size_t m = 0; m < seq.size(); ++m) {
+				if (seq[m].empty()) continue;
+				num_total_reads += (double)seq[m].size();
+				for (unsigned c = 1; c < (1u << K); ++c) {
+					double s = 0;
+					for (int k2 = 0; k2 < K; ++k2) s += old_th[(size_t)k2] * row(m, c, k2);
+					z[c] = 0.0;                   // a skipped term: adding +0.0 leaves the running sum as it is
+					if (s > 0) {
+						const double local = old_th[(size_t)k] * row(m, c, k);
+						if (local > 0) z[c] = local / s;
+					}
+				}
+				for (unsigned char c : seq[m]) sum_zeta += z[c];
+			}
+			new_th[(size_t)k] = sum_zeta / num_total_reads;
+		}
+	}
+	unsigned run(std::vector<double> &theta, double &logll) const {
+		theta.assign((size_t)K, (double)1.0 / (double)K);
+		std::vector<double> old_theta;
+		double ll, old_ll;
+		unsigned iters = 0;
+		do {
+			old_theta = theta;
+			old_ll = log_likelihood(old_theta);
+			step(old_theta, theta);
+			ll = log_likelihood(theta);
+			++iters;
+		} while (std::fabs(1.0 - old_ll / ll) > 1E-6);
+		logll = ll;              // solve/solve.cpp:824: the log-likelihood at the final theta, the same sum once more
+		return iters;
+	}
+};
+
+// std::string operator< on the decimal forms of two numbers
+bool decimal_less(unsigned a, unsigned b) {
+	char sa[12], sb[12];
+	int na = 0, nb = 0;
+	do { sa[na++] = (char)('0' + a % 10u); a /= 10u; } while (a);
+	do { sb[nb++] = (char)('0' + b % 10u); b /= 10u; } while (b);
+	for (int i = 0; i < na && i < nb; ++i) { const char ca = sa[na - 1 - i], cb = sb[nb - 1 - i]; if (ca != cb) return ca < cb; }
+	return na < nb;
+}
+
+std::string read_name(const lsq::MethodReads &mr, const std::string &names, const std::vector<unsigned long long> &name_off, unsigned line) {
+	if (mr.named) return names.substr((size_t)name_off[line], (size_t)(name_off[line + 1] - name_off[line]));
+	return "read-" + std::to_string(line);          // count/count.cpp:293-295
+}
+
+} // namespace
+
+namespace lsq {
+
+// Redoes every event of the latest solve that carries flag bit 0 and not yet bit 2.  Both streams are idle on return.
+int replay_flagged(lsq_ctx *c, unsigned *n_done) {
+	if (n_done) *n_done = 0;
+	if (!c->solved) return LSQ_OK;
+	{ int rc = sync_all(c); if (rc) return rc; }
+	const lsq_events &E = *c->E;
+	const size_t n_ev = E.dev2out.size(), M = (size_t)E.n_methods, n_cls = E.n_cls_total, n_iso = E.n_iso_total;
+	if (!n_ev) return LSQ_OK;
+	std::vector<uint8_t> flags(n_ev);
+	HIP_TRY(hipMemcpy(flags.data(), c->flags.p, n_ev, hipMemcpyDeviceToHost));
+	std::vector<size_t> todo;
+	for (size_t d = 0; d < n_ev; ++d) if ((flags[d] & 1u) && !(flags[d] & 4u)) todo.push_back(d);
+	// counts that came from outside (lsq_results_set_counts: sums over processes that each hold a slice of the
+	// reads): the reads behind them are not all here, the flag stays as the kernel set it
+	if (todo.empty() || c->counts_external) return LSQ_OK;
+	// bucket of a device event: the last one whose first event is <= d
+	std::vector<std::string> names(M);
+	std::vector<std::vector<unsigned long long>> name_off(M);
+	for (size_t m = 0; m < M; ++m) {
+		const MethodReads &mr = c->reads[m];
+		if (!mr.named || !mr.present) continue;
+		std::vector<char> blob;
+		int rc = fetch(blob, mr.names.p, 0, mr.names.n); if (rc) return rc;
+		names[m].assign(blob.begin(), blob.end());
+		rc = fetch(name_off[m], mr.name_off.p, 0, mr.name_off.n); if (rc) return rc;
+	}
+	// flagged events by bucket: a bucket's reads come back once per read file
+	auto bucket_of = [&](size_t d) {
+		size_t lo = 0, hi = E.buckets.size();
+		while (hi - lo > 1) { const size_t mid = (lo + hi) / 2; if (E.buckets[mid].ev_base <= d) lo = mid; else hi = mid; }
+		return lo;
+	};
+	struct BucketReads {                       // one read file's reads of one bucket, as the pools hold them
+		std::vector<int32_t> p1, p2, pn_se;
+		std::vector<uint8_t> p1_strand, p2_strand, pn_strand;
+		std::vector<uint32_t> p1_line, p2_line, pn_line, pn_blk_off, pn_nblk;
+		unsigned long long pnb0 = 0, pnb1 = 0;
+	};
+	for (size_t t0 = 0; t0 < todo.size();) {
+		const size_t b = bucket_of(todo[t0]);
+		size_t t1 = t0;
+		while (t1 < todo.size() && bucket_of(todo[t1]) == b) ++t1;
+		std::vector<ExactEm> ems(t1 - t0);
+		for (size_t t = t0; t < t1; ++t) {
+			const Event &ev = E.ev[(size_t)E.dev2out[todo[t]]];
+			ExactEm &em = ems[t - t0];
+			em.K = ev.K; em.G.resize(M); em.seq.resize(M);
+			for (size_t m = 0; m < M; ++m) {
+				em.G[m].resize((size_t)ev.K);
+				for (int j = 0; j < ev.K; ++j) { const double nd = (double)ev.ars[m][(size_t)j]; em.G[m][(size_t)j] = nd <= 0 ? 0.0 : (double)1.0 / nd; }   // read.h:331-340
+			}
+		}
+		for (size_t m = 0; m < M; ++m) {
+			const MethodReads &mr = c->reads[m];
+			if (!mr.present) return fail(LSQ_E_STATE, "the exact-order EM replay needs the reads of method %zu on the device", m);
+			BucketReads R;
+			{
+				unsigned long long o1[2], o2[2], on[2], ob[2];
+				HIP_TRY(hipMemcpy(o1, mr.p1_off.p + b, sizeof o1, hipMemcpyDeviceToHost));
+				HIP_TRY(hipMemcpy(o2, mr.p2_off.p + b, sizeof o2, hipMemcpyDeviceToHost));
+				HIP_TRY(hipMemcpy(on, mr.pn_off.p + b, sizeof on, hipMemcpyDeviceToHost));
+				HIP_TRY(hipMemcpy(ob, mr.pnb_off.p + b, sizeof ob, hipMemcpyDeviceToHost));
+				const size_t n1 = (size_t)(o1[1] - o1[0]), n2 = (size_t)(o2[1] - o2[0]), nn = (size_t)(on[1] - on[0]);
+				int rc;
+				if ((rc = fetch(R.p1, mr.p1.p, 2 * (size_t)o1[0], 2 * n1)) || (rc = fetch(R.p1_strand, mr.p1_strand.p, (size_t)o1[0], n1)) || (rc = fetch(R.p1_line, mr.p1_line.p, (size_t)o1[0], n1)) ||
+				    (rc = fetch(R.p2, mr.p2.p, 4 * (size_t)o2[0], 4 * n2)) || (rc = fetch(R.p2_strand, mr.p2_strand.p, (size_t)o2[0], n2)) || (rc = fetch(R.p2_line, mr.p2_line.p, (size_t)o2[0], n2)) ||
+				    (rc = fetch(R.pn_blk_off, mr.pn_blk_off.p, (size_t)on[0], nn)) || (rc = fetch(R.pn_nblk, mr.pn_nblk.p, (size_t)on[0], nn)) ||
+				    (rc = fetch(R.pn_strand, mr.pn_strand.p, (size_t)on[0], nn)) || (rc = fetch(R.pn_line, mr.pn_line.p, (size_t)on[0], nn)) ||
+				    (rc = fetch(R.pn_se, mr.pn_se.p, 2 * (size_t)ob[0], 2 * (size_t)(ob[1] - ob[0])))) return rc;
+				R.pnb0 = ob[0]; R.pnb1 = ob[1];
+			}
+			for (size_t t = t0; t < t1; ++t) {
+				const size_t d = todo[t];
+				const Event &ev = E.ev[(size_t)E.dev2out[d]];
+				std::vector<HostRead> valid;
+				auto consider = [&](const int2 *blk, int nblk, unsigned char strand, unsigned line) {
+					const int p = blk[0].x, q = blk[nblk - 1].y;
+					bool first = false;
+					if (p == ev.gene_start && q == ev.gene_end) {          // the (strand, name) part of the key decides
+						const std::string &rs = E.strands.names[strand];
+						first = rs != ev.strand ? rs < ev.strand : read_name(mr, names[m], name_off[m], line) < ev.gname;
+					}
+					const unsigned cls = eval_read(ev, blk, nblk, first);
+					if (cls) valid.push_back({p, q, line, strand, (unsigned char)cls});
+				};
+				for (size_t i = 0; i < R.p1_line.size(); ++i) { const int2 blk = make_int2(R.p1[2 * i], R.p1[2 * i + 1]); consider(&blk, 1, R.p1_strand[i], R.p1_line[i]); }
+				for (size_t i = 0; i < R.p2_line.size(); ++i) {
+					const int2 blk[2] = {make_int2(R.p2[4 * i], R.p2[4 * i + 1]), make_int2(R.p2[4 * i + 2], R.p2[4 * i + 3])};
+					consider(blk, 2, R.p2_strand[i], R.p2_line[i]);
+				}
+				for (size_t i = 0; i < R.pn_line.size(); ++i) {
+					if (R.pn_blk_off[i] < R.pnb0 || (unsigned long long)R.pn_blk_off[i] + R.pn_nblk[i] > R.pnb1)
+						return fail(LSQ_E_STATE, "exact-order EM replay: block offsets of a multi-block read lie outside its bucket");
+					consider(reinterpret_cast<const int2 *>(R.pn_se.data()) + (R.pn_blk_off[i] - R.pnb0), (int)R.pn_nblk[i], R.pn_strand[i], R.pn_line[i]);
+				}
+				// the read index's order (count/count.cpp:64-85; the chromosome is the event's for all of them)
+				const bool named = mr.named;
+				std::sort(valid.begin(), valid.end(), [&](const HostRead &x, const HostRead &y) {
+					if (x.start != y.start) return x.start < y.start;
+					if (x.end != y.end) return x.end < y.end;
+					if (x.strand != y.strand) return E.strands.names[x.strand] < E.strands.names[y.strand];
+					if (!named) return decimal_less(x.line, y.line);       // "read-<n>" against "read-<n'>": the digits as strings
+					return read_name(mr, names[m], name_off[m], x.line) < read_name(mr, names[m], name_off[m], y.line);
+				});
+				// the same reads the device counted?  (the replay must not drift from the count tables)
+				std::vector<unsigned long long> mine((size_t)(1u << ev.K), 0), dev((size_t)(1u << ev.K) - 1);
+				for (const HostRead &r : valid) ++mine[r.cls];
+				HIP_TRY(hipMemcpy(dev.data(), c->cnt.p + m * n_cls + E.dev_cls_base[d], dev.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+				for (size_t k = 0; k < dev.size(); ++k)
+					if (dev[k] != mine[k + 1])
+						return fail(LSQ_E_STATE, "exact-order EM replay of gene %s: class %zu has %llu reads here, %llu in the count tables", ev.gname.c_str(), k + 1, mine[k + 1], dev[k]);
+				std::vector<unsigned char> &seq = ems[t - t0].seq[m];
+				seq.reserve(valid.size());
+				for (const HostRead &r : valid) seq.push_back(r.cls);
+			}
+		}
+		for (size_t t = t0; t < t1; ++t) {
+			const size_t d = todo[t];
+			const Event &ev = E.ev[(size_t)E.dev2out[d]];
+			std::vector<double> theta;
+			double logll = 0;
+			const unsigned iters = ems[t - t0].run(theta, logll);
+			const uint8_t f = (uint8_t)(flags[d] | 4u);
+			HIP_TRY(hipMemcpy(c->theta.p + E.dev_iso_base[d], theta.data(), (size_t)ev.K * sizeof(double), hipMemcpyHostToDevice));
+			HIP_TRY(hipMemcpy(c->logll.p + d, &logll, sizeof(double), hipMemcpyHostToDevice));
+			HIP_TRY(hipMemcpy(c->iters.p + d, &iters, sizeof(unsigned), hipMemcpyHostToDevice));
+			HIP_TRY(hipMemcpy(c->flags.p + d, &f, 1, hipMemcpyHostToDevice));
+			if (n_done) ++*n_done;
+		}
+		t0 = t1;
+	}
+	(void)n_iso;
+	return LSQ_OK;
+}
+
+} // namespace lsq
+
+extern "C" {
+
+int lsq_set_em_guard_band(lsq_ctx *c, double band) {
+	if (!c) return fail(LSQ_E_ARG, "null context");
+	if (!(band >= 0.0)) return fail(LSQ_E_ARG, "the guard band must be a non-negative number");
+	c->em_band = band;
+	return LSQ_OK;
+}
+
+int lsq_solve_finalize(lsq_ctx *c, uint32_t *n_replayed) {
+	if (!c) return fail(LSQ_E_ARG, "null context");
+	if (!c->solved) return fail(LSQ_E_STATE, "lsq_solve must come first");
+	HIP_TRY(hipSetDevice(c->device));
+	{ int rc = ensure_counts_complete(c); if (rc) return rc; }
+	unsigned n = 0;
+	int rc = lsq::replay_flagged(c, &n);
+	if (n_replayed) *n_replayed = n;
+	return rc;
+}
+
+} // extern "C"
