@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LSQ_ABI_VERSION 1
+#define LSQ_ABI_VERSION 2
 
 typedef enum {
 	LSQ_OK = 0,
@@ -204,6 +204,21 @@ uint64_t lsq_reads_retained_blocks(const lsq_ctx *c, int method);
  * pass over every uploaded method's reads; fills per-(method, event, compatibility class)
  * read counts and matched-base sums on the device.  Asynchronous on the context stream. */
 int lsq_count(lsq_ctx *c);
+/* Per read file of the latest lsq_count (arrays of n_methods, either may be NULL; synchronises): the
+ * (read, event) pairs the streaming kernel handed to the exception pass -- span-start ties that the
+ * strand / name order decides (count/count.cpp:64-85), two blocks that touch -- and whether that list
+ * overflowed, in which case two kernels behind the exception pass on the result stream zeroed the
+ * method's tables and counted every read again (slow, complete).  The decision is taken on the
+ * device, so every table that leaves the context -- also through lsq_results_copy_device in a loop
+ * that never synchronises -- is whole. */
+int lsq_count_status(lsq_ctx *c, uint32_t *exceptions, uint32_t *recounted);
+/* Tuning knobs; results never depend on them.  "grid_multiplier" (workgroups per resident slot of the
+ * count kernel's grid, 0 = chosen from the read set's skew), "exception_capacity" (entries of a read
+ * file's exception list, 0 = a quarter of its reads and at least 65 536; applies to read sets uploaded
+ * afterwards), "recount_every_read" (1: every count is redone by the one-lane-per-read kernel, a
+ * self-check), "em_guard_band" (lsq_set_em_guard_band).  LSQ_E_ARG for an unknown name.  The executables
+ * pass LSQ_OPTIONS="name=value,..." from the environment through this call. */
+int lsq_ctx_set_option(lsq_ctx *c, const char *name, double value);
 
 /* Replaces solve/solve.cpp:796-806,823-826 (common/read.h:592-660): batched EM over the
  * class counts, one event per lane, fp64.  Needs lsq_count first.  Asynchronous. */
@@ -253,7 +268,11 @@ int lsq_results_fim_offsets(const lsq_ctx *c, uint64_t *fim_off /* n_events+1 */
 int lsq_results_fim(lsq_ctx *c, double *fim, double *var_by_diag, double *var_by_inverse);
 
 /* Copies the raw device-order results into caller-provided DEVICE buffers (e.g. tensors of a
- * framework that will run a collective on them), asynchronously on the context stream:
+ * framework that will run a collective on them), asynchronously on the context's RESULT stream (the
+ * one the EM runs on, not lsq_ctx_stream's: lsq_ctx_synchronize waits for both), behind the count's
+ * exception pass -- and its recount, should the exception list have overflowed -- and the EM, so the
+ * tables are complete.  theta / logll are the kernel's numbers; an event inside the EM guard band
+ * (rare; em_flags bit 0) gets the reference's exact-order numbers from lsq_solve_finalize.
  * d_class_count [n_methods * n_classes] uint64, d_theta [n_isoforms] f64, d_logll [n_events]
  * f64; any may be NULL.  lsq_results_device_order() gives, per device-order event, its output
  * index, so a gathered buffer can be put in output order on the receiving side. */

@@ -238,6 +238,17 @@ class Context:
     def solve(self):
         check(lib.lsq_solve(self.h))
 
+    def set_option(self, name, value):
+        """lsq_ctx_set_option: grid_multiplier, exception_capacity, recount_every_read, em_guard_band"""
+        check(lib.lsq_ctx_set_option(self.h, _b(name), float(value)))
+
+    def count_status(self):
+        """per read file: (pairs handed to the exception pass, recount ran) of the latest count()"""
+        M = max(self.events.n_methods, 1)
+        e, r = (u32 * M)(), (u32 * M)()
+        check(lib.lsq_count_status(self.h, e, r))
+        return list(e)[:self.events.n_methods], list(r)[:self.events.n_methods]
+
     def set_em_guard_band(self, band):
         """events whose EM stop test comes within `band` of its threshold are replayed in the reference's per-read order"""
         check(lib.lsq_set_em_guard_band(self.h, float(band)))

@@ -215,6 +215,20 @@ int run_count_solve(bool solve, int argc, const char *const *argv, std::string &
 		if (const char *e = getenv("LSQ_DEVICE")) dev = atoi(e);
 		ctx_status = lsq_ctx_create(dev, &ctx_bg);
 		if (ctx_status) { ctx_error = lsq_last_error(); return; }          // the message lives in that thread
+		// LSQ_OPTIONS="name=value,...": tuning knobs for lsq_ctx_set_option, read once per process
+		if (const char *o = getenv("LSQ_OPTIONS")) {
+			std::string all(o);
+			size_t pos = 0;
+			while (pos < all.size() && !ctx_status) {
+				size_t end = all.find(',', pos);
+				if (end == std::string::npos) end = all.size();
+				const std::string item = all.substr(pos, end - pos);
+				const size_t eq = item.find('=');
+				if (eq != std::string::npos) ctx_status = lsq_ctx_set_option(ctx_bg, item.substr(0, eq).c_str(), atof(item.c_str() + eq + 1));
+				pos = end + 1;
+			}
+			if (ctx_status) { ctx_error = lsq_last_error(); return; }
+		}
 		for (int m = 0; m < M; ++m)
 			if (strcmp(fmts[m], "MRF_SINGLE") == 0 && lsq_text_stage(ctx_bg, paths[m], &texts[(size_t)m]) != LSQ_OK) texts[(size_t)m] = nullptr;
 	});

@@ -26,6 +26,14 @@ namespace {
 constexpr int COUNT_BLOCK = LSQ_COUNT_BLOCK;       // threads per workgroup of the count kernels
 constexpr unsigned long long BASES_MASK = (1ull << 40) - 1;
 
+// Ablation switches of the developer build (-DLSQ_DEV: liblesseq_hip_dev.so, tools/kbench.py): parts of the kernels
+// can be switched off to see what they cost.  The release object carries none of these branches.
+#ifdef LSQ_DEV
+#define ABL(args, bits) ((((args).ablate) & (bits)) != 0u)
+#else
+#define ABL(args, bits) false
+#endif
+
 
 struct CountArgs {
 	const BucketDesc *buckets;
@@ -328,7 +336,7 @@ __device__ inline bool fast_trip(const FastCtx &C, const int4 v, const int total
 		exc = exc || touching;
 		covers = covers && !touching;
 	}
-	if (exc && !(C.ablate & 128u)) emit_exception(C, r, i, 0u);
+	if (exc && !ABL(C, 128u)) emit_exception(C, r, i, 0u);
 	const int sx[4] = {(int)w1.x, (int)w1.z, (int)w2.x, (int)w2.z};
 	const int sy[4] = {(int)w1.y, (int)w1.w, (int)w2.y, (int)w2.w};
 	const unsigned abut = (w0.y >> FAST_ABUT_SHIFT) & 7u;
@@ -354,7 +362,7 @@ __device__ inline bool fast_trip(const FastCtx &C, const int4 v, const int total
 	const unsigned cls = (unsigned)(tbl >> (4u * mask)) & 0xFu;
 	{
 		const bool add = covers && cls != 0 && 50 * matched > 49 * total;
-		if (!(C.ablate & 2u)) { if (add) atomicAdd(&C.hist[(w0.y & 0xFFFFu) + cls - 1u], (1ull << 40) | (unsigned long long)(unsigned)matched); }
+		if (!ABL(C, 2u)) { if (add) atomicAdd(&C.hist[(w0.y & 0xFFFFu) + cls - 1u], (1ull << 40) | (unsigned long long)(unsigned)matched); }
 		else asm volatile("" ::"v"(matched), "v"(cls));
 	}
 	return started && (!(p <= ge) || (w0.y & FAST_FLAG_OVERLAPS_NEXT)) && i + 1 < C.n_events;
@@ -419,7 +427,7 @@ __device__ inline void walk_parked(const FastCtx &C, Ring<NB> &R, const bool to_
 	while (R.live() >= (to_empty ? 1u : 64u)) {
 		const unsigned n = min(R.live(), 64u);
 		const bool on = lane < n;
-		if ((C.ablate & 256u) && lane == 0) { atomicAdd(&C.dbg[2], 1ull); atomicAdd(&C.dbg[3], (unsigned long long)n); }
+		if (ABL(C, 256u) && lane == 0) { atomicAdd(&C.dbg[2], 1ull); atomicAdd(&C.dbg[3], (unsigned long long)n); }
 		const unsigned at = (R.head + (on ? lane : 0u)) % Ring<NB>::CAP;
 		uint4 e0, e1 = make_uint4(0, 0, 0, 0);
 		if (NB == 1) e0 = R.q[at];
@@ -445,7 +453,7 @@ __device__ inline void walk_parked(const FastCtx &C, Ring<NB> &R, const bool to_
 			if (i == PARK_EVENT_UNKNOWN) { i = first; e1.x = first; }
 		}
 		const int total = NB == 1 ? rd.y - rd.x : (rd.y - rd.x) + (rd.w - rd.z);
-		const bool more = fast_trip<NB>(C, rd, total, rel, i, on) && !one_event && !(C.ablate & 64u);
+		const bool more = fast_trip<NB>(C, rd, total, rel, i, on) && !one_event && !ABL(C, 64u);
 		wave_sync_lds();
 		if (NB == 1) e0.z = i + 1u; else e1.x = i + 1u;     // (i is the resolved event)
 		R.push(more, lane, e0, e1);
@@ -503,7 +511,7 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 		if (wt + WAVES * TILE < ww1) fetch(wt + WAVES * TILE);
 #pragma unroll
 		for (int k0 = 0; k0 < SW; k0 += GW) {
-		if (A.ablate & 512u) {      // developer switch: stream only
+		if (ABL(A, 512u)) {      // developer switch: stream only
 #pragma unroll
 			for (int kg = 0; kg < GW; ++kg) asm volatile("" ::"v"(cur[k0 + kg].x), "v"(cur[k0 + kg].y), "v"(cur[k0 + kg].z), "v"(cur[k0 + kg].w));
 			continue;
@@ -524,7 +532,7 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 					unsigned ci, evf;
 					locate((int)cur[k0].x, ci, evf);
 					const uint4 cw = cells[min(ci, n_cells - 1u)];           // lo, hi, hi2, slots
-					const bool has = ci < n_cells && !(A.ablate & 8u);
+					const bool has = ci < n_cells && !ABL(A, 8u);
 					const unsigned info = cell_info[min(ci, n_cells - 1u)];
 					const unsigned owner_word = info == CELL_INFO_SHARED ? PARK_EVENT_UNKNOWN : ((info >> 8) | PARK_ONE_EVENT);
 					const int lo = (int)cw.x, hi = (int)cw.y, hi2 = (int)cw.z;
@@ -546,15 +554,15 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 							const unsigned len = (unsigned)(rb - ra);
 							nA += a ? 1u : 0u; sA += a ? len : 0u;
 							nX += x ? 1u : 0u; sX += x ? len : 0u;
-							park[j] = in && !a && !x && !(A.ablate & 17u);
-							if ((A.ablate & 256u) && park[j]) atomicAdd(&A.dbg[5 + (m ? (info == CELL_INFO_SHARED ? 2 : 1) : 0)], 1ull);
+							park[j] = in && !a && !x && !ABL(A, 17u);
+							if (ABL(A, 256u) && park[j]) atomicAdd(&A.dbg[5 + (m ? (info == CELL_INFO_SHARED ? 2 : 1) : 0)], 1ull);
 							pe0[j] = make_uint4((unsigned)ra, (unsigned)rb, m ? owner_word : PARK_EVENT_UNKNOWN, rel);
 							pe1[j] = make_uint4(0, 0, 0, 0);
 						}
 					};
 					if (interior) decide(std::true_type{}); else decide(std::false_type{});
 					const unsigned sa = cw.w & 0xFFFFu, sb = cw.w >> 16;
-					if (!(A.ablate & (1u | 16384u))) {
+					if (!ABL(A, (1u | 16384u))) {
 						const unsigned long long addA = ((unsigned long long)nA << 40) | sA;
 						if (nA && sa != CELL_NONE) atomicAdd(&C.hist[sa], addA);
 						if (nA && hi2 == hi && sb != CELL_NONE) atomicAdd(&C.hist[sb], addA);        // second owner of the cell
@@ -581,7 +589,7 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 				const bool junction = c1 < n_cells && c2 < n_cells && i1 != CELL_INFO_SHARED && i2 != CELL_INFO_SHARED &&
 				                      rd.y == (int)cw1.y && (i1 & 2u) &&          // block 1 ends on its segment's end
 				                      rd.z == (int)cw2.x && (i2 & 1u) &&          // block 2 starts on its segment's start
-				                      (i1 >> 8) == (i2 >> 8) && ((i2 >> 2) & 0x3Fu) > ((i1 >> 2) & 0x3Fu) && !(A.ablate & 8u);
+				                      (i1 >> 8) == (i2 >> 8) && ((i2 >> 2) & 0x3Fu) > ((i1 >> 2) & 0x3Fu) && !ABL(A, 8u);
 				const bool hit = in && junction && (int)cw1.x <= rd.x && rd.w <= (int)cw2.y;
 				const unsigned ev = junction ? i1 >> 8 : 0u;
 				const uint4 w0r = C.recs[3u * ev];
@@ -589,7 +597,7 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 				const unsigned mask = (1u << ((i1 >> 2) & 0x3u)) | (1u << ((i2 >> 2) & 0x3u));
 				const unsigned cls = (unsigned)(tbl >> (4u * mask)) & 0xFu;
 				unsigned n_add = hit ? 1u : 0u, s_add = hit ? (unsigned)((rd.y - rd.x) + (rd.w - rd.z)) : 0u;
-				park[0] = in && !hit && !(A.ablate & 17u);
+				park[0] = in && !hit && !ABL(A, 17u);
 				pe0[0] = u;
 				const bool owned1 = c1 < n_cells && i1 != CELL_INFO_SHARED && (int)cw1.x <= rd.x && rd.x < (int)cw1.y;
 				pe1[0] = make_uint4(owned1 ? ((i1 >> 8) | PARK_ONE_EVENT) : evf, rel, 0u, 0u);
@@ -605,28 +613,28 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 					const bool hit2 = same && (int)cw1.x <= r2.x && r2.x < r2.y && r2.w <= (int)cw2.y;
 					n_add += hit2 ? 1u : 0u;
 					s_add += hit2 ? (unsigned)((r2.y - r2.x) + (r2.w - r2.z)) : 0u;
-					park[j] = in2 && !hit2 && !(A.ablate & 17u);
+					park[j] = in2 && !hit2 && !ABL(A, 17u);
 					pe0[j] = v;
 					// a read of the same junction that starts left of the cell, or overshoots: same owner, one look; anything else scans
 					pe1[j] = make_uint4(same && (int)cw1.x <= r2.x && r2.x < (int)cw1.y ? ((i1 >> 8) | PARK_ONE_EVENT) : PARK_EVENT_UNKNOWN, rel2, 0u, 0u);
 				}
-				if (!(A.ablate & 1u)) { if (n_add && cls != 0) atomicAdd(&C.hist[(w0r.y & 0xFFFFu) + cls - 1u], ((unsigned long long)n_add << 40) | s_add); }
+				if (!ABL(A, 1u)) { if (n_add && cls != 0) atomicAdd(&C.hist[(w0r.y & 0xFFFFu) + cls - 1u], ((unsigned long long)n_add << 40) | s_add); }
 				else asm volatile("" ::"v"(n_add), "v"(s_add));
 			}
 		}
 #pragma unroll
 		for (int q = 0; q < N_READS; ++q) {
-			if ((A.ablate & 256u) && park[q]) atomicAdd(&A.dbg[NB - 1], 1ull);
+			if (ABL(A, 256u) && park[q]) atomicAdd(&A.dbg[NB - 1], 1ull);
 			R.push(park[q], lane, pe0[q], pe1[q]);
 			// the ring holds what one walk leaves behind (< 64) plus 128 one-block or 64 two-block entries
 			if ((NB == 2 || (q & 1) == 1) && R.live() >= 64u) {             // wave-uniform
-				if (!(A.ablate & 32u)) walk_parked<NB>(C, R, false);
+				if (!ABL(A, 32u)) walk_parked<NB>(C, R, false);
 				else R.head = R.tail;
 			}
 		}
 		}
 	}
-	if (R.live() && !(A.ablate & 32u)) walk_parked<NB>(C, R, true);
+	if (R.live() && !ABL(A, 32u)) walk_parked<NB>(C, R, true);
 }
 
 // the bucket each workgroup of the fast kernel starts in: a dependent chain of a dozen global loads
@@ -794,14 +802,14 @@ __global__ void __launch_bounds__(COUNT_BLOCK, LSQ_FAST_WAVES) lsq_count_fast_ke
 	const unsigned long long s_begin = A.total_slots * wg / n_wg;
 	const unsigned long long s_end = A.total_slots * (wg + 1ull) / n_wg;
 	if (s_begin >= s_end) return;
-	if (A.ablate & 4096u) return;       // developer switch: dispatch cost only
+	if (ABL(A, 4096u)) return;       // developer switch: dispatch cost only
 	{
 		const unsigned b0 = find_bucket(A, A.wg_first[wg], s_begin, s_end);   // wg_first: lsq_wg_plan_kernel
 		if (b0 >= A.n_buckets) return;
 		stage_bucket(A, b0, lds);
 	}
 	__syncthreads();
-	if (A.ablate & 8192u) return;       // developer switch: dispatch + first staging
+	if (ABL(A, 8192u)) return;       // developer switch: dispatch + first staging
 	for (;;) {
 		unsigned char *buf = lds;
 		// the visit record, wave-uniform: every dword through readfirstlane so that it lives in scalar registers
@@ -830,10 +838,10 @@ __global__ void __launch_bounds__(COUNT_BLOCK, LSQ_FAST_WAVES) lsq_count_fast_ke
 		const unsigned long long l1 = (s_end < V.be ? s_end : V.be) - V.bs;
 		const unsigned long long n1 = V.p1n, n2 = V.p2n;
 		// ---- pool 1
-		if (l0 < n1 && !(A.ablate & 1024u))
+		if (l0 < n1 && !ABL(A, 1024u))
 			stream_pool_fast<2>(C, bins, cells, cell_info, d.iso_off, d, A, wave_queue, reinterpret_cast<const uint4 *>(A.p1), V.p1o + l0, V.p1o + (l1 < n1 ? l1 : n1));
 		// ---- pool 2
-		if (l1 > n1 && l0 < n1 + n2 && !(A.ablate & 2048u))
+		if (l1 > n1 && l0 < n1 + n2 && !ABL(A, 2048u))
 			stream_pool_fast<1>(C, bins, cells, cell_info, d.iso_off, d, A, wave_queue, reinterpret_cast<const uint4 *>(A.p2), V.p2o + ((l0 > n1 ? l0 : n1) - n1),
 			                    V.p2o + ((l1 < n1 + n2 ? l1 : n1 + n2) - n1));
 		// (reads with three or more blocks are the workers')
@@ -844,7 +852,7 @@ __global__ void __launch_bounds__(COUNT_BLOCK, LSQ_FAST_WAVES) lsq_count_fast_ke
 			unsigned long long v = 0;
 #pragma unroll
 			for (unsigned r = 0; r < HIST_REPLICAS; ++r) v += h0[r * (d.n_cls | 1u)];       // counts stay below 2^24, bases below 2^40
-			if (v && !(A.ablate & 4u)) {
+			if (v && !ABL(A, 4u)) {
 				atomicAdd(&A.cnt[d.cls_base + i], v >> 40);
 				atomicAdd(&A.bases[d.cls_base + i], v & BASES_MASK);
 			}
@@ -921,52 +929,65 @@ __device__ inline unsigned first_event_for(const GlobalBucket &G, int p) {
 	return G.bins[4u * bin] >> 16;
 }
 
-__global__ void __launch_bounds__(256) lsq_count_cleanup_kernel(CountArgs A, unsigned long long n_p1, unsigned long long n_p2,
-                                                                unsigned long long n_pn, int all_reads) {
+__global__ void __launch_bounds__(256) lsq_count_cleanup_kernel(CountArgs A, int force_recount) {
 	__builtin_amdgcn_s_setprio(3);          // runs beside the next count's streaming kernel: short, and the EM waits for it
 	const unsigned long long gtid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
 	const unsigned long long gsz = (unsigned long long)gridDim.x * blockDim.x;
-	// ---- exception list
-	if (!all_reads) {
-		const unsigned n_raw = A.exc_count[0];
-		if (n_raw > A.exc_cap && gtid == 0) A.exc_count[1] = 1u;       // overflow: the host redoes the pass in all_reads mode
-		const unsigned n = min(n_raw, A.exc_cap);
-		for (unsigned long long k = gtid; k < n; k += gsz) {
-			const ExcEntry e = A.exc[k];
-			const GlobalBucket G = global_bucket(A, e.bucket);
-			const unsigned i = e.ev_pool_scan & 0x1FFFFFFFu, pool = (e.ev_pool_scan >> 29) & 3u;
-			const bool scan = (e.ev_pool_scan >> 31) != 0;
-			int2 blk[2];
-			if (pool == 2) { const unsigned o0 = A.pn_blk_off[e.slot]; eval_read_global(A, G, A.pn_se + o0, (int)A.pn_nblk[e.slot], i, scan, A.pn_strand[e.slot], A.pn_line[e.slot]); }
-			else if (pool == 0) { blk[0] = A.p1[e.slot]; eval_read_global(A, G, blk, 1, i, scan, A.p1_strand[e.slot], A.p1_line[e.slot]); }
-			else { const int4 v = A.p2[e.slot]; blk[0] = make_int2(v.x, v.y); blk[1] = make_int2(v.z, v.w); eval_read_global(A, G, blk, 2, i, scan, A.p2_strand[e.slot], A.p2_line[e.slot]); }
-		}
+	const unsigned n_raw = A.exc_count[0];
+	// overflow: the list does not hold every pair the fast kernel left open.  The two recount kernels behind this one
+	// on the stream see the flag and redo the method's packed buckets from zero, over every read.
+	if ((n_raw > A.exc_cap || force_recount) && gtid == 0) A.exc_count[1] = 1u;
+	if (n_raw > A.exc_cap || force_recount) return;
+	for (unsigned long long k = gtid; k < n_raw; k += gsz) {
+		const ExcEntry e = A.exc[k];
+		const GlobalBucket G = global_bucket(A, e.bucket);
+		const unsigned i = e.ev_pool_scan & 0x1FFFFFFFu, pool = (e.ev_pool_scan >> 29) & 3u;
+		const bool scan = (e.ev_pool_scan >> 31) != 0;
+		int2 blk[2];
+		if (pool == 2) { const unsigned o0 = A.pn_blk_off[e.slot]; eval_read_global(A, G, A.pn_se + o0, (int)A.pn_nblk[e.slot], i, scan, A.pn_strand[e.slot], A.pn_line[e.slot]); }
+		else if (pool == 0) { blk[0] = A.p1[e.slot]; eval_read_global(A, G, blk, 1, i, scan, A.p1_strand[e.slot], A.p1_line[e.slot]); }
+		else { const int4 v = A.p2[e.slot]; blk[0] = make_int2(v.x, v.y); blk[1] = make_int2(v.z, v.w); eval_read_global(A, G, blk, 2, i, scan, A.p2_strand[e.slot], A.p2_line[e.slot]); }
 	}
-	// ---- all_reads mode: the reads with three or more blocks, one lane each (otherwise the fast kernel's
-	// pool-n workers have done them)
-	for (unsigned long long g = gtid; all_reads && g < n_pn; g += gsz) {
+}
+
+// The recount, decided on the device: both kernels follow the exception pass on the result stream and return at once
+// unless it raised the method's overflow flag.  PHASE 0 zeroes the class counters of the packed buckets (what the
+// fast kernel and its workers added), PHASE 1 counts every read of those buckets again: one lane per read, tables
+// from L2, the reference's candidate scan event by event (count/count.cpp:429-464), global atomics.  Slow, complete,
+// and it keeps every table that leaves the context whole -- also those handed over by lsq_results_copy_device.
+template <int PHASE>
+__global__ void __launch_bounds__(256) lsq_count_recount_kernel(CountArgs A, unsigned long long n_pn) {
+	if (!A.exc_count[1]) return;
+	const unsigned long long gtid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+	const unsigned long long gsz = (unsigned long long)gridDim.x * blockDim.x;
+	const unsigned lane = threadIdx.x & 63u;
+	const unsigned wave_id = (unsigned)(gtid >> 6), n_waves = (unsigned)(gsz >> 6);
+	if (PHASE == 0) {
+		for (unsigned b = wave_id; b < A.n_buckets; b += n_waves) {
+			const BucketDesc &d = A.buckets[b];
+			if (d.kind != 1) continue;
+			for (unsigned i = lane; i < d.n_cls; i += 64u) { A.cnt[d.cls_base + i] = 0; A.bases[d.cls_base + i] = 0; }
+		}
+		return;
+	}
+	for (unsigned long long g = gtid; g < n_pn; g += gsz) {
 		const unsigned b = A.pn_bucket[g];
 		if (A.buckets[b].kind != 1) continue;
 		const GlobalBucket G = global_bucket(A, b);
 		const unsigned o0 = A.pn_blk_off[g], o1 = o0 + A.pn_nblk[g];
 		eval_read_global(A, G, A.pn_se + o0, (int)(o1 - o0), first_event_for(G, A.pn_se[o0].x), true, A.pn_strand[g], A.pn_line[g]);
 	}
-	// ---- all_reads mode: every one- and two-block read as well, bucket by bucket, one wave at a time
-	if (all_reads) {
-		const unsigned lane = threadIdx.x & 63u;
-		const unsigned wave_id = (unsigned)(gtid >> 6), n_waves = (unsigned)(gsz >> 6);
-		for (unsigned b = wave_id; b < A.n_buckets; b += n_waves) {
-			if (A.buckets[b].kind != 1) continue;
-			const GlobalBucket G = global_bucket(A, b);
-			for (unsigned long long g = A.p1_off[b] + lane; g < A.p1_off[b + 1]; g += 64u) {
-				int2 blk[1] = {A.p1[g]};
-				eval_read_global(A, G, blk, 1, first_event_for(G, blk[0].x), true, A.p1_strand[g], A.p1_line[g]);
-			}
-			for (unsigned long long g = A.p2_off[b] + lane; g < A.p2_off[b + 1]; g += 64u) {
-				const int4 v = A.p2[g];
-				int2 blk[2] = {make_int2(v.x, v.y), make_int2(v.z, v.w)};
-				eval_read_global(A, G, blk, 2, first_event_for(G, v.x), true, A.p2_strand[g], A.p2_line[g]);
-			}
+	for (unsigned b = wave_id; b < A.n_buckets; b += n_waves) {
+		if (A.buckets[b].kind != 1) continue;
+		const GlobalBucket G = global_bucket(A, b);
+		for (unsigned long long g = A.p1_off[b] + lane; g < A.p1_off[b + 1]; g += 64u) {
+			int2 blk[1] = {A.p1[g]};
+			eval_read_global(A, G, blk, 1, first_event_for(G, blk[0].x), true, A.p1_strand[g], A.p1_line[g]);
+		}
+		for (unsigned long long g = A.p2_off[b] + lane; g < A.p2_off[b + 1]; g += 64u) {
+			const int4 v = A.p2[g];
+			int2 blk[2] = {make_int2(v.x, v.y), make_int2(v.z, v.w)};
+			eval_read_global(A, G, blk, 2, first_event_for(G, v.x), true, A.p2_strand[g], A.p2_line[g]);
 		}
 	}
 }
@@ -975,7 +996,7 @@ __global__ void __launch_bounds__(256) lsq_count_cleanup_kernel(CountArgs A, uns
 
 namespace lsq {
 
-int run_count(lsq_ctx *c, bool all_reads) {
+int run_count(lsq_ctx *c) {
 	const lsq_events &E = *c->E;
 	const size_t n_cls = E.n_cls_total;
 	const int M = E.n_methods;
@@ -991,7 +1012,7 @@ int run_count(lsq_ctx *c, bool all_reads) {
 	c->mark_recorded = true;
 	select_counter_set(c, set);
 	c->fast_launched = 0;
-	struct Cleanup { CountArgs A; unsigned long long n_p1, n_p2, n_pn; unsigned grid; };
+	struct Cleanup { CountArgs A; unsigned long long n_pn; };
 	std::vector<Cleanup> cleanups;
 	bool counted_signalled = false;
 	if (c->time_events) HIP_TRY(hipEventRecord(c->ev0, st));      // ev0..ev1 brackets the count kernel launches only
@@ -1013,14 +1034,13 @@ int run_count(lsq_ctx *c, bool all_reads) {
 		}
 		if (c->occ_blocks >= 1) per_cu = std::min(per_cu, (unsigned)c->occ_blocks);
 	}
-	int mult_env = 0;
-	if (const char *e = getenv("LSQ_GRID_MULT")) { int v = atoi(e); if (v >= 1 && v <= 64) mult_env = v; }
 	for (int m = 0; m < M; ++m) {
 		MethodReads &mr = c->reads[m];
 		if (mr.total_slots == 0 || E.buckets.empty()) continue;
 		// workgroups per resident slot: 2 for even read depth (fewest table stagings), more when a few buckets
-		// hold most of the reads (measured on the skewed workload: 2 -> 0.48 ms, 8 -> 0.30 ms)
-		const unsigned mult = mult_env ? (unsigned)mult_env : (mr.skew >= 32.0 ? 8u : (mr.skew >= 4.0 ? 4u : 2u));
+		// hold most of the reads (measured on the skewed workload: 2 -> 0.48 ms, 8 -> 0.30 ms); lsq_ctx_set_option
+		// "grid_multiplier" overrides
+		const unsigned mult = c->opt_grid_mult ? (unsigned)c->opt_grid_mult : (mr.skew >= 32.0 ? 8u : (mr.skew >= 4.0 ? 4u : 2u));
 		unsigned long long grid = (unsigned long long)c->n_cu * per_cu * mult;
 		// one workgroup's share must keep the packed LDS counters (24-bit count, 40-bit bases) exact
 		grid = std::max(grid, mr.total_slots / (1ull << 21) + 1);
@@ -1040,8 +1060,7 @@ int run_count(lsq_ctx *c, bool all_reads) {
 		A.gene_names = c->gene_names.p; A.gene_name_off = c->gene_name_off.p;
 		A.n_buckets = (unsigned)E.buckets.size();
 		A.tables_lds_bytes = tables_bytes;
-		A.ablate = 0;
-		if (const char *e = getenv("LSQ_ABLATE")) A.ablate = (unsigned)atoi(e);
+		A.ablate = c->dev_ablate;
 		A.p1 = reinterpret_cast<const int2 *>(mr.p1.p); A.p1_strand = mr.p1_strand.p; A.p1_line = mr.p1_line.p;
 		A.p2 = reinterpret_cast<const int4 *>(mr.p2.p); A.p2_strand = mr.p2_strand.p; A.p2_line = mr.p2_line.p;
 		A.pn_blk_off = mr.pn_blk_off.p; A.pn_nblk = mr.pn_nblk.p; A.pn_se = reinterpret_cast<const int2 *>(mr.pn_se.p);
@@ -1051,29 +1070,25 @@ int run_count(lsq_ctx *c, bool all_reads) {
 		A.cnt = c->cnt.p + (size_t)m * n_cls; A.bases = c->bases.p + (size_t)m * n_cls;
 		A.exc = mr.exc.p + (size_t)set * mr.exc_cap; A.exc_count = c->exc_count.p + 2 * m; A.exc_cap = (unsigned)mr.exc_cap;
 		A.dbg = c->dbg.p;
-		const unsigned long long n_p1 = mr.p1.n / 2, n_p2 = mr.p2.n / 4, n_pn = mr.pn_strand.n;
+		const unsigned long long n_pn = mr.pn_strand.n;
 		// pool-n workers: one workgroup per CU at most, one lane per read and pass
 		A.n_pn = n_pn;
 		const unsigned workers_per_cu = 2;          // 1, 4 and 8 measured within 2 % of each other
 		A.n_workers = (unsigned)std::min<unsigned long long>((n_pn + COUNT_BLOCK - 1) / COUNT_BLOCK, (unsigned long long)c->n_cu * workers_per_cu);
 		if (c->has_fast) {
-			if (!all_reads) {
-				if (c->time_events) HIP_TRY(hipEventRecord(c->evf0[m], st));
-				// the last streaming kernel of the step carries ev_counted as its own completion signal: a separate
-				// event record is one more packet between this kernel and the next count's (measured ~5 us each)
-				const bool last_streaming = m == M - 1 && !c->has_generic && !c->time_events;
-				if (last_streaming) {
-					hipExtLaunchKernelGGL(lsq_count_fast_kernel, dim3((unsigned)grid + A.n_workers), dim3(COUNT_BLOCK), lds_bytes, st, nullptr, c->ev_counted, 0, A);
-					counted_signalled = true;
-				} else
-					hipLaunchKernelGGL(lsq_count_fast_kernel, dim3((unsigned)grid + A.n_workers), dim3(COUNT_BLOCK), lds_bytes, st, A);
-				HIP_TRY(hipGetLastError());
-				if (c->time_events) HIP_TRY(hipEventRecord(c->evf1[m], st));
-				c->fast_launched |= 1 << m;
-			}
-			const unsigned long long work = all_reads ? std::max<unsigned long long>(n_pn, 64ull * E.buckets.size()) : 4096ull;
-			const unsigned cgrid = (unsigned)std::min<unsigned long long>((work + 255) / 256, (unsigned long long)c->n_cu * 32);
-			cleanups.push_back({A, n_p1, n_p2, n_pn, std::max(cgrid, 1u)});
+			if (c->time_events) HIP_TRY(hipEventRecord(c->evf0[m], st));
+			// the last streaming kernel of the step carries ev_counted as its own completion signal: a separate
+			// event record is one more packet between this kernel and the next count's (measured ~5 us each)
+			const bool last_streaming = m == M - 1 && !c->has_generic && !c->time_events;
+			if (last_streaming) {
+				hipExtLaunchKernelGGL(lsq_count_fast_kernel, dim3((unsigned)grid + A.n_workers), dim3(COUNT_BLOCK), lds_bytes, st, nullptr, c->ev_counted, 0, A);
+				counted_signalled = true;
+			} else
+				hipLaunchKernelGGL(lsq_count_fast_kernel, dim3((unsigned)grid + A.n_workers), dim3(COUNT_BLOCK), lds_bytes, st, A);
+			HIP_TRY(hipGetLastError());
+			if (c->time_events) HIP_TRY(hipEventRecord(c->evf1[m], st));
+			c->fast_launched |= 1 << m;
+			cleanups.push_back({A, n_pn});
 		}
 		if (c->has_generic) {
 			hipLaunchKernelGGL(lsq_count_generic_kernel, dim3((unsigned)grid), dim3(COUNT_BLOCK), generic_tables_bytes, st, A);
@@ -1082,32 +1097,16 @@ int run_count(lsq_ctx *c, bool all_reads) {
 	}
 	if (c->time_events) HIP_TRY(hipEventRecord(c->ev1, st));
 	c->count_timed = c->time_events;
-	// the exception pass, and everything that reads the counts, on the result stream behind the streaming kernels
+	// the exception pass, and everything that reads the counts, on the result stream behind the streaming kernels;
+	// behind it the two recount kernels, which do nothing unless the exception list overflowed
 	if (!counted_signalled) HIP_TRY(hipEventRecord(c->ev_counted, st));
 	HIP_TRY(hipStreamWaitEvent(st_em, c->ev_counted, 0));
+	const unsigned rgrid = (unsigned)c->n_cu * 4u;
 	for (const Cleanup &u : cleanups) {
-		hipLaunchKernelGGL(lsq_count_cleanup_kernel, dim3(u.grid), dim3(256), 0, st_em, u.A, u.n_p1, u.n_p2, u.n_pn, all_reads ? 1 : 0);
+		hipLaunchKernelGGL(lsq_count_cleanup_kernel, dim3(16), dim3(256), 0, st_em, u.A, c->opt_recount ? 1 : 0);
+		hipLaunchKernelGGL(lsq_count_recount_kernel<0>, dim3(rgrid), dim3(256), 0, st_em, u.A, u.n_pn);
+		hipLaunchKernelGGL(lsq_count_recount_kernel<1>, dim3(rgrid), dim3(256), 0, st_em, u.A, u.n_pn);
 		HIP_TRY(hipGetLastError());
-	}
-	return LSQ_OK;
-}
-
-// After a synchronisation point: did any method's exception list overflow?  Then the counts
-// (and a solve based on them) are redone with the cleanup kernel over every read.
-int ensure_counts_complete(lsq_ctx *c) {
-	if (c->redo_checked || !c->counted) return LSQ_OK;
-	{ int rc = sync_all(c); if (rc) return rc; }
-	std::vector<unsigned> h(c->exc_count.n, 0);
-	HIP_TRY(hipMemcpy(h.data(), c->exc_count.p, h.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
-	bool overflow = false;
-	for (size_t m = 0; m * 2 + 1 < h.size(); ++m) overflow = overflow || h[2 * m + 1] != 0;
-	c->redo_checked = true;
-	if (overflow || getenv("LSQ_FORCE_REDO")) {
-		int rc = run_count(c, true);
-		if (rc) return rc;
-		if (c->solved) { rc = run_solve(c); if (rc) return rc; }
-		rc = sync_all(c);
-		if (rc) return rc;
 	}
 	return LSQ_OK;
 }
@@ -1115,6 +1114,21 @@ int ensure_counts_complete(lsq_ctx *c) {
 } // namespace lsq
 
 extern "C" {
+
+// per read file of the latest lsq_count: pairs handed to the exception pass, and whether the recount ran
+int lsq_count_status(lsq_ctx *c, uint32_t *exceptions, uint32_t *recounted) {
+	if (!c) return fail(LSQ_E_ARG, "null context");
+	if (!c->counted) return fail(LSQ_E_STATE, "lsq_count must come first");
+	HIP_TRY(hipSetDevice(c->device));
+	{ int rc = sync_all(c); if (rc) return rc; }
+	std::vector<unsigned> h(c->exc_count.n);
+	HIP_TRY(hipMemcpy(h.data(), c->exc_count.p, h.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+	for (int m = 0; m < c->E->n_methods; ++m) {
+		if (exceptions) exceptions[m] = h[2 * (size_t)m];
+		if (recounted) recounted[m] = h[2 * (size_t)m + 1];
+	}
+	return LSQ_OK;
+}
 
 // developer aid (include/lesseq_hip_dev.h): counters filled when LSQ_ABLATE & 256
 int lsq_debug_counters(lsq_ctx *c, unsigned long long *out8) {

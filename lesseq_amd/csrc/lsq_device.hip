@@ -192,11 +192,14 @@ int lsq_count(lsq_ctx *c) {
 	if (!c->E) return fail(LSQ_E_STATE, "lsq_events_upload must come first");
 	HIP_TRY(hipSetDevice(c->device));
 	for (int m = 0; m < c->E->n_methods; ++m) if (!c->reads[m].present) return fail(LSQ_E_STATE, "reads of method %d were not uploaded", m);
-	int rc = run_count(c, false);
+#ifdef LSQ_DEV
+	if (const char *e = getenv("LSQ_ABLATE")) c->dev_ablate = (unsigned)atoi(e); else c->dev_ablate = 0;
+	if (const char *e = getenv("LSQ_GRID_MULT")) { const int v = atoi(e); if (v >= 1 && v <= 64) c->opt_grid_mult = v; }
+#endif
+	int rc = run_count(c);
 	if (rc) return rc;
 	c->counted = true;
 	c->solved = false;
-	c->redo_checked = false;
 	c->counts_external = false;
 	return LSQ_OK;
 }
@@ -307,7 +310,6 @@ int lsq_results_counts(lsq_ctx *c, uint64_t *class_count, uint64_t *class_bases)
 	if (!c || !class_count) return fail(LSQ_E_ARG, "null argument");
 	if (!c->counted) return fail(LSQ_E_STATE, "lsq_count must come first");
 	HIP_TRY(hipSetDevice(c->device));
-	{ int rc = ensure_counts_complete(c); if (rc) return rc; }
 	const lsq_events &E = *c->E;
 	// device arrays hold the classes of this process's events (device order); the caller's arrays
 	// hold every selected event's classes (output order), zero outside the shard
@@ -357,7 +359,7 @@ int lsq_results_set_counts(lsq_ctx *c, const uint64_t *class_count, const uint64
 		HIP_TRY(hipMemcpyAsync(c->bases.p, hb.data(), M * n_cls * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
 		HIP_TRY(hipStreamSynchronize(c->stream));
 	}
-	c->counted = true; c->solved = false; c->redo_checked = true;
+	c->counted = true; c->solved = false;
 	c->counts_external = true;
 	return LSQ_OK;
 }
@@ -366,7 +368,6 @@ int lsq_results_solve(lsq_ctx *c, double *theta, double *logll, uint32_t *em_ite
 	if (!c || !theta || !logll) return fail(LSQ_E_ARG, "null argument");
 	if (!c->solved) return fail(LSQ_E_STATE, "lsq_solve must come first");
 	HIP_TRY(hipSetDevice(c->device));
-	{ int rc = ensure_counts_complete(c); if (rc) return rc; }
 	{ int rc = replay_flagged(c, nullptr); if (rc) return rc; }      // guard-band events: the reference's per-read summation order
 	const lsq_events &E = *c->E;
 	const size_t n_ev = E.dev2out.size(), n_iso = E.n_iso_total;
@@ -498,6 +499,26 @@ int lsq_debug_set_em_order(lsq_ctx *c, const uint32_t *order, unsigned n_small_p
 	if (rc) return rc;
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	c->em_small_places = n_small_places; c->em_places = n_places;
+	return LSQ_OK;
+}
+
+// Tuning knobs of a context (none is needed for correct results).
+int lsq_ctx_set_option(lsq_ctx *c, const char *name, double value) {
+	if (!c || !name) return fail(LSQ_E_ARG, "null argument");
+	const std::string n(name);
+	if (n == "grid_multiplier") {
+		if (!(value >= 0 && value <= 64)) return fail(LSQ_E_ARG, "grid_multiplier must lie in 0..64 (0 = automatic)");
+		c->opt_grid_mult = (int)value;
+		for (auto &r : c->reads) r.wg_grid = 0;
+	} else if (n == "exception_capacity") {
+		if (!(value >= 0 && value <= 4e9)) return fail(LSQ_E_ARG, "exception_capacity must lie in 0..4e9 (0 = automatic)");
+		c->opt_exc_cap = (size_t)value;          // takes effect with the next upload of a read set
+	} else if (n == "recount_every_read") {
+		c->opt_recount = value != 0;
+	} else if (n == "em_guard_band") {
+		return lsq_set_em_guard_band(c, value);
+	} else
+		return fail(LSQ_E_ARG, "unknown option '%s'", name);
 	return LSQ_OK;
 }
 

@@ -126,7 +126,12 @@ struct lsq_ctx {
 	DevBuf<unsigned> bin_base;             // per bucket: first of its bins among all bins (n_buckets + 1)
 	size_t n_fine = 0;
 	unsigned n_chrom_tables = 0;
-	bool redo_checked = true;
+	// lsq_ctx_set_option: grid multiplier (0 = by the read set's skew), entries of a method's exception list
+	// (0 = a quarter of its reads, at least 64 Ki), recount every read with the one-lane-per-read kernel (self-check)
+	int opt_grid_mult = 0;
+	size_t opt_exc_cap = 0;
+	bool opt_recount = false;
+	unsigned dev_ablate = 0;                // developer build only (LSQ_ABLATE)
 	MethodReads reads[LSQ_MAX_METHODS];
 	bool counted = false, solved = false;
 	bool counts_external = false;           // lsq_results_set_counts: the counts are sums the reads here do not explain
@@ -150,8 +155,7 @@ struct lsq_text {
 
 namespace lsq {
 int upload_strand_ranks(lsq_ctx *c);                 // lsq_device.hip
-int run_count(lsq_ctx *c, bool all_reads);           // lsq_count.hip
-int ensure_counts_complete(lsq_ctx *c);              // lsq_count.hip: redo over every read when an exception list overflowed
+int run_count(lsq_ctx *c);                           // lsq_count.hip
 int run_solve(lsq_ctx *c);
 int run_fim(lsq_ctx *c);
 int sync_all(lsq_ctx *c);                 // both streams

@@ -473,7 +473,9 @@ int run_solve(lsq_ctx *c) {
 		A.order = c->em_order.p;
 		A.max_iters = 1000000u;
 		A.band = c->em_band;
-		if (const char *e = getenv("LSQ_EM_CAP")) { const int v = atoi(e); if (v > 0) A.max_iters = (unsigned)v; }
+#ifdef LSQ_DEV
+		if (const char *e = getenv("LSQ_EM_CAP")) { const int v = atoi(e); if (v > 0) A.max_iters = (unsigned)v; }      // timing experiments
+#endif
 		A.cnt = c->cnt.p; A.G = c->G.p; A.theta = c->theta.p; A.logll = c->logll.p; A.iters = c->iters.p; A.flags = c->flags.p;
 		// one wave per workgroup: beside a streaming kernel that fills the device, a wave that is done gives its
 		// registers back without waiting for three others (measured 0.259 -> 0.254 ms per pipelined step)

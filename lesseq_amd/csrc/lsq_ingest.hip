@@ -381,7 +381,7 @@ static int ingest_device(lsq_ctx *c, int method, const IngestRaw &Rw, uint64_t n
 	{
 		// exception list: a quarter of the one- and two-block reads, at least 64 Ki entries
 		size_t want = std::max<size_t>(65536, (n1 + n2) / 4);
-		if (const char *e = getenv("LSQ_EXC_CAP")) { const long v = atol(e); if (v >= 1) want = (size_t)v; }      // developer switch: provoke the overflow path
+		if (c->opt_exc_cap) want = c->opt_exc_cap;           // lsq_ctx_set_option "exception_capacity" (the tests provoke the overflow path with it)
 		if (mr.exc_cap != want) {
 			if ((rc = mr.exc.alloc(2 * want))) return rc;
 			mr.exc_cap = want;

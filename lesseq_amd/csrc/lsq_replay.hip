@@ -303,7 +303,6 @@ int lsq_solve_finalize(lsq_ctx *c, uint32_t *n_replayed) {
 	if (!c) return fail(LSQ_E_ARG, "null context");
 	if (!c->solved) return fail(LSQ_E_STATE, "lsq_solve must come first");
 	HIP_TRY(hipSetDevice(c->device));
-	{ int rc = ensure_counts_complete(c); if (rc) return rc; }
 	unsigned n = 0;
 	int rc = lsq::replay_flagged(c, &n);
 	if (n_replayed) *n_replayed = n;

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) > 40 and "lsq_debug_counters" in names
     for n in sorted(names):
         assert hasattr(L.lib, n), "missing export " + n
-    assert L.lib.lsq_abi_version() == 1
+    assert L.lib.lsq_abi_version() == 2
 
 
 def test_device_calls_fail_loudly_without_a_gpu():

@@ -174,10 +174,10 @@ def test_results_do_not_depend_on_launch_geometry(tmp_path, monkeypatch):
     results = []
     for budget, mult in (("8192", "2"), ("1024", "1"), ("65536", "7"), ("90000", "16")):
         monkeypatch.setenv("LSQ_LDS_BUDGET", budget)
-        monkeypatch.setenv("LSQ_GRID_MULT", mult)
         a = L.Annotation(os.path.join(a_dir, "g.interval"), os.path.join(a_dir, "g.map"))
         ev = L.Events(a, ("SHORT_READ",), (100,))
         ctx = L.Context(0)
+        ctx.set_option("grid_multiplier", int(mult))
         ctx.upload_events(ev)
         ctx.upload_reads(0, L.Reads.synthetic(spec, ev))
         ctx.count()
@@ -721,10 +721,10 @@ def test_solve_fim_extension_keeps_the_table_and_appends_the_matrices(tmp_path, 
     assert rc == 1                      # the reference's usage error: an incomplete read group
 
 
-def test_redo_pass_over_every_read_gives_the_same_tables(tmp_path, monkeypatch):
-    """when the exception list overflows the counts are redone by the cleanup kernel over every read (checked at
-    result fetch); LSQ_FORCE_REDO takes that path without an overflow: same integers, same theta, also when further
-    steps were submitted behind the one that is fetched"""
+def test_recount_over_every_read_gives_the_same_tables(tmp_path):
+    """when the exception list overflows, two kernels behind the exception pass zero the method's tables and count
+    every read again, one lane per read; the option "recount_every_read" takes that path without an overflow: same
+    integers, same theta, also when further steps were submitted behind the one that is fetched"""
     spec = L.SynthSpec(91, 3000, 400000, 100, 3, L.EVENT_TYPES)
     L.synth_write(spec, str(tmp_path), "r", write_mrf=False)
     ann = L.Annotation(str(tmp_path / "r.interval"), str(tmp_path / "r.map"))
@@ -735,22 +735,25 @@ def test_redo_pass_over_every_read_gives_the_same_tables(tmp_path, monkeypatch):
     ctx.count(); ctx.solve()
     cnt0, bases0 = [x.copy() for x in ctx.counts()]
     sol0 = [x.copy() for x in ctx.solution()]
-    monkeypatch.setenv("LSQ_FORCE_REDO", "1")
+    assert ctx.count_status()[1] == [0]
+    ctx.set_option("recount_every_read", 1)
     for steps in (1, 3):
         for _ in range(steps):
             ctx.count(); ctx.solve()
         cnt1, bases1 = ctx.counts()
         sol1 = ctx.solution()
+        assert ctx.count_status()[1] == [1]
         assert np.array_equal(cnt0, cnt1) and np.array_equal(bases0, bases1)
         assert np.array_equal(sol0[0], sol1[0]) and np.array_equal(sol0[1], sol1[1], equal_nan=True) and np.array_equal(sol0[2], sol1[2])
     ctx.close()
 
 
-def test_exception_list_overflow_is_noticed_and_redone(tmp_path, monkeypatch):
-    """an exception list that is too small (LSQ_EXC_CAP = 1, a developer switch) overflows on an input full of reads
-    that cover an event's span exactly (the strand/name order decides, count/count.cpp:64-85); the fetch notices the
-    flag and redoes the pass over every read: the oracle's tables still come out"""
-    import ctypes as C
+def test_exception_list_overflow_is_settled_on_the_device(tmp_path, monkeypatch):
+    """an exception list that is too small (option "exception_capacity") overflows on an input full of reads that cover
+    an event's span exactly (the strand/name order decides, count/count.cpp:64-85).  The recount runs on the result
+    stream without the host looking: the oracle's tables come out of the executables, and the tables a pipelined loop
+    takes through lsq_results_copy_device -- no fetch, no check in between -- are the complete ones at every step."""
+    import torch
     import golden_inputs as gi
     info = gi.write_events_case(str(tmp_path), "x", seed=77, n_events=40, n_reads=3000, R=60, n_chrom=2)
     lines = open(tmp_path / "x.mrf").read().split("\n")
@@ -768,23 +771,43 @@ def test_exception_list_overflow_is_noticed_and_redone(tmp_path, monkeypatch):
     assert orc == 0 and orc2 == 0
     for cap in ("1", "7", None):
         if cap is None:
-            monkeypatch.delenv("LSQ_EXC_CAP")
+            monkeypatch.delenv("LSQ_OPTIONS")
         else:
-            monkeypatch.setenv("LSQ_EXC_CAP", cap)
+            monkeypatch.setenv("LSQ_OPTIONS", "exception_capacity=" + cap)
         rc, text = L.cli_run("count", argv)
         assert rc == 0 and text == otext, cap
         rc, text = L.cli_run("solve", argv + ["200000"])
         assert rc == 0 and ob.solve_text_close(text, otext2), cap
-    # the input does raise more exceptions than such a list holds
-    monkeypatch.setenv("LSQ_EXC_CAP", "7")
     ann = L.Annotation(argv[4], argv[6], 0, 1000)
     ev = L.Events(ann, ("SHORT_READ",), (60,))
+    reads = L.Reads.from_mrf(argv[12], ev)
+    ref = L.Context(0)
+    ref.upload_events(ev)
+    ref.upload_reads(0, reads)
+    ref.count(); ref.solve()
+    ref_cnt = ref.counts()[0].copy()
+    assert ref.count_status()[1] == [0] and ref.count_status()[0][0] > 7
+    n_cls = int(L.lib.lsq_results_num_classes(ref.h))
+    order = ref.device_order()
+    ref.close()
     ctx = L.Context(0)
+    ctx.set_option("exception_capacity", 7)
     ctx.upload_events(ev)
-    ctx.upload_reads(0, L.Reads.from_mrf(argv[12], ev))
-    ctx.count()
-    buf = (C.c_ulonglong * 8)()
-    L.lib.lsq_debug_counters.argtypes = [C.c_void_p, C.c_void_p]
-    assert L.lib.lsq_debug_counters(ctx.h, buf) == 0
-    assert buf[4] > 7, int(buf[4])
+    ctx.upload_reads(0, reads)
+    bufs = [torch.zeros(n_cls, dtype=torch.int64, device="cuda:0") for _ in range(6)]
+    for b in bufs:                       # submitted back to back, each step hands its table to its own buffer
+        ctx.count(); ctx.solve()
+        ctx.copy_results_device(b.data_ptr(), None, None)
+    ctx.synchronize()
+    exc, rec = ctx.count_status()
+    assert rec == [1] and exc[0] > 7
+    off = ev.class_offsets()
+    want = np.zeros(n_cls, np.int64)     # the fetched (output-order) counts in device order
+    pos = 0
+    for d in order:
+        nc = off[d + 1] - off[d]
+        want[pos:pos + nc] = ref_cnt[0, off[d]:off[d + 1]]
+        pos += nc
+    for b in bufs:
+        assert np.array_equal(b.cpu().numpy(), want)
     ctx.close()

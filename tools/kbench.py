@@ -4,6 +4,7 @@ usage: python tools/kbench.py c2|c3 [budgets csv] [mults csv]"""
 import os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("LSQ_LIB", os.path.join(ROOT, "lesseq_amd", "_build", "liblesseq_hip_dev.so"))      # the ablation switches live in the developer build
 import numpy as np
 import lesseq_amd as L
 from bench import WORKLOADS

@@ -4,6 +4,7 @@ event inside or after the loop (for A/B runs of launch-sequence changes).  usage
 import os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("LSQ_LIB", os.path.join(ROOT, "lesseq_amd", "_build", "liblesseq_hip_dev.so"))      # developer build: LSQ_EM_CAP etc.
 import torch
 import lesseq_amd as L
 from bench import WORKLOADS
