@@ -181,8 +181,11 @@ __device__ inline void em_pass_lean(const double (&kd)[SLOTS], const double (&gm
 		safe[t] = (on_t[t] && sm[t] > 0) ? sm[t] : 1.0;     // an empty pair slot must not send the wave down the library path
 		r[t] = fast_recip(safe[t]);
 		d[t] = (safe[t] - P.s[t]) * P.r[t];
-		// outside the series' range, or log of zero (the full routine gives the reference's -inf)
-		far_t[t] = on_t[t] && (!(fabs(d[t]) < 0.03125) || !(sm[t] > 0));
+		// outside the series' range, or log of zero (the full routine gives the reference's -inf), or a mixture next
+		// to 1 (an isoform with a handful of accessible starts): the carried logarithm keeps the absolute error of its
+		// history, which is no relative accuracy at all once log s itself comes down to zero (a lone read on such an
+		// isoform has log-likelihood exactly 0 in the reference) -- there the full routine is exact
+		far_t[t] = on_t[t] && (!(fabs(d[t]) < 0.03125) || !(sm[t] > 0) || fabs(sm[t] - 1.0) < 0.015625);
 		far = far || far_t[t];
 	}
 	// the numerators first: the next pass waits for them, and nothing in them waits for the logarithm

@@ -126,8 +126,16 @@ def main():
         def sp(info, R=R):
             c, s = std_args("ev", 0, 1000, [("SHORT_READ", R, "ev.mrf", info["total_read_bases"])])
             c1, s1 = std_args("ev", 5, 17, [("SHORT_READ", R, "ev.mrf", info["total_read_bases"])])
-            return {"count": [c, c1], "solve": [s, s1]}
+            # classify over a gene range (seed 2) or everything: one .matrix per selected gene with two or more isoforms
+            lo, hi = ("3", "20") if seed == 2 else ("0", "1000")
+            return {"count": [c, c1], "solve": [s, s1], "classify": ["0", "ev", "classify/", "LH_GENE_TXT", "ev.interval", "UCSC_GENE2ISOFORM", "ev.map", lo, hi]}
         case("events_s%d" % seed, w, sp)
+
+    # classify's own filter: single-isoform genes leave no file (classify/classify.cpp:159)
+    def cm_spec(info):
+        c, s = std_args("cm", 0, 100, [("SHORT_READ", 10, "cm.mrf", 110)])
+        return {"count": [c], "solve": [s], "classify": ["0", "cm", "classify/", "LH_GENE_TXT", "cm.interval", "UCSC_GENE2ISOFORM", "cm.map", "0", "100"]}
+    case("classify_mix", gi.write_classify_mix, cm_spec)
 
     # arbitrary isoform structures, tiny coordinate range, adversarial names / strands / blocks
     for seed in (11, 12, 13, 14, 15, 16):

@@ -85,6 +85,27 @@ def write_toy(d):
     return {}
 
 
+def write_classify_mix(d):
+    """classify keeps genes with two or more isoforms only (classify/classify.cpp:159): `solo` must leave no file; `tri`
+    has three isoforms with overlapping, nested and abutting exons; `far` sits on another chromosome and strand; the last
+    line of the map has no newline (dropped by the reference's reader: `cut` then has one isoform left and vanishes too)."""
+    iv = (
+        interval_line("solo.1", "chr1", "+", [(100, 300), (500, 800)])
+        + interval_line("tri.a", "chr1", "-", [(2000, 2100), (2300, 2500), (2900, 3000)])
+        + interval_line("tri.b", "chr1", "-", [(2000, 2150), (2300, 2400), (2400, 2500), (2900, 3000)])
+        + interval_line("tri.c", "chr1", "-", [(2050, 2100), (2900, 3000)])
+        + interval_line("far.x", "chrX", "-", [(10, 20)])
+        + interval_line("far.y", "chrX", "-", [(10, 20), (30, 40)])
+        + interval_line("cut.1", "chr2", "+", [(5, 50)])
+        + interval_line("cut.2", "chr2", "+", [(5, 50), (70, 90)])
+    )
+    mp = "solo\tsolo.1\ntri\ttri.a\ntri\ttri.b\ntri\ttri.c\nfar\tfar.x\nfar\tfar.y\ncut\tcut.1\ncut\tcut.2"
+    _w(os.path.join(d, "cm.interval"), iv)
+    _w(os.path.join(d, "cm.map"), mp)
+    _w(os.path.join(d, "cm.mrf"), "AlignmentBlocks\nchr1:+:111:160:1:50\nchr1:-:2011:2060:1:50\nchr1:-:2301:2350:1:50\nchr1:-:2091:2100:1:10,chr1:-:2301:2340:11:50\nchrX:-:12:20:1:9\nchr2:+:11:40:1:30\n")
+    return {}
+
+
 def write_edge(d):
     iv = (
         interval_line("10.a", "chr1", "+", [(1000, 1100), (1200, 1300), (1500, 1600)])

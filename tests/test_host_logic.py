@@ -172,8 +172,15 @@ def test_mrf_parse_threads_agree(tmp_path):
     assert r1.num_blocks == r4.num_blocks == rs.num_blocks
 
 
-def test_classify_matches_reference(tmp_path, monkeypatch):
-    c, d = load_case("toy", tmp_path)
+CLASSIFY_CASES = ["toy", "classify_mix", "events_s1", "events_s2", "events_s3"]
+
+
+@pytest.mark.parametrize("name", CLASSIFY_CASES)
+def test_classify_matches_reference(name, tmp_path, monkeypatch):
+    """one .matrix per selected gene with two or more isoforms (classify/classify.cpp:159,199-228), byte for byte what
+    the reference's classify wrote: single-isoform genes (classify_mix: `solo`, and `cut` whose second map line has no
+    newline) leave no file; events_s2 selects a gene range"""
+    c, d = load_case(name, tmp_path)
     out = tmp_path / "classify"
     out.mkdir()
     monkeypatch.chdir(d)
@@ -181,9 +188,59 @@ def test_classify_matches_reference(tmp_path, monkeypatch):
     argv[2] = str(out) + "/"
     rc, _ = L.cli_run("classify", argv)
     assert rc == c["classify"]["exit"] == 0
+    assert sorted(os.listdir(out)) == c["classify"]["files"] and c["classify"]["files"]
+    for fn in c["classify"]["files"]:
+        assert open(out / fn).read() == open(os.path.join(d, "classify", fn)).read()
+
+
+BIN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lesseq_amd", "bin")
+
+
+def test_classify_executable_as_a_process(tmp_path):
+    """lesseq_amd/bin/classify spawned like the reference's: files as above, nothing on stdout, log lines with the
+    reference's prefix (jsc/util/log.hpp:64-70) on stderr at log level 2, exit 0; needs no GPU"""
+    import re
+    import subprocess
+    c, d = load_case("classify_mix", tmp_path)
+    out = tmp_path / "cls"
+    out.mkdir()
+    argv = list(c["classify"]["argv"])
+    argv[0], argv[2] = "2", str(out) + "/"
+    p = subprocess.run([os.path.join(BIN, "classify")] + argv, cwd=d, capture_output=True, text=True)
+    assert p.returncode == 0 and p.stdout == ""
     assert sorted(os.listdir(out)) == c["classify"]["files"]
     for fn in c["classify"]["files"]:
         assert open(out / fn).read() == open(os.path.join(d, "classify", fn)).read()
+    lines = [ln for ln in p.stderr.split("\n") if ln]
+    assert lines and all(re.match(r"^\[LOG \d{4}-\d{2}-\d{2} \d{2}:\d{2}:\d{2} [A-Z]+\d?\] ", ln) for ln in lines), p.stderr
+    # too few arguments: usage error, exit 1 (classify/classify.cpp:20-23,58-60)
+    p = subprocess.run([os.path.join(BIN, "classify")] + argv[:5], cwd=d, capture_output=True, text=True)
+    assert p.returncode == 1 and p.stdout == ""
+
+
+def test_executables_exit_statuses_decided_before_the_gpu_as_processes(tmp_path):
+    """count / solve spawned with the `errors` golden argvs whose status the reference decides before any read is
+    counted: usage (too few arguments), bad number, unknown format -> exit 1 with an error line; an isoform file that
+    does not open -> the reference asserts (SIGABRT, shell status 134; count/count.cpp:139)"""
+    import subprocess
+    c, d = load_case("errors", tmp_path)
+    n = 0
+    for tool in ("count", "solve"):
+        for r in c[tool]:
+            fmt_err = r["argv"][3] != "LH_GENE_TXT" or "MRF_PAIRED" in r["argv"] or len(r["argv"]) < 13 or "fifty" in r["argv"] or "abc" in r["argv"]
+            if not fmt_err:
+                continue
+            p = subprocess.run([os.path.join(BIN, tool)] + r["argv"], cwd=d, capture_output=True, text=True)
+            if p.returncode == 3:
+                continue          # a status the reference reaches only after loading reads: needs the device (GPU suite)
+            assert p.returncode == r["exit"] == 1 and p.stdout == "", (tool, r["argv"], p.returncode)
+            assert "ERROR" in p.stderr
+            n += 1
+    assert n >= 3
+    base = ["0", "x", "./", "LH_GENE_TXT", "no_such_file.interval", "UCSC_GENE2ISOFORM", "toy.map", "0", "10", "MRF_SINGLE", "SHORT_READ", "50", "toy.mrf"]
+    p = subprocess.run([os.path.join(BIN, "count")] + base, cwd=d, capture_output=True, text=True)
+    # the reference's assert(ifs) aborts: a shell sees status 134 (128 + SIGABRT); this executable exits with that status
+    assert p.returncode in (134, -6) and p.stdout == "" and "cannot open" in p.stderr, p.returncode
 
 
 def test_exit_statuses_decided_before_the_gpu(tmp_path, monkeypatch):

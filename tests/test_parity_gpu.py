@@ -811,3 +811,49 @@ def test_exception_list_overflow_is_settled_on_the_device(tmp_path, monkeypatch)
     for b in bufs:
         assert np.array_equal(b.cpu().numpy(), want)
     ctx.close()
+
+
+BIN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lesseq_amd", "bin")
+
+
+@pytest.mark.parametrize("name", ["toy", "edge", "events_s1", "multi_method", "classify_mix", "errors"])
+def test_executables_as_processes_match_reference_golden(name, tmp_path):
+    """lesseq_amd/bin/{count,solve} spawned the way the reference's binaries are: stdout carries the table only (count byte
+    for byte, solve as printed), the exit status is the reference's (0, 1 -- also for the statuses it reaches only after
+    the reads were loaded: unknown read type, bad number inside an MRF line), stderr carries log lines with the
+    reference's `[LOG date time LEVEL] ` prefix (jsc/util/log.hpp:64-70) and nothing else"""
+    import re
+    import subprocess
+    c, d = load_case(name, tmp_path)
+    n = 0
+    for tool, r in runs(c):
+        argv = list(r["argv"])
+        argv[0] = "2"                       # log level 2: progress lines on stderr, never on stdout
+        p = subprocess.run([os.path.join(BIN, tool)] + argv, cwd=d, capture_output=True, text=True)
+        exp = open(os.path.join(d, r["stdout"])).read()
+        assert p.returncode == r["exit"], (name, tool, argv, p.returncode, p.stderr)
+        if tool == "count":
+            assert p.stdout == exp, (name, argv)
+        else:
+            assert ob.solve_text_close(p.stdout, exp), (name, argv)
+        lines = [ln for ln in p.stderr.split("\n") if ln]
+        # (a usage error is one log entry of several lines, as in the reference: count/count.cpp:20-23)
+        assert lines and all(re.match(r"^\[LOG \d{4}-\d{2}-\d{2} \d{2}:\d{2}:\d{2} [A-Z]+\d?\] ", ln) for ln in lines if ln.startswith("[") or ln is lines[0]), p.stderr
+        if r["exit"] == 0:
+            assert all(ln.startswith("[LOG ") for ln in lines) and any("oaded" in ln for ln in lines)
+        n += 1
+    assert n
+
+
+def test_executable_device_selection_and_missing_device(tmp_path):
+    """LSQ_DEVICE picks the GPU; a device that does not exist is a start-up failure of this build (exit 3, an error line),
+    not a silent fallback: there is no CPU implementation behind the executables"""
+    import subprocess
+    c, d = load_case("toy", tmp_path)
+    r = c["count"][0]
+    env = dict(os.environ, LSQ_DEVICE="0")
+    p = subprocess.run([os.path.join(BIN, "count")] + r["argv"], cwd=d, capture_output=True, text=True, env=env)
+    assert p.returncode == 0 and p.stdout == open(os.path.join(d, r["stdout"])).read()
+    env["LSQ_DEVICE"] = "63"
+    p = subprocess.run([os.path.join(BIN, "count")] + r["argv"], cwd=d, capture_output=True, text=True, env=env)
+    assert p.returncode == 3 and p.stdout == "" and "ERROR" in p.stderr
