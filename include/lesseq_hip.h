@@ -277,6 +277,28 @@ int lsq_results_fim(lsq_ctx *c, double *fim, double *var_by_diag, double *var_by
  * f64; any may be NULL.  lsq_results_device_order() gives, per device-order event, its output
  * index, so a gathered buffer can be put in output order on the receiving side. */
 int lsq_results_copy_device(lsq_ctx *c, void *d_class_count, void *d_theta, void *d_logll);
+/* The stream those hand-offs run on (hipStream_t in a void*): a caller that launches its own work on the
+ * handed-over buffers -- a collective, say -- orders it behind an event recorded here. */
+void *lsq_ctx_result_stream(lsq_ctx *c);
+
+/* ---- one job over several GPUs: events sharded by index, per-event records gathered -------------------
+ * The reference's scale-out unit is a slice gene_begin_idx..gene_end_idx of the sorted gene list, one process
+ * per slice, outputs concatenated (count/count.cpp:204-215).  Here: every process compiles the WHOLE selected
+ * range (so the load-time read filter is the unsharded one), takes its slice with lsq_events_set_shard --
+ * lsq_shard_bounds cuts the list into `world` contiguous slices of equal weight, e.g. reads per event from a
+ * first unsharded count -- counts and solves it, packs its per-event records in output order
+ * (lsq_results_pack_device: lsq_record_words(e, first, count) words of 8 bytes -- class counts
+ * [method][class], matched bases [method][class], theta, log-likelihood -- asynchronously on the result
+ * stream), the blocks are all-gathered (RCCL: ncclAllGather of blocks padded to the longest; liblesseq_rccl's
+ * lsq_gather does that for a C host, torch.distributed for lesseq_amd/dist.py and bench.py) and
+ * lsq_gathered_unpack lays them out as the whole job's tables for lsq_format_count / lsq_format_solve. */
+int lsq_shard_bounds(const lsq_events *e, int world, const double *weights /* per event, or NULL */,
+                     uint64_t *first /* world */, uint64_t *count /* world */);
+uint64_t lsq_record_words(const lsq_events *e, uint64_t first, uint64_t count);
+int lsq_results_pack_device(lsq_ctx *c, void *d_block);
+int lsq_gathered_unpack(const lsq_events *e, int world, const uint64_t *first, const uint64_t *count,
+                        const uint64_t *blocks, uint64_t stride_words,
+                        uint64_t *class_count, uint64_t *class_bases, double *theta, double *logll);
 int lsq_results_device_order(const lsq_ctx *c, int32_t *dev2out /* n_events */);
 
 /* Device timing, for bench.py and the developer tools.  Off by default: the event records between

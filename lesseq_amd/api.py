@@ -117,6 +117,40 @@ class Events:
     def set_shard(self, first_event, n_events):
         check(lib.lsq_events_set_shard(self.h, first_event, n_events))
 
+    def shard_bounds(self, world, weights=None):
+        """lsq_shard_bounds: [(first, count)] per process, contiguous slices of equal weight"""
+        first, count = (u64 * world)(), (u64 * world)()
+        w = None
+        if weights is not None:
+            w = np.ascontiguousarray(weights, np.float64)
+            assert len(w) == len(self)
+        check(lib.lsq_shard_bounds(self.h, world, _ptr(w, C.c_double) if w is not None else None, first, count))
+        return [(int(first[r]), int(count[r])) for r in range(world)]
+
+    def record_words(self, first, count):
+        return int(lib.lsq_record_words(self.h, first, count))
+
+    def gathered_unpack(self, bounds, blocks, stride_words):
+        """blocks: uint64 array [world * stride_words] of packed records -> (cnt, bases, theta, logll) of the whole job"""
+        world = len(bounds)
+        first = (u64 * world)(*[b[0] for b in bounds])
+        count = (u64 * world)(*[b[1] for b in bounds])
+        off = self.class_offsets()
+        n_cls, n_ev, M = off[-1], len(self), self.n_methods
+        cnt = np.zeros((max(M, 1), max(n_cls, 1)), np.uint64)
+        bases = np.zeros((max(M, 1), max(n_cls, 1)), np.uint64)
+        theta = np.zeros(max(self.total_isoforms, 1), np.float64)
+        ll = np.zeros(max(n_ev, 1), np.float64)
+        blocks = np.ascontiguousarray(blocks).view(np.uint64)
+        # the C side indexes [method][n_classes] rows of exactly n_cls entries
+        c2 = np.zeros(max(M * n_cls, 1), np.uint64)
+        b2 = np.zeros(max(M * n_cls, 1), np.uint64)
+        check(lib.lsq_gathered_unpack(self.h, world, first, count, _ptr(blocks, u64), stride_words, _ptr(c2, u64), _ptr(b2, u64),
+                                      _ptr(theta, C.c_double), _ptr(ll, C.c_double)))
+        cnt = c2[:M * n_cls].reshape(M, n_cls) if M * n_cls else cnt[:M, :n_cls]
+        bases = b2[:M * n_cls].reshape(M, n_cls) if M * n_cls else bases[:M, :n_cls]
+        return cnt, bases, theta[:self.total_isoforms], ll[:n_ev]
+
     def chrom_id(self, name):
         return lib.lsq_events_chrom_id(self.h, _b(name))
 
@@ -278,6 +312,14 @@ class Context:
     def copy_results_device(self, d_class_count=None, d_theta=None, d_logll=None):
         """raw device-order results into caller device buffers (integer addresses), async"""
         check(lib.lsq_results_copy_device(self.h, vp(d_class_count), vp(d_theta), vp(d_logll)))
+
+    def pack_results_device(self, d_block):
+        """the shard's per-event records in output order into a caller device buffer (integer address), async on the result stream"""
+        check(lib.lsq_results_pack_device(self.h, vp(d_block)))
+
+    @property
+    def result_stream(self):
+        return lib.lsq_ctx_result_stream(self.h)
 
     def device_order(self):
         o = np.zeros(max(len(self.events), 1), np.int32)

@@ -847,6 +847,66 @@ int lsq_events_set_shard(lsq_events *e, uint64_t first_event, uint64_t n_events)
 	return plan_device(*e);
 }
 
+// Contiguous slices of the output-ordered events for `world` processes, balanced by weight (reads per event from a
+// pre-pass; NULL = by event count): slice r ends where the running weight first reaches r/world of the total.
+int lsq_shard_bounds(const lsq_events *e, int world, const double *weights, uint64_t *first, uint64_t *count) {
+	if (!e || world < 1 || !first || !count) return fail(LSQ_E_ARG, "bad argument");
+	const size_t n = e->ev.size();
+	std::vector<double> cum(n + 1, 0.0);
+	for (size_t i = 0; i < n; ++i) {
+		const double w = weights ? weights[i] : 1.0;
+		if (!(w >= 0.0)) return fail(LSQ_E_ARG, "negative or non-finite weight for event %zu", i);
+		cum[i + 1] = cum[i] + w;
+	}
+	const double total = cum[n];
+	std::vector<uint64_t> cuts((size_t)world + 1, 0);
+	for (int r = 1; r < world; ++r) {
+		const double target = total * (double)r / (double)world;
+		size_t c = (size_t)(std::lower_bound(cum.begin(), cum.end(), target) - cum.begin());
+		c = std::min(c, n);
+		cuts[(size_t)r] = std::max<uint64_t>(c, cuts[(size_t)r - 1]);
+	}
+	cuts[(size_t)world] = n;
+	for (int r = 0; r < world; ++r) { first[r] = cuts[(size_t)r]; count[r] = cuts[(size_t)r + 1] - cuts[(size_t)r]; }
+	return LSQ_OK;
+}
+
+// words (8 bytes) of the packed per-event records of events [first, first + count): class counts and matched bases
+// per read file, theta, log-likelihood -- lsq_results_pack_device's block
+uint64_t lsq_record_words(const lsq_events *e, uint64_t first, uint64_t count) {
+	if (!e || first > e->ev.size()) return 0;
+	const size_t a = (size_t)first, b = (size_t)std::min<uint64_t>(first + count, e->ev.size());
+	const uint64_t C = e->class_off[b] - e->class_off[a], I = e->iso_off[b] - e->iso_off[a];
+	return 2 * (uint64_t)e->n_methods * C + I + (uint64_t)(b - a);
+}
+
+// The gathered blocks of `world` processes (block r at blocks + r * stride_words, holding the records of events
+// [first[r], first[r] + count[r]) in output order) put together as the whole job's tables, in the layout
+// lsq_results_counts / lsq_results_solve use.
+int lsq_gathered_unpack(const lsq_events *e, int world, const uint64_t *first, const uint64_t *count, const uint64_t *blocks, uint64_t stride_words,
+                        uint64_t *class_count, uint64_t *class_bases, double *theta, double *logll) {
+	if (!e || world < 1 || !first || !count || !blocks || !class_count) return fail(LSQ_E_ARG, "null argument");
+	const size_t n = e->ev.size(), M = (size_t)e->n_methods, n_out = (size_t)e->class_off[n];
+	memset(class_count, 0, M * n_out * sizeof(uint64_t));
+	if (class_bases) memset(class_bases, 0, M * n_out * sizeof(uint64_t));
+	if (theta) memset(theta, 0, (size_t)e->iso_off[n] * sizeof(double));
+	if (logll) memset(logll, 0, n * sizeof(double));
+	for (int r = 0; r < world; ++r) {
+		if (first[r] > n || count[r] > n - first[r]) return fail(LSQ_E_ARG, "slice %d lies outside the events", r);
+		const size_t a = (size_t)first[r], b = a + (size_t)count[r];
+		const size_t C = (size_t)(e->class_off[b] - e->class_off[a]), I = (size_t)(e->iso_off[b] - e->iso_off[a]);
+		if (2 * M * C + I + (b - a) > stride_words) return fail(LSQ_E_ARG, "block %d is longer than the stride", r);
+		const uint64_t *blk = blocks + (size_t)r * stride_words;
+		for (size_t m = 0; m < M; ++m) {
+			memcpy(class_count + m * n_out + e->class_off[a], blk + m * C, C * sizeof(uint64_t));
+			if (class_bases) memcpy(class_bases + m * n_out + e->class_off[a], blk + (M + m) * C, C * sizeof(uint64_t));
+		}
+		if (theta) memcpy(theta + e->iso_off[a], blk + 2 * M * C, I * sizeof(double));
+		if (logll) memcpy(logll + a, blk + 2 * M * C + I, (b - a) * sizeof(double));
+	}
+	return LSQ_OK;
+}
+
 int lsq_events_chrom_id(lsq_events *e, const char *chrom) {
 	if (!e || !chrom) return LSQ_E_ARG;
 	int id = e->chroms.intern(chrom);

@@ -131,6 +131,24 @@ int lsq_events_upload(lsq_ctx *c, lsq_events *E) {
 		if ((rc = c->gene_names.upload(blob.data(), blob.size(), c->stream))) return rc;
 		if ((rc = c->gene_name_off.upload(goff.data(), goff.size(), c->stream))) return rc;
 	}
+	{
+		// lsq_results_pack_device: where every class slot, isoform and event of the shard sits in the device arrays,
+		// listed in output order (the shard is a contiguous run of output-ordered events)
+		const size_t n_dev = E->dev2out.size();
+		std::vector<uint32_t> order(n_dev);
+		std::iota(order.begin(), order.end(), 0u);
+		std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return E->dev2out[a] < E->dev2out[b]; });
+		std::vector<uint32_t> pc, pi, pe;
+		for (uint32_t dd : order) {
+			const int K = E->dev_K[dd];
+			for (uint32_t k = 0; k < (1u << K) - 1u; ++k) pc.push_back(E->dev_cls_base[dd] + k);
+			for (int j = 0; j < K; ++j) pi.push_back(E->dev_iso_base[dd] + (uint32_t)j);
+			pe.push_back(dd);
+		}
+		if ((rc = c->pack_cls.upload(pc.data(), pc.size(), c->stream))) return rc;
+		if ((rc = c->pack_iso.upload(pi.data(), pi.size(), c->stream))) return rc;
+		if ((rc = c->pack_ev.upload(pe.data(), pe.size(), c->stream))) return rc;
+	}
 	// G = 1/ARS (common/read.h:331-340), device isoform order, per method
 	const size_t n_iso = E->n_iso_total, M = (size_t)E->n_methods;
 	std::vector<double> G(std::max<size_t>(M * n_iso, 1), 0.0);
@@ -430,6 +448,45 @@ int lsq_results_copy_device(lsq_ctx *c, void *d_class_count, void *d_theta, void
 	}
 	return LSQ_OK;
 }
+
+extern "C++" {
+namespace {
+// the shard's records in output order: [method][class] counts, [method][class] bases, theta, log-likelihood
+__global__ void __launch_bounds__(256) lsq_pack_results_kernel(unsigned long long *dst, const unsigned long long *cnt, const unsigned long long *bases,
+                                                               const unsigned long long *theta, const unsigned long long *logll, const unsigned *pack_cls,
+                                                               const unsigned *pack_iso, const unsigned *pack_ev, size_t M, size_t C, size_t I, size_t N,
+                                                               size_t n_cls_dev) {
+	const size_t total = 2 * M * C + I + N, gsz = (size_t)gridDim.x * blockDim.x;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gsz) {
+		unsigned long long v;
+		if (i < M * C) { const size_t m = i / C, k = i - m * C; v = cnt[m * n_cls_dev + pack_cls[k]]; }
+		else if (i < 2 * M * C) { const size_t q = i - M * C, m = q / C, k = q - m * C; v = bases[m * n_cls_dev + pack_cls[k]]; }
+		else if (i < 2 * M * C + I) v = theta[pack_iso[i - 2 * M * C]];
+		else v = logll[pack_ev[i - 2 * M * C - I]];
+		dst[i] = v;
+	}
+}
+} // namespace
+} // extern "C++"
+
+int lsq_results_pack_device(lsq_ctx *c, void *d_block) {
+	if (!c || !d_block) return fail(LSQ_E_ARG, "null argument");
+	if (!c->solved) return fail(LSQ_E_STATE, "lsq_solve must come first");
+	HIP_TRY(hipSetDevice(c->device));
+	const lsq_events &E = *c->E;
+	const size_t M = (size_t)E.n_methods, C = c->pack_cls.n, I = c->pack_iso.n, N = c->pack_ev.n;
+	const size_t total = 2 * M * C + I + N;
+	if (total) {
+		const unsigned grid = (unsigned)std::min<size_t>((total + 255) / 256, (size_t)c->n_cu * 8);
+		hipLaunchKernelGGL(lsq_pack_results_kernel, dim3(grid), dim3(256), 0, c->stream_em, (unsigned long long *)d_block, c->cnt.p, c->bases.p,
+		                   (const unsigned long long *)c->theta.p, (const unsigned long long *)c->logll.p, c->pack_cls.p, c->pack_iso.p, c->pack_ev.p, M, C, I, N,
+		                   (size_t)E.n_cls_total);
+		HIP_TRY(hipGetLastError());
+	}
+	return LSQ_OK;
+}
+
+void *lsq_ctx_result_stream(lsq_ctx *c) { return c ? (void *)c->stream_em : nullptr; }
 
 int lsq_results_device_order(const lsq_ctx *c, int32_t *dev2out) {
 	if (!c || !c->E || !dev2out) return fail(LSQ_E_ARG, "null argument");

@@ -108,6 +108,7 @@ struct lsq_ctx {
 	DevBuf<TieRec> ties;
 	DevBuf<uint32_t> cls_base, iso_base, iters, em_order, gene_name_off;
 	DevBuf<char> gene_names;                // device event order
+	DevBuf<uint32_t> pack_cls, pack_iso, pack_ev;      // lsq_results_pack_device: device index of every class / isoform / event of the shard, in output order
 	unsigned em_places = 0;
 	unsigned em_small_places = 0;           // the first of them: events of the lean EM kernel
 	DevBuf<double> G, theta, logll;

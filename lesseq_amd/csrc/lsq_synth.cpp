@@ -234,18 +234,46 @@ int lsq_synth_write(const lsq_synth_spec *S, const char *dir, const char *stem, 
 		FILE *fr = fopen((base + ".mrf").c_str(), "w");
 		if (!fr) return fail(LSQ_E_IO, "cannot write under %s", dir);
 		fputs("AlignmentBlocks\n", fr);
-		OneRead r;
-		for (uint64_t i = 0; i < S->n_reads; ++i) {
-			gen_read(*S, Mo, S->first_read + i, r);
-			int q = 1;
-			for (int b = 0; b < r.nb; ++b) {
-				int ln = r.be[b] - r.bs[b];
-				fprintf(fr, "%s%s:%c:%d:%d:%d:%d", b ? "," : "", chrom_name(r.chrom).c_str(), r.strand, r.bs[b] + 1, r.be[b], q, q + ln - 1);
-				q += ln;
+		// reads are a function of their number (counter-based generator): rounds of T chunks formatted by T threads,
+		// written in order
+		const int T = host_threads(0);
+		const uint64_t CHUNK = 1u << 18;
+		std::vector<std::string> bufs((size_t)T);
+		auto put_int = [](std::string &o, long long v) {
+			char tmp[24]; int n = 0;
+			if (v < 0) { o.push_back('-'); v = -v; }
+			do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+			while (n) o.push_back(tmp[--n]);
+		};
+		bool io_ok = true;
+		for (uint64_t round0 = 0; round0 < S->n_reads && io_ok; round0 += CHUNK * (uint64_t)T) {
+			std::vector<std::thread> th;
+			for (int t = 0; t < T; ++t) {
+				th.emplace_back([&, t] {
+					std::string &o = bufs[(size_t)t];
+					o.clear();
+					const uint64_t i0 = round0 + CHUNK * (uint64_t)t, i1 = std::min<uint64_t>(i0 + CHUNK, S->n_reads);
+					OneRead r;
+					for (uint64_t i = i0; i < i1; ++i) {
+						gen_read(*S, Mo, S->first_read + i, r);
+						int q = 1;
+						for (int b = 0; b < r.nb; ++b) {
+							const int ln = r.be[b] - r.bs[b];
+							if (b) o.push_back(',');
+							o += "chr"; put_int(o, r.chrom + 1);
+							o.push_back(':'); o.push_back(r.strand); o.push_back(':');
+							put_int(o, (long long)r.bs[b] + 1); o.push_back(':'); put_int(o, r.be[b]); o.push_back(':');
+							put_int(o, q); o.push_back(':'); put_int(o, (long long)q + ln - 1);
+							q += ln;
+						}
+						o.push_back('\n');
+					}
+				});
 			}
-			fputc('\n', fr);
+			for (auto &x : th) x.join();
+			for (int t = 0; t < T; ++t) if (!bufs[(size_t)t].empty() && fwrite(bufs[(size_t)t].data(), 1, bufs[(size_t)t].size(), fr) != bufs[(size_t)t].size()) io_ok = false;
 		}
-		fclose(fr);
+		if (fclose(fr) != 0 || !io_ok) return fail(LSQ_E_IO, "cannot write %s.mrf", base.c_str());
 	}
 	return LSQ_OK;
 }

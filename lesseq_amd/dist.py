@@ -5,10 +5,11 @@ Events are independent (the reference already scales out by running disjoint
 gene_begin_idx..gene_end_idx slices, count/count.cpp:204-215).  Here every rank loads the whole
 selected range -- so the covered regions, hence the load-time read filter, are those of the
 unsharded run -- restricts its device plan to a contiguous slice of the output-ordered events
-(lsq_events_set_shard), counts and solves its slice on its GPU, and the fixed-stride per-event
-outputs (class counts, class bases, theta, log-likelihood) are combined over the process group:
-RCCL over xGMI with backend "nccl", gloo on CPU tensors in the tests.  Slices are disjoint, so the
-sum over ranks of zero-padded arrays IS the concatenation; integer sums keep it exact.
+(lsq_events_set_shard: slices of equal read weight from a first unsharded count, lsq_shard_bounds),
+counts and solves its slice on its GPU, packs its per-event records (class counts, class bases, theta,
+log-likelihood) in output order on the device (lsq_results_pack_device), and one all-gather over the
+process group -- RCCL over xGMI with backend "nccl", gloo on host copies in the tests -- gives every rank
+the blocks of all; lsq_gathered_unpack lays them out as the whole job's tables.
 """
 import numpy as np
 
@@ -36,11 +37,16 @@ def shard_bounds(n_events, world, weights=None):
 
 
 def combine(arrays, group=None, device=None):
-    """all-reduce(SUM) of zero-padded per-rank arrays; uint64 travels as int64 (counts < 2^63)."""
+    """all-reduce(SUM) of per-rank arrays (numpy, or torch tensors already on the communication device, which stay
+    there); uint64 travels as int64 (counts < 2^63).  Used by the read-sharded run, whose exchange is a sum."""
     import torch
     import torch.distributed as dist
     out = []
     for a in arrays:
+        if isinstance(a, torch.Tensor):
+            dist.all_reduce(a, op=dist.ReduceOp.SUM, group=group)
+            out.append(a)
+            continue
         a = np.ascontiguousarray(a)
         view = a.view(np.int64) if a.dtype == np.uint64 else a
         t = torch.from_numpy(view.copy())
@@ -55,37 +61,105 @@ def combine(arrays, group=None, device=None):
 def parse_cli(tool, argv):
     per = 5 if tool == "solve" else 4
     groups = [argv[9 + i * per: 9 + (i + 1) * per] for i in range((len(argv) - 9) // per)]
-    return dict(isoforms=argv[4], g2i=argv[6], begin=int(argv[7]), end=int(argv[8]),
-                read_types=tuple(g[1] for g in groups), read_lengths=tuple(int(g[2]) for g in groups),
+    return dict(isoform_format=argv[3], isoforms=argv[4], g2i_format=argv[5], g2i=argv[6], begin=int(argv[7]), end=int(argv[8]),
+                read_formats=[g[0] for g in groups], read_types=tuple(g[1] for g in groups), read_lengths=tuple(int(g[2]) for g in groups),
                 read_paths=[g[3] for g in groups], total_read_bases=[float(g[4]) for g in groups] if tool == "solve" else None)
 
 
-def run_sharded(tool, argv, rank, world, device_index=0, group=None, comm_device=None, weights=None):
-    """count / solve over `world` ranks.  Returns the table text on every rank (they all hold the
-    combined arrays after the all-reduce); byte-identical to the single-process run."""
+class StagedReads:
+    """The read files of a job, ready to be ingested more than once (the weight pre-pass, then the shard): MRF_SINGLE text is
+    copied to HBM once and parsed there by every upload; the name-keyed formats are parsed on the host once."""
+
+    def __init__(self, ctx, ev, a):
+        self.ctx, self.items = ctx, []
+        try:
+            for fmt, path in zip(a["read_formats"], a["read_paths"]):
+                if fmt == "MRF_SINGLE":
+                    self.items.append(("text", ctx.stage_text(path)))
+                else:
+                    self.items.append(("host", api.Reads.from_mrf(path, ev, read_format=fmt)))
+        except Exception:
+            self.free()
+            raise
+
+    def upload(self):
+        for m, (kind, x) in enumerate(self.items):
+            if kind == "text":
+                self.ctx.upload_reads_text(m, x, free=False)
+            else:
+                self.ctx.upload_reads(m, x)
+
+    def free(self):
+        for kind, x in self.items:
+            if kind == "text":
+                api.lib.lsq_text_free(x)
+        self.items = []
+
+
+def event_weights(ev, cnt):
+    """reads per output-ordered event from a count table [method][class] (a read valid for an event is in one class)"""
+    off = np.asarray(ev.class_offsets(), np.int64)
+    tot = np.concatenate([[0], np.cumsum(np.asarray(cnt, np.float64).sum(axis=0))])
+    return tot[off[1:]] - tot[off[:-1]]
+
+
+def gather_blocks(block, stride, world, group=None, comm_device=None):
+    """all-gather of every rank's packed record block (a device tensor of `stride` int64 words, zero-padded behind its
+    records): RCCL's ncclAllGather with backend "nccl", gloo on a host copy in the CPU tests.  Returns uint64 [world * stride]."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return block.cpu().numpy().view(np.uint64)
+    if comm_device is None and dist.get_backend(group) == "gloo":
+        comm_device = torch.device("cpu")
+    mine = block if comm_device is None or block.device == comm_device else block.to(comm_device)
+    out = torch.zeros(world * stride, dtype=torch.int64, device=mine.device)
+    dist.all_gather_into_tensor(out, mine, group=group)
+    return out.cpu().numpy().view(np.uint64)
+
+
+def run_sharded(tool, argv, rank, world, device_index=0, group=None, comm_device=None, weights="prepass"):
+    """count / solve of ONE job over `world` ranks, events sharded (BASELINE configs[3]).  Every rank compiles the whole
+    selected range, so the covered regions -- hence the load-time read filter -- are those of the unsharded run.  The slices
+    are balanced by reads per event from a first, unsharded count (weights="prepass"; None = by event count; or an array).
+    Each rank then ingests the reads against its slice only (reads that start in no event of the slice are dropped at
+    ingest), counts and solves, packs its per-event records in output order on the device, and one all-gather puts the
+    blocks of all ranks on every rank.  Returns the table text: byte-identical to the single-process run."""
+    import torch
     a = parse_cli(tool, argv)
-    ann = api.Annotation(a["isoforms"], a["g2i"], a["begin"], a["end"])
+    ann = api.Annotation(a["isoforms"], a["g2i"], a["begin"], a["end"], a["isoform_format"], a["g2i_format"])
     ev = api.Events(ann, a["read_types"], a["read_lengths"])
-    first, count = shard_bounds(len(ev), world, weights)[rank]
-    ev.set_shard(first, count)
     ctx = api.Context(device_index)
-    ctx.upload_events(ev)
-    for m, path in enumerate(a["read_paths"]):
-        ctx.upload_reads(m, api.Reads.from_mrf(path, ev))
+    staged = StagedReads(ctx, ev, a)
+    try:
+        if world > 1 and isinstance(weights, str) and weights == "prepass":
+            ctx.upload_events(ev)
+            staged.upload()
+            ctx.count()
+            weights = event_weights(ev, ctx.counts()[0])
+        elif isinstance(weights, str):
+            weights = None
+        bounds = ev.shard_bounds(world, weights)
+        first, count = bounds[rank]
+        ev.set_shard(first, count)
+        ctx.upload_events(ev)
+        staged.upload()
+    finally:
+        staged.free()
     ctx.count()
-    if tool == "solve":
-        ctx.solve()
-    cnt, bases = ctx.counts()
-    parts = [cnt, bases]
-    if tool == "solve":
-        theta, ll, iters, flags = ctx.solution()
-        parts += [theta, ll]          # events outside the slice hold zeros
+    ctx.solve()
+    ctx.solve_finalize()          # guard-band events in the reference's summation order (each rank holds its events' reads)
+    stride = max(max(ev.record_words(f, c) for f, c in bounds), 1)
+    dev = torch.device("cuda", device_index)
+    block = torch.zeros(stride, dtype=torch.int64, device=dev)
+    ctx.pack_results_device(block.data_ptr())
+    ctx.synchronize()
+    blocks = gather_blocks(block, stride, world, group, comm_device)
     ctx.close()
-    if world > 1:
-        parts = combine(parts, group, comm_device)
+    cnt, bases, theta, ll = ev.gathered_unpack(bounds, blocks, stride)
     if tool == "count":
-        return api.format_count(ev, parts[0])
-    return api.format_solve(ev, parts[0], parts[1], parts[2], parts[3], a["total_read_bases"])
+        return api.format_count(ev, cnt)
+    return api.format_solve(ev, cnt, bases, theta, ll, a["total_read_bases"])
 
 
 # ----------------------------------------------------------------------------------------------
@@ -123,30 +197,38 @@ def slice_bounds(path, world, window=1 << 16):
 
 def run_read_sharded(tool, argv, rank, world, device_index=0, group=None, comm_device=None):
     """count / solve of one job over `world` ranks, reads sharded.  Returns the table text (the same
-    on every rank, byte-identical to the single-process run)."""
+    on every rank, byte-identical to the single-process run).  MRF_SINGLE read files only: the name-keyed
+    formats of `solve` group lines by read name across the whole file, which a byte slice cannot do."""
     import torch
     import torch.distributed as dist
     a = parse_cli(tool, argv)
-    ann = api.Annotation(a["isoforms"], a["g2i"], a["begin"], a["end"])
+    for fmt in a["read_formats"]:
+        if fmt != "MRF_SINGLE":
+            raise ValueError("the read-sharded run takes MRF_SINGLE read files only (got %s); use --shard events" % fmt)
+    ann = api.Annotation(a["isoforms"], a["g2i"], a["begin"], a["end"], a["isoform_format"], a["g2i_format"])
     ev = api.Events(ann, a["read_types"], a["read_lengths"])
     ctx = api.Context(device_index)
     ctx.upload_events(ev)
     texts = []
-    for path in a["read_paths"]:
-        cuts = slice_bounds(path, world)
-        texts.append(ctx.stage_text(path, cuts[rank], cuts[rank + 1]))
-    # file-wide line numbers: a data line's number is the count of newlines before it
-    mine = torch.tensor([ctx.text_lines(t) for t in texts], dtype=torch.int64)
-    if comm_device is not None:
-        mine = mine.to(comm_device)
-    if world > 1:
-        every = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(every, mine, group=group)
-    else:
-        every = [mine]
-    for m, t in enumerate(texts):
-        before = sum(int(every[r][m].item()) for r in range(rank))
-        ctx.upload_reads_text(m, t, has_header=(rank == 0), first_line=(1 if rank == 0 else before))
+    try:
+        for path in a["read_paths"]:
+            cuts = slice_bounds(path, world)
+            texts.append(ctx.stage_text(path, cuts[rank], cuts[rank + 1]))
+        # file-wide line numbers: a data line's number is the count of newlines before it
+        mine = torch.tensor([ctx.text_lines(t) for t in texts], dtype=torch.int64)
+        if comm_device is not None:
+            mine = mine.to(comm_device)
+        if world > 1:
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine, group=group)
+        else:
+            every = [mine]
+        for m, t in enumerate(texts):
+            before = sum(int(every[r][m].item()) for r in range(rank))
+            ctx.upload_reads_text(m, t, has_header=(rank == 0), first_line=(1 if rank == 0 else before), free=False)
+    finally:
+        for t in texts:
+            api.lib.lsq_text_free(t)
     ctx.count()
     cnt, bases = ctx.counts()
     if world > 1:

@@ -64,6 +64,26 @@ def _worker(rank, world, port, iv, mp_path, q):
         g_cnt, g_bases, g_theta, g_ll = ld.combine([cnt, bases, theta, ll])
         ok = (np.array_equal(g_cnt, full_cnt) and np.array_equal(g_bases, full_bases)
               and np.array_equal(g_theta, full_theta) and np.array_equal(g_ll, full_ll))
+        # the event-sharded run's exchange: every rank's packed record block (what lsq_results_pack_device writes:
+        # counts, bases, theta, log-likelihood of its slice in output order), all-gathered, then lsq_gathered_unpack;
+        # slices weighted as a read-depth pre-pass would weight them (a few heavy events)
+        wts = np.ones(n_ev)
+        wts[::17] = 500.0
+        bounds = ev.shard_bounds(world, wts)
+        assert bounds == ld.shard_bounds(n_ev, world, wts)
+        f2, c2 = bounds[rank]
+        stride = max(ev.record_words(f, c) for f, c in bounds)
+        blk = np.concatenate([full_cnt[0, off[f2]:off[f2 + c2]], full_bases[0, off[f2]:off[f2 + c2]],
+                              full_theta[io[f2]:io[f2 + c2]].view(np.uint64), full_ll[f2:f2 + c2].view(np.uint64)])
+        assert len(blk) == ev.record_words(f2, c2)
+        block = torch.zeros(stride, dtype=torch.int64)
+        block[:len(blk)] = torch.from_numpy(blk.view(np.int64).copy())
+        blocks = ld.gather_blocks(block, stride, world)
+        u_cnt, u_bases, u_theta, u_ll = ev.gathered_unpack(bounds, blocks, stride)
+        ok = ok and (np.array_equal(u_cnt, full_cnt) and np.array_equal(u_bases, full_bases)
+                     and np.array_equal(u_theta, full_theta) and np.array_equal(u_ll, full_ll))
+        sums = [wts[f:f + c].sum() for f, c in bounds]
+        ok = ok and max(sums) <= wts.sum() / world + 500.0
         text = L.format_solve(ev, g_cnt, g_bases, g_theta, g_ll, [1e6])
         ref = L.format_solve(ev, full_cnt, full_bases, full_theta, full_ll, [1e6])
         q.put((rank, ok and text == ref and L.format_count(ev, g_cnt) == L.format_count(ev, full_cnt)))
@@ -99,10 +119,13 @@ def _gpu_worker(rank, world, port, argv_count, argv_solve, q):
 
 
 @pytest.mark.gpu
-def test_two_ranks_sharded_run_equals_single_process(tmp_path):
+@pytest.mark.parametrize("zipf", [False, True], ids=["even_depth", "zipf_depth"])
+def test_two_ranks_sharded_run_equals_single_process(zipf, tmp_path):
     """two ranks (sharing the one GPU of the test box, gloo for the exchange) give the byte-identical
-    count table and the identical solve table of the unsharded run"""
-    spec = L.SynthSpec(31, 300, 60000, 100, 3, L.EVENT_TYPES)
+    count table and the identical solve table of the unsharded run: MRF text parsed on the device by each
+    rank, slices weighted by reads per event from a first unsharded count (with Zipf depth the cut is far
+    from the middle of the event list), records packed on the device, all-gathered, unpacked"""
+    spec = L.SynthSpec(31, 300, 60000, 100, 3, L.EVENT_TYPES, zipf)
     L.synth_write(spec, str(tmp_path), "d")
     base = ["0", "d", "./", "LH_GENE_TXT", str(tmp_path / "d.interval"), "UCSC_GENE2ISOFORM", str(tmp_path / "d.map"),
             "0", "100000000", "MRF_SINGLE", "SHORT_READ", "100", str(tmp_path / "d.mrf")]
