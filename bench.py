@@ -1,28 +1,38 @@
 #!/usr/bin/env python3
 """bench.py -- count+solve hot path on synthetic MRF reads, one process per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c1]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c1|c5s|c5] [--mode strong|weak]
 
-A step = one pass of the hot path over the reads resident in HBM: the count kernel over every
-retained read, the batched EM kernel over every event, and the hand-off of the per-event
-outputs to the caller's device buffers.
-Parsing, the containment filter and the bucket/pool layout are ingest: done once before the
-timed region (their wall time is reported under config.ingest_s, never in `value`).
+The job: BASELINE.json configs[2] (default workload c3: 100 M synthetic 100-bp MRF reads over 50 k mixed local
+events on 24 chromosomes).  Rank 0 writes the job's files once (annotation + MRF text, deterministic in the
+seed); every rank copies the MRF text to its GPU and parses and ingests it there (lsq_text_stage /
+lsq_reads_upload_text: the device parser, the load-time containment filter, the bucket / pool layout).
 
-Weak scaling: every rank holds its own shard -- `n_events` events and the reads over them
-(the reference shards by gene index range the same way, count/count.cpp:204-215).  The shards
-are independent: no collective runs inside the timed loop; one RCCL all-gather after it puts the
-per-event tables of all ranks together.
+A step = one pass of the hot path over the reads resident in HBM: the count kernels over every retained read of
+the rank's events, the batched EM over those events, the per-event records packed in output order on the device
+-- and, with N > 1, the RCCL all-gather that puts the records of all ranks on every rank, inside the timed loop.
 
-The JSON line carries `roofline` for the count kernel (algorithmic bytes = 8 B per retained
-read block + the event tables read once + the class tables written once, SURVEY.md 8(d);
-duration from HIP events recorded on the library's stream around the kernel launches) and
-`cpu_baseline`: the oracle (a port; never part of the product path) timed single-threaded on
-a bounded prefix of the same read stream over the same events.
+N > 1, --mode strong (default; BASELINE.json configs[3]): ONE job for all ranks.  The output-ordered events are
+cut into N contiguous slices of equal read weight (reads per event from a first unsharded count,
+lsq_shard_bounds; the reference's own scale-out unit is such a slice, count/count.cpp:204-215), every rank
+ingests the reads of its slice, and `value` = the job's retained reads x steps / time: strong scaling.  After the
+loop rank 0 checks that the gathered tables equal the unsharded run's.
+N > 1, --mode weak: every rank runs its own job of the workload's size (seed + 1000 x rank), no collective in the
+loop (the path has no exchange step); one all-gather after it.
+
+The JSON line carries `roofline` for the count kernel (algorithmic bytes = 8 B per retained read block + the event
+tables read once + the class tables written once; duration from HIP events recorded on the
+library's stream around the kernel launches), the end-to-end figures of SURVEY 8(d) under `config` (kernel-resident
+is `value`; device-resident from parsed arrays in host memory; from MRF text, in-process and as the `solve`
+executable), and `cpu_baseline`: the oracle (a port; never part of the product path) on a bounded prefix of the
+same read stream over the same events.
 """
 import argparse
+import hashlib
 import json
 import os
+import shutil
+import subprocess
 import sys
 import tempfile
 import time
@@ -42,20 +52,27 @@ WORKLOADS = {
     # one GPU's share of configs[4] (1 B reads / 200 k events over 8 GPUs), skewed read depth (hot genes)
     "c5s": dict(n_events=25_000, n_reads=125_000_000, R=100, n_chrom=24, types=None, seed=5, zipf=True,
                 desc="one eighth of BASELINE configs[4]: 125M synthetic 100bp reads over 25k mixed events, Zipf read depth (hot genes), 24 chromosomes"),
-    # all of configs[4] on ONE GPU (a size check: ~25 GB of parsed reads on the host, ~10 GB of pools in HBM)
+    # all of configs[4]: on one GPU a size check (37 GB of MRF text); over 8 GPUs (--gpus 8) the config itself
     "c5": dict(n_events=200_000, n_reads=1_000_000_000, R=100, n_chrom=24, types=None, seed=5, zipf=True,
                desc="BASELINE configs[4] whole: 1B synthetic 100bp reads over 200k mixed events, Zipf read depth (hot genes), 24 chromosomes"),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 measured copy rate
 
 
+def shared_dir(tag):
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    return os.path.join(base, "lsq_bench_%s_%s" % (os.environ.get("USER", "u"), tag))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)       # 0.25 ms each: the loop itself is ~50 ms
+    ap.add_argument("--steps", type=int, default=200)       # ~0.25 ms each at N = 1: the loop itself is ~50 ms
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--mode", default="strong", choices=("strong", "weak"), help="N > 1: one job sharded by events (strong), or one job per rank (weak)")
     ap.add_argument("--cpu-sample", type=int, default=15_000_000, help="reads in the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end legs (N = 1 only)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -63,16 +80,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and world > 1:
         a.gpus = world
+    strong = world > 1 and a.mode == "strong"
 
     import numpy as np
     import torch
     import torch.distributed as dist
     import lesseq_amd as L
+    from lesseq_amd import dist as ld
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the hot path has no CPU implementation")
     # rehearsal on a one-GPU box (developer aid): LSQ_BENCH_REHEARSE=1 puts every rank on cuda:0 and
-    # moves the per-event outputs over gloo instead of RCCL; the driver never sets it
+    # moves the per-event records over gloo instead of RCCL; the driver never sets it
     rehearse = os.environ.get("LSQ_BENCH_REHEARSE") == "1"
     if rehearse:
         local_rank = 0
@@ -83,51 +102,129 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
-    comm_dev = torch.device("cpu") if (rehearse and world > 1) else dev
+    on_host = rehearse and world > 1          # gloo moves host tensors
 
     W = WORKLOADS[a.workload]
     types = W["types"] or L.EVENT_TYPES
-    spec = L.SynthSpec(W["seed"] + 1000 * rank, W["n_events"], W["n_reads"], W["R"], W["n_chrom"], types, W.get("zipf", False))
-    tmp = tempfile.mkdtemp(prefix="lsq_bench_r%d_" % rank)
+    job_rank = 0 if (strong or world == 1) else rank            # weak mode: a job of its own per rank
+    spec = L.SynthSpec(W["seed"] + 1000 * job_rank, W["n_events"], W["n_reads"], W["R"], W["n_chrom"], types, W.get("zipf", False))
+    tmp = shared_dir("%s_%s_j%d" % (os.environ.get("MASTER_PORT", "solo"), a.workload, job_rank))
+    writer = rank == 0 or not strong
 
-    # ---- ingest (untimed): annotation -> compiled events -> reads -> bucketed pools in HBM
+    # ---- the job's files (untimed): annotation + MRF text, written once per job
     t0 = time.time()
-    L.synth_write(spec, tmp, "w", write_mrf=False)
-    ann = L.Annotation(os.path.join(tmp, "w.interval"), os.path.join(tmp, "w.map"))
-    ev = L.Events(ann, ("SHORT_READ",), (W["R"],))
-    reads = L.Reads.synthetic(spec, ev)
-    n_mrf_reads = len(reads)
+    if writer:
+        shutil.rmtree(tmp, ignore_errors=True)
+        os.makedirs(tmp)
+        L.synth_write(spec, tmp, "w", write_mrf=True)
     t_gen = time.time() - t0
-    ctx = L.Context(local_rank)
-    ctx.upload_events(ev)
-    t0 = time.time()
-    ctx.upload_reads(0, reads)
-    t_ingest = time.time() - t0
-    del reads
-    retained, retained_blocks = ctx.retained(0), ctx.retained_blocks(0)
-    n_ev = len(ev)
-    n_cls = int(L.lib.lsq_results_num_classes(ctx.h))
-    n_iso = ev.total_isoforms
-
-    # per-event outputs as torch tensors so that RCCL can move them
-    t_cnt = torch.zeros(max(n_cls, 1), dtype=torch.int64, device=dev)
-    t_theta = torch.zeros(max(n_iso, 1), dtype=torch.float64, device=dev)
-    t_ll = torch.zeros(max(n_ev, 1), dtype=torch.float64, device=dev)
     if world > 1:
-        g_cnt = torch.zeros(world * t_cnt.numel(), dtype=torch.int64, device=comm_dev)
-        g_theta = torch.zeros(world * t_theta.numel(), dtype=torch.float64, device=comm_dev)
-        g_ll = torch.zeros(world * t_ll.numel(), dtype=torch.float64, device=comm_dev)
+        dist.barrier()
+    mrf = os.path.join(tmp, "w.mrf")
+    argv_solve = ["0", "w", "./", "LH_GENE_TXT", os.path.join(tmp, "w.interval"), "UCSC_GENE2ISOFORM", os.path.join(tmp, "w.map"),
+                  "0", "1000000000", "MRF_SINGLE", "SHORT_READ", str(W["R"]), mrf, str(W["n_reads"] * W["R"])]
 
-    count_ms, solve_ms, fast_ms = [], [], []
+    # ---- (iii) the `solve` executable on the text, as a child process, before this process holds a context
+    e2e = {}
+    if world == 1 and not a.no_e2e:
+        exe = os.path.join(ROOT, "lesseq_amd", "bin", "solve")
+        for tool, av in (("count", argv_solve[:-1]), ("solve", argv_solve)):
+            t0 = time.perf_counter()
+            p = subprocess.run([os.path.join(ROOT, "lesseq_amd", "bin", tool)] + av, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+            dt = time.perf_counter() - t0
+            assert p.returncode == 0, "lesseq_amd/bin/%s failed" % tool
+            e2e["e2e_cli_%s_s" % tool] = dt
+            e2e["e2e_cli_%s_rows" % tool] = p.stdout.count(b"\n")
+            if tool == "solve":
+                e2e["e2e_cli_solve_table_sha256"] = hashlib.sha256(p.stdout).hexdigest()
+        e2e["e2e_cli_solve_mrf_reads_per_s"] = W["n_reads"] / e2e["e2e_cli_solve_s"]
+        e2e["e2e_cli_note"] = ("wall-clock of lesseq_amd/bin/{count,solve} as child processes on the %d-byte MRF text (page cache): process start, HIP "
+                               "initialisation, annotation load, text copy, device parse, ingest, count, EM, formatting, every output row" % os.path.getsize(mrf))
+        del exe
 
-    def step(_=None):
-        # one pass of the hot path over this rank's shard.  The shards are independent (LESSeq's own
-        # scale-out unit is a gene range, each with its own output rows, count/count.cpp:204-215):
-        # there is no exchange step, so no collective sits in the timed loop; the per-event tables of
-        # all ranks are put together once, after it
+    # ---- ingest (untimed): annotation -> compiled events -> MRF text -> HBM -> parsed, filtered, pooled
+    ann = L.Annotation(argv_solve[4], argv_solve[6])
+    ev = L.Events(ann, ("SHORT_READ",), (W["R"],))
+    n_ev = len(ev)
+    ctx = L.Context(local_rank)
+    t0 = time.perf_counter()
+    text = ctx.stage_text(mrf)
+    ctx.upload_events(ev)
+    ctx.upload_reads_text(0, text, free=False)
+    t_ingest = time.perf_counter() - t0
+    ctx.count()
+    ctx.solve()
+    cnt_full, bases_full = [x.copy() for x in ctx.counts()]
+    theta_full, ll_full, iters_full, flags_full = [x.copy() for x in ctx.solution()]
+    t_first = time.perf_counter() - t0
+    job_retained, job_blocks = ctx.retained(0), ctx.retained_blocks(0)
+    if world == 1 and not a.no_e2e:
+        # (iii, in-process) text in the page cache -> the formatted solve table, given the compiled events
+        table = L.format_solve(ev, cnt_full, bases_full, theta_full, ll_full, [float(W["n_reads"] * W["R"])])
+        e2e["e2e_from_text_s"] = time.perf_counter() - t0
+        e2e["e2e_from_text_reads_per_s"] = W["n_reads"] / e2e["e2e_from_text_s"]
+        e2e["e2e_from_text_note"] = "in-process: lsq_text_stage (H2D of the text) + event upload + device parse + ingest + count + EM + fetch + lsq_format_solve"
+        e2e["e2e_from_text_table_matches_cli"] = hashlib.sha256(table.encode()).hexdigest() == e2e.get("e2e_cli_solve_table_sha256")
+    bounds = [(0, n_ev)]
+    if strong:
+        # slices of equal read weight; then this rank's slice only: event tables re-planned, reads re-ingested
+        bounds = ev.shard_bounds(world, ld.event_weights(ev, cnt_full))
+        ev.set_shard(*bounds[rank])
+        ctx.upload_events(ev)
+        ctx.upload_reads_text(0, text, free=False)
+    L.lib.lsq_text_free(text)
+    n_ev_mine = bounds[rank][1] if strong else n_ev
+    my_weight = float(ld.event_weights(ev, cnt_full)[bounds[rank][0]:bounds[rank][0] + bounds[rank][1]].sum()) if strong else float(cnt_full.sum())
+
+    # ---- (ii) device-resident end to end, from parsed arrays in host memory (N = 1)
+    if world == 1 and not a.no_e2e:
+        reads = L.Reads.synthetic(spec, ev)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        ctx.upload_reads(0, reads)
         ctx.count()
         ctx.solve()
-        ctx.copy_results_device(t_cnt.data_ptr(), t_theta.data_ptr(), t_ll.data_ptr())
+        c2, b2 = ctx.counts()
+        th2 = ctx.solution()[0]
+        e2e["e2e_device_resident_s"] = time.perf_counter() - t0
+        e2e["e2e_device_resident_reads_per_s"] = W["n_reads"] / e2e["e2e_device_resident_s"]
+        e2e["e2e_device_resident_note"] = "parsed blocks in host memory -> H2D -> ingest kernels -> count -> EM -> D2H of the tables (PCIe-inclusive; never `value`)"
+        assert np.array_equal(c2, cnt_full) and np.array_equal(b2, bases_full) and np.array_equal(th2, theta_full)
+        del reads
+
+    # ---- the records a step hands over: packed in output order; all-gathered with N > 1
+    stride = max(max(ev.record_words(f, c) for f, c in bounds), 1)
+    blocks = [torch.zeros(stride, dtype=torch.int64, device=dev) for _ in range(2)]
+    # LSQ_BENCH_SELFTEST=1 (developer aid, one GPU): the stream / event ordering of the in-loop gather with a device copy in its place
+    selftest = world == 1 and os.environ.get("LSQ_BENCH_SELFTEST") == "1"
+    gathered = [torch.zeros(world * stride, dtype=torch.int64, device=("cpu" if on_host else dev)) for _ in range(2)] if (world > 1 or selftest) else None
+    in_loop_gather = strong or selftest
+    ext = torch.cuda.ExternalStream(ctx.result_stream, device=dev)       # the library's result stream, for event ordering
+    cur = torch.cuda.current_stream(dev)
+    packed_ev = [torch.cuda.Event() for _ in range(2)]
+    gathered_ev = [None, None]
+
+    def step(k):
+        b = k & 1
+        if in_loop_gather and gathered_ev[b] is not None and not on_host:
+            ext.wait_event(gathered_ev[b])            # the gather of two steps ago has read this block
+        ctx.count()
+        ctx.solve()
+        ctx.pack_results_device(blocks[b].data_ptr())
+        if in_loop_gather:
+            if on_host:
+                ctx.synchronize()
+                dist.all_gather_into_tensor(gathered[b], blocks[b].cpu())
+            else:
+                packed_ev[b].record(ext)
+                cur.wait_event(packed_ev[b])
+                if world > 1:
+                    dist.all_gather_into_tensor(gathered[b], blocks[b])
+                else:
+                    gathered[b].copy_(blocks[b])
+                if gathered_ev[b] is None:
+                    gathered_ev[b] = torch.cuda.Event()
+                gathered_ev[b].record(cur)
 
     def fence():
         ctx.synchronize()
@@ -137,88 +234,121 @@ def main():
         ctx.synchronize()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
+    for k in range(a.warmup):
+        step(k)
     fence()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
+    for k in range(a.steps):
+        step(k)
     fence()
     elapsed = time.perf_counter() - t0
+    last = (a.steps - 1) & 1
+
     # Kernel durations, right after the timed loop, with the library's HIP events switched on (the
     # event records of a step cost ~25 us of queue time, so the timed loop runs without them).
     # (a) as in the timed loop: steps submitted back to back, so the count kernel runs beside the
     #     tail of the previous step's EM on the second stream; the events of the last step are read.
     #     That duration of lsq_count_fast_kernel is the roofline's.
     # (b) one step at a time (synchronised): the kernels on their own.
+    count_ms, solve_ms, fast_ms, alone_fast_ms = [], [], [], []
+    saved = in_loop_gather
+    in_loop_gather = False
     ctx.set_timing(True)
     for _ in range(min(a.steps, 10)):
-        for _ in range(3):
-            step()
+        for k in range(3):
+            step(k)
         ctx.synchronize()
         fast_ms.append(ctx.fast_kernel_ms())
-    alone_fast_ms = []
     for _ in range(min(a.steps, 10)):
-        step()
+        step(0)
         ctx.synchronize()
         c, s = ctx.timing()
         count_ms.append(c)
         solve_ms.append(s)
         alone_fast_ms.append(ctx.fast_kernel_ms())
     ctx.set_timing(False)
+    in_loop_gather = saved
     fence()
+    # what the gather costs on its own (N > 1): submitted alone, timed on the host
+    gather_ms = None
+    if world > 1:
+        ts = []
+        for _ in range(5):
+            fence()
+            tg = time.perf_counter()
+            dist.all_gather_into_tensor(gathered[last], blocks[last].cpu() if on_host else blocks[last])
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - tg) * 1e3)
+        gather_ms = min(ts[1:])
 
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
-    tot = torch.tensor([float(retained), float(retained_blocks), float(n_mrf_reads)], dtype=torch.float64, device=comm_dev)
+    # ---- the tables of the last step: every rank's records on every rank
+    cmp_dev = "cpu" if on_host else dev
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=cmp_dev)
+    retained_mine, blocks_mine = ctx.retained(0), ctx.retained_blocks(0)
+    per_rank = torch.tensor([float(np.mean(fast_ms)), float(np.mean(alone_fast_ms)), float(np.mean(solve_ms)), my_weight, float(n_ev_mine),
+                             float(job_retained), float(job_blocks)], dtype=torch.float64, device=cmp_dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        allr = [torch.zeros_like(per_rank) for _ in range(world)]
+        dist.all_gather(allr, per_rank)
+        allr = [x.cpu().numpy() for x in allr]
+    else:
+        allr = [per_rank.cpu().numpy()]
     elapsed = float(tmax.item())
-    total_retained, total_blocks, total_mrf = [float(x) for x in tot.tolist()]
+    if strong:
+        total_retained, total_blocks, total_mrf = float(job_retained), float(job_blocks), float(W["n_reads"])
+    else:
+        total_retained, total_blocks, total_mrf = float(sum(x[5] for x in allr)), float(sum(x[6] for x in allr)), float(W["n_reads"] * world)
 
-    if world > 1:
-        # the whole job's tables on every rank (untimed hand-off; over RCCL on a real multi-GPU node)
-        ctx.synchronize()          # the library's stream -> visible to torch's stream
-        gather_ms = []
-        for _ in range(3):         # first call sets the communicator up; the last is the one reported
-            torch.cuda.synchronize()
-            dist.barrier()
-            tg = time.perf_counter()
-            dist.all_gather_into_tensor(g_cnt, t_cnt.to(comm_dev))
-            dist.all_gather_into_tensor(g_theta, t_theta.to(comm_dev))
-            dist.all_gather_into_tensor(g_ll, t_ll.to(comm_dev))
-            torch.cuda.synchronize()
-            gather_ms.append((time.perf_counter() - tg) * 1e3)
-        assert int(g_cnt.view(world, -1)[rank].sum().item()) == int(t_cnt.sum().item())
-
-    # sanity of the resident result (every step recomputes it from zeroed tables)
-    cnt, bases = ctx.counts()
-    theta, ll, iters, flags = ctx.solution()
-    assert int(cnt.sum()) == int(t_cnt.sum().item()), "device copy and fetched counts disagree"
-    assert 0 < int(cnt.sum()) <= 4 * retained
-    assert np.isfinite(theta).all() and abs(float(theta.sum()) - n_ev) < 1e-6 * n_ev
+    tables_equal, max_theta_diff = None, None
+    if strong:
+        g = gathered[last].cpu().numpy().view(np.uint64)
+        cnt, bases, theta, ll = ev.gathered_unpack(bounds, g, stride)
+        tables_equal = bool(np.array_equal(cnt, cnt_full) and np.array_equal(bases, bases_full) and
+                            np.array_equal(theta, theta_full) and np.array_equal(ll, ll_full, equal_nan=True))
+        max_theta_diff = float(np.max(np.abs(theta - theta_full))) if len(theta) else 0.0
+        assert np.array_equal(cnt, cnt_full) and np.array_equal(bases, bases_full), "gathered count tables differ from the unsharded run"
+        assert max_theta_diff <= 1e-12, "gathered theta differs from the unsharded run"
+    else:
+        blk = (gathered[last] if selftest else blocks[last]).cpu().numpy().view(np.uint64)
+        cnt, bases, theta, ll = ev.gathered_unpack([(0, n_ev)], blk, stride)
+        assert np.array_equal(cnt, cnt_full) and np.array_equal(bases, bases_full) and np.array_equal(theta, theta_full), "a step's tables differ from the first count"
+        if world > 1:         # weak mode: one all-gather of the per-event records after the loop
+            dist.all_gather_into_tensor(gathered[last], blocks[last].cpu() if on_host else blocks[last])
+    assert 0 < int(cnt_full.sum()) <= 4 * job_retained
+    assert np.isfinite(theta_full).all() and abs(float(theta_full.sum()) - n_ev) < 1e-6 * n_ev
+    exc, recounted = ctx.count_status()
 
     if rank == 0:
-        ck = float(np.mean(count_ms))
         fk = float(np.mean(fast_ms))
-        off = ev.class_offsets()
         ev_bytes = 0
-        for i in range(0, n_ev):
+        lo_e, n_e = bounds[0] if strong else (0, n_ev)
+        for i in range(lo_e, lo_e + n_e):
             K, N = ev.K(i), ev.N(i)
             ev_bytes += 8 * N + 8 * K + 16 + 8 * ((1 << K) - 1) + 8
-        alg_bytes = 8.0 * retained_blocks + ev_bytes
+        alg_bytes = 8.0 * blocks_mine + ev_bytes            # of rank 0's launch
         achieved = alg_bytes / (fk * 1e-3) / 1e9
-        # HBM bytes per launch of the same kernel from the committed rocprofv3 PMC passes (tools/bench_prof.sh)
-        traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic_%s.json" % a.workload)
-        if world == 1 and os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("count_fast_kernel_hbm_bytes_per_launch")
-            traffic_src = "profiles/r01_traffic_%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; 2 x FETCH_SIZE + WRITE_SIZE)" % a.workload
+        # HBM bytes per launch of the same kernel from the committed rocprofv3 PMC passes (tools/bench_prof.sh): not measured by this run
+        committed = None
+        for rr in ("r02", "r01"):
+            tpath = os.path.join(ROOT, "profiles", "%s_traffic_%s.json" % (rr, a.workload))
+            if world == 1 and os.path.exists(tpath):
+                committed = {"hbm_bytes_per_launch": json.load(open(tpath)).get("count_fast_kernel_hbm_bytes_per_launch"),
+                             "source": "profiles/%s_traffic_%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; 2 x FETCH_SIZE + WRITE_SIZE)" % (rr, a.workload)}
+                break
         # what a plain streaming read of the same number of bytes reaches on this device (state both ceilings)
         import ctypes as C
         L.lib.lsq_debug_stream_read_rate.argtypes = [C.c_void_p, C.c_ulonglong, C.POINTER(C.c_double)]
         rate = C.c_double(0.0)
         plain_read = rate.value if L.lib.lsq_debug_stream_read_rate(ctx.h, int(max(alg_bytes, 1 << 26)), C.byref(rate)) == 0 else None
+        if world == 1:
+            par = "single GPU"
+        elif strong:
+            par = ("one job over %d GPUs: output-ordered events cut into contiguous slices of equal read weight (pre-pass count), each rank parses the whole MRF text "
+                   "on its GPU and keeps the reads of its slice; per step count + EM + pack on the library's two streams and one RCCL all-gather of the packed "
+                   "per-event records (%d bytes per rank) inside the timed loop, overlapped with the next step's count" % (world, stride * 8))
+        else:
+            par = "one job per rank (weak): events and their reads per rank, no collective in the timed loop; one RCCL all-gather of the per-event records after it"
         out = {
             "metric": "MRF reads/sec through count+solve",
             "value": total_retained * a.steps / elapsed,
@@ -228,44 +358,54 @@ def main():
             "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / a.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "int32 coordinates / u64 counters (count), f64 (EM)",
             "data": "synthetic",
             "config": {
-                "workload": W["desc"],
-                "events_per_gpu": n_ev, "mrf_reads_per_gpu": n_mrf_reads, "retained_reads_per_gpu": retained,
-                "retained_blocks_per_gpu": retained_blocks, "buckets": ev.num_buckets,
-                "reads_counted": "retained reads (those that pass the load-time containment filter, count/count.cpp:319); off-target reads are dropped at ingest",
+                "workload": W["desc"] + ("; BASELINE configs[3]: the same job sharded by event index over %d GPUs with an RCCL gather" % world if strong and a.workload == "c3" else ""),
+                "events": n_ev * (1 if strong or world == 1 else world), "mrf_reads": total_mrf, "retained_reads": total_retained,
+                "retained_blocks": total_blocks, "buckets_rank0": ev.num_buckets,
+                "reads_counted": "`value` counts retained reads (those that pass the load-time containment filter, count/count.cpp:319) per pass over the pools resident in HBM; "
+                                 "off-target reads are dropped at ingest.  The rate from MRF text on disk is e2e_cli_solve_mrf_reads_per_s / e2e_from_text_reads_per_s",
                 "count_fast_kernel_ms": fk, "count_fast_kernel_ms_alone": float(np.mean(alone_fast_ms)),
-                "count_stream_ms_alone": ck, "em_kernel_ms_alone": float(np.mean(solve_ms)),
-                "pipeline": "lsq_count on one HIP stream; exception pass, EM, result hand-off and counter zeroing on a second one, beside the next step's count (two counter sets)",
-                "valid_read_assignments": int(cnt.sum()), "em_flagged_events": int((flags & 1).sum()),
-                "em_max_iters": int(iters.max()) if n_ev else 0,
-                "generate_s": t_gen, "ingest_s": t_ingest,
-                "gather_ms_after_loop": (gather_ms[-1] if world > 1 else None),
-                "parallelism": "events and their reads sharded by rank, no collective in the timed loop; one RCCL all-gather of the per-event tables after it" if world > 1 else "single GPU",
+                "count_stream_ms_alone": float(np.mean(count_ms)), "em_kernel_ms_alone": float(np.mean(solve_ms)),
+                "pipeline": "lsq_count on one HIP stream; exception pass (+ recount kernels that return at once unless the exception list overflowed), EM, record "
+                            "packing and counter zeroing on a second one, beside the next step's count (two counter sets)",
+                "valid_read_assignments": int(cnt_full.sum()), "exception_pairs": int(sum(exc)), "recounted": int(sum(recounted)),
+                "em_guard_band_events": int((flags_full & 1).sum()), "em_replayed_events": int(((flags_full >> 2) & 1).sum()),
+                "em_max_iters": int(iters_full.max()) if n_ev else 0,
+                "generate_s": t_gen, "ingest_from_text_s": t_ingest, "first_count_solve_fetch_s": t_first - t_ingest,
+                "gather_ms_alone": gather_ms,
+                "tables_equal_unsharded_run": tables_equal, "max_abs_theta_diff_vs_unsharded": max_theta_diff,
+                "count_table_sha256": hashlib.sha256(cnt_full.tobytes()).hexdigest(),
+                "per_rank": [{"rank": r, "events": int(x[4]), "valid_read_assignments": x[3], "count_fast_kernel_ms": x[0],
+                              "count_fast_kernel_ms_alone": x[1], "em_kernel_ms_alone": x[2]} for r, x in enumerate(allr)] if world > 1 else None,
+                "parallelism": par,
             },
             "roofline": {
-                "bound": "hbm", "kernel": "lsq_count_fast_kernel",
+                "bound": "hbm", "kernel": "lsq_count_fast_kernel" + (" (rank 0's launch)" if world > 1 else ""),
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 # the same kernel on an otherwise idle device (steps synchronised one by one, no EM beside it)
                 "frac_alone": alg_bytes / (float(np.mean(alone_fast_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "plain_read_GBps_this_device": plain_read, "frac_of_plain_read": (achieved / plain_read if plain_read else None),
-                "traffic": traffic,
-                "traffic_source": traffic_src,
+                "traffic": None,
+                "traffic_from_committed_profile": committed,
                 "algorithmic_bytes_per_launch": alg_bytes,
             },
         }
+        out["config"].update(e2e)
         # ---- cpu_baseline: the oracle on a bounded prefix of the same stream (rank 0, N = 1 only)
         if world == 1 and a.cpu_sample > 0:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_binding as ob
             ns = min(a.cpu_sample, W["n_reads"])
-            sspec = L.SynthSpec(W["seed"], W["n_events"], ns, W["R"], W["n_chrom"], types)
-            L.synth_write(sspec, tmp, "s", write_mrf=True)
-            argv = ["0", "s", "./", "LH_GENE_TXT", os.path.join(tmp, "w.interval"), "UCSC_GENE2ISOFORM", os.path.join(tmp, "w.map"),
-                    "0", "1000000000", "MRF_SINGLE", "SHORT_READ", str(W["R"]), os.path.join(tmp, "s.mrf"), str(ns * W["R"])]
+            sspec = L.SynthSpec(W["seed"], W["n_events"], ns, W["R"], W["n_chrom"], types, W.get("zipf", False))
+            sdir = os.path.join(tmp, "sample")
+            os.makedirs(sdir, exist_ok=True)
+            L.synth_write(sspec, sdir, "s", write_mrf=True)
+            argv = list(argv_solve)
+            argv[12], argv[13] = os.path.join(sdir, "s.mrf"), str(ns * W["R"])
             t0 = time.perf_counter()
             rc, _, exact = ob.run("solve", argv)
             dt = time.perf_counter() - t0
@@ -278,7 +418,6 @@ def main():
             }
             # the reference's own scale-out on the host's cores: one process per slice of the sorted gene list
             # (gene_begin_idx..gene_end_idx, count/count.cpp:204-215), each reading the whole file; wall-clock of the slowest
-            import subprocess
             P = max(1, min(os.cpu_count() or 1, 16))
             child = ("import sys,time; sys.path.insert(0, %r); import oracle_binding as ob; a = sys.argv[1:]; t0 = time.perf_counter(); "
                      "rc, _, _ = ob.run('solve', a); print(rc, time.perf_counter() - t0)") % os.path.join(ROOT, "tests")
@@ -298,6 +437,10 @@ def main():
                 }
         print(json.dumps(out))
     ctx.close()
+    if world > 1:
+        dist.barrier()
+    if writer:
+        shutil.rmtree(tmp, ignore_errors=True)
     if world > 1:
         dist.destroy_process_group()
 
