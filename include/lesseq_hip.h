@@ -296,6 +296,10 @@ int lsq_shard_bounds(const lsq_events *e, int world, const double *weights /* pe
                      uint64_t *first /* world */, uint64_t *count /* world */);
 uint64_t lsq_record_words(const lsq_events *e, uint64_t first, uint64_t count);
 int lsq_results_pack_device(lsq_ctx *c, void *d_block);
+/* Device buffers for a host without HIP of its own (zeroed; lsq_device_read waits for both streams of the context). */
+int lsq_device_alloc(lsq_ctx *c, uint64_t bytes, void **out);
+void lsq_device_free(lsq_ctx *c, void *p);
+int lsq_device_read(lsq_ctx *c, void *host_dst, const void *device_src, uint64_t bytes);
 int lsq_gathered_unpack(const lsq_events *e, int world, const uint64_t *first, const uint64_t *count,
                         const uint64_t *blocks, uint64_t stride_words,
                         uint64_t *class_count, uint64_t *class_bases, double *theta, double *logll);

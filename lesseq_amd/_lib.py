@@ -106,6 +106,9 @@ _sig("lsq_shard_bounds", C.c_int, vp, C.c_int, P(C.c_double), P(u64), P(u64))
 _sig("lsq_record_words", u64, vp, u64, u64)
 _sig("lsq_results_pack_device", C.c_int, vp, vp)
 _sig("lsq_gathered_unpack", C.c_int, vp, C.c_int, P(u64), P(u64), P(u64), u64, P(u64), P(u64), P(C.c_double), P(C.c_double))
+_sig("lsq_device_alloc", C.c_int, vp, u64, P(vp))
+_sig("lsq_device_free", None, vp, vp)
+_sig("lsq_device_read", C.c_int, vp, vp, vp, u64)
 _sig("lsq_results_device_order", C.c_int, vp, P(i32))
 _sig("lsq_fim", C.c_int, vp)
 _sig("lsq_results_fim_size", C.c_int64, vp)

@@ -1,5 +1,7 @@
 // Host side of the path, part 3: output rows (count/count.cpp:486-492, solve/solve.cpp:808-847)
 // and the three executables' argv handling, exit codes and stderr log.
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cctype>
 #include <cerrno>
@@ -166,6 +168,157 @@ struct PhaseTimer {
 	}
 };
 
+// LSQ_OPTIONS="name=value,...": tuning knobs for lsq_ctx_set_option, read once per process
+int apply_env_options(lsq_ctx *c) {
+	const char *o = getenv("LSQ_OPTIONS");
+	if (!o) return LSQ_OK;
+	const std::string all(o);
+	size_t pos = 0;
+	while (pos < all.size()) {
+		size_t end = all.find(',', pos);
+		if (end == std::string::npos) end = all.size();
+		const std::string item = all.substr(pos, end - pos);
+		const size_t eq = item.find('=');
+		if (eq != std::string::npos) { const int st = lsq_ctx_set_option(c, item.substr(0, eq).c_str(), atof(item.c_str() + eq + 1)); if (st) return st; }
+		pos = end + 1;
+	}
+	return LSQ_OK;
+}
+
+// ---- one job over several GPUs (LSQ_GPUS=N): the reference's scale-out -- a process per slice
+// gene_begin_idx..gene_end_idx of the sorted gene list, stdout concatenated (count/count.cpp:204-215) -- inside one
+// process: a host thread per GPU, slices of equal read weight (the first, unsharded count on GPU 0 is the pre-pass),
+// every thread compiles the whole selected range (so the load-time filter is the unsharded one), takes its slice,
+// ingests, counts, solves, packs its per-event records on its GPU; an RCCL all-gather (liblesseq_rccl.so, loaded here
+// on demand; LSQ_GATHER=host moves the blocks through host memory instead -- for boxes where the "GPUs" are one device)
+// puts the blocks together and thread 0 prints the table, byte-identical to the single-GPU run.
+struct ShardedJob {
+	bool solve; int G; int M;
+	const lsq_annotation *ann;
+	std::vector<const char *> fmts, types, paths;
+	std::vector<uint64_t> lens;
+	std::vector<int> devices;
+};
+
+struct RcclApi {
+	void *handle = nullptr;
+	int (*init_all)(int, const int *, void **) = nullptr;
+	void (*destroy)(void *) = nullptr;
+	int (*gather)(lsq_ctx *, void *, const void *, void *, uint64_t) = nullptr;
+	const char *(*last_error)(void) = nullptr;
+	bool load() {
+		Dl_info info;
+		std::string dir;
+		if (dladdr((const void *)&lsq_abi_version, &info) && info.dli_fname) { dir = info.dli_fname; const size_t s = dir.rfind('/'); dir = s == std::string::npos ? "" : dir.substr(0, s + 1); }
+		handle = dlopen((dir + "liblesseq_rccl.so").c_str(), RTLD_NOW | RTLD_LOCAL);
+		if (!handle) handle = dlopen("liblesseq_rccl.so", RTLD_NOW | RTLD_LOCAL);
+		if (!handle) return false;
+		init_all = (int (*)(int, const int *, void **))dlsym(handle, "lsq_comm_init_all");
+		destroy = (void (*)(void *))dlsym(handle, "lsq_comm_destroy");
+		gather = (int (*)(lsq_ctx *, void *, const void *, void *, uint64_t))dlsym(handle, "lsq_gather");
+		last_error = (const char *(*)(void))dlsym(handle, "lsq_rccl_last_error");
+		return init_all && destroy && gather && last_error;
+	}
+};
+
+// F.c / F.e: GPU 0's context with the whole job counted on it (the pre-pass); texts0: its staged MRF texts (kept)
+int run_sharded_job(const ShardedJob &J, lsq_ctx *ctx0, lsq_events *ev0, std::vector<lsq_text *> &texts0, const std::vector<double> &trb, std::string &out) {
+	const int G = J.G, M = J.M;
+	const int64_t n_ev = lsq_events_count(ev0);
+	// pre-pass: reads per event from the unsharded count
+	const size_t n_cls = (size_t)lsq_results_num_classes(ctx0);
+	std::vector<uint64_t> cnt0(std::max<size_t>((size_t)M * n_cls, 1));
+	int st = lsq_results_counts(ctx0, cnt0.data(), nullptr);
+	if (st) { logf(0, "%s", lsq_last_error()); return 3; }
+	std::vector<uint64_t> coff((size_t)n_ev + 1);
+	lsq_results_class_offsets(ctx0, coff.data());
+	std::vector<double> weights((size_t)n_ev, 0.0);
+	for (int64_t i = 0; i < n_ev; ++i)
+		for (int m = 0; m < M; ++m)
+			for (uint64_t k = coff[(size_t)i]; k < coff[(size_t)i + 1]; ++k) weights[(size_t)i] += (double)cnt0[(size_t)m * n_cls + k];
+	std::vector<uint64_t> first((size_t)G), count((size_t)G);
+	st = lsq_shard_bounds(ev0, G, weights.data(), first.data(), count.data());
+	if (st) { logf(0, "%s", lsq_last_error()); return 2; }
+	uint64_t stride = 1;
+	for (int r = 0; r < G; ++r) stride = std::max(stride, lsq_record_words(ev0, first[(size_t)r], count[(size_t)r]));
+	const char *gmode = getenv("LSQ_GATHER");
+	const bool via_host = gmode && strcmp(gmode, "host") == 0;
+	RcclApi rccl;
+	std::vector<void *> comms((size_t)G, nullptr);
+	if (!via_host) {
+		if (!rccl.load()) { logf(0, "LSQ_GPUS=%d needs liblesseq_rccl.so beside the library (%s)", G, dlerror() ? dlerror() : "symbols missing"); return 3; }
+		st = rccl.init_all(G, J.devices.data(), comms.data());
+		if (st) { logf(0, "%s", rccl.last_error()); return 3; }
+	}
+	std::vector<uint64_t> host_blocks((size_t)G * stride, 0);
+	std::vector<int> status((size_t)G, LSQ_OK);
+	std::vector<std::string> errors((size_t)G);
+	std::vector<lsq_ctx *> ctxs((size_t)G, nullptr);
+	std::vector<lsq_events *> evs((size_t)G, nullptr);
+	ctxs[0] = ctx0; evs[0] = ev0;
+	auto work = [&](int r) {
+		auto bad = [&](int s, const char *msg) { status[(size_t)r] = s ? s : LSQ_E_STATE; errors[(size_t)r] = msg; };
+		int s;
+		if (r > 0) {
+			if ((s = lsq_ctx_create(J.devices[(size_t)r], &ctxs[(size_t)r])) || (s = apply_env_options(ctxs[(size_t)r]))) return bad(s, lsq_last_error());
+			if ((s = lsq_events_compile(J.ann, M, J.types.data(), J.lens.data(), &evs[(size_t)r]))) return bad(s, lsq_last_error());
+		}
+		lsq_ctx *c = ctxs[(size_t)r];
+		lsq_events *e = evs[(size_t)r];
+		if ((s = lsq_events_set_shard(e, first[(size_t)r], count[(size_t)r])) || (s = lsq_events_upload(c, e))) return bad(s, lsq_last_error());
+		for (int m = 0; m < M; ++m) {
+			if (r == 0 && texts0[(size_t)m]) s = lsq_reads_upload_text(c, m, J.fmts[(size_t)m], texts0[(size_t)m]);
+			else if (strcmp(J.fmts[(size_t)m], "MRF_SINGLE") == 0 && (r > 0 || !texts0[(size_t)m])) s = lsq_reads_upload_mrf(c, m, J.fmts[(size_t)m], J.paths[(size_t)m]);
+			else s = LSQ_E_UNSUPPORTED;
+			if (s == LSQ_E_UNSUPPORTED) {         // name-keyed formats, long strand strings: the host parser
+				lsq_reads *rd = nullptr;
+				s = lsq_reads_parse(J.fmts[(size_t)m], J.paths[(size_t)m], e, 0, &rd);
+				if (!s) { s = lsq_reads_upload(c, m, rd); lsq_reads_free(rd); }
+			}
+			if (s) return bad(s, lsq_last_error());
+		}
+		uint32_t replayed = 0;
+		if ((s = lsq_count(c)) || (s = lsq_solve(c)) || (s = lsq_solve_finalize(c, &replayed))) return bad(s, lsq_last_error());
+		void *d_block = nullptr, *d_all = nullptr;
+		if ((s = lsq_device_alloc(c, stride * 8, &d_block))) return bad(s, lsq_last_error());
+		if ((s = lsq_results_pack_device(c, d_block))) { lsq_device_free(c, d_block); return bad(s, lsq_last_error()); }
+		if (via_host) {
+			s = lsq_device_read(c, host_blocks.data() + (size_t)r * stride, d_block, stride * 8);
+			if (s) bad(s, lsq_last_error());
+		} else {
+			if ((s = lsq_device_alloc(c, (uint64_t)G * stride * 8, &d_all))) { lsq_device_free(c, d_block); return bad(s, lsq_last_error()); }
+			s = rccl.gather(c, comms[(size_t)r], d_block, d_all, stride);
+			if (s) bad(s, rccl.last_error());
+			else if (r == 0) { s = lsq_device_read(c, host_blocks.data(), d_all, (uint64_t)G * stride * 8); if (s) bad(s, lsq_last_error()); }
+			else { s = lsq_ctx_synchronize(c); if (s) bad(s, lsq_last_error()); }
+			lsq_device_free(c, d_all);
+		}
+		lsq_device_free(c, d_block);
+		logf(2, "GPU %d: events %llu..%llu of the sorted list%s", J.devices[(size_t)r], (unsigned long long)first[(size_t)r],
+		     (unsigned long long)(first[(size_t)r] + count[(size_t)r]), replayed ? " (guard-band events solved again in per-read order)" : "");
+	};
+	std::vector<std::thread> th;
+	for (int r = 1; r < G; ++r) th.emplace_back(work, r);
+	work(0);
+	for (auto &t : th) t.join();
+	for (int r = 1; r < G; ++r) { if (ctxs[(size_t)r]) lsq_ctx_destroy(ctxs[(size_t)r]); lsq_events_free(evs[(size_t)r]); }
+	if (!via_host) for (void *cm : comms) if (cm) rccl.destroy(cm);
+	for (int r = 0; r < G; ++r) if (status[(size_t)r]) { logf(0, "GPU %d: %s", J.devices[(size_t)r], errors[(size_t)r].c_str()); return 3; }
+	// the whole job's tables, in output order
+	const size_t n_iso = (size_t)lsq_events_total_isoforms(ev0);
+	std::vector<uint64_t> cnt(std::max<size_t>((size_t)M * n_cls, 1)), bases(cnt.size());
+	std::vector<double> theta(std::max<size_t>(n_iso, 1)), ll(std::max<size_t>((size_t)n_ev, 1));
+	st = lsq_gathered_unpack(ev0, G, first.data(), count.data(), host_blocks.data(), stride, cnt.data(), bases.data(), theta.data(), ll.data());
+	if (st) { logf(0, "%s", lsq_last_error()); return 2; }
+	char *text = nullptr;
+	st = J.solve ? lsq_format_solve(ev0, M, cnt.data(), bases.data(), theta.data(), ll.data(), trb.data(), &text) : lsq_format_count(ev0, M, cnt.data(), &text);
+	if (st || !text) { logf(0, "%s", lsq_last_error()); return 2; }
+	out.assign(text);
+	free(text);
+	logf(2, "Processed %lld genes on %d GPUs... Done", (long long)n_ev, G);
+	return 0;
+}
+
 int run_count_solve(bool solve, int argc, const char *const *argv, std::string &out) {
 	PhaseTimer T;
 	const int per = solve ? 5 : 4;
@@ -200,6 +353,15 @@ int run_count_solve(bool solve, int argc, const char *const *argv, std::string &
 	}
 	const int M = (int)paths.size();
 	if (M > LSQ_MAX_METHODS) { logf(0, "more than %d read files", LSQ_MAX_METHODS); return 2; }
+	// LSQ_DEVICE picks the GPU; LSQ_GPUS=N runs the job over N of them (LSQ_DEVICES="a,b,..." names them, default 0..N-1)
+	int G = 1;
+	if (const char *e = getenv("LSQ_GPUS")) G = std::max(1, atoi(e));
+	if (want_fim) G = 1;
+	std::vector<int> devices;
+	if (const char *e = getenv("LSQ_DEVICES")) { const char *q = e; while (*q) { devices.push_back(atoi(q)); q = strchr(q, ','); if (!q) break; ++q; } }
+	if (G > 1 && devices.size() < (size_t)G) { devices.clear(); for (int r = 0; r < G; ++r) devices.push_back(r); }
+	if (G == 1) { int dev = 0; if (const char *e = getenv("LSQ_DEVICE")) dev = atoi(e); devices.assign(1, dev); }
+	devices.resize((size_t)G);
 	Freer F;
 	// the device context (HIP start-up, a tenth of a second or more) is created on a second thread while
 	// this one reads the annotation; its status is looked at only where the reference would be past
@@ -211,24 +373,10 @@ int run_count_solve(bool solve, int argc, const char *const *argv, std::string &
 	// table); a file that does not open or is not MRF_SINGLE is left to the main thread, which reports it
 	std::vector<lsq_text *> texts((size_t)M, nullptr);
 	std::thread ctx_thread([&] {
-		int dev = 0;
-		if (const char *e = getenv("LSQ_DEVICE")) dev = atoi(e);
-		ctx_status = lsq_ctx_create(dev, &ctx_bg);
+		ctx_status = lsq_ctx_create(devices[0], &ctx_bg);
 		if (ctx_status) { ctx_error = lsq_last_error(); return; }          // the message lives in that thread
-		// LSQ_OPTIONS="name=value,...": tuning knobs for lsq_ctx_set_option, read once per process
-		if (const char *o = getenv("LSQ_OPTIONS")) {
-			std::string all(o);
-			size_t pos = 0;
-			while (pos < all.size() && !ctx_status) {
-				size_t end = all.find(',', pos);
-				if (end == std::string::npos) end = all.size();
-				const std::string item = all.substr(pos, end - pos);
-				const size_t eq = item.find('=');
-				if (eq != std::string::npos) ctx_status = lsq_ctx_set_option(ctx_bg, item.substr(0, eq).c_str(), atof(item.c_str() + eq + 1));
-				pos = end + 1;
-			}
-			if (ctx_status) { ctx_error = lsq_last_error(); return; }
-		}
+		ctx_status = apply_env_options(ctx_bg);
+		if (ctx_status) { ctx_error = lsq_last_error(); return; }
 		for (int m = 0; m < M; ++m)
 			if (strcmp(fmts[m], "MRF_SINGLE") == 0 && lsq_text_stage(ctx_bg, paths[m], &texts[(size_t)m]) != LSQ_OK) texts[(size_t)m] = nullptr;
 	});
@@ -277,7 +425,7 @@ int run_count_solve(bool solve, int argc, const char *const *argv, std::string &
 		// MRF text -> HBM -> parsed and ingested there; the name-keyed formats are grouped by name on the host first
 		if (texts[(size_t)m]) {
 			st = lsq_reads_upload_text(F.c, m, fmts[m], texts[(size_t)m]);
-			lsq_text_free(texts[(size_t)m]); texts[(size_t)m] = nullptr;
+			if ((G == 1 && !getenv("LSQ_GATHER")) || st) { lsq_text_free(texts[(size_t)m]); texts[(size_t)m] = nullptr; }      // several GPUs: GPU 0 ingests it again, for its slice
 		} else st = named_read_format(fmts[m]) ? LSQ_E_UNSUPPORTED : lsq_reads_upload_mrf(F.c, m, fmts[m], paths[m]);
 		if (st == LSQ_E_UNSUPPORTED) {
 			// a strand string beyond the device parser's 7 bytes: the host parser reads such files
@@ -294,7 +442,16 @@ int run_count_solve(bool solve, int argc, const char *const *argv, std::string &
 	if (bad_type && n_ev > 0) { logf(0, "Unknown read type error: %s", bad_type_name.c_str()); return 1; }
 	logf(2, "Processing reads info for genes");
 	st = lsq_count(F.c);
-	if (!st && solve) st = lsq_solve(F.c);
+	if (st) { logf(0, "%s", lsq_last_error()); return 3; }
+	// (LSQ_GPUS=1 with LSQ_GATHER=rccl spelled out takes the same path with one slice: a self-check of the gather on one GPU)
+	const char *gm = getenv("LSQ_GATHER");
+	if ((G > 1 || (getenv("LSQ_GPUS") && gm && strcmp(gm, "rccl") == 0 && !want_fim)) && n_ev > 0) {
+		ShardedJob J{solve, G, M, F.a, fmts, use_types, paths, lens, devices};
+		const int rc = run_sharded_job(J, F.c, F.e, texts, trb, out);
+		T.mark("sharded job");
+		return rc;
+	}
+	if (solve) st = lsq_solve(F.c);
 	if (st) { logf(0, "%s", lsq_last_error()); return 3; }
 	const size_t n_cls = (size_t)lsq_results_num_classes(F.c);
 	std::vector<uint64_t> cnt(std::max<size_t>((size_t)M * n_cls, 1)), bases(std::max<size_t>((size_t)M * n_cls, 1));

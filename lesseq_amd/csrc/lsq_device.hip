@@ -488,6 +488,27 @@ int lsq_results_pack_device(lsq_ctx *c, void *d_block) {
 
 void *lsq_ctx_result_stream(lsq_ctx *c) { return c ? (void *)c->stream_em : nullptr; }
 
+// device buffers for a C host that has no HIP of its own (the executables hold the packed / gathered records in them)
+int lsq_device_alloc(lsq_ctx *c, uint64_t bytes, void **out) {
+	if (!c || !out) return fail(LSQ_E_ARG, "null argument");
+	HIP_TRY(hipSetDevice(c->device));
+	HIP_TRY(hipMalloc(out, (size_t)std::max<uint64_t>(bytes, 8)));
+	HIP_TRY(hipMemset(*out, 0, (size_t)std::max<uint64_t>(bytes, 8)));
+	return LSQ_OK;
+}
+void lsq_device_free(lsq_ctx *c, void *p) {
+	if (!c || !p) return;
+	(void)hipSetDevice(c->device);
+	(void)hipFree(p);
+}
+int lsq_device_read(lsq_ctx *c, void *host_dst, const void *device_src, uint64_t bytes) {
+	if (!c || !host_dst || !device_src) return fail(LSQ_E_ARG, "null argument");
+	HIP_TRY(hipSetDevice(c->device));
+	{ int rc = sync_all(c); if (rc) return rc; }
+	HIP_TRY(hipMemcpy(host_dst, device_src, (size_t)bytes, hipMemcpyDeviceToHost));
+	return LSQ_OK;
+}
+
 int lsq_results_device_order(const lsq_ctx *c, int32_t *dev2out) {
 	if (!c || !c->E || !dev2out) return fail(LSQ_E_ARG, "null argument");
 	memcpy(dev2out, c->E->dev2out.data(), c->E->dev2out.size() * sizeof(int32_t));

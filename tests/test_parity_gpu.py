@@ -857,3 +857,30 @@ def test_executable_device_selection_and_missing_device(tmp_path):
     env["LSQ_DEVICE"] = "63"
     p = subprocess.run([os.path.join(BIN, "count")] + r["argv"], cwd=d, capture_output=True, text=True, env=env)
     assert p.returncode == 3 and p.stdout == "" and "ERROR" in p.stderr
+
+
+@pytest.mark.parametrize("name,env", [("events_s1", dict(LSQ_GPUS="2", LSQ_DEVICES="0,0", LSQ_GATHER="host")),
+                                      ("multi_method", dict(LSQ_GPUS="3", LSQ_DEVICES="0,0,0", LSQ_GATHER="host")),
+                                      ("readfmts", dict(LSQ_GPUS="2", LSQ_DEVICES="0,0", LSQ_GATHER="host")),
+                                      ("events_s2", dict(LSQ_GPUS="1", LSQ_GATHER="rccl"))])
+def test_executables_run_one_job_over_several_gpu_slices(name, env, tmp_path):
+    """LSQ_GPUS=N: the executables cut the sorted gene list into N slices of equal read weight (first count = pre-pass), a host
+    thread per slice compiles the whole range, ingests, counts, solves and packs its slice, the blocks are gathered and the
+    table printed is the single-GPU one -- i.e. the reference's golden table.  The test box has one GPU: every "GPU" is
+    device 0 and the blocks go through host memory (LSQ_GATHER=host); the RCCL all-gather itself (liblesseq_rccl.so,
+    ncclCommInitAll + ncclAllGather on the result stream) runs here with a single slice."""
+    import subprocess
+    c, d = load_case(name, tmp_path)
+    n = 0
+    for tool, r in runs(c):
+        if r["exit"] != 0:
+            continue
+        p = subprocess.run([os.path.join(BIN, tool)] + r["argv"], cwd=d, capture_output=True, text=True, env=dict(os.environ, **env))
+        exp = open(os.path.join(d, r["stdout"])).read()
+        assert p.returncode == 0, (name, tool, p.stderr)
+        if tool == "count":
+            assert p.stdout == exp, (name, r["argv"])
+        else:
+            assert ob.solve_text_close(p.stdout, exp), (name, r["argv"])
+        n += 1
+    assert n
