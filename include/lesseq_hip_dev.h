@@ -14,8 +14,9 @@ extern "C" {
 
 /* Counters the count kernels fill when LSQ_ABLATE has bit 256 set: [0] parked one-block reads,
  * [1] parked two-block reads, [2] walk steps, [3] walk lanes, [4] exception-list entries,
- * [5..7] reasons for parking one-block reads. */
-int lsq_debug_counters(lsq_ctx *c, unsigned long long *out8);
+ * [5..7] reasons for parking one-block reads, [8..10], [13], [14] reasons for parking two-block reads, [11] / [12]
+ * one-block steps of a wave with a parked read / all of them.  out16 holds 16 values. */
+int lsq_debug_counters(lsq_ctx *c, unsigned long long *out16);
 
 /* The combined slot offsets of a method's buckets (n_buckets + 1 values): the work partition of
  * the count kernels. */

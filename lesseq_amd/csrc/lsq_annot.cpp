@@ -449,7 +449,7 @@ int plan_device(lsq_events &E) {
 		if (i >= E.shard_first && i - E.shard_first < E.shard_count) per_chrom[E.ev[i].chrom_id].push_back((int32_t)i);
 	auto ev_bytes = [&](const Event &e) -> uint32_t {
 		// packed bucket: record 48 B, ~1.5 cells of 20 B per segment, 8 bin records of 16 B, class histogram
-		return std::max(48u + 40u * (uint32_t)e.N + 20u + 128u, 16u + 8u * (uint32_t)e.N + 4u * (uint32_t)e.K) + 8u * HIST_REPLICAS * ((1u << e.K) - 1u);
+		return std::max(48u + 40u * (uint32_t)e.N + 40u + 128u, 16u + 8u * (uint32_t)e.N + 4u * (uint32_t)e.K) + 8u * HIST_REPLICAS * ((1u << e.K) - 1u);
 	};
 	for (size_t c = 0; c < per_chrom.size(); ++c) {
 		auto &lst = per_chrom[c];
@@ -547,10 +547,30 @@ int plan_device(lsq_events &E) {
 				std::vector<Tmp> tmp;
 				for (size_t q = 0; q + 1 < bps.size(); ++q) {
 					const int64_t x0 = bps[q], x1 = bps[q + 1];
-					if (std::binary_search(first_bases.begin(), first_bases.end(), x0) && x1 == x0 + 1) continue;   // first base of a span
+					const bool first_base = std::binary_search(first_bases.begin(), first_bases.end(), x0) && x1 == x0 + 1;   // first base of a span
 					const SegRef *own[3]; int n_own = 0;
 					for (size_t r = 0; r < segs_all.size() && segs_all[r].sx <= x0; ++r)
 						if (segs_all[r].sy >= x1) { if (n_own < 3) own[n_own] = &segs_all[r]; ++n_own; }
+					if (first_base) {
+						// The first base of a span is no cell: a read that starts there is a candidate of the event only if
+						// it is not ordered before (gene_start, gene_end, strand, name) in the read index (count/count.cpp:64-85,
+						// 429-432).  But where that base is covered by this one segment only -- one event starts here, no other
+						// event has a segment here -- such a read can match no other event either (its first block starts in
+						// none of their segments), so a read that ends before gene_end counts for nobody.  A start cell says so:
+						// one base wide, "runs into the next stretch" up to gene_end - 1, both slots empty; a read that reaches
+						// gene_end or beyond is parked with the event as its one candidate, as before.
+						const auto fb = std::equal_range(first_bases.begin(), first_bases.end(), x0);
+						if (n_own != 1 || fb.second - fb.first != 1 || own[0]->sx != x0) continue;
+						const Event &e0 = E.ev[lst[b_begin + own[0]->ev]];
+						if (e0.gene_start != x0 || e0.gene_end - 1 < x1) continue;
+						Tmp t;
+						t.c.lo = (int32_t)x0; t.c.hi = (int32_t)x1; t.c.hi2 = (int32_t)(e0.gene_end - 1);
+						t.c.slots = CELL_NONE | (CELL_NONE << 16);
+						t.single = true; t.ev = own[0]->ev; t.k = CELL_K_START;
+						t.info = (own[0]->ev << 8) | (CELL_K_START << 2);
+						tmp.push_back(t);
+						continue;
+					}
 					if (n_own == 0 || n_own > 2) continue;
 					Tmp t;
 					t.c.lo = (int32_t)x0; t.c.hi = (int32_t)x1; t.c.hi2 = (int32_t)x1;

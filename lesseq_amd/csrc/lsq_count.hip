@@ -473,7 +473,8 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 	C.pool = RPW == 2 ? 0u : 1u;
 	C.slot0 = g0;
 	global_words src = (global_words)src_generic;       // kernel-argument memory: global address space
-	const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	// (the wave's number through readfirstlane: step counters and range tests then live in scalar registers)
+	const unsigned lane = threadIdx.x & 63u, wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	// words [w0, w1) of the workgroup, dealt to its waves a step at a time (wave, wave + 4, ...): the
 	// reads that need the general walk sit together in the start-ordered pool, and a contiguous
 	// quarter per wave would leave three waves waiting for the one that got them
@@ -486,29 +487,31 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 	auto fetch_into = [&](uint4 (&dst)[SW], unsigned wt) {
 #pragma unroll
 		for (int k = 0; k < SW; ++k) {
-			const unsigned w = wt + lane * (unsigned)SW + (unsigned)k;      // a lane's words are neighbours in the pool
-			u32x4 t = {0u, 0u, 0u, 0u};
-			if (w < ww1) t = src[w0 + w];
+			// a lane's words are neighbours in the pool; past the end of the range the last word is read again
+			// (no predication: every read is tested against the range before it counts)
+			const unsigned w = min(wt + lane * (unsigned)SW + (unsigned)k, ww1 - 1u);
+			const u32x4 t = src[w0 + w];
 			dst[k] = make_uint4(t.x, t.y, t.z, t.w);
 		}
 	};
 	auto fetch = [&](unsigned wt) { fetch_into(nxt, wt); };
-	// bin record of position p -> (cell that can hold p, first event of the bin)
+	// bin record of position p -> (the last cell that starts at or before p, first event of the bin).  The record
+	// names the bin's first cell and the ends of it and of the next two; in a bin with more cells the search goes on
+	// through the cell table (rare: bins are laid out for about one event each).
 	auto locate = [&](int p, unsigned &cell, unsigned &first_event) {
 		const int rel = p - d.lo;
 		unsigned bin = rel <= 0 ? 0u : ((unsigned)rel >> d.shift);
 		const uint4 br = bins[min(bin, d.n_bins - 1u)];     // first cell | first event << 16, ends of that cell and the next two
 		cell = (br.x & 0xFFFFu) + (unsigned)(p >= (int)br.y) + (unsigned)(p >= (int)br.z) + (unsigned)(p >= (int)br.w);
 		first_event = br.x >> 16;
+		if (__any(p >= (int)br.w) && !ABL(A, 65536u)) {
+			while (cell + 1u < n_cells && p >= (int)cells[cell + 1u].x) ++cell;
+		}
 	};
 	Ring<NB> R;
 	R.q = queue;
-	if (ww0 < ww1) fetch(ww0);
-	for (unsigned wt = ww0; wt < ww1; wt += WAVES * TILE) {
-		uint4 cur[SW];
-#pragma unroll
-		for (int k = 0; k < SW; ++k) cur[k] = nxt[k];
-		if (wt + WAVES * TILE < ww1) fetch(wt + WAVES * TILE);
+	// one step of the wave over the words in `cur` (the step's words, fetched a step ahead)
+	auto do_step = [&](const uint4 (&cur)[SW], const unsigned wt) {
 #pragma unroll
 		for (int k0 = 0; k0 < SW; k0 += GW) {
 		if (ABL(A, 512u)) {      // developer switch: stream only
@@ -527,17 +530,19 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 				// start-ordered pool, so the cell of the first one is the cell of (nearly) all of
 				// them.  A read is decided against that cell -- inside it: the owners' slots; running
 				// into the owner's next segment: the two-segment slot -- and the lane adds its totals
-				// once.  Everything else (a different cell, no cell, a longer run) is parked.
+				// once.  Everything else (a different cell, no cell, a longer run) is parked -- and only
+				// then is anything built for the ring: most steps park nothing in any lane.
 				if (kg == 0) {
 					unsigned ci, evf;
 					locate((int)cur[k0].x, ci, evf);
 					const uint4 cw = cells[min(ci, n_cells - 1u)];           // lo, hi, hi2, slots
 					const bool has = ci < n_cells && !ABL(A, 8u);
-					const unsigned info = cell_info[min(ci, n_cells - 1u)];
-					const unsigned owner_word = info == CELL_INFO_SHARED ? PARK_EVENT_UNKNOWN : ((info >> 8) | PARK_ONE_EVENT);
 					const int lo = (int)cw.x, hi = (int)cw.y, hi2 = (int)cw.z;
 					const unsigned width = has ? (unsigned)(hi - lo) : 0u;
-					unsigned nA = 0, sA = 0, nX = 0, sX = 0;
+					// reads that end inside the cell (A) and reads that end inside the cell or the abutting segment (L):
+					// counts and lengths; the run into the next segment is L minus A
+					unsigned nA = 0, sA = 0, nL = 0, sL = 0;
+					bool lane_parks = false;
 					// all but the first and last steps of a workgroup's range lie wholly inside it: no per-read range test there
 					const bool interior = wt + TILE <= ww1 && (wt > 0u || first_rel == 0u) && (wt + TILE) * 2u - first_rel <= n_rel;
 					auto decide = [&](auto whole_step) {
@@ -545,62 +550,128 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 						for (int j = 0; j < N_READS; ++j) {
 							const int kk = k0 + j / 2;
 							const int ra = (j & 1) ? (int)cur[kk].z : (int)cur[kk].x, rb = (j & 1) ? (int)cur[kk].w : (int)cur[kk].y;
-							const unsigned wj = wt + lane * (unsigned)SW + (unsigned)kk;
-							const unsigned rel = wj * 2u + (unsigned)(j & 1) - first_rel;      // position in the range (wraps above n_rel when outside)
-							const bool in = decltype(whole_step)::value || (wj < ww1 && rel < n_rel);
+							bool in = true;
+							if (!decltype(whole_step)::value) {
+								const unsigned wj = wt + lane * (unsigned)SW + (unsigned)kk;
+								const unsigned rel = wj * 2u + (unsigned)(j & 1) - first_rel;      // position in the range (wraps above n_rel when outside)
+								in = wj < ww1 && rel < n_rel;
+							}
 							const bool m = in && (unsigned)(ra - lo) < width;
 							const bool a = m && rb <= hi;
-							const bool x = m && !a && rb <= hi2;
+							const bool l = m && rb <= hi2;
 							const unsigned len = (unsigned)(rb - ra);
 							nA += a ? 1u : 0u; sA += a ? len : 0u;
-							nX += x ? 1u : 0u; sX += x ? len : 0u;
-							park[j] = in && !a && !x && !ABL(A, 17u);
-							if (ABL(A, 256u) && park[j]) atomicAdd(&A.dbg[5 + (m ? (info == CELL_INFO_SHARED ? 2 : 1) : 0)], 1ull);
-							pe0[j] = make_uint4((unsigned)ra, (unsigned)rb, m ? owner_word : PARK_EVENT_UNKNOWN, rel);
-							pe1[j] = make_uint4(0, 0, 0, 0);
+							nL += l ? 1u : 0u; sL += l ? len : 0u;
+							lane_parks = lane_parks || (in && !l);
 						}
 					};
 					if (interior) decide(std::true_type{}); else decide(std::false_type{});
 					const unsigned sa = cw.w & 0xFFFFu, sb = cw.w >> 16;
 					if (!ABL(A, (1u | 16384u))) {
 						const unsigned long long addA = ((unsigned long long)nA << 40) | sA;
+						const unsigned nX = nL - nA, sX = sL - sA;
 						if (nA && sa != CELL_NONE) atomicAdd(&C.hist[sa], addA);
 						if (nA && hi2 == hi && sb != CELL_NONE) atomicAdd(&C.hist[sb], addA);        // second owner of the cell
 						if (nX && sb != CELL_NONE) atomicAdd(&C.hist[sb], ((unsigned long long)nX << 40) | sX);
-					} else asm volatile("" ::"v"(nA), "v"(sA), "v"(nX), "v"(sX));
+					} else asm volatile("" ::"v"(nA), "v"(sA), "v"(nL), "v"(sL));
+					if (ABL(A, 256u) && lane == 0) atomicAdd(&A.dbg[12], 1ull);
+					if (ABL(A, 256u) && lane == 0 && __any(lane_parks)) atomicAdd(&A.dbg[11], 1ull);
+					if (__any(lane_parks) && !ABL(A, 17u)) {
+						// Some read of some lane is not settled by its lane's cell.  Second chance: its own cell (the lane's reads
+						// straddle a cell boundary); what that does not settle either is parked for the general walk.
+						const unsigned info = cell_info[min(ci, n_cells - 1u)];
+#pragma unroll
+						for (int j = 0; j < N_READS; ++j) {
+							const int kk = k0 + j / 2;
+							const int ra = (j & 1) ? (int)cur[kk].z : (int)cur[kk].x, rb = (j & 1) ? (int)cur[kk].w : (int)cur[kk].y;
+							const unsigned wj = wt + lane * (unsigned)SW + (unsigned)kk;
+							const unsigned rel = wj * 2u + (unsigned)(j & 1) - first_rel;
+							const bool in = wj < ww1 && rel < n_rel;
+							const bool m = in && (unsigned)(ra - lo) < width;
+							bool pk = in && !(m && rb <= hi2);
+							unsigned own_info = info;
+							bool m_any = m;
+							if (__any(pk && !m)) {
+								unsigned c2, e2;
+								locate(ra, c2, e2);
+								const uint4 cv = cells[min(c2, n_cells - 1u)];
+								const bool m2 = pk && !m && c2 < n_cells && ra >= (int)cv.x && ra < (int)cv.y;
+								const bool a2 = m2 && rb <= (int)cv.y, l2 = m2 && rb <= (int)cv.z;
+								const unsigned long long add1 = (1ull << 40) | (unsigned long long)(unsigned)(rb - ra);
+								const unsigned sa2 = cv.w & 0xFFFFu, sb2 = cv.w >> 16;
+								if (a2 && sa2 != CELL_NONE) atomicAdd(&C.hist[sa2], add1);
+								if (a2 && (int)cv.z == (int)cv.y && sb2 != CELL_NONE) atomicAdd(&C.hist[sb2], add1);
+								if (l2 && !a2 && sb2 != CELL_NONE) atomicAdd(&C.hist[sb2], add1);
+								pk = pk && !l2;
+								if (m2) { own_info = cell_info[min(c2, n_cells - 1u)]; m_any = true; }
+							}
+							const unsigned owner_word = own_info == CELL_INFO_SHARED ? PARK_EVENT_UNKNOWN : ((own_info >> 8) | PARK_ONE_EVENT);
+							if (ABL(A, 256u) && pk) { atomicAdd(&A.dbg[5 + (m_any ? (own_info == CELL_INFO_SHARED ? 2 : 1) : 0)], 1ull); atomicAdd(&A.dbg[0], 1ull); }
+							R.push(pk, lane, make_uint4((unsigned)ra, (unsigned)rb, m_any ? owner_word : PARK_EVENT_UNKNOWN, rel), make_uint4(0, 0, 0, 0));
+							// the ring holds what one walk leaves behind (< 64) plus 128 entries
+							if ((j & 1) == 1 && R.live() >= 64u) {             // wave-uniform
+								if (!ABL(A, 32u)) walk_parked<NB>(C, R, false);
+								else R.head = R.tail;
+							}
+						}
+					}
 				}
 			} else if (kg == 0) {
-				// Two-block reads, a lane's two neighbours at a time.  The ingest groups the reads of a bin
-				// by their junction (end of block 1, start of block 2), so the second read almost always
-				// crosses the junction of the first: the first is looked up in full -- block 1 must run to the
-				// end of one segment, block 2 start on the first base of a later segment of the same event
-				// and end inside it -- and the second only has to lie inside the same two cells.  The lane
-				// adds its one or two reads with one LDS atomic; a second read with another junction is parked.
+				// Two-block reads, a lane's two neighbours at a time.  A read is settled here when its first block lies in a
+				// cell with one owner (then only that event can match it, common/read.h:204-274):
+				//   J  block 1 runs to the end of its segment, block 2 starts on the first base of a later segment of the same
+				//      event and ends inside it: both segments match, matched == total, the class of the two-segment mask;
+				//   S  block 2 cannot continue the match -- block 1 stops short of its segment's end, or block 2 starts inside a
+				//      segment (not on its first base) or in a stretch only another event covers: the walk of Read::build stops
+				//      after block 1, so the read matches that one segment with matched = |block 1|, valid only if that is more
+				//      than 98 % of the read (count/count.cpp:441);
+				//   a read from a start cell that ends before gene_end counts for nobody (see CELL_K_START).
+				// Everything else -- shared cells, a run over abutting segments, touching blocks -- is parked for the general walk.
+				// The ingest groups the reads of a bin by junction, so a lane's second read mostly crosses the junction of its
+				// first and only needs its outer ends compared; when it does not, it is parked.
+				struct Look { bool add, park; unsigned slot, matched, hint; bool junction; int4 c; };       // c: lo of cell 1, end of block 1, start of block 2, hi of cell 2
+				auto look2 = [&](const int4 rd, const bool in) {
+					Look L;
+					unsigned c1, c2, evf, evf2;
+					locate(rd.x, c1, evf);
+					locate(rd.z, c2, evf2);
+					const uint4 cw1 = cells[min(c1, n_cells - 1u)], cw2 = cells[min(c2, n_cells - 1u)];
+					const unsigned i1 = cell_info[min(c1, n_cells - 1u)], i2 = cell_info[min(c2, n_cells - 1u)];
+					const unsigned k1 = (i1 >> 2) & 0x3Fu, k2 = (i2 >> 2) & 0x3Fu;
+					const bool v1 = c1 < n_cells && i1 != CELL_INFO_SHARED && (int)cw1.x <= rd.x && rd.x < (int)cw1.y && !ABL(A, 8u);   // block 1 starts in a one-owner cell
+					const bool v2 = c2 < n_cells && i2 != CELL_INFO_SHARED && (int)cw2.x <= rd.z && rd.z < (int)cw2.y;
+					const bool start1 = k1 == CELL_K_START;
+					const bool inside1 = v1 && !start1 && rd.y <= (int)cw1.y && rd.z != rd.y;         // (touching blocks: the exception pass decides)
+					const bool ends1 = inside1 && rd.y == (int)cw1.y && (i1 & 2u);                       // block 1 ends on its segment's end
+					const bool cont = ends1 && v2 && (i1 >> 8) == (i2 >> 8) && rd.z == (int)cw2.x && (i2 & 1u) && k2 != CELL_K_START && k2 > k1;
+					const bool J = cont && rd.w <= (int)cw2.y;
+					const bool S = inside1 && (!ends1 || (v2 && !cont));
+					const bool drop = v1 && start1 && rd.w <= (int)cw1.z;
+					const unsigned len1 = (unsigned)(rd.y - rd.x), total = len1 + (unsigned)(rd.w - rd.z);
+					const uint4 w0r = C.recs[3u * (J ? i1 >> 8 : 0u)];
+					const unsigned long long tbl = ((unsigned long long)w0r.w << 32) | w0r.z;
+					const unsigned cls = (unsigned)(tbl >> (4u * ((1u << (k1 & 3u)) | (1u << (k2 & 3u))))) & 0xFu;
+					const unsigned sa = cw1.w & 0xFFFFu;
+					L.junction = J;
+					L.add = in && ((J && cls != 0u) || (S && sa != CELL_NONE && 50u * len1 > 49u * total));
+					L.slot = J ? (w0r.y & 0xFFFFu) + cls - 1u : sa;
+					L.matched = J ? total : len1;
+					L.park = in && !(J || S || drop);
+					L.hint = v1 ? ((i1 >> 8) | PARK_ONE_EVENT) : evf;
+					L.c = make_int4((int)cw1.x, rd.y, rd.z, (int)cw2.y);
+					if (ABL(A, 256u) && L.park) atomicAdd(&A.dbg[8 + (v1 ? 1 : 0)], 1ull);       // parked: block 1 in no one-owner cell / in one
+					return L;
+				};
 				const uint4 u = cur[k0];
 				const int4 rd = make_int4((int)u.x, (int)u.y, (int)u.z, (int)u.w);
 				const unsigned w0i = wt + lane * (unsigned)SW + (unsigned)k0;
 				const unsigned rel = w0i - first_rel;
 				const bool in = w0i < ww1 && rel < n_rel;
-				unsigned c1, c2, evf, evf2;
-				locate(rd.x, c1, evf);
-				locate(rd.z, c2, evf2);
-				const uint4 cw1 = cells[min(c1, n_cells - 1u)], cw2 = cells[min(c2, n_cells - 1u)];
-				const unsigned i1 = cell_info[min(c1, n_cells - 1u)], i2 = cell_info[min(c2, n_cells - 1u)];
-				const bool junction = c1 < n_cells && c2 < n_cells && i1 != CELL_INFO_SHARED && i2 != CELL_INFO_SHARED &&
-				                      rd.y == (int)cw1.y && (i1 & 2u) &&          // block 1 ends on its segment's end
-				                      rd.z == (int)cw2.x && (i2 & 1u) &&          // block 2 starts on its segment's start
-				                      (i1 >> 8) == (i2 >> 8) && ((i2 >> 2) & 0x3Fu) > ((i1 >> 2) & 0x3Fu) && !ABL(A, 8u);
-				const bool hit = in && junction && (int)cw1.x <= rd.x && rd.w <= (int)cw2.y;
-				const unsigned ev = junction ? i1 >> 8 : 0u;
-				const uint4 w0r = C.recs[3u * ev];
-				const unsigned long long tbl = ((unsigned long long)w0r.w << 32) | w0r.z;
-				const unsigned mask = (1u << ((i1 >> 2) & 0x3u)) | (1u << ((i2 >> 2) & 0x3u));
-				const unsigned cls = (unsigned)(tbl >> (4u * mask)) & 0xFu;
-				unsigned n_add = hit ? 1u : 0u, s_add = hit ? (unsigned)((rd.y - rd.x) + (rd.w - rd.z)) : 0u;
-				park[0] = in && !hit && !ABL(A, 17u);
+				const Look L1 = look2(rd, in);
+				unsigned n_add = L1.add ? 1u : 0u, s_add = L1.add ? L1.matched : 0u;
+				park[0] = L1.park && !ABL(A, 17u);
 				pe0[0] = u;
-				const bool owned1 = c1 < n_cells && i1 != CELL_INFO_SHARED && (int)cw1.x <= rd.x && rd.x < (int)cw1.y;
-				pe1[0] = make_uint4(owned1 ? ((i1 >> 8) | PARK_ONE_EVENT) : evf, rel, 0u, 0u);
+				pe1[0] = make_uint4(L1.hint, rel, 0u, 0u);
 #pragma unroll
 				for (int j = 1; j < N_READS; ++j) {
 					const uint4 v = cur[k0 + j];
@@ -609,30 +680,40 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 					const unsigned rel2 = wj - first_rel;
 					const bool in2 = wj < ww1 && rel2 < n_rel;
 					// same junction: block 1 ends and block 2 starts where the first read's do; then only the outer ends matter
-					const bool same = in2 && junction && r2.y == rd.y && r2.z == rd.z;
-					const bool hit2 = same && (int)cw1.x <= r2.x && r2.x < r2.y && r2.w <= (int)cw2.y;
-					n_add += hit2 ? 1u : 0u;
-					s_add += hit2 ? (unsigned)((r2.y - r2.x) + (r2.w - r2.z)) : 0u;
-					park[j] = in2 && !hit2 && !ABL(A, 17u);
+					const bool same = in2 && in && L1.junction && r2.y == rd.y && r2.z == rd.z && L1.c.x <= r2.x && r2.x < r2.y && r2.w <= L1.c.w;
+					n_add += (same && L1.add) ? 1u : 0u;
+					s_add += (same && L1.add) ? (unsigned)((r2.y - r2.x) + (r2.w - r2.z)) : 0u;
+					// another junction (or none): parked -- a full look of its own for the second read cost more than the
+					// walk it saved (measured: 0.246 against 0.253 ms)
+					park[j] = in2 && !same && !ABL(A, 17u);
 					pe0[j] = v;
-					// a read of the same junction that starts left of the cell, or overshoots: same owner, one look; anything else scans
-					pe1[j] = make_uint4(same && (int)cw1.x <= r2.x && r2.x < (int)cw1.y ? ((i1 >> 8) | PARK_ONE_EVENT) : PARK_EVENT_UNKNOWN, rel2, 0u, 0u);
+					pe1[j] = make_uint4(PARK_EVENT_UNKNOWN, rel2, 0u, 0u);
 				}
-				if (!ABL(A, 1u)) { if (n_add && cls != 0) atomicAdd(&C.hist[(w0r.y & 0xFFFFu) + cls - 1u], ((unsigned long long)n_add << 40) | s_add); }
+				if (!ABL(A, 1u)) { if (n_add) atomicAdd(&C.hist[L1.slot], ((unsigned long long)n_add << 40) | s_add); }
 				else asm volatile("" ::"v"(n_add), "v"(s_add));
 			}
 		}
+		if (RPW == 1) {
 #pragma unroll
-		for (int q = 0; q < N_READS; ++q) {
-			if (ABL(A, 256u) && park[q]) atomicAdd(&A.dbg[NB - 1], 1ull);
-			R.push(park[q], lane, pe0[q], pe1[q]);
-			// the ring holds what one walk leaves behind (< 64) plus 128 one-block or 64 two-block entries
-			if ((NB == 2 || (q & 1) == 1) && R.live() >= 64u) {             // wave-uniform
-				if (!ABL(A, 32u)) walk_parked<NB>(C, R, false);
-				else R.head = R.tail;
+			for (int q = 0; q < N_READS; ++q) {
+				if (ABL(A, 256u) && park[q]) atomicAdd(&A.dbg[NB - 1], 1ull);
+				R.push(park[q], lane, pe0[q], pe1[q]);
+				// the ring holds what one walk leaves behind (< 64) plus 64 two-block entries
+				if (R.live() >= 64u) {             // wave-uniform
+					if (!ABL(A, 32u)) walk_parked<NB>(C, R, false);
+					else R.head = R.tail;
+				}
 			}
 		}
 		}
+	};
+	if (ww0 < ww1) fetch(ww0);
+	for (unsigned wt = ww0; wt < ww1; wt += WAVES * TILE) {
+		uint4 cur[SW];
+#pragma unroll
+		for (int k = 0; k < SW; ++k) cur[k] = nxt[k];
+		if (wt + WAVES * TILE < ww1) fetch(wt + WAVES * TILE);
+		do_step(cur, wt);
 	}
 	if (R.live() && !ABL(A, 32u)) walk_parked<NB>(C, R, true);
 }
@@ -1045,6 +1126,9 @@ int run_count(lsq_ctx *c) {
 		// one workgroup's share must keep the packed LDS counters (24-bit count, 40-bit bases) exact
 		grid = std::max(grid, mr.total_slots / (1ull << 21) + 1);
 		grid = std::min<unsigned long long>(grid, std::max<unsigned long long>(mr.total_slots / 64, 1));
+#ifdef LSQ_DEV
+		if (const char *e = getenv("LSQ_GRID_WGS")) { const long v = atol(e); if (v >= 1) grid = (unsigned long long)v; }      // timing experiments
+#endif
 		if (mr.wg_grid != grid) {
 			int rc = mr.wg_first.alloc((size_t)grid);
 			if (rc) return rc;
@@ -1075,6 +1159,9 @@ int run_count(lsq_ctx *c) {
 		A.n_pn = n_pn;
 		const unsigned workers_per_cu = 2;          // 1, 4 and 8 measured within 2 % of each other
 		A.n_workers = (unsigned)std::min<unsigned long long>((n_pn + COUNT_BLOCK - 1) / COUNT_BLOCK, (unsigned long long)c->n_cu * workers_per_cu);
+#ifdef LSQ_DEV
+		if (c->dev_ablate & 32768u) A.n_workers = 0;          // timing experiment: no pool-n workers (their reads go uncounted)
+#endif
 		if (c->has_fast) {
 			if (c->time_events) HIP_TRY(hipEventRecord(c->evf0[m], st));
 			// the last streaming kernel of the step carries ev_counted as its own completion signal: a separate
@@ -1134,7 +1221,7 @@ int lsq_count_status(lsq_ctx *c, uint32_t *exceptions, uint32_t *recounted) {
 int lsq_debug_counters(lsq_ctx *c, unsigned long long *out8) {
 	HIP_TRY(hipSetDevice(c->device));
 	{ int rc = sync_all(c); if (rc) return rc; }
-	HIP_TRY(hipMemcpy(out8, c->dbg.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(out8, c->dbg.p, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
 	std::vector<unsigned> h(c->exc_count.n);
 	HIP_TRY(hipMemcpy(h.data(), c->exc_count.p, h.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
 	out8[4] = h[0];

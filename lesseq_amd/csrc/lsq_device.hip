@@ -164,9 +164,9 @@ int lsq_events_upload(lsq_ctx *c, lsq_events *E) {
 	const size_t n_cls = E->n_cls_total, n_ev = E->dev2out.size();
 	{
 		const size_t per = std::max<size_t>(M, 1) * n_cls;
-		c->counters_per_set = 2 * per + LSQ_MAX_METHODS + 8;
+		c->counters_per_set = 2 * per + LSQ_MAX_METHODS + 16;
 		if ((rc = c->counters.alloc(2 * c->counters_per_set))) return rc;
-		c->cnt.n = per; c->bases.n = per; c->exc_count.n = 2 * LSQ_MAX_METHODS; c->dbg.n = 8;
+		c->cnt.n = per; c->bases.n = per; c->exc_count.n = 2 * LSQ_MAX_METHODS; c->dbg.n = 16;
 		c->mark_recorded = false;
 		c->fim_uploaded = false; c->fim_done = false;
 		select_counter_set(c, 0);

@@ -128,6 +128,10 @@ inline uint32_t hist_stride(uint32_t n_cls) { return n_cls | 1u; }
 // per cell, for junction reads: owner event << 8 | segment << 2 | hi is the segment's end << 1 |
 // lo is the segment's start; CELL_INFO_SHARED for two-owner cells
 constexpr uint32_t CELL_INFO_SHARED = 0xFFFFFFFFu;
+// segment number of a start cell (the first base of an event's span where that event's first segment is the only cover):
+// lo = gene_start, hi = lo + 1, hi2 = gene_end - 1, both slots CELL_NONE -- a one-block read from there that ends before
+// gene_end is ordered before the event in the read index and counts for nobody
+constexpr uint32_t CELL_K_START = 63u;
 
 struct TieRec {            // global memory, device event order; read only on start ties
 	uint8_t strand_id;

@@ -73,10 +73,51 @@ def std_args(stem, lo, hi, reads):
     return c, s
 
 
+def make_full():
+    """tests/golden_full: the reference's whole runs on BASELINE configs[0] and configs[1]: inputs from
+    lsq_synth_write (not stored), stdout gzip'd, wall-clock / CPU time / peak RSS of each run into meta.json.  The 10 M-read
+    runs take ~2.7 minutes and ~4.8 GB each."""
+    import gzip
+    import hashlib
+    import resource
+    import tempfile
+    import time
+    sys.path.insert(0, ROOT)
+    import lesseq_amd as L
+    full = os.path.join(ROOT, "tests", "golden_full")
+    meta = json.load(open(os.path.join(full, "meta.json")))
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(HERE, "_ref", "lib"))
+    with tempfile.TemporaryDirectory() as d:
+        for name, c in sorted(meta["cases"].items()):
+            sp = c["spec"]
+            L.synth_write(L.SynthSpec(sp["seed"], sp["n_events"], sp["n_reads"], sp["read_length"], sp["n_chrom"], tuple(sp["event_types"])), d, name, write_mrf=True)
+            os.makedirs(os.path.join(full, name), exist_ok=True)
+            for tool in ("count", "solve"):
+                argv = [os.path.join(REF, "bin", tool), "0", name, "./", "LH_GENE_TXT", name + ".interval", "UCSC_GENE2ISOFORM", name + ".map", "0", "100000000",
+                        "MRF_SINGLE", "SHORT_READ", str(sp["read_length"]), name + ".mrf"] + ([c["total_read_bases"]] if tool == "solve" else [])
+                r0, t0 = resource.getrusage(resource.RUSAGE_CHILDREN), time.perf_counter()
+                p = subprocess.run(argv, cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+                dt, r1 = time.perf_counter() - t0, resource.getrusage(resource.RUSAGE_CHILDREN)
+                assert p.returncode == 0
+                with open(os.path.join(full, name, tool + ".out.gz"), "wb") as f:
+                    f.write(gzip.compress(p.stdout, 9, mtime=0))
+                c["reference"][tool] = {"wall_s": round(dt, 2), "user_s": round(r1.ru_utime - r0.ru_utime, 2), "sys_s": round(r1.ru_stime - r0.ru_stime, 2),
+                                        "maxrss_MB": int(r1.ru_maxrss / 1024), "rows": p.stdout.count(b"\n"), "stdout_sha256": hashlib.sha256(p.stdout).hexdigest()}
+                print("  %s %s: %.1f s, %d rows" % (name, tool, dt, p.stdout.count(b"\n")))
+    with open(os.path.join(full, "meta.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
+    ap.add_argument("--full", action="store_true", help="regenerate tests/golden_full (whole reference runs on configs[0] and [1]; minutes)")
     a = ap.parse_args()
+    if a.full:
+        if not os.path.isdir(REF):
+            sys.exit("reference tree not present")
+        subprocess.check_call(["make", "-C", HERE, "ref"])
+        return make_full()
     if not os.path.isdir(REF):
         sys.exit("reference tree not present: golden vectors can only be regenerated in the build container")
     if not os.path.exists(os.path.join(HERE, "_ref", "lib", "libgsl.so.0")):

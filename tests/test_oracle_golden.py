@@ -50,3 +50,40 @@ def test_golden_set_covers_the_edge_cases():
     assert {"toy", "edge", "quirks", "multi_method", "errors", "fmt1m"} <= set(CASES)
     assert sum(1 for c in CASES if c.startswith("wild_")) >= 6
     assert "1.2e+06" in open(os.path.join(GOLD, "fmt1m", "count.out")).read()
+
+
+FULL = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_full")
+
+
+def full_case(name, tmp_path):
+    """(argv for solve, expected count stdout, expected solve stdout) of a tests/golden_full case; the inputs are re-created"""
+    import gzip
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import lesseq_amd as L
+    c = json.load(open(os.path.join(FULL, "meta.json")))["cases"][name]
+    sp = c["spec"]
+    L.synth_write(L.SynthSpec(sp["seed"], sp["n_events"], sp["n_reads"], sp["read_length"], sp["n_chrom"], tuple(sp["event_types"])), str(tmp_path), name, write_mrf=True)
+    argv = ["0", name, "./", "LH_GENE_TXT", str(tmp_path / (name + ".interval")), "UCSC_GENE2ISOFORM", str(tmp_path / (name + ".map")), "0", "100000000",
+            "MRF_SINGLE", "SHORT_READ", str(sp["read_length"]), str(tmp_path / (name + ".mrf")), c["total_read_bases"]]
+    exp = [gzip.open(os.path.join(FULL, name, t + ".out.gz")).read().decode() for t in ("count", "solve")]
+    return argv, exp[0], exp[1]
+
+
+def test_oracle_matches_reference_on_whole_config0(tmp_path):
+    """BASELINE.json configs[0] (10 k reads, 100 SE events), the reference's own CPU-runnable case: whole stdout of the
+    reference's count and solve"""
+    argv, cexp, sexp = full_case("c1", tmp_path)
+    rc, text, _ = ob.run("count", argv[:-1])
+    assert rc == 0 and text == cexp
+    rc, text, _ = ob.run("solve", argv)
+    assert rc == 0 and text == sexp
+
+
+def test_oracle_matches_reference_on_whole_config1_count(tmp_path):
+    """BASELINE.json configs[1] at full size (10 M reads, 5 k SE/RI events): the 10 000 rows the reference's count printed
+    in its 158 s run, byte for byte (the solve table is compared on the GPU side; the oracle reproduced it too when the
+    vectors were made)"""
+    argv, cexp, sexp = full_case("c2", tmp_path)
+    rc, text, _ = ob.run("count", argv[:-1])
+    assert rc == 0 and text == cexp

@@ -884,3 +884,17 @@ def test_executables_run_one_job_over_several_gpu_slices(name, env, tmp_path):
             assert ob.solve_text_close(p.stdout, exp), (name, r["argv"])
         n += 1
     assert n
+
+
+@pytest.mark.parametrize("name", ["c1", "c2"])
+def test_whole_reference_runs_of_config0_and_config1(name, tmp_path):
+    """tests/golden_full: stdout of the reference's own binaries on BASELINE.json configs[0] and configs[1] at full size
+    (10 M reads; 158 s / 166 s of the reference).  The executables' count table is that output byte for byte, the solve
+    table equals it as printed."""
+    import subprocess
+    from test_oracle_golden import full_case
+    argv, cexp, sexp = full_case(name, tmp_path)
+    p = subprocess.run([os.path.join(BIN, "count")] + argv[:-1], capture_output=True, text=True)
+    assert p.returncode == 0 and p.stdout == cexp
+    p = subprocess.run([os.path.join(BIN, "solve")] + argv, capture_output=True, text=True)
+    assert p.returncode == 0 and ob.solve_text_close(p.stdout, sexp)

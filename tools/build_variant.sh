@@ -7,8 +7,8 @@ cd "$(dirname "$0")/../lesseq_amd/csrc"
 name=$1; shift
 B=../_build
 OBJS=""
-for f in lsq_device lsq_count lsq_em lsq_ingest; do
-	/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off "$@" -c -o $B/${f}_$name.o $f.hip &
+for f in lsq_device lsq_count lsq_em lsq_ingest lsq_replay; do
+	/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -DLSQ_DEV "$@" -c -o $B/${f}_$name.o $f.hip &
 	OBJS="$OBJS $B/${f}_$name.o"
 done
 wait
