@@ -383,7 +383,10 @@ __device__ inline bool fast_trip(const FastCtx &C, const int4 v, const int total
 #define LSQ_STREAM_WORDS 2
 #endif
 constexpr int STREAM_WORDS = LSQ_STREAM_WORDS;                // 16-byte words per lane in flight
-constexpr int GROUP_WORDS = 2;                                // words per lane looked up together (independent chains)
+#ifndef LSQ_GROUP_WORDS
+#define LSQ_GROUP_WORDS 2
+#endif
+constexpr int GROUP_WORDS = LSQ_GROUP_WORDS;                  // words per lane looked up together (independent chains)
 constexpr unsigned WAVE_QUEUE_WORDS = 256;                    // 16-byte words of parking per wave (4 KiB): 63 left over + what is pushed between two walks
 constexpr unsigned WAVES = COUNT_BLOCK / 64;
 
