@@ -1018,10 +1018,19 @@ __global__ void __launch_bounds__(256) lsq_count_cleanup_kernel(CountArgs A, int
 	const unsigned long long gtid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
 	const unsigned long long gsz = (unsigned long long)gridDim.x * blockDim.x;
 	const unsigned n_raw = A.exc_count[0];
-	// overflow: the list does not hold every pair the fast kernel left open.  The two recount kernels behind this one
-	// on the stream see the flag and redo the method's packed buckets from zero, over every read.
-	if ((n_raw > A.exc_cap || force_recount) && gtid == 0) A.exc_count[1] = 1u;
-	if (n_raw > A.exc_cap || force_recount) return;
+	// overflow: the list does not hold every pair the fast kernel left open.  The recount kernel behind this one on
+	// the stream sees the flag and counts every read of the method's packed buckets again, from zero.
+	if (n_raw > A.exc_cap || force_recount) {
+		if (gtid == 0) A.exc_count[1] = 1u;
+		// ... and this launch clears what the fast kernel and its workers added to the packed buckets' class counters
+		const unsigned lane = threadIdx.x & 63u, wave_id = (unsigned)(gtid >> 6), n_waves = (unsigned)(gsz >> 6);
+		for (unsigned b = wave_id; b < A.n_buckets; b += n_waves) {
+			const BucketDesc &d = A.buckets[b];
+			if (d.kind != 1) continue;
+			for (unsigned i = lane; i < d.n_cls; i += 64u) { A.cnt[d.cls_base + i] = 0; A.bases[d.cls_base + i] = 0; }
+		}
+		return;
+	}
 	for (unsigned long long k = gtid; k < n_raw; k += gsz) {
 		const ExcEntry e = A.exc[k];
 		const GlobalBucket G = global_bucket(A, e.bucket);
@@ -1034,26 +1043,21 @@ __global__ void __launch_bounds__(256) lsq_count_cleanup_kernel(CountArgs A, int
 	}
 }
 
-// The recount, decided on the device: both kernels follow the exception pass on the result stream and return at once
-// unless it raised the method's overflow flag.  PHASE 0 zeroes the class counters of the packed buckets (what the
-// fast kernel and its workers added), PHASE 1 counts every read of those buckets again: one lane per read, tables
-// from L2, the reference's candidate scan event by event (count/count.cpp:429-464), global atomics.  Slow, complete,
-// and it keeps every table that leaves the context whole -- also those handed over by lsq_results_copy_device.
-template <int PHASE>
-__global__ void __launch_bounds__(256) lsq_count_recount_kernel(CountArgs A, unsigned long long n_pn) {
-	if (!A.exc_count[1]) return;
+// The recount, decided on the device: this kernel follows the exception pass on the result stream and returns at once
+// unless that pass raised the method's overflow flag (and cleared the packed buckets' counters).  It then counts every
+// read of those buckets again: one lane per read, tables from L2, the reference's candidate scan event by event
+// (count/count.cpp:429-464), global atomics.  Slow, complete, and it keeps every table that leaves the context
+// whole -- also those handed over by lsq_results_pack_device / lsq_results_copy_device in a loop that never looks.
+// (The arguments come through a pointer, not by value: the evaluation functions take them by reference, and a by-value
+// kernel argument whose address is taken is copied to every thread's private segment in the prologue -- 288 bytes
+// per thread, written before the flag is even looked at: measured 115 us per launch of a 1 024-workgroup grid.)
+__global__ void __launch_bounds__(256) lsq_count_recount_kernel(const CountArgs *Ap, unsigned long long n_pn) {
+	if (!Ap->exc_count[1]) return;
+	const CountArgs &A = *Ap;
 	const unsigned long long gtid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
 	const unsigned long long gsz = (unsigned long long)gridDim.x * blockDim.x;
 	const unsigned lane = threadIdx.x & 63u;
 	const unsigned wave_id = (unsigned)(gtid >> 6), n_waves = (unsigned)(gsz >> 6);
-	if (PHASE == 0) {
-		for (unsigned b = wave_id; b < A.n_buckets; b += n_waves) {
-			const BucketDesc &d = A.buckets[b];
-			if (d.kind != 1) continue;
-			for (unsigned i = lane; i < d.n_cls; i += 64u) { A.cnt[d.cls_base + i] = 0; A.bases[d.cls_base + i] = 0; }
-		}
-		return;
-	}
 	for (unsigned long long g = gtid; g < n_pn; g += gsz) {
 		const unsigned b = A.pn_bucket[g];
 		if (A.buckets[b].kind != 1) continue;
@@ -1096,7 +1100,7 @@ int run_count(lsq_ctx *c) {
 	c->mark_recorded = true;
 	select_counter_set(c, set);
 	c->fast_launched = 0;
-	struct Cleanup { CountArgs A; unsigned long long n_pn; };
+	struct Cleanup { CountArgs A; unsigned long long n_pn; int m; };
 	std::vector<Cleanup> cleanups;
 	bool counted_signalled = false;
 	if (c->time_events) HIP_TRY(hipEventRecord(c->ev0, st));      // ev0..ev1 brackets the count kernel launches only
@@ -1178,7 +1182,7 @@ int run_count(lsq_ctx *c) {
 			HIP_TRY(hipGetLastError());
 			if (c->time_events) HIP_TRY(hipEventRecord(c->evf1[m], st));
 			c->fast_launched |= 1 << m;
-			cleanups.push_back({A, n_pn});
+			cleanups.push_back({A, n_pn, m});
 		}
 		if (c->has_generic) {
 			hipLaunchKernelGGL(lsq_count_generic_kernel, dim3((unsigned)grid), dim3(COUNT_BLOCK), generic_tables_bytes, st, A);
@@ -1191,11 +1195,23 @@ int run_count(lsq_ctx *c) {
 	// behind it the two recount kernels, which do nothing unless the exception list overflowed
 	if (!counted_signalled) HIP_TRY(hipEventRecord(c->ev_counted, st));
 	HIP_TRY(hipStreamWaitEvent(st_em, c->ev_counted, 0));
-	const unsigned rgrid = (unsigned)c->n_cu * 4u;
+	// few workgroups: these launches normally find the flag clear and return, beside the next count's kernel on a full device
+	const unsigned rgrid = std::max(16u, (unsigned)c->n_cu / 4u);
+	if (c->recount_args.n < 2 * (size_t)LSQ_MAX_METHODS * sizeof(CountArgs)) {
+		int rc = c->recount_args.alloc(2 * (size_t)LSQ_MAX_METHODS * sizeof(CountArgs));
+		if (rc) return rc;
+		c->recount_args_host.assign(2 * (size_t)LSQ_MAX_METHODS * sizeof(CountArgs), 0);
+	}
 	for (const Cleanup &u : cleanups) {
 		hipLaunchKernelGGL(lsq_count_cleanup_kernel, dim3(16), dim3(256), 0, st_em, u.A, c->opt_recount ? 1 : 0);
-		hipLaunchKernelGGL(lsq_count_recount_kernel<0>, dim3(rgrid), dim3(256), 0, st_em, u.A, u.n_pn);
-		hipLaunchKernelGGL(lsq_count_recount_kernel<1>, dim3(rgrid), dim3(256), 0, st_em, u.A, u.n_pn);
+		// the recount kernels' arguments live in device memory, one record per (counter set, read file); rewritten only when they change
+		const size_t slot = ((size_t)set * LSQ_MAX_METHODS + (size_t)u.m) * sizeof(CountArgs);
+		if (memcmp(c->recount_args_host.data() + slot, &u.A, sizeof(CountArgs)) != 0) {
+			memcpy(c->recount_args_host.data() + slot, &u.A, sizeof(CountArgs));
+			HIP_TRY(hipMemcpyAsync(c->recount_args.p + slot, c->recount_args_host.data() + slot, sizeof(CountArgs), hipMemcpyHostToDevice, st_em));
+		}
+		const CountArgs *dA = reinterpret_cast<const CountArgs *>(c->recount_args.p + slot);
+		hipLaunchKernelGGL(lsq_count_recount_kernel, dim3(rgrid), dim3(256), 0, st_em, dA, u.n_pn);
 		HIP_TRY(hipGetLastError());
 	}
 	return LSQ_OK;

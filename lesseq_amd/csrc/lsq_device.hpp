@@ -133,6 +133,8 @@ struct lsq_ctx {
 	size_t opt_exc_cap = 0;
 	bool opt_recount = false;
 	unsigned dev_ablate = 0;                // developer build only (LSQ_ABLATE)
+	DevBuf<unsigned char> recount_args;     // the recount kernels' argument records (lsq_count.hip), and the host's copy of what was last written
+	std::vector<unsigned char> recount_args_host;
 	MethodReads reads[LSQ_MAX_METHODS];
 	bool counted = false, solved = false;
 	bool counts_external = false;           // lsq_results_set_counts: the counts are sums the reads here do not explain
