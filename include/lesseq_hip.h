@@ -46,6 +46,9 @@ typedef enum {
 #define LSQ_MAX_SEGMENTS 32   /* atomic exon segments per event (LESSeq local events: <= 4) */
 #define LSQ_MAX_ISOFORMS 6    /* isoforms per event (LESSeq local events: 2) */
 #define LSQ_MAX_METHODS 8     /* read files ("sampling methods") per run */
+/* Genes beyond the two kernel limits above are not refused: they are evaluated on the host inside lsq_count / lsq_solve
+ * (same rules, the reference's own per-read EM; those calls then block).  The hard limits are 64 segments and: */
+#define LSQ_HOST_MAX_ISOFORMS 16
 
 const char *lsq_last_error(void);
 int lsq_abi_version(void);

@@ -470,6 +470,7 @@ int plan_device(lsq_events &E) {
 			size_t b_begin = i;
 			uint32_t bytes = 0;
 			size_t n_ev = 0;
+			bool host_bucket = false;
 			while (i < lst.size()) {
 				size_t j = i;
 				int64_t max_end = E.ev[lst[j]].gene_end;
@@ -481,11 +482,16 @@ int plan_device(lsq_events &E) {
 					++cn; ++j;
 				}
 				uint32_t cap = E.lds_budget;
+				// a cluster with an event beyond the kernels' limits, or too large for the CU's LDS, is a bucket of its own
+				// that the host evaluates (BucketDesc::kind 2)
+				bool cluster_host = cb > 96u * 1024u || cn > 60000;
+				for (size_t q = i; q < j; ++q) { const Event &e = E.ev[lst[q]]; if (e.K > LSQ_MAX_ISOFORMS || e.N > LSQ_MAX_SEGMENTS) cluster_host = true; }
+				if (cluster_host) {
+					if (n_ev > 0) break;
+					host_bucket = true; n_ev = cn; i = j;
+					break;
+				}
 				if (n_ev > 0 && (bytes + cb > cap || n_ev + cn > 60000)) break;
-				// a single cluster may exceed the budget as long as it fits the CU's LDS
-				if (n_ev == 0 && (cb > 96u * 1024u || cn > 60000))
-					return fail(LSQ_E_UNSUPPORTED, "%zu mutually overlapping events on %s need %u bytes of LDS tables (budget %u): not supported by the device path yet",
-					            cn, E.chroms.names[c].c_str(), cb, E.lds_budget);
 				bytes += cb; n_ev += cn; i = j;
 			}
 			// ---- emit bucket [b_begin, i)
@@ -503,6 +509,31 @@ int plan_device(lsq_events &E) {
 				if (e.N > 4 || e.K > 4 || e.seg_s.front() < 0 || e.gene_start != e.seg_s.front()) fast = false;
 			}
 			if (getenv("LSQ_FORCE_GENERIC")) fast = false;
+			if (host_bucket) {
+				// no LDS image: the reads that start in the bucket's range are pooled as for any bucket (one bin), the count
+				// kernels pass the bucket over, the host evaluates it
+				fast = false;
+				d.kind = 2u; d.n_bins = 1; d.shift = 31; d.lo = (int32_t)lo; d.hi = (int32_t)hi;
+				d.n_cls = ncls; d.cls_base = E.n_cls_total; d.ev_base = (uint32_t)E.dev2out.size();
+				uint32_t io = 0, co = 0;
+				for (size_t k = b_begin; k < i; ++k) {
+					const Event &e = E.ev[lst[k]];
+					E.dev2out.push_back(lst[k]);
+					E.dev_cls_base.push_back(E.n_cls_total + co);
+					E.dev_iso_base.push_back(E.n_iso_total + io);
+					E.dev_K.push_back((uint8_t)e.K);
+					TieRec t;
+					memset(&t, 0, sizeof t);
+					t.strand_id = (uint8_t)e.strand_id;
+					E.ties.push_back(t);
+					io += (uint32_t)e.K; co += (1u << e.K) - 1u;
+				}
+				E.n_cls_total += ncls; E.n_iso_total += niso;
+				if (E.chrom_first_bucket[c] < 0) E.chrom_first_bucket[c] = (int32_t)E.buckets.size();
+				E.cut_lo[c].push_back((int32_t)lo);
+				E.buckets.push_back(d);
+				continue;
+			}
 			if (nseg > 65535 || niso > 65535 || ncls > 65535) return fail(LSQ_E_UNSUPPORTED, "bucket tables exceed 16-bit offsets");
 			uint32_t want = 16;
 			while (want < 8 * d.n_events && want < 4096) want <<= 1;
@@ -758,10 +789,11 @@ int compile_events(const lsq_annotation *a, int n_methods, const char *const *re
 		e.gene_end = span.e.back();
 		e.N = (int)segs.size();
 		e.K = (int)g.isos.size();
-		if (e.N > 64 && !device_plan) return fail(LSQ_E_UNSUPPORTED, "gene %s has %d segments (limit 64)", g.name.c_str(), e.N);
-		if (!device_plan) { /* no device limits */ }
-		else if (e.N > LSQ_MAX_SEGMENTS) return fail(LSQ_E_UNSUPPORTED, "gene %s has %d segments (device limit %d)", g.name.c_str(), e.N, LSQ_MAX_SEGMENTS);
-		if (device_plan && e.K > LSQ_MAX_ISOFORMS) return fail(LSQ_E_UNSUPPORTED, "gene %s has %d isoforms (device limit %d)", g.name.c_str(), e.K, LSQ_MAX_ISOFORMS);
+		// segment masks are 64 bits wide; a gene's compatibility classes are kept as a dense table of 2^K - 1 counters.
+		// Genes beyond the kernels' limits (LSQ_MAX_SEGMENTS, LSQ_MAX_ISOFORMS) are not refused: plan_device puts them
+		// into host buckets, which lsq_count / lsq_solve evaluate on the host (lsq_replay.hip).
+		if (e.N > 64) return fail(LSQ_E_UNSUPPORTED, "gene %s has %d segments (limit 64)", g.name.c_str(), e.N);
+		if (device_plan && e.K > LSQ_HOST_MAX_ISOFORMS) return fail(LSQ_E_UNSUPPORTED, "gene %s has %d isoforms (limit %d: the class table of a gene has 2^K - 1 entries)", g.name.c_str(), e.K, LSQ_HOST_MAX_ISOFORMS);
 		for (const Seg &s : segs) { e.seg_s.push_back(s.start); e.seg_e.push_back(s.end); }
 		// build_isoform_array (splicing_graph.h:318-361): per isoform walk the segments in order;
 		// the exon search resumes at the exon that held the previous segment

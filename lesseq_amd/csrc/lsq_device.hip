@@ -97,8 +97,10 @@ int lsq_events_upload(lsq_ctx *c, lsq_events *E) {
 	if (E->max_lds_bytes > 160 * 1024) return fail(LSQ_E_UNSUPPORTED, "bucket tables exceed the CU's LDS");
 	c->E = E;
 	c->counted = c->solved = false;
-	c->has_fast = c->has_generic = false;
-	for (const BucketDesc &bd : E->buckets) { if (bd.kind == 1) c->has_fast = true; else c->has_generic = true; }
+	c->has_fast = c->has_generic = c->has_host = false;
+	for (const BucketDesc &bd : E->buckets) { if (bd.kind == 1) c->has_fast = true; else if (bd.kind == 0) c->has_generic = true; else c->has_host = true; }
+	std::vector<bool> host_event(E->dev2out.size(), false);
+	for (const BucketDesc &bd : E->buckets) if (bd.kind == 2) for (uint32_t q = 0; q < bd.n_events; ++q) host_event[bd.ev_base + q] = true;
 	for (auto &r : c->reads) r.present = false;
 	int rc;
 	if ((rc = c->buckets.upload(E->buckets.data(), E->buckets.size(), c->stream))) return rc;
@@ -116,6 +118,7 @@ int lsq_events_upload(lsq_ctx *c, lsq_events *E) {
 		for (int pass = 0; pass < 2; ++pass) {
 			for (size_t d = 0; d < n_dev; ++d) {
 				const int K = E->dev_K[d];
+				if (host_event[d]) continue;            // solved on the host (host_solve)
 				const bool small = K <= 2 && E->n_methods * ((1 << K) - 1) <= EM_LANES;
 				if (small == (pass == 0)) order.push_back((uint32_t)d);
 			}
@@ -216,6 +219,7 @@ int lsq_count(lsq_ctx *c) {
 #endif
 	int rc = run_count(c);
 	if (rc) return rc;
+	if (c->has_host && (rc = host_count(c))) return rc;        // genes beyond the kernels' limits: evaluated here (blocks)
 	c->counted = true;
 	c->solved = false;
 	c->counts_external = false;
@@ -228,6 +232,8 @@ int lsq_solve(lsq_ctx *c) {
 	HIP_TRY(hipSetDevice(c->device));
 	int rc = run_solve(c);
 	if (rc) return rc;
+	if (c->has_host && c->counts_external) return fail(LSQ_E_UNSUPPORTED, "genes beyond the kernels' limits are solved from their reads, which counts set from outside do not come with");
+	if (c->has_host && (rc = host_solve(c))) return rc;
 	c->solved = true;
 	c->fim_done = false;
 	return LSQ_OK;

@@ -139,7 +139,8 @@ struct lsq_ctx {
 	bool counted = false, solved = false;
 	bool counts_external = false;           // lsq_results_set_counts: the counts are sums the reads here do not explain
 	double em_band = 1E-11;                 // lsq_set_em_guard_band: events whose stop test comes this close to its threshold are replayed
-	bool has_fast = false, has_generic = false;
+	bool has_fast = false, has_generic = false, has_host = false;
+	std::map<size_t, std::vector<unsigned short>> host_seq;     // host buckets: [device event * M + method] -> classes of its valid reads, index order
 	float count_ms = 0, solve_ms = 0;
 	float mrf_h2d_ms = 0, mrf_parse_ms = 0;
 };
@@ -162,6 +163,8 @@ int run_count(lsq_ctx *c);                           // lsq_count.hip
 int run_solve(lsq_ctx *c);
 int run_fim(lsq_ctx *c);
 int sync_all(lsq_ctx *c);                 // both streams
+int host_count(lsq_ctx *c);                          // lsq_replay.hip: host buckets (genes beyond the kernels' limits)
+int host_solve(lsq_ctx *c);
 int replay_flagged(lsq_ctx *c, unsigned *n_done);    // lsq_replay.hip: the EM of guard-band events in the reference's per-read order
 void select_counter_set(lsq_ctx *c, int set);                           // lsq_em.hip
 } // namespace lsq

@@ -74,7 +74,7 @@ struct BucketDesc {
 	uint32_t cls_base;     // first class slot of the bucket in device class order
 	uint32_t ev_base;      // first event of the bucket in device event order
 	int32_t chrom_id;
-	uint32_t kind;         // 0: generic records (EventRec + segments + masks); 1: packed 48-byte FastRec
+	uint32_t kind;         // 0: generic records (EventRec + segments + masks); 1: packed 48-byte FastRec; 2: no tables, evaluated on the host
 	int32_t hi;            // largest span end in the bucket (reads that start right of it have no candidate)
 };
 static_assert(sizeof(BucketDesc) == 64, "BucketDesc is copied to the device verbatim");

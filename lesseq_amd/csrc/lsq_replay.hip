@@ -13,13 +13,20 @@
 // Flagged events are rare (3 of 200 000 on the skewed 1 B-read workload), so this is not a throughput path.
 #include "lsq_device.hpp"
 
+// The same unit evaluates HOST BUCKETS (BucketDesc::kind 2): clusters of events that hold a gene beyond the kernels'
+// limits (more than LSQ_MAX_ISOFORMS isoforms or LSQ_MAX_SEGMENTS segments: the whole-gene annotations solve's further
+// formats carry) or that do not fit the CU's LDS.  Their reads are pooled on the device like any bucket's; lsq_count
+// brings them back, evaluates every read against every event of the bucket with the rules above and writes the class
+// counts into the device tables; lsq_solve runs the per-read EM for them.  Those calls then block.
+
 namespace {
 
 struct HostRead {
 	int start, end;            // first merged start, last merged end
 	unsigned line;             // MRF line number, or index into the method's name table
+	unsigned matched;          // bases matched (Read::get_read_length)
+	unsigned short cls;        // compatibility class (bit j: isoform j), 0 = not valid for this event
 	unsigned char strand;
-	unsigned char cls;         // compatibility class (bit j: isoform j), 0 = not valid for this event
 };
 
 // Read_single::build against one event's ascending segments (common/read.h:204-274), as lsq_count.hip's Walk
@@ -48,7 +55,7 @@ struct HostWalk {
 };
 
 // class of a read given by its merged blocks; 0 when it is no candidate of the event or not valid
-unsigned eval_read(const lsq::Event &e, const int2 *blk, int nblk, bool read_orders_first) {
+unsigned eval_read(const lsq::Event &e, const int2 *blk, int nblk, bool read_orders_first, unsigned *matched) {
 	const long long p = blk[0].x, q = blk[nblk - 1].y;
 	if (p < e.gene_start || p > e.gene_end) return 0;
 	// count/count.cpp:429-432: lower_bound on (chrom, gene_start, gene_end, strand, name)
@@ -66,6 +73,7 @@ unsigned eval_read(const lsq::Event &e, const int2 *blk, int nblk, bool read_ord
 		const uint64_t iso = e.iso_mask[(size_t)j];
 		if ((w.mask & ~iso) == 0 && (iso & span) == w.mask) cls |= 1u << j;       // read.h:44-79
 	}
+	*matched = (unsigned)w.matched;
 	return cls;
 }
 
@@ -80,11 +88,11 @@ int fetch(std::vector<T> &dst, const T *src, size_t first, size_t count) {
 struct ExactEm {
 	int K = 0;
 	std::vector<std::vector<double>> G;               // [method][K]
-	std::vector<std::vector<unsigned char>> seq;      // [method] classes of the valid reads, index order
+	std::vector<std::vector<unsigned short>> seq;     // [method] classes of the valid reads, index order
 	double row(size_t m, unsigned c, int k) const { return (c >> k & 1u) ? G[m][(size_t)k] : 0.0; }
 	double log_likelihood(const std::vector<double> &th) const {            // read.h:620-636
 		double ll = 0;
-		std::vector<double> lg(1u << K);
+		std::vector<double> lg((size_t)1 << K);
 		for (size_t m = 0; m < seq.size(); ++m) {
 			if (seq[m].empty()) continue;
 			for (unsigned c = 1; c < (1u << K); ++c) {
@@ -92,12 +100,12 @@ struct ExactEm {
 				for (int k = 0; k < K; ++k) s += th[(size_t)k] * row(m, c, k);
 				lg[c] = std::log(s);
 			}
-			for (unsigned char c : seq[m]) ll += lg[c];
+			for (unsigned short c : seq[m]) ll += lg[c];
 		}
 		return ll;
 	}
 	void step(const std::vector<double> &old_th, std::vector<double> &new_th) const {      // read.h:592-618
-		std::vector<double> z(1u << K);
+		std::vector<double> z((size_t)1 << K);
 		for (int k = 0; k < K; ++k) {
 			double sum_zeta = 0, num_total_reads = 0;
 			for (size_t m = 0; m < seq.size(); ++m) {
@@ -112,13 +120,18 @@ struct ExactEm {
 						if (local > 0) z[c] = local / s;
 					}
 				}
-				for (unsigned char c : seq[m]) sum_zeta += z[c];
+				for (unsigned short c : seq[m]) sum_zeta += z[c];
 			}
 			new_th[(size_t)k] = sum_zeta / num_total_reads;
 		}
 	}
+	// solve/solve.cpp:796-806,823-826: no valid read at all -> 1/K each; one isoform -> 1; else the EM.  Returns the iterations.
 	unsigned run(std::vector<double> &theta, double &logll) const {
+		bool any = false;
+		for (const auto &q : seq) any = any || !q.empty();
 		theta.assign((size_t)K, (double)1.0 / (double)K);
+		if (!any) { logll = 0; return 0; }
+		if (K == 1) { theta[0] = 1.0; logll = log_likelihood(theta); return 0; }
 		std::vector<double> old_theta;
 		double ll, old_ll;
 		unsigned iters = 0;
@@ -144,9 +157,102 @@ bool decimal_less(unsigned a, unsigned b) {
 	return na < nb;
 }
 
-std::string read_name(const lsq::MethodReads &mr, const std::string &names, const std::vector<unsigned long long> &name_off, unsigned line) {
-	if (mr.named) return names.substr((size_t)name_off[line], (size_t)(name_off[line + 1] - name_off[line]));
+struct NameTable { bool named = false; std::string blob; std::vector<unsigned long long> off; };
+
+std::string read_name(const NameTable &nt, unsigned line) {
+	if (nt.named) return nt.blob.substr((size_t)nt.off[line], (size_t)(nt.off[line + 1] - nt.off[line]));
 	return "read-" + std::to_string(line);          // count/count.cpp:293-295
+}
+
+int fetch_names(lsq_ctx *c, std::vector<NameTable> &out) {
+	const size_t M = (size_t)c->E->n_methods;
+	out.assign(M, NameTable());
+	for (size_t m = 0; m < M; ++m) {
+		const lsq::MethodReads &mr = c->reads[m];
+		if (!mr.named || !mr.present) continue;
+		out[m].named = true;
+		std::vector<char> blob;
+		int rc = fetch(blob, mr.names.p, 0, mr.names.n); if (rc) return rc;
+		out[m].blob.assign(blob.begin(), blob.end());
+		rc = fetch(out[m].off, mr.name_off.p, 0, mr.name_off.n); if (rc) return rc;
+	}
+	return LSQ_OK;
+}
+
+struct BucketReads {                       // one read file's reads of one bucket, as the pools hold them
+	std::vector<int32_t> p1, p2, pn_se;
+	std::vector<uint8_t> p1_strand, p2_strand, pn_strand;
+	std::vector<uint32_t> p1_line, p2_line, pn_line, pn_blk_off, pn_nblk;
+	unsigned long long pnb0 = 0, pnb1 = 0;
+};
+
+int fetch_bucket(const lsq::MethodReads &mr, size_t b, BucketReads &R) {
+	unsigned long long o1[2], o2[2], on[2], ob[2];
+	HIP_TRY(hipMemcpy(o1, mr.p1_off.p + b, sizeof o1, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(o2, mr.p2_off.p + b, sizeof o2, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(on, mr.pn_off.p + b, sizeof on, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(ob, mr.pnb_off.p + b, sizeof ob, hipMemcpyDeviceToHost));
+	const size_t n1 = (size_t)(o1[1] - o1[0]), n2 = (size_t)(o2[1] - o2[0]), nn = (size_t)(on[1] - on[0]);
+	int rc;
+	if ((rc = fetch(R.p1, mr.p1.p, 2 * (size_t)o1[0], 2 * n1)) || (rc = fetch(R.p1_strand, mr.p1_strand.p, (size_t)o1[0], n1)) || (rc = fetch(R.p1_line, mr.p1_line.p, (size_t)o1[0], n1)) ||
+	    (rc = fetch(R.p2, mr.p2.p, 4 * (size_t)o2[0], 4 * n2)) || (rc = fetch(R.p2_strand, mr.p2_strand.p, (size_t)o2[0], n2)) || (rc = fetch(R.p2_line, mr.p2_line.p, (size_t)o2[0], n2)) ||
+	    (rc = fetch(R.pn_blk_off, mr.pn_blk_off.p, (size_t)on[0], nn)) || (rc = fetch(R.pn_nblk, mr.pn_nblk.p, (size_t)on[0], nn)) ||
+	    (rc = fetch(R.pn_strand, mr.pn_strand.p, (size_t)on[0], nn)) || (rc = fetch(R.pn_line, mr.pn_line.p, (size_t)on[0], nn)) ||
+	    (rc = fetch(R.pn_se, mr.pn_se.p, 2 * (size_t)ob[0], 2 * (size_t)(ob[1] - ob[0])))) return rc;
+	R.pnb0 = ob[0]; R.pnb1 = ob[1];
+	return LSQ_OK;
+}
+
+// the reads of the bucket that are valid for the event, in the order of the reference's read index
+// (count/count.cpp:64-85: start, end, strand, name; the chromosome is the event's for all of them)
+int valid_reads(const lsq_events &E, const lsq::Event &ev, const BucketReads &R, const NameTable &nt, std::vector<HostRead> &valid) {
+	valid.clear();
+	auto consider = [&](const int2 *blk, int nblk, unsigned char strand, unsigned line) {
+		const int p = blk[0].x, q = blk[nblk - 1].y;
+		bool first = false;
+		if (p == ev.gene_start && q == ev.gene_end) {          // the (strand, name) part of the key decides
+			const std::string &rs = E.strands.names[strand];
+			first = rs != ev.strand ? rs < ev.strand : read_name(nt, line) < ev.gname;
+		}
+		unsigned matched = 0;
+		const unsigned cls = eval_read(ev, blk, nblk, first, &matched);
+		if (cls) valid.push_back({p, q, line, matched, (unsigned short)cls, strand});
+	};
+	for (size_t i = 0; i < R.p1_line.size(); ++i) { const int2 blk = make_int2(R.p1[2 * i], R.p1[2 * i + 1]); consider(&blk, 1, R.p1_strand[i], R.p1_line[i]); }
+	for (size_t i = 0; i < R.p2_line.size(); ++i) {
+		const int2 blk[2] = {make_int2(R.p2[4 * i], R.p2[4 * i + 1]), make_int2(R.p2[4 * i + 2], R.p2[4 * i + 3])};
+		consider(blk, 2, R.p2_strand[i], R.p2_line[i]);
+	}
+	for (size_t i = 0; i < R.pn_line.size(); ++i) {
+		if (R.pn_blk_off[i] < R.pnb0 || (unsigned long long)R.pn_blk_off[i] + R.pn_nblk[i] > R.pnb1)
+			return lsq::fail(LSQ_E_STATE, "host evaluation: block offsets of a multi-block read lie outside its bucket");
+		consider(reinterpret_cast<const int2 *>(R.pn_se.data()) + (R.pn_blk_off[i] - R.pnb0), (int)R.pn_nblk[i], R.pn_strand[i], R.pn_line[i]);
+	}
+	std::sort(valid.begin(), valid.end(), [&](const HostRead &x, const HostRead &y) {
+		if (x.start != y.start) return x.start < y.start;
+		if (x.end != y.end) return x.end < y.end;
+		if (x.strand != y.strand) return E.strands.names[x.strand] < E.strands.names[y.strand];
+		if (!nt.named) return decimal_less(x.line, y.line);       // "read-<n>" against "read-<n'>": the digits as strings
+		return read_name(nt, x.line) < read_name(nt, y.line);
+	});
+	return LSQ_OK;
+}
+
+void fill_G(const lsq::Event &ev, size_t M, ExactEm &em) {
+	em.K = ev.K; em.G.resize(M); em.seq.resize(M);
+	for (size_t m = 0; m < M; ++m) {
+		em.G[m].resize((size_t)ev.K);
+		for (int j = 0; j < ev.K; ++j) { const double nd = (double)ev.ars[m][(size_t)j]; em.G[m][(size_t)j] = nd <= 0 ? 0.0 : (double)1.0 / nd; }   // read.h:331-340
+	}
+}
+
+int write_solution(lsq_ctx *c, size_t d, const lsq::Event &ev, const std::vector<double> &theta, double logll, unsigned iters, uint8_t flags) {
+	const lsq_events &E = *c->E;
+	HIP_TRY(hipMemcpy(c->theta.p + E.dev_iso_base[d], theta.data(), (size_t)ev.K * sizeof(double), hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(c->logll.p + d, &logll, sizeof(double), hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(c->iters.p + d, &iters, sizeof(unsigned), hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(c->flags.p + d, &flags, 1, hipMemcpyHostToDevice));
+	return LSQ_OK;
 }
 
 } // namespace
@@ -159,7 +265,7 @@ int replay_flagged(lsq_ctx *c, unsigned *n_done) {
 	if (!c->solved) return LSQ_OK;
 	{ int rc = sync_all(c); if (rc) return rc; }
 	const lsq_events &E = *c->E;
-	const size_t n_ev = E.dev2out.size(), M = (size_t)E.n_methods, n_cls = E.n_cls_total, n_iso = E.n_iso_total;
+	const size_t n_ev = E.dev2out.size(), M = (size_t)E.n_methods, n_cls = E.n_cls_total;
 	if (!n_ev) return LSQ_OK;
 	std::vector<uint8_t> flags(n_ev);
 	HIP_TRY(hipMemcpy(flags.data(), c->flags.p, n_ev, hipMemcpyDeviceToHost));
@@ -168,123 +274,110 @@ int replay_flagged(lsq_ctx *c, unsigned *n_done) {
 	// counts that came from outside (lsq_results_set_counts: sums over processes that each hold a slice of the
 	// reads): the reads behind them are not all here, the flag stays as the kernel set it
 	if (todo.empty() || c->counts_external) return LSQ_OK;
-	// bucket of a device event: the last one whose first event is <= d
-	std::vector<std::string> names(M);
-	std::vector<std::vector<unsigned long long>> name_off(M);
-	for (size_t m = 0; m < M; ++m) {
-		const MethodReads &mr = c->reads[m];
-		if (!mr.named || !mr.present) continue;
-		std::vector<char> blob;
-		int rc = fetch(blob, mr.names.p, 0, mr.names.n); if (rc) return rc;
-		names[m].assign(blob.begin(), blob.end());
-		rc = fetch(name_off[m], mr.name_off.p, 0, mr.name_off.n); if (rc) return rc;
-	}
-	// flagged events by bucket: a bucket's reads come back once per read file
+	std::vector<NameTable> names;
+	{ int rc = fetch_names(c, names); if (rc) return rc; }
+	// bucket of a device event: the last one whose first event is <= d; flagged events by bucket, so that a bucket's
+	// reads come back once per read file
 	auto bucket_of = [&](size_t d) {
 		size_t lo = 0, hi = E.buckets.size();
 		while (hi - lo > 1) { const size_t mid = (lo + hi) / 2; if (E.buckets[mid].ev_base <= d) lo = mid; else hi = mid; }
 		return lo;
-	};
-	struct BucketReads {                       // one read file's reads of one bucket, as the pools hold them
-		std::vector<int32_t> p1, p2, pn_se;
-		std::vector<uint8_t> p1_strand, p2_strand, pn_strand;
-		std::vector<uint32_t> p1_line, p2_line, pn_line, pn_blk_off, pn_nblk;
-		unsigned long long pnb0 = 0, pnb1 = 0;
 	};
 	for (size_t t0 = 0; t0 < todo.size();) {
 		const size_t b = bucket_of(todo[t0]);
 		size_t t1 = t0;
 		while (t1 < todo.size() && bucket_of(todo[t1]) == b) ++t1;
 		std::vector<ExactEm> ems(t1 - t0);
-		for (size_t t = t0; t < t1; ++t) {
-			const Event &ev = E.ev[(size_t)E.dev2out[todo[t]]];
-			ExactEm &em = ems[t - t0];
-			em.K = ev.K; em.G.resize(M); em.seq.resize(M);
-			for (size_t m = 0; m < M; ++m) {
-				em.G[m].resize((size_t)ev.K);
-				for (int j = 0; j < ev.K; ++j) { const double nd = (double)ev.ars[m][(size_t)j]; em.G[m][(size_t)j] = nd <= 0 ? 0.0 : (double)1.0 / nd; }   // read.h:331-340
-			}
-		}
+		for (size_t t = t0; t < t1; ++t) fill_G(E.ev[(size_t)E.dev2out[todo[t]]], M, ems[t - t0]);
 		for (size_t m = 0; m < M; ++m) {
 			const MethodReads &mr = c->reads[m];
 			if (!mr.present) return fail(LSQ_E_STATE, "the exact-order EM replay needs the reads of method %zu on the device", m);
 			BucketReads R;
-			{
-				unsigned long long o1[2], o2[2], on[2], ob[2];
-				HIP_TRY(hipMemcpy(o1, mr.p1_off.p + b, sizeof o1, hipMemcpyDeviceToHost));
-				HIP_TRY(hipMemcpy(o2, mr.p2_off.p + b, sizeof o2, hipMemcpyDeviceToHost));
-				HIP_TRY(hipMemcpy(on, mr.pn_off.p + b, sizeof on, hipMemcpyDeviceToHost));
-				HIP_TRY(hipMemcpy(ob, mr.pnb_off.p + b, sizeof ob, hipMemcpyDeviceToHost));
-				const size_t n1 = (size_t)(o1[1] - o1[0]), n2 = (size_t)(o2[1] - o2[0]), nn = (size_t)(on[1] - on[0]);
-				int rc;
-				if ((rc = fetch(R.p1, mr.p1.p, 2 * (size_t)o1[0], 2 * n1)) || (rc = fetch(R.p1_strand, mr.p1_strand.p, (size_t)o1[0], n1)) || (rc = fetch(R.p1_line, mr.p1_line.p, (size_t)o1[0], n1)) ||
-				    (rc = fetch(R.p2, mr.p2.p, 4 * (size_t)o2[0], 4 * n2)) || (rc = fetch(R.p2_strand, mr.p2_strand.p, (size_t)o2[0], n2)) || (rc = fetch(R.p2_line, mr.p2_line.p, (size_t)o2[0], n2)) ||
-				    (rc = fetch(R.pn_blk_off, mr.pn_blk_off.p, (size_t)on[0], nn)) || (rc = fetch(R.pn_nblk, mr.pn_nblk.p, (size_t)on[0], nn)) ||
-				    (rc = fetch(R.pn_strand, mr.pn_strand.p, (size_t)on[0], nn)) || (rc = fetch(R.pn_line, mr.pn_line.p, (size_t)on[0], nn)) ||
-				    (rc = fetch(R.pn_se, mr.pn_se.p, 2 * (size_t)ob[0], 2 * (size_t)(ob[1] - ob[0])))) return rc;
-				R.pnb0 = ob[0]; R.pnb1 = ob[1];
-			}
+			{ int rc = fetch_bucket(mr, b, R); if (rc) return rc; }
 			for (size_t t = t0; t < t1; ++t) {
 				const size_t d = todo[t];
 				const Event &ev = E.ev[(size_t)E.dev2out[d]];
 				std::vector<HostRead> valid;
-				auto consider = [&](const int2 *blk, int nblk, unsigned char strand, unsigned line) {
-					const int p = blk[0].x, q = blk[nblk - 1].y;
-					bool first = false;
-					if (p == ev.gene_start && q == ev.gene_end) {          // the (strand, name) part of the key decides
-						const std::string &rs = E.strands.names[strand];
-						first = rs != ev.strand ? rs < ev.strand : read_name(mr, names[m], name_off[m], line) < ev.gname;
-					}
-					const unsigned cls = eval_read(ev, blk, nblk, first);
-					if (cls) valid.push_back({p, q, line, strand, (unsigned char)cls});
-				};
-				for (size_t i = 0; i < R.p1_line.size(); ++i) { const int2 blk = make_int2(R.p1[2 * i], R.p1[2 * i + 1]); consider(&blk, 1, R.p1_strand[i], R.p1_line[i]); }
-				for (size_t i = 0; i < R.p2_line.size(); ++i) {
-					const int2 blk[2] = {make_int2(R.p2[4 * i], R.p2[4 * i + 1]), make_int2(R.p2[4 * i + 2], R.p2[4 * i + 3])};
-					consider(blk, 2, R.p2_strand[i], R.p2_line[i]);
-				}
-				for (size_t i = 0; i < R.pn_line.size(); ++i) {
-					if (R.pn_blk_off[i] < R.pnb0 || (unsigned long long)R.pn_blk_off[i] + R.pn_nblk[i] > R.pnb1)
-						return fail(LSQ_E_STATE, "exact-order EM replay: block offsets of a multi-block read lie outside its bucket");
-					consider(reinterpret_cast<const int2 *>(R.pn_se.data()) + (R.pn_blk_off[i] - R.pnb0), (int)R.pn_nblk[i], R.pn_strand[i], R.pn_line[i]);
-				}
-				// the read index's order (count/count.cpp:64-85; the chromosome is the event's for all of them)
-				const bool named = mr.named;
-				std::sort(valid.begin(), valid.end(), [&](const HostRead &x, const HostRead &y) {
-					if (x.start != y.start) return x.start < y.start;
-					if (x.end != y.end) return x.end < y.end;
-					if (x.strand != y.strand) return E.strands.names[x.strand] < E.strands.names[y.strand];
-					if (!named) return decimal_less(x.line, y.line);       // "read-<n>" against "read-<n'>": the digits as strings
-					return read_name(mr, names[m], name_off[m], x.line) < read_name(mr, names[m], name_off[m], y.line);
-				});
+				{ int rc = valid_reads(E, ev, R, names[m], valid); if (rc) return rc; }
 				// the same reads the device counted?  (the replay must not drift from the count tables)
-				std::vector<unsigned long long> mine((size_t)(1u << ev.K), 0), dev((size_t)(1u << ev.K) - 1);
+				std::vector<unsigned long long> mine((size_t)1 << ev.K, 0), dev(((size_t)1 << ev.K) - 1);
 				for (const HostRead &r : valid) ++mine[r.cls];
 				HIP_TRY(hipMemcpy(dev.data(), c->cnt.p + m * n_cls + E.dev_cls_base[d], dev.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
 				for (size_t k = 0; k < dev.size(); ++k)
 					if (dev[k] != mine[k + 1])
 						return fail(LSQ_E_STATE, "exact-order EM replay of gene %s: class %zu has %llu reads here, %llu in the count tables", ev.gname.c_str(), k + 1, mine[k + 1], dev[k]);
-				std::vector<unsigned char> &seq = ems[t - t0].seq[m];
+				std::vector<unsigned short> &seq = ems[t - t0].seq[m];
 				seq.reserve(valid.size());
 				for (const HostRead &r : valid) seq.push_back(r.cls);
 			}
 		}
 		for (size_t t = t0; t < t1; ++t) {
 			const size_t d = todo[t];
-			const Event &ev = E.ev[(size_t)E.dev2out[d]];
 			std::vector<double> theta;
 			double logll = 0;
 			const unsigned iters = ems[t - t0].run(theta, logll);
-			const uint8_t f = (uint8_t)(flags[d] | 4u);
-			HIP_TRY(hipMemcpy(c->theta.p + E.dev_iso_base[d], theta.data(), (size_t)ev.K * sizeof(double), hipMemcpyHostToDevice));
-			HIP_TRY(hipMemcpy(c->logll.p + d, &logll, sizeof(double), hipMemcpyHostToDevice));
-			HIP_TRY(hipMemcpy(c->iters.p + d, &iters, sizeof(unsigned), hipMemcpyHostToDevice));
-			HIP_TRY(hipMemcpy(c->flags.p + d, &f, 1, hipMemcpyHostToDevice));
+			int rc = write_solution(c, d, E.ev[(size_t)E.dev2out[d]], theta, logll, iters, (uint8_t)(flags[d] | 4u));
+			if (rc) return rc;
 			if (n_done) ++*n_done;
 		}
 		t0 = t1;
 	}
-	(void)n_iso;
+	return LSQ_OK;
+}
+
+// Host buckets, count: every read of the bucket against every event of it; the class counts and matched bases go
+// into the device tables, the class sequences stay in the context for host_solve.
+int host_count(lsq_ctx *c) {
+	const lsq_events &E = *c->E;
+	const size_t M = (size_t)E.n_methods, n_cls = E.n_cls_total;
+	c->host_seq.clear();
+	{ int rc = sync_all(c); if (rc) return rc; }
+	std::vector<NameTable> names;
+	{ int rc = fetch_names(c, names); if (rc) return rc; }
+	for (size_t b = 0; b < E.buckets.size(); ++b) {
+		const BucketDesc &bd = E.buckets[b];
+		if (bd.kind != 2) continue;
+		for (size_t m = 0; m < M; ++m) {
+			const MethodReads &mr = c->reads[m];
+			BucketReads R;
+			{ int rc = fetch_bucket(mr, b, R); if (rc) return rc; }
+			for (size_t d = bd.ev_base; d < (size_t)bd.ev_base + bd.n_events; ++d) {
+				const Event &ev = E.ev[(size_t)E.dev2out[d]];
+				std::vector<HostRead> valid;
+				{ int rc = valid_reads(E, ev, R, names[m], valid); if (rc) return rc; }
+				const size_t nc = ((size_t)1 << ev.K) - 1;
+				std::vector<unsigned long long> cnt(nc, 0), bases(nc, 0);
+				std::vector<unsigned short> &seq = c->host_seq[d * M + m];
+				seq.reserve(valid.size());
+				for (const HostRead &r : valid) { ++cnt[r.cls - 1u]; bases[r.cls - 1u] += r.matched; seq.push_back(r.cls); }
+				HIP_TRY(hipMemcpy(c->cnt.p + m * n_cls + E.dev_cls_base[d], cnt.data(), nc * sizeof(unsigned long long), hipMemcpyHostToDevice));
+				HIP_TRY(hipMemcpy(c->bases.p + m * n_cls + E.dev_cls_base[d], bases.data(), nc * sizeof(unsigned long long), hipMemcpyHostToDevice));
+			}
+		}
+	}
+	return LSQ_OK;
+}
+
+// Host buckets, solve: the reference's per-read EM over the sequences host_count kept (flag bit 2: exact order)
+int host_solve(lsq_ctx *c) {
+	const lsq_events &E = *c->E;
+	const size_t M = (size_t)E.n_methods;
+	{ int rc = sync_all(c); if (rc) return rc; }
+	for (size_t b = 0; b < E.buckets.size(); ++b) {
+		const BucketDesc &bd = E.buckets[b];
+		if (bd.kind != 2) continue;
+		for (size_t d = bd.ev_base; d < (size_t)bd.ev_base + bd.n_events; ++d) {
+			const Event &ev = E.ev[(size_t)E.dev2out[d]];
+			ExactEm em;
+			fill_G(ev, M, em);
+			for (size_t m = 0; m < M; ++m) { auto it = c->host_seq.find(d * M + m); if (it != c->host_seq.end()) em.seq[m] = it->second; }
+			std::vector<double> theta;
+			double logll = 0;
+			const unsigned iters = em.run(theta, logll);
+			int rc = write_solution(c, d, ev, theta, logll, iters, (uint8_t)4u);
+			if (rc) return rc;
+		}
+	}
 	return LSQ_OK;
 }
 
