@@ -52,6 +52,7 @@ struct CountArgs {
 	const unsigned *pn_blk_off; const unsigned *pn_nblk; const int2 *pn_se; const unsigned char *pn_strand; const unsigned *pn_line; const unsigned *pn_bucket;
 	const unsigned long long *p1_off, *p2_off, *pn_off, *slot_off;    // n_buckets + 1 each
 	const unsigned *wg_first;          // per workgroup of the fast kernel's grid: the bucket its slot range starts in
+	const unsigned long long *wg_cut;  // ... and the ranges' bounds in slots (grid + 1 values)
 	unsigned long long total_slots;
 	unsigned long long n_pn;           // reads with three or more blocks
 	unsigned n_workers;                // leading workgroups of the fast kernel's grid that take them
@@ -624,36 +625,39 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 				// cell with one owner (then only that event can match it, common/read.h:204-274):
 				//   J  block 1 runs to the end of its segment, block 2 starts on the first base of a later segment of the same
 				//      event and ends inside it: both segments match, matched == total, the class of the two-segment mask;
-				//   S  block 2 cannot continue the match -- block 1 stops short of its segment's end, or block 2 starts inside a
-				//      segment (not on its first base) or in a stretch only another event covers: the walk of Read::build stops
-				//      after block 1, so the read matches that one segment with matched = |block 1|, valid only if that is more
-				//      than 98 % of the read (count/count.cpp:441);
+				//   S  block 2 cannot continue the match -- block 1 stops short of its segment's end, or block 2 starts on the
+				//      first base of no later segment of that event (the event's packed record lists them): the walk of
+				//      Read::build stops after block 1, so the read matches that one segment with matched = |block 1|, valid
+				//      only if that is more than 98 % of the read (count/count.cpp:441);
 				//   a read from a start cell that ends before gene_end counts for nobody (see CELL_K_START).
 				// Everything else -- shared cells, a run over abutting segments, touching blocks -- is parked for the general walk.
 				// The ingest groups the reads of a bin by junction, so a lane's second read mostly crosses the junction of its
 				// first and only needs its outer ends compared; when it does not, it is parked.
-				struct Look { bool add, park; unsigned slot, matched, hint; bool junction; int4 c; };       // c: lo of cell 1, end of block 1, start of block 2, hi of cell 2
+				struct Look { bool add, park; unsigned slot, matched, hint; bool junction; int4 c; };       // c: lo of cell 1, end of block 1, start of block 2, end of block 2's segment
 				auto look2 = [&](const int4 rd, const bool in) {
 					Look L;
-					unsigned c1, c2, evf, evf2;
+					unsigned c1, evf;
 					locate(rd.x, c1, evf);
-					locate(rd.z, c2, evf2);
-					const uint4 cw1 = cells[min(c1, n_cells - 1u)], cw2 = cells[min(c2, n_cells - 1u)];
-					const unsigned i1 = cell_info[min(c1, n_cells - 1u)], i2 = cell_info[min(c2, n_cells - 1u)];
-					const unsigned k1 = (i1 >> 2) & 0x3Fu, k2 = (i2 >> 2) & 0x3Fu;
+					const uint4 cw1 = cells[min(c1, n_cells - 1u)];
+					const unsigned i1 = cell_info[min(c1, n_cells - 1u)];
+					const unsigned k1 = (i1 >> 2) & 0x3Fu;
 					const bool v1 = c1 < n_cells && i1 != CELL_INFO_SHARED && (int)cw1.x <= rd.x && rd.x < (int)cw1.y && !ABL(A, 8u);   // block 1 starts in a one-owner cell
-					const bool v2 = c2 < n_cells && i2 != CELL_INFO_SHARED && (int)cw2.x <= rd.z && rd.z < (int)cw2.y;
 					const bool start1 = k1 == CELL_K_START;
 					const bool inside1 = v1 && !start1 && rd.y <= (int)cw1.y && rd.z != rd.y;         // (touching blocks: the exception pass decides)
 					const bool ends1 = inside1 && rd.y == (int)cw1.y && (i1 & 2u);                       // block 1 ends on its segment's end
-					const bool cont = ends1 && v2 && (i1 >> 8) == (i2 >> 8) && rd.z == (int)cw2.x && (i2 & 1u) && k2 != CELL_K_START && k2 > k1;
-					const bool J = cont && rd.w <= (int)cw2.y;
-					const bool S = inside1 && (!ends1 || (v2 && !cont));
+					// the owner's record: where its segments start and end (unused ones hold INT32_MAX, which no block reaches)
+					const unsigned ri = 3u * (v1 ? i1 >> 8 : 0u);
+					const uint4 w0r = C.recs[ri], w1r = C.recs[ri + 1u], w2r = C.recs[ri + 2u];
+					// block 2 continues the match only from the first base of a later segment of the same event
+					const unsigned k2 = rd.z == (int)w1r.z ? 1u : (rd.z == (int)w2r.x ? 2u : (rd.z == (int)w2r.z ? 3u : 0u));
+					const int end2 = k2 == 1u ? (int)w1r.w : (k2 == 2u ? (int)w2r.y : (int)w2r.w);
+					const bool cont = ends1 && k2 > k1;
+					const bool J = cont && rd.w <= end2;
+					const bool S = inside1 && !cont;
 					const bool drop = v1 && start1 && rd.w <= (int)cw1.z;
 					const unsigned len1 = (unsigned)(rd.y - rd.x), total = len1 + (unsigned)(rd.w - rd.z);
-					const uint4 w0r = C.recs[3u * (J ? i1 >> 8 : 0u)];
 					const unsigned long long tbl = ((unsigned long long)w0r.w << 32) | w0r.z;
-					const unsigned cls = (unsigned)(tbl >> (4u * ((1u << (k1 & 3u)) | (1u << (k2 & 3u))))) & 0xFu;
+					const unsigned cls = (unsigned)(tbl >> (4u * ((1u << (k1 & 3u)) | (1u << k2)))) & 0xFu;
 					const unsigned sa = cw1.w & 0xFFFFu;
 					L.junction = J;
 					L.add = in && ((J && cls != 0u) || (S && sa != CELL_NONE && 50u * len1 > 49u * total));
@@ -661,7 +665,7 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 					L.matched = J ? total : len1;
 					L.park = in && !(J || S || drop);
 					L.hint = v1 ? ((i1 >> 8) | PARK_ONE_EVENT) : evf;
-					L.c = make_int4((int)cw1.x, rd.y, rd.z, (int)cw2.y);
+					L.c = make_int4((int)cw1.x, rd.y, rd.z, end2);
 					if (ABL(A, 256u) && L.park) atomicAdd(&A.dbg[8 + (v1 ? 1 : 0)], 1ull);       // parked: block 1 in no one-owner cell / in one
 					return L;
 				};
@@ -719,21 +723,6 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 		do_step(cur, wt);
 	}
 	if (R.live() && !ABL(A, 32u)) walk_parked<NB>(C, R, true);
-}
-
-// the bucket each workgroup of the fast kernel starts in: a dependent chain of a dozen global loads
-// per workgroup, done once per read set and grid instead of at the head of every launch
-__global__ void __launch_bounds__(256) lsq_wg_plan_kernel(const unsigned long long *slot_off, unsigned n_buckets, unsigned long long total_slots,
-                                                          unsigned grid, unsigned *wg_first) {
-	const unsigned g = blockIdx.x * blockDim.x + threadIdx.x;
-	if (g >= grid) return;
-	const unsigned long long s_begin = total_slots * g / grid;
-	unsigned lo_b = 0, hi_b = n_buckets;
-	while (hi_b - lo_b > 1) {
-		const unsigned mid = (lo_b + hi_b) >> 1;
-		if (slot_off[mid] <= s_begin) lo_b = mid; else hi_b = mid;
-	}
-	wg_first[g] = lo_b;
 }
 
 // Global count/bases adds of a whole wave, merged by class before they reach L2: with skewed read
@@ -883,8 +872,8 @@ __global__ void __launch_bounds__(COUNT_BLOCK, LSQ_FAST_WAVES) lsq_count_fast_ke
 	if (blockIdx.x < A.n_workers) { pool_n_worker(A, A.n_pn, A.n_workers); return; }
 	const unsigned wg = blockIdx.x - A.n_workers, n_wg = gridDim.x - A.n_workers;     // the streaming workgroups
 	uint4 *wave_queue = reinterpret_cast<uint4 *>(lds + A.tables_lds_bytes) + (tid >> 6) * WAVE_QUEUE_WORDS;
-	const unsigned long long s_begin = A.total_slots * wg / n_wg;
-	const unsigned long long s_end = A.total_slots * (wg + 1ull) / n_wg;
+	(void)n_wg;
+	const unsigned long long s_begin = A.wg_cut[wg], s_end = A.wg_cut[wg + 1u];
 	if (s_begin >= s_end) return;
 	if (ABL(A, 4096u)) return;       // developer switch: dispatch cost only
 	{
@@ -1137,16 +1126,40 @@ int run_count(lsq_ctx *c) {
 		if (const char *e = getenv("LSQ_GRID_WGS")) { const long v = atol(e); if (v >= 1) grid = (unsigned long long)v; }      // timing experiments
 #endif
 		if (mr.wg_grid != grid) {
-			int rc = mr.wg_first.alloc((size_t)grid);
+			// The workgroups' shares: equal in reads, with a cut moved onto a bucket boundary when one lies within 30 % of
+			// a share of it -- a workgroup that owns whole buckets stages, drains and flushes each once, where a cut through
+			// the middle makes two workgroups do it (the planner's buckets of an evenly deep read set are about a share long).
+			const std::vector<unsigned long long> &so = mr.slot_off_host;
+			const size_t B = E.buckets.size();
+			std::vector<unsigned long long> cut((size_t)grid + 1, 0);
+			std::vector<unsigned> first((size_t)grid, 0);
+			const double share = (double)mr.total_slots / (double)grid;
+			size_t bb = 0;
+			for (unsigned long long g = 1; g < grid; ++g) {
+				unsigned long long t = mr.total_slots * g / grid;
+				while (bb + 1 < B && so[bb + 1] <= t) ++bb;
+				const unsigned long long lo = so[bb], hi = so[bb + 1];
+				if (c->opt_snap_shares) {
+					if (t - lo <= hi - t && (double)(t - lo) < 0.3 * share) t = lo;
+					else if ((double)(hi - t) < 0.3 * share) t = hi;
+				}
+				cut[(size_t)g] = std::max(t, cut[(size_t)g - 1]);
+			}
+			cut[(size_t)grid] = mr.total_slots;
+			bb = 0;
+			for (unsigned long long g = 0; g < grid; ++g) {
+				while (bb + 1 < B && so[bb + 1] <= cut[(size_t)g]) ++bb;
+				first[(size_t)g] = (unsigned)bb;
+			}
+			int rc = mr.wg_first.upload(first.data(), first.size(), st);
+			if (!rc) rc = mr.wg_cut.upload(cut.data(), cut.size(), st);
 			if (rc) return rc;
-			hipLaunchKernelGGL(lsq_wg_plan_kernel, dim3((unsigned)(grid / 256 + 1)), dim3(256), 0, st, mr.slot_off.p, (unsigned)E.buckets.size(), mr.total_slots,
-			                   (unsigned)grid, mr.wg_first.p);
-			HIP_TRY(hipGetLastError());
+			HIP_TRY(hipStreamSynchronize(st));          // the host vectors go out of scope
 			mr.wg_grid = grid;
 		}
 		CountArgs A{};
 		A.buckets = c->buckets.p; A.images = c->images.p; A.ties = c->ties.p; A.strand_rank = c->strand_rank.p;
-		A.wg_first = mr.wg_first.p;
+		A.wg_first = mr.wg_first.p; A.wg_cut = mr.wg_cut.p;
 		A.read_names = mr.named ? mr.names.p : nullptr; A.read_name_off = mr.named ? mr.name_off.p : nullptr;
 		A.gene_names = c->gene_names.p; A.gene_name_off = c->gene_name_off.p;
 		A.n_buckets = (unsigned)E.buckets.size();

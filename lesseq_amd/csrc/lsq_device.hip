@@ -597,6 +597,9 @@ int lsq_ctx_set_option(lsq_ctx *c, const char *name, double value) {
 	} else if (n == "exception_capacity") {
 		if (!(value >= 0 && value <= 4e9)) return fail(LSQ_E_ARG, "exception_capacity must lie in 0..4e9 (0 = automatic)");
 		c->opt_exc_cap = (size_t)value;          // takes effect with the next upload of a read set
+	} else if (n == "snap_shares") {
+		c->opt_snap_shares = value != 0;
+		for (auto &r : c->reads) r.wg_grid = 0;
 	} else if (n == "recount_every_read") {
 		c->opt_recount = value != 0;
 	} else if (n == "em_guard_band") {

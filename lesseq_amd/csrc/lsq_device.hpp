@@ -73,7 +73,9 @@ struct MethodReads {
 	bool named = false;                     // the reads carry their own names (the *_line arrays index name_off)
 	DevBuf<char> names;
 	DevBuf<unsigned long long> name_off;
-	DevBuf<unsigned> wg_first;             // lsq_wg_plan_kernel's table for `wg_grid` workgroups
+	DevBuf<unsigned> wg_first;             // per workgroup of the fast kernel's grid (`wg_grid` of them): the bucket its share starts in
+	DevBuf<unsigned long long> wg_cut;     // ... and the shares' bounds in slots (wg_grid + 1 values)
+	std::vector<unsigned long long> slot_off_host;   // the buckets' slot offsets (n_buckets + 1), for the share plan
 	unsigned long long wg_grid = 0;
 };
 
@@ -132,6 +134,7 @@ struct lsq_ctx {
 	int opt_grid_mult = 0;
 	size_t opt_exc_cap = 0;
 	bool opt_recount = false;
+	bool opt_snap_shares = true;            // workgroup shares cut on bucket boundaries where one is near
 	unsigned dev_ablate = 0;                // developer build only (LSQ_ABLATE)
 	DevBuf<unsigned char> recount_args;     // the recount kernels' argument records (lsq_count.hip), and the host's copy of what was last written
 	std::vector<unsigned char> recount_args_host;

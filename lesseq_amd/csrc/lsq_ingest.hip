@@ -403,6 +403,7 @@ static int ingest_device(lsq_ctx *c, int method, const IngestRaw &Rw, uint64_t n
 		HIP_TRY(hipStreamSynchronize(st));
 		unsigned long long mx = 0;
 		for (unsigned b = 0; b < B; ++b) mx = std::max(mx, so[b + 1] - so[b]);
+		mr.slot_off_host = so;
 		mr.skew = (B && mr.total_slots) ? (double)mx * (double)B / (double)mr.total_slots : 1.0;
 	}
 	mr.present = true;

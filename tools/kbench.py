@@ -24,6 +24,8 @@ for bud in budgets:
     ev = L.Events(ann, ("SHORT_READ",), (W["R"],))
     reads = L.Reads.synthetic(spec, ev)
     ctx = L.Context(0)
+    if os.environ.get("KB_SNAP"):
+        ctx.set_option("snap_shares", int(os.environ["KB_SNAP"]))
     ctx.set_timing(True)
     ctx.upload_events(ev)
     t0 = time.time(); ctx.upload_reads(0, reads); ti = time.time() - t0
