@@ -199,6 +199,7 @@ def main():
     selftest = world == 1 and os.environ.get("LSQ_BENCH_SELFTEST") == "1"
     gathered = [torch.zeros(world * stride, dtype=torch.int64, device=("cpu" if on_host else dev)) for _ in range(2)] if (world > 1 or selftest) else None
     in_loop_gather = strong or selftest
+    torch.cuda.synchronize()          # torch's zero fills run on torch's stream; the library packs into these buffers on its own
     ext = torch.cuda.ExternalStream(ctx.result_stream, device=dev)       # the library's result stream, for event ordering
     cur = torch.cuda.current_stream(dev)
     packed_ev = [torch.cuda.Event() for _ in range(2)]

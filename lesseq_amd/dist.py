@@ -152,6 +152,7 @@ def run_sharded(tool, argv, rank, world, device_index=0, group=None, comm_device
     stride = max(max(ev.record_words(f, c) for f, c in bounds), 1)
     dev = torch.device("cuda", device_index)
     block = torch.zeros(stride, dtype=torch.int64, device=dev)
+    torch.cuda.current_stream(dev).synchronize()      # torch's fill runs on torch's stream, the pack on the library's: the fill must be done first
     ctx.pack_results_device(block.data_ptr())
     ctx.synchronize()
     blocks = gather_blocks(block, stride, world, group, comm_device)

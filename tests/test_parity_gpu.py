@@ -803,6 +803,7 @@ def test_exception_list_overflow_is_settled_on_the_device(tmp_path, monkeypatch)
     ctx.upload_events(ev)
     ctx.upload_reads(0, reads)
     bufs = [torch.zeros(n_cls, dtype=torch.int64, device="cuda:0") for _ in range(6)]
+    torch.cuda.synchronize()             # torch's fills run on torch's stream, the hand-offs on the library's
     for b in bufs:                       # submitted back to back, each step hands its table to its own buffer
         ctx.count(); ctx.solve()
         ctx.copy_results_device(b.data_ptr(), None, None)
