@@ -302,18 +302,26 @@ def main():
         total_retained, total_blocks, total_mrf = float(sum(x[5] for x in allr)), float(sum(x[6] for x in allr)), float(W["n_reads"] * world)
 
     tables_equal, max_theta_diff = None, None
+    # events that took the exact-order replay in the first solve (ctx.solution() runs it; rare: none on C3, 3 of 200 000 on
+    # the 1 B-read workload) carry the replayed theta in theta_full, the loop's records the kernel's: left out of the comparison
+    off_iso = np.concatenate([[0], np.cumsum([ev.K(i) for i in range(n_ev)])]) if (flags_full & 4).any() else None
+    keep = np.ones(len(theta_full), bool)
+    if off_iso is not None:
+        for i in np.nonzero(flags_full & 4)[0]:
+            keep[off_iso[i]:off_iso[i + 1]] = False
+    keep_ev = (flags_full & 4) == 0
     if strong:
         g = gathered[last].cpu().numpy().view(np.uint64)
         cnt, bases, theta, ll = ev.gathered_unpack(bounds, g, stride)
         tables_equal = bool(np.array_equal(cnt, cnt_full) and np.array_equal(bases, bases_full) and
-                            np.array_equal(theta, theta_full) and np.array_equal(ll, ll_full, equal_nan=True))
-        max_theta_diff = float(np.max(np.abs(theta - theta_full))) if len(theta) else 0.0
+                            np.array_equal(theta[keep], theta_full[keep]) and np.array_equal(ll[keep_ev], ll_full[keep_ev], equal_nan=True))
+        max_theta_diff = float(np.max(np.abs(theta[keep] - theta_full[keep]))) if keep.any() else 0.0
         assert np.array_equal(cnt, cnt_full) and np.array_equal(bases, bases_full), "gathered count tables differ from the unsharded run"
         assert max_theta_diff <= 1e-12, "gathered theta differs from the unsharded run"
     else:
         blk = (gathered[last] if selftest else blocks[last]).cpu().numpy().view(np.uint64)
         cnt, bases, theta, ll = ev.gathered_unpack([(0, n_ev)], blk, stride)
-        assert np.array_equal(cnt, cnt_full) and np.array_equal(bases, bases_full) and np.array_equal(theta, theta_full), "a step's tables differ from the first count"
+        assert np.array_equal(cnt, cnt_full) and np.array_equal(bases, bases_full) and np.array_equal(theta[keep], theta_full[keep]), "a step's tables differ from the first count"
         if world > 1:         # weak mode: one all-gather of the per-event records after the loop
             dist.all_gather_into_tensor(gathered[last], blocks[last].cpu() if on_host else blocks[last])
     assert 0 < int(cnt_full.sum()) <= 4 * job_retained
