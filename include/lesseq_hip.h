@@ -16,7 +16,9 @@
  *              text formatting, the synthetic workload generator;
  *   device     (HIP, gfx950):    context, uploads, the count and EM kernels, result fetch.
  * There is no CPU implementation of the device group: without a usable GPU these calls
- * fail with LSQ_E_DEVICE.
+ * fail with LSQ_E_DEVICE.  (Two things inside the device group do run on the host, on reads that were
+ * filtered and pooled on the device: the exact-order EM of guard-band events, and genes beyond the
+ * kernel limits below -- lesseq_amd/csrc/lsq_replay.hip.)
  */
 #ifndef LESSEQ_HIP_H
 #define LESSEQ_HIP_H
@@ -42,7 +44,7 @@ typedef enum {
 	LSQ_E_STATE = -8         /* call order violated (e.g. count before uploads) */
 } lsq_status;
 
-/* device kernel limits (events beyond them are refused by lsq_events_upload) */
+/* kernel limits (what the count and EM kernels hold in registers / LDS per event) */
 #define LSQ_MAX_SEGMENTS 32   /* atomic exon segments per event (LESSeq local events: <= 4) */
 #define LSQ_MAX_ISOFORMS 6    /* isoforms per event (LESSeq local events: 2) */
 #define LSQ_MAX_METHODS 8     /* read files ("sampling methods") per run */
