@@ -182,18 +182,23 @@ int lsq_events_upload(lsq_ctx *c, lsq_events *E) {
 	{
 		// ingest tables: covered regions (by chromosome id) and the bucket cuts
 		const size_t nc = E->covered.size();
-		std::vector<unsigned> cov_off(nc + 1, 0), cut_off(nc + 1, 0);
-		std::vector<int> cs, ce, cl, cfb(std::max<size_t>(nc, 1), -1);
+		std::vector<unsigned> cov_off(nc + 1, 0), cut_off(nc + 1, 0), clu_off(nc + 1, 0);
+		std::vector<int> cs, ce, cl, cfb(std::max<size_t>(nc, 1), -1), us, ue;
 		for (size_t ch = 0; ch < nc; ++ch) {
 			for (size_t q = 0; q < E->covered[ch].s.size(); ++q) { cs.push_back((int)E->covered[ch].s[q]); ce.push_back((int)E->covered[ch].e[q]); }
 			cov_off[ch + 1] = (unsigned)cs.size();
 			if (ch < E->cut_lo.size()) for (int32_t v : E->cut_lo[ch]) cl.push_back(v);
 			cut_off[ch + 1] = (unsigned)cl.size();
+			if (ch < E->clu_s.size()) for (size_t q = 0; q < E->clu_s[ch].size(); ++q) { us.push_back(E->clu_s[ch][q]); ue.push_back(E->clu_e[ch][q]); }
+			clu_off[ch + 1] = (unsigned)us.size();
 			if (ch < E->chrom_first_bucket.size()) cfb[ch] = E->chrom_first_bucket[ch];
 		}
 		c->n_chrom_tables = (unsigned)nc;
 		if ((rc = c->cov_off.upload(cov_off.data(), cov_off.size(), c->stream))) return rc;
 		if ((rc = c->cut_off.upload(cut_off.data(), cut_off.size(), c->stream))) return rc;
+		if ((rc = c->clu_off.upload(clu_off.data(), clu_off.size(), c->stream))) return rc;
+		if ((rc = c->clu_s.upload(us.data(), us.size(), c->stream))) return rc;
+		if ((rc = c->clu_e.upload(ue.data(), ue.size(), c->stream))) return rc;
 		if ((rc = c->cov_s.upload(cs.data(), cs.size(), c->stream))) return rc;
 		if ((rc = c->cov_e.upload(ce.data(), ce.size(), c->stream))) return rc;
 		if ((rc = c->cut_lo.upload(cl.data(), cl.size(), c->stream))) return rc;
@@ -499,7 +504,10 @@ int lsq_device_alloc(lsq_ctx *c, uint64_t bytes, void **out) {
 	if (!c || !out) return fail(LSQ_E_ARG, "null argument");
 	HIP_TRY(hipSetDevice(c->device));
 	HIP_TRY(hipMalloc(out, (size_t)std::max<uint64_t>(bytes, 8)));
-	HIP_TRY(hipMemset(*out, 0, (size_t)std::max<uint64_t>(bytes, 8)));
+	// zeroed on the result stream, i.e. ahead of any hand-off into the buffer (a plain hipMemset runs on the null stream,
+	// which the context's non-blocking streams do not wait for: it could land behind the pack and wipe it)
+	HIP_TRY(hipMemsetAsync(*out, 0, (size_t)std::max<uint64_t>(bytes, 8), c->stream_em));
+	HIP_TRY(hipStreamSynchronize(c->stream_em));
 	return LSQ_OK;
 }
 void lsq_device_free(lsq_ctx *c, void *p) {

@@ -124,7 +124,8 @@ struct lsq_ctx {
 	DevBuf<unsigned long long> counters;   // two sets of cnt | bases | exc_count | dbg (one memset per count); the views below are the latest count's
 	DevView<unsigned long long> cnt, bases, dbg;
 	DevView<unsigned> exc_count;           // per method: [2m] appended, [2m+1] overflow flag
-	DevBuf<unsigned> cov_off, cut_off;     // ingest tables: covered regions and bucket cuts per chromosome id
+	DevBuf<unsigned> cov_off, cut_off, clu_off;     // ingest tables: covered regions, bucket cuts and event clusters per chromosome id
+	DevBuf<int> clu_s, clu_e;
 	DevBuf<int> cov_s, cov_e, cut_lo, chrom_first_bucket;
 	DevBuf<unsigned> bin_base;             // per bucket: first of its bins among all bins (n_buckets + 1)
 	size_t n_fine = 0;

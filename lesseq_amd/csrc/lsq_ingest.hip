@@ -53,6 +53,8 @@ struct IngestTables {
 	const unsigned *cut_off;       // per chromosome id: range of its bucket cuts
 	const int *cut_lo;
 	const int *chrom_first_bucket;
+	const unsigned *clu_off;       // per chromosome id: range of its event clusters (merged spans of the planned events)
+	const int *clu_s, *clu_e;
 	const BucketDesc *buckets;
 	const unsigned *bin_base;      // per bucket: first of its bins in the fine counters (n_buckets + 1)
 	unsigned n_chrom;
@@ -143,7 +145,16 @@ __global__ void __launch_bounds__(256) lsq_ingest_classify_kernel(IngestTables T
 				while (lo < hi) { const unsigned mid = (lo + hi) >> 1; if (T.cut_lo[mid] <= s[0]) lo = mid + 1; else hi = mid; }
 				if (lo > c0) {
 					const unsigned b = (unsigned)first + (lo - c0 - 1);
-					if (s[0] <= T.buckets[b].hi) {
+					// the first base must lie in the span of some planned event (a cluster): otherwise the read is a
+					// candidate of none of them (count/count.cpp:429-432,463) -- with a shard, the other shards' reads
+					bool in_cluster = false;
+					{
+						const unsigned u0 = T.clu_off[chrom], u1 = T.clu_off[chrom + 1];
+						unsigned ul = u0, uh = u1;                 // upper_bound(cluster starts, p)
+						while (ul < uh) { const unsigned mid = (ul + uh) >> 1; if (T.clu_s[mid] <= s[0]) ul = mid + 1; else uh = mid; }
+						in_cluster = ul > u0 && s[0] <= T.clu_e[ul - 1];
+					}
+					if (in_cluster && s[0] <= T.buckets[b].hi) {
 						const unsigned pool = n == 1 ? 0u : (n == 2 ? 1u : 2u);
 						key = b * 4u + pool;
 						const BucketDesc &d = T.buckets[b];
@@ -317,6 +328,7 @@ static int ingest_device(lsq_ctx *c, int method, const IngestRaw &Rw, uint64_t n
 	IngestTables T{};
 	T.cov_off = c->cov_off.p; T.cov_s = c->cov_s.p; T.cov_e = c->cov_e.p;
 	T.cut_off = c->cut_off.p; T.cut_lo = c->cut_lo.p; T.chrom_first_bucket = c->chrom_first_bucket.p;
+	T.clu_off = c->clu_off.p; T.clu_s = c->clu_s.p; T.clu_e = c->clu_e.p;
 	T.buckets = c->buckets.p; T.bin_base = c->bin_base.p; T.n_chrom = c->n_chrom_tables;
 	IngestWork W{};
 	W.key = d_key.p; W.fine = d_fine.p; W.nb = d_nb.p; W.strand = d_strand.p; W.ms = d_ms.p; W.me = d_me.p;

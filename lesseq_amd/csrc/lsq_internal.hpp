@@ -177,6 +177,11 @@ struct lsq_events {
 	uint32_t n_cls_total = 0, n_iso_total = 0;
 	uint32_t max_lds_bytes = 0;                    // image + histogram, max over buckets
 	// bucket lookup: per chrom id, ascending cut coordinates and the bucket of each range
+	// per chrom id: the merged spans of the planned events (clusters of transitively overlapping spans), ascending.  A read
+	// is a candidate of an event only if its first base lies in the event's span (count/count.cpp:429-432,463), so a read
+	// that starts outside every cluster is dropped at ingest -- with a shard (lsq_events_set_shard) those are the reads of
+	// the other shards' events, which pass the load-time filter of the whole range but concern no event planned here
+	std::vector<std::vector<int32_t>> clu_s, clu_e;
 	std::vector<std::vector<int32_t>> cut_lo;      // cut_lo[chrom][i] = buckets[first+i].lo
 	std::vector<int32_t> chrom_first_bucket;       // -1 when the chromosome has no bucket
 	std::vector<uint64_t> class_off;               // output order, n_events+1
