@@ -200,17 +200,22 @@ def main():
     gathered = [torch.zeros(world * stride, dtype=torch.int64, device=("cpu" if on_host else dev)) for _ in range(2)] if (world > 1 or selftest) else None
     in_loop_gather = strong or selftest
     torch.cuda.synchronize()          # torch's zero fills run on torch's stream; the library packs into these buffers on its own
-    ext = torch.cuda.ExternalStream(ctx.result_stream, device=dev)       # the library's result stream, for event ordering
+    ext_streams = {}                          # the library's result streams (two lanes, taken in turn), for event ordering
     cur = torch.cuda.current_stream(dev)
     packed_ev = [torch.cuda.Event() for _ in range(2)]
     gathered_ev = [None, None]
 
     def step(k):
         b = k & 1
-        if in_loop_gather and gathered_ev[b] is not None and not on_host:
-            ext.wait_event(gathered_ev[b])            # the gather of two steps ago has read this block
         ctx.count()
         ctx.solve()
+        if in_loop_gather and not on_host:
+            ptr = ctx.result_stream               # this step's lane
+            ext = ext_streams.get(ptr)
+            if ext is None:
+                ext = ext_streams[ptr] = torch.cuda.ExternalStream(ptr, device=dev)
+            if gathered_ev[b] is not None:
+                ext.wait_event(gathered_ev[b])        # the gather of two steps ago has read this block
         ctx.pack_results_device(blocks[b].data_ptr())
         if in_loop_gather:
             if on_host:

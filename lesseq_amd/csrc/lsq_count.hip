@@ -1078,16 +1078,19 @@ int run_count(lsq_ctx *c) {
 	const size_t n_cls = E.n_cls_total;
 	const int M = E.n_methods;
 	hipStream_t st = c->stream;
-	hipStream_t st_em = c->stream_em;
+	hipStream_t st_em = nullptr;
 	// This count writes the counter set the solve before last read; the previous count had it
 	// zeroed on the result stream, behind those readers, and recorded ev_mark after that.  Now the
 	// same for the next count: zero the set the latest solve reads, behind it.
+	// (Lanes: this count takes lane `set`; the lane of the count before -- its result stream carries that step's EM and
+	// hand-off -- gets the zeroing of its counters and its mark queued behind them now.)
 	const int set = c->flip ^ 1, other = c->flip;
-	if (c->mark_recorded) HIP_TRY(hipStreamWaitEvent(st, c->ev_mark, 0));
-	HIP_TRY(hipMemsetAsync(c->counters.p + (size_t)other * c->counters_per_set, 0, c->counters_per_set * sizeof(unsigned long long), st_em));
-	HIP_TRY(hipEventRecord(c->ev_mark, st_em));
-	c->mark_recorded = true;
+	if (c->mark_recorded2[set]) HIP_TRY(hipStreamWaitEvent(st, c->ev_mark2[set], 0));
+	HIP_TRY(hipMemsetAsync(c->counters.p + (size_t)other * c->counters_per_set, 0, c->counters_per_set * sizeof(unsigned long long), c->stream_em2[other]));
+	HIP_TRY(hipEventRecord(c->ev_mark2[other], c->stream_em2[other]));
+	c->mark_recorded2[other] = true;
 	select_counter_set(c, set);
+	st_em = c->stream_em;
 	c->fast_launched = 0;
 	struct Cleanup { CountArgs A; unsigned long long n_pn; int m; };
 	std::vector<Cleanup> cleanups;
@@ -1188,7 +1191,7 @@ int run_count(lsq_ctx *c) {
 			// event record is one more packet between this kernel and the next count's (measured ~5 us each)
 			const bool last_streaming = m == M - 1 && !c->has_generic && !c->time_events;
 			if (last_streaming) {
-				hipExtLaunchKernelGGL(lsq_count_fast_kernel, dim3((unsigned)grid + A.n_workers), dim3(COUNT_BLOCK), lds_bytes, st, nullptr, c->ev_counted, 0, A);
+				hipExtLaunchKernelGGL(lsq_count_fast_kernel, dim3((unsigned)grid + A.n_workers), dim3(COUNT_BLOCK), lds_bytes, st, nullptr, c->ev_counted2[set], 0, A);
 				counted_signalled = true;
 			} else
 				hipLaunchKernelGGL(lsq_count_fast_kernel, dim3((unsigned)grid + A.n_workers), dim3(COUNT_BLOCK), lds_bytes, st, A);
@@ -1206,8 +1209,8 @@ int run_count(lsq_ctx *c) {
 	c->count_timed = c->time_events;
 	// the exception pass, and everything that reads the counts, on the result stream behind the streaming kernels;
 	// behind it the two recount kernels, which do nothing unless the exception list overflowed
-	if (!counted_signalled) HIP_TRY(hipEventRecord(c->ev_counted, st));
-	HIP_TRY(hipStreamWaitEvent(st_em, c->ev_counted, 0));
+	if (!counted_signalled) HIP_TRY(hipEventRecord(c->ev_counted2[set], st));
+	HIP_TRY(hipStreamWaitEvent(st_em, c->ev_counted2[set], 0));
 	// few workgroups: these launches normally find the flag clear and return, beside the next count's kernel on a full device
 	const unsigned rgrid = std::max(16u, (unsigned)c->n_cu / 4u);
 	if (c->recount_args.n < 2 * (size_t)LSQ_MAX_METHODS * sizeof(CountArgs)) {

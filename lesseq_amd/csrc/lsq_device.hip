@@ -20,7 +20,8 @@ int upload_strand_ranks(lsq_ctx *c) {
 
 int sync_all(lsq_ctx *c) {
 	HIP_TRY(hipStreamSynchronize(c->stream));
-	HIP_TRY(hipStreamSynchronize(c->stream_em));
+	HIP_TRY(hipStreamSynchronize(c->stream_em2[0]));
+	HIP_TRY(hipStreamSynchronize(c->stream_em2[1]));
 	return LSQ_OK;
 }
 
@@ -28,6 +29,11 @@ void select_counter_set(lsq_ctx *c, int set) {
 	unsigned long long *base = c->counters.p + (size_t)set * c->counters_per_set;
 	const size_t per = c->cnt.n;
 	c->flip = set;
+	c->stream_em = c->stream_em2[set];
+	c->theta.p = c->theta2[set].p; c->theta.n = c->theta2[set].n;
+	c->logll.p = c->logll2[set].p; c->logll.n = c->logll2[set].n;
+	c->iters.p = c->iters2[set].p; c->iters.n = c->iters2[set].n;
+	c->flags.p = c->flags2[set].p; c->flags.n = c->flags2[set].n;
 	c->cnt.p = base;
 	c->bases.p = base + per;
 	c->exc_count.p = reinterpret_cast<unsigned *>(base + 2 * per);
@@ -53,9 +59,12 @@ int lsq_ctx_create(int device_id, lsq_ctx **out) {
 	c->device = device_id;
 	c->n_cu = prop.multiProcessorCount;
 	HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-	HIP_TRY(hipStreamCreateWithFlags(&c->stream_em, hipStreamNonBlocking));      // (a higher stream priority changed nothing measurable)
-	HIP_TRY(hipEventCreateWithFlags(&c->ev_counted, hipEventDisableTiming));
-	HIP_TRY(hipEventCreateWithFlags(&c->ev_mark, hipEventDisableTiming));
+	for (int l = 0; l < 2; ++l) {
+		HIP_TRY(hipStreamCreateWithFlags(&c->stream_em2[l], hipStreamNonBlocking));      // (a higher stream priority changed nothing measurable)
+		HIP_TRY(hipEventCreateWithFlags(&c->ev_counted2[l], hipEventDisableTiming));
+		HIP_TRY(hipEventCreateWithFlags(&c->ev_mark2[l], hipEventDisableTiming));
+	}
+	c->stream_em = c->stream_em2[0];
 	HIP_TRY(hipEventCreate(&c->ev0)); HIP_TRY(hipEventCreate(&c->ev1));
 	HIP_TRY(hipEventCreate(&c->ev2)); HIP_TRY(hipEventCreate(&c->ev3));
 	HIP_TRY(hipEventCreate(&c->evt0)); HIP_TRY(hipEventCreate(&c->evt1));
@@ -68,9 +77,11 @@ void lsq_ctx_destroy(lsq_ctx *c) {
 	if (!c) return;
 	(void)hipSetDevice(c->device);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
-	if (c->stream_em) (void)hipStreamSynchronize(c->stream_em);
-	if (c->ev_counted) (void)hipEventDestroy(c->ev_counted);
-	if (c->ev_mark) (void)hipEventDestroy(c->ev_mark);
+	for (int l = 0; l < 2; ++l) {
+		if (c->stream_em2[l]) (void)hipStreamSynchronize(c->stream_em2[l]);
+		if (c->ev_counted2[l]) (void)hipEventDestroy(c->ev_counted2[l]);
+		if (c->ev_mark2[l]) (void)hipEventDestroy(c->ev_mark2[l]);
+	}
 	if (c->ev0) (void)hipEventDestroy(c->ev0);
 	if (c->ev1) (void)hipEventDestroy(c->ev1);
 	if (c->ev2) (void)hipEventDestroy(c->ev2);
@@ -79,7 +90,7 @@ void lsq_ctx_destroy(lsq_ctx *c) {
 	if (c->evt1) (void)hipEventDestroy(c->evt1);
 	for (int m = 0; m < LSQ_MAX_METHODS; ++m) { if (c->evf0[m]) (void)hipEventDestroy(c->evf0[m]); if (c->evf1[m]) (void)hipEventDestroy(c->evf1[m]); }
 	if (c->stream) (void)hipStreamDestroy(c->stream);
-	if (c->stream_em) (void)hipStreamDestroy(c->stream_em);
+	for (int l = 0; l < 2; ++l) if (c->stream_em2[l]) (void)hipStreamDestroy(c->stream_em2[l]);
 	delete c;
 }
 
@@ -170,15 +181,16 @@ int lsq_events_upload(lsq_ctx *c, lsq_events *E) {
 		c->counters_per_set = 2 * per + LSQ_MAX_METHODS + 16;
 		if ((rc = c->counters.alloc(2 * c->counters_per_set))) return rc;
 		c->cnt.n = per; c->bases.n = per; c->exc_count.n = 2 * LSQ_MAX_METHODS; c->dbg.n = 16;
-		c->mark_recorded = false;
+		c->mark_recorded2[0] = c->mark_recorded2[1] = false;
 		c->fim_uploaded = false; c->fim_done = false;
 		select_counter_set(c, 0);
 		HIP_TRY(hipMemsetAsync(c->counters.p, 0, c->counters.n * sizeof(unsigned long long), c->stream));      // both sets start out zero
 	}
-	if ((rc = c->theta.alloc(n_iso))) return rc;
-	if ((rc = c->logll.alloc(n_ev))) return rc;
-	if ((rc = c->iters.alloc(n_ev))) return rc;
-	if ((rc = c->flags.alloc(n_ev))) return rc;
+	for (int l = 0; l < 2; ++l) {
+		if ((rc = c->theta2[l].alloc(n_iso)) || (rc = c->logll2[l].alloc(n_ev)) || (rc = c->iters2[l].alloc(n_ev)) || (rc = c->flags2[l].alloc(n_ev))) return rc;
+		HIP_TRY(hipMemsetAsync(c->flags2[l].p, 0, std::max<size_t>(n_ev, 1), c->stream));
+	}
+	select_counter_set(c, 0);
 	{
 		// ingest tables: covered regions (by chromosome id) and the bucket cuts
 		const size_t nc = E->covered.size();

@@ -92,9 +92,14 @@ struct lsq_ctx {
 	// before last read); ev_counted: end of the latest count's streaming kernels; ev_mark: recorded
 	// on the result stream when a count is submitted, behind the zeroing of the set the NEXT count
 	// writes -- that count waits for it, i.e. for the readers of its set and not for the EM in between.
-	hipStream_t stream_em = nullptr;
-	hipEvent_t ev_counted = nullptr, ev_mark = nullptr;
-	bool mark_recorded = false;
+	// ... and all of that exists twice, as two LANES that consecutive counts take in turn: a counter set, exception
+	// lists, a result stream, the EM's output arrays and the two events.  The EM of step k (a chain of dependent passes on a
+	// handful of waves) then runs beside the exception pass and the EM of step k+1 instead of ahead of them: with small
+	// shards (a rank of an event-sharded job) the result stream's chain, not the count kernel, bounded the step.
+	hipStream_t stream_em = nullptr;        // the latest count's lane (= stream_em2[flip])
+	hipStream_t stream_em2[2] = {nullptr, nullptr};
+	hipEvent_t ev_counted2[2] = {nullptr, nullptr}, ev_mark2[2] = {nullptr, nullptr};
+	bool mark_recorded2[2] = {false, false};
 	int flip = 0;                           // counter set of the latest count
 	size_t counters_per_set = 0;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
@@ -108,19 +113,23 @@ struct lsq_ctx {
 	DevBuf<BucketDesc> buckets;
 	DevBuf<uint8_t> images, strand_rank, dK;
 	DevBuf<TieRec> ties;
-	DevBuf<uint32_t> cls_base, iso_base, iters, em_order, gene_name_off;
+	DevBuf<uint32_t> cls_base, iso_base, em_order, gene_name_off;
 	DevBuf<char> gene_names;                // device event order
 	DevBuf<uint32_t> pack_cls, pack_iso, pack_ev;      // lsq_results_pack_device: device index of every class / isoform / event of the shard, in output order
 	unsigned em_places = 0;
 	unsigned em_small_places = 0;           // the first of them: events of the lean EM kernel
-	DevBuf<double> G, theta, logll;
+	DevBuf<double> G, theta2[2], logll2[2];
+	DevBuf<uint32_t> iters2[2];
+	DevBuf<uint8_t> flags2[2];
+	DevView<double> theta, logll;           // the latest count's lane
+	DevView<uint32_t> iters;
+	DevView<uint8_t> flags;
 	// lsq_fim (fim.h / linalg.h): per device event the offset of its accessible-start class counts and of its
 	// (K-1) x (K-1) matrix; counts per method; results
 	DevBuf<uint32_t> fim_start_base, fim_mat_base, fim_starts;
 	DevBuf<double> fim, fim_var;
 	size_t fim_starts_total = 0, fim_mat_total = 0;
 	bool fim_uploaded = false, fim_done = false;
-	DevBuf<uint8_t> flags;
 	DevBuf<unsigned long long> counters;   // two sets of cnt | bases | exc_count | dbg (one memset per count); the views below are the latest count's
 	DevView<unsigned long long> cnt, bases, dbg;
 	DevView<unsigned> exc_count;           // per method: [2m] appended, [2m+1] overflow flag
