@@ -203,6 +203,10 @@ int lsq_mrf_parse_device(lsq_ctx *c, const char *read_format, const char *path, 
 int lsq_last_mrf_timing(lsq_ctx *c, float *h2d_ms, float *parse_ms);
 uint64_t lsq_reads_retained(const lsq_ctx *c, int method);      /* "loaded N reads" log line */
 uint64_t lsq_reads_retained_blocks(const lsq_ctx *c, int method);
+/* Of the retained reads, those kept in the pools: reads whose first base lies in the span of an event planned on this
+ * context.  Without a shard that is every retained read; with lsq_events_set_shard the slice's share (a read that starts
+ * in no event of the slice is a candidate of none of them, count/count.cpp:429-432,463, and is dropped at ingest). */
+uint64_t lsq_reads_pooled(const lsq_ctx *c, int method);
 
 /* Replaces the per-gene candidate scan + Read::build + compatibility + validity + counting
  * (count/count.cpp:420-482 == solve/solve.cpp:719-793; common/read.h:44-79,198-274): one

@@ -90,6 +90,7 @@ _sig("lsq_mrf_parse_device", C.c_int, vp, cs, cs, P(vp))
 _sig("lsq_last_mrf_timing", C.c_int, vp, P(C.c_float), P(C.c_float))
 _sig("lsq_reads_retained", u64, vp, C.c_int)
 _sig("lsq_reads_retained_blocks", u64, vp, C.c_int)
+_sig("lsq_reads_pooled", u64, vp, C.c_int)
 _sig("lsq_count", C.c_int, vp)
 _sig("lsq_solve", C.c_int, vp)
 _sig("lsq_results_num_classes", i64, vp)

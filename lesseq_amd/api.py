@@ -263,6 +263,10 @@ class Context:
     def retained(self, method):
         return lib.lsq_reads_retained(self.h, method)
 
+    def pooled(self, method):
+        """retained reads kept in the pools: those that start in the span of an event planned on this context"""
+        return lib.lsq_reads_pooled(self.h, method)
+
     def retained_blocks(self, method):
         return lib.lsq_reads_retained_blocks(self.h, method)
 

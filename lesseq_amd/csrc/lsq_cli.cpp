@@ -294,8 +294,10 @@ int run_sharded_job(const ShardedJob &J, lsq_ctx *ctx0, lsq_events *ev0, std::ve
 			lsq_device_free(c, d_all);
 		}
 		lsq_device_free(c, d_block);
-		logf(2, "GPU %d: events %llu..%llu of the sorted list%s", J.devices[(size_t)r], (unsigned long long)first[(size_t)r],
-		     (unsigned long long)(first[(size_t)r] + count[(size_t)r]), replayed ? " (guard-band events solved again in per-read order)" : "");
+		unsigned long long pooled = 0;
+		for (int m = 0; m < M; ++m) pooled += lsq_reads_pooled(c, m);
+		logf(2, "GPU %d: events %llu..%llu of the sorted list, %llu reads pooled for them%s", J.devices[(size_t)r], (unsigned long long)first[(size_t)r],
+		     (unsigned long long)(first[(size_t)r] + count[(size_t)r]), pooled, replayed ? " (guard-band events solved again in per-read order)" : "");
 	};
 	std::vector<std::thread> th;
 	for (int r = 1; r < G; ++r) th.emplace_back(work, r);

@@ -551,6 +551,7 @@ int lsq_last_mrf_timing(lsq_ctx *c, float *h2d_ms, float *parse_ms) {
 }
 
 uint64_t lsq_reads_retained(const lsq_ctx *c, int method) { return (c && method >= 0 && method < LSQ_MAX_METHODS) ? c->reads[method].n_retained : 0; }
+uint64_t lsq_reads_pooled(const lsq_ctx *c, int method) { return (c && method >= 0 && method < LSQ_MAX_METHODS) ? c->reads[method].total_slots : 0; }
 uint64_t lsq_reads_retained_blocks(const lsq_ctx *c, int method) { return (c && method >= 0 && method < LSQ_MAX_METHODS) ? c->reads[method].n_retained_blocks : 0; }
 
 } // extern "C"

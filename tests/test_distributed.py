@@ -198,3 +198,38 @@ def test_three_ranks_read_sharded_run_equals_single_process(tmp_path):
     for rank, c, s in res:
         assert c == single_count
         assert s == single_solve
+
+
+@pytest.mark.gpu
+def test_a_shard_pools_only_the_reads_of_its_events(tmp_path):
+    """lsq_events_set_shard: the load-time filter stays that of the whole range (same retained count), but only reads that
+    start in the span of one of the slice's events are kept in the pools -- a half-job shard holds about half of them, the two
+    halves together every read once (plus the few that start in overlapping events of both halves), and the buckets of a
+    sparse slice stay short on the chromosome"""
+    spec = L.SynthSpec(41, 2000, 400000, 100, 4, L.EVENT_TYPES)
+    L.synth_write(spec, str(tmp_path), "d", write_mrf=False)
+    ann = L.Annotation(str(tmp_path / "d.interval"), str(tmp_path / "d.map"))
+    ev = L.Events(ann, ("SHORT_READ",), (100,))
+    reads = L.Reads.synthetic(spec, ev)
+    ctx = L.Context(0)
+    ctx.upload_events(ev)
+    ctx.upload_reads(0, reads)
+    full_retained, full_pooled, full_buckets = ctx.retained(0), ctx.pooled(0), ev.num_buckets
+    assert full_pooled == full_retained > 300000
+    ctx.count()
+    cnt_full = ctx.counts()[0].copy()
+    bounds = ev.shard_bounds(2, ld.event_weights(ev, cnt_full))
+    pooled, total = [], np.zeros_like(cnt_full)
+    for f, c in bounds:
+        ev.set_shard(f, c)
+        ctx.upload_events(ev)
+        ctx.upload_reads(0, reads)
+        assert ctx.retained(0) == full_retained
+        pooled.append(ctx.pooled(0))
+        assert ev.num_buckets < 0.75 * full_buckets
+        ctx.count()
+        total += ctx.counts()[0]
+    ctx.close()
+    assert all(0.4 * full_pooled < p < 0.6 * full_pooled for p in pooled), (pooled, full_pooled)
+    assert full_pooled <= sum(pooled) < 1.1 * full_pooled
+    assert np.array_equal(total, cnt_full)
