@@ -75,6 +75,12 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end legs (N = 1 only)")
     a = ap.parse_args()
 
+    # stdout carries the one JSON line and nothing else: libraries that greet on stdout (RCCL's version banner, gloo's
+    # connection notes) are sent to stderr for the duration
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -196,10 +202,48 @@ def main():
     stride = max(max(ev.record_words(f, c) for f, c in bounds), 1)
     blocks = [torch.zeros(stride, dtype=torch.int64, device=dev) for _ in range(2)]
     # LSQ_BENCH_SELFTEST=1 (developer aid, one GPU): the stream / event ordering of the in-loop gather with a device copy in its place
-    selftest = world == 1 and os.environ.get("LSQ_BENCH_SELFTEST") == "1"
+    # (LSQ_BENCH_SELFTEST=2: the same through liblesseq_rccl's lsq_gather with a communicator of one rank)
+    selftest = world == 1 and os.environ.get("LSQ_BENCH_SELFTEST") in ("1", "2")
     gathered = [torch.zeros(world * stride, dtype=torch.int64, device=("cpu" if on_host else dev)) for _ in range(2)] if (world > 1 or selftest) else None
     in_loop_gather = strong or selftest
     torch.cuda.synchronize()          # torch's zero fills run on torch's stream; the library packs into these buffers on its own
+    # The gather itself: liblesseq_rccl's lsq_gather (include/lesseq_rccl.h) -- ncclAllGather on the step's result lane, right
+    # behind the pack, one C call and no stream hand-over -- when its communicator comes up on every rank (rank 0's RCCL id
+    # travels through torch.distributed); otherwise torch.distributed's all_gather_into_tensor on torch's stream, ordered
+    # against the lane by events.  LSQ_BENCH_GATHER=torch forces the latter.
+    import ctypes as C
+    rccl, comm = None, C.c_void_p()
+    want_lsq = ((strong and not rehearse) or os.environ.get("LSQ_BENCH_SELFTEST") == "2") and os.environ.get("LSQ_BENCH_GATHER", "lsq") != "torch"
+    if want_lsq:
+        ok = 1
+        try:
+            rccl = C.CDLL(os.path.join(os.path.dirname(L._lib.LIB_PATH), "liblesseq_rccl.so"))
+            rccl.lsq_comm_unique_id.argtypes = [C.c_void_p]
+            rccl.lsq_comm_init_rank.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+            rccl.lsq_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+            rccl.lsq_comm_destroy.argtypes = [C.c_void_p]
+            uid = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                buf = (C.c_ubyte * 128)()
+                ok = 1 if rccl.lsq_comm_unique_id(buf) == 0 else 0
+                uid = torch.tensor(list(buf), dtype=torch.uint8)
+            if world > 1:
+                uid_d = uid.to(dev)
+                dist.broadcast(uid_d, 0)
+                uid = uid_d.cpu()
+            idb = (C.c_ubyte * 128)(*uid.tolist())
+            if ok and rccl.lsq_comm_init_rank(world, rank, idb, local_rank, C.byref(comm)) != 0:
+                ok = 0
+        except Exception:
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        if world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if comm.value:
+                rccl.lsq_comm_destroy(comm)
+            rccl, comm = None, C.c_void_p()
+    use_lsq_gather = rccl is not None and bool(comm.value)
     ext_streams = {}                          # the library's result streams (two lanes, taken in turn), for event ordering
     cur = torch.cuda.current_stream(dev)
     packed_ev = [torch.cuda.Event() for _ in range(2)]
@@ -209,6 +253,13 @@ def main():
         b = k & 1
         ctx.count()
         ctx.solve()
+        if in_loop_gather and use_lsq_gather:
+            # block b is always this lane's (lanes and blocks both alternate): the gather that read it two steps ago sits
+            # ahead of this pack on the same stream
+            ctx.pack_results_device(blocks[b].data_ptr())
+            if rccl.lsq_gather(ctx.h, comm, blocks[b].data_ptr(), gathered[b].data_ptr(), stride) != 0:
+                raise RuntimeError("lsq_gather failed")
+            return
         if in_loop_gather and not on_host:
             ptr = ctx.result_stream               # this step's lane
             ext = ext_streams.get(ptr)
@@ -282,7 +333,11 @@ def main():
         for _ in range(5):
             fence()
             tg = time.perf_counter()
-            dist.all_gather_into_tensor(gathered[last], blocks[last].cpu() if on_host else blocks[last])
+            if use_lsq_gather:
+                rccl.lsq_gather(ctx.h, comm, blocks[last].data_ptr(), gathered[last].data_ptr(), stride)
+                ctx.synchronize()
+            else:
+                dist.all_gather_into_tensor(gathered[last], blocks[last].cpu() if on_host else blocks[last])
             torch.cuda.synchronize()
             ts.append((time.perf_counter() - tg) * 1e3)
         gather_ms = min(ts[1:])
@@ -391,6 +446,8 @@ def main():
                 "em_max_iters": int(iters_full.max()) if n_ev else 0,
                 "generate_s": t_gen, "ingest_from_text_s": t_ingest, "first_count_solve_fetch_s": t_first - t_ingest,
                 "gather_ms_alone": gather_ms,
+                "gather_through": ("liblesseq_rccl lsq_gather (ncclAllGather on the step's result lane)" if use_lsq_gather else
+                                   ("torch.distributed all_gather_into_tensor" if world > 1 else None)),
                 "tables_equal_unsharded_run": tables_equal, "max_abs_theta_diff_vs_unsharded": max_theta_diff,
                 "count_table_sha256": hashlib.sha256(cnt_full.tobytes()).hexdigest(),
                 "per_rank": [{"rank": r, "events": int(x[4]), "valid_read_assignments": x[3], "count_fast_kernel_ms": x[0],
@@ -449,7 +506,11 @@ def main():
                     "how": "%d oracle processes over disjoint gene_begin_idx..gene_end_idx slices of the same sample (each parses the whole "
                            "file, as the reference's own scale-out does), wall-clock %.1f s" % (P, dt_all),
                 }
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if comm.value:
+        ctx.synchronize()
+        rccl.lsq_comm_destroy(comm)
     ctx.close()
     if world > 1:
         dist.barrier()

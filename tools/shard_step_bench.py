@@ -39,6 +39,7 @@ for r in order:
     t0 = time.perf_counter()
     K = 300
     for _ in range(K): step()
+    t_submit = (time.perf_counter() - t0) / K * 1e3
     ctx.synchronize()
     dt = (time.perf_counter() - t0) / K * 1e3
     ctx.set_timing(True)
@@ -49,7 +50,7 @@ for r in order:
     B = ev.num_buckets
     so = (C.c_ulonglong * (B + 1))()
     L.lib.lsq_debug_slot_offsets(ctx.h, 0, so, B + 1)
-    print("rank %d/%d events %6d max_iters %4d: %.4f ms per step (count stream alone %.4f, EM alone %.4f); buckets %d, pooled reads %d" % (r, N, c, int(iters[f:f + c].max()), dt, cm, sm, B, so[B]), flush=True)
+    print("rank %d/%d events %6d max_iters %4d: %.4f ms per step (host submission %.4f; count stream alone %.4f, EM alone %.4f); buckets %d, pooled reads %d" % (r, N, c, int(iters[f:f + c].max()), dt, t_submit, cm, sm, B, so[B]), flush=True)
     sz = np.diff(np.array(so[:], dtype=np.int64))
     print("      reads per bucket: min %d p10 %d median %d mean %.0f p90 %d max %d; skew %.2f" % (sz.min(), np.percentile(sz, 10), np.median(sz), sz.mean(), np.percentile(sz, 90), sz.max(), sz.max() * len(sz) / max(sz.sum(), 1)), flush=True)
     if os.environ.get("LSQ_ABLATE"):
