@@ -1002,8 +1002,9 @@ __device__ inline unsigned first_event_for(const GlobalBucket &G, int p) {
 	return G.bins[4u * bin] >> 16;
 }
 
-__global__ void __launch_bounds__(256) lsq_count_cleanup_kernel(CountArgs A, int force_recount) {
+__global__ void __launch_bounds__(256) lsq_count_cleanup_kernel(const CountArgs *Ap, int force_recount) {
 	__builtin_amdgcn_s_setprio(3);          // runs beside the next count's streaming kernel: short, and the EM waits for it
+	const CountArgs &A = *Ap;               // (through a pointer, like the recount kernel below: no private copy of the record)
 	const unsigned long long gtid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
 	const unsigned long long gsz = (unsigned long long)gridDim.x * blockDim.x;
 	const unsigned n_raw = A.exc_count[0];
@@ -1219,14 +1220,14 @@ int run_count(lsq_ctx *c) {
 		c->recount_args_host.assign(2 * (size_t)LSQ_MAX_METHODS * sizeof(CountArgs), 0);
 	}
 	for (const Cleanup &u : cleanups) {
-		hipLaunchKernelGGL(lsq_count_cleanup_kernel, dim3(16), dim3(256), 0, st_em, u.A, c->opt_recount ? 1 : 0);
-		// the recount kernels' arguments live in device memory, one record per (counter set, read file); rewritten only when they change
+		// the arguments of these two kernels live in device memory, one record per (counter set, read file); rewritten only when they change
 		const size_t slot = ((size_t)set * LSQ_MAX_METHODS + (size_t)u.m) * sizeof(CountArgs);
 		if (memcmp(c->recount_args_host.data() + slot, &u.A, sizeof(CountArgs)) != 0) {
 			memcpy(c->recount_args_host.data() + slot, &u.A, sizeof(CountArgs));
 			HIP_TRY(hipMemcpyAsync(c->recount_args.p + slot, c->recount_args_host.data() + slot, sizeof(CountArgs), hipMemcpyHostToDevice, st_em));
 		}
 		const CountArgs *dA = reinterpret_cast<const CountArgs *>(c->recount_args.p + slot);
+		hipLaunchKernelGGL(lsq_count_cleanup_kernel, dim3(16), dim3(256), 0, st_em, dA, c->opt_recount ? 1 : 0);
 		hipLaunchKernelGGL(lsq_count_recount_kernel, dim3(rgrid), dim3(256), 0, st_em, dA, u.n_pn);
 		HIP_TRY(hipGetLastError());
 	}
