@@ -225,7 +225,11 @@ int lsq_count_status(lsq_ctx *c, uint32_t *exceptions, uint32_t *recounted);
  * count kernel's grid, 0 = chosen from the read set's skew), "exception_capacity" (entries of a read
  * file's exception list, 0 = a quarter of its reads and at least 65 536; applies to read sets uploaded
  * afterwards), "recount_every_read" (1: every count is redone by the one-lane-per-read kernel, a
- * self-check), "em_guard_band" (lsq_set_em_guard_band).  LSQ_E_ARG for an unknown name.  The executables
+ * self-check), "em_guard_band" (lsq_set_em_guard_band), "snap_shares" (0: the count kernel's workgroup
+ * shares are cut at even read counts instead of at bucket ends), "em_regroup" (0: lsq_solve keeps the
+ * placement of events in its grid chosen at lsq_events_upload; default 1: each of the two step lanes
+ * re-sorts the placement by the iteration counts of one of its own earlier solves, refreshed every
+ * sixteenth solve, so that events of similar cost share a wavefront).  LSQ_E_ARG for an unknown name.  The executables
  * pass LSQ_OPTIONS="name=value,..." from the environment through this call. */
 int lsq_ctx_set_option(lsq_ctx *c, const char *name, double value);
 

@@ -277,7 +277,8 @@ class Context:
         check(lib.lsq_solve(self.h))
 
     def set_option(self, name, value):
-        """lsq_ctx_set_option: grid_multiplier, exception_capacity, recount_every_read, em_guard_band"""
+        """lsq_ctx_set_option: grid_multiplier, exception_capacity, recount_every_read, em_guard_band,
+        snap_shares, em_regroup"""
         check(lib.lsq_ctx_set_option(self.h, _b(name), float(value)))
 
     def count_status(self):

@@ -137,6 +137,7 @@ int lsq_events_upload(lsq_ctx *c, lsq_events *E) {
 			if (pass == 0) c->em_small_places = (unsigned)order.size();
 		}
 		c->em_places = (unsigned)order.size();
+		c->em_order_lane_valid[0] = c->em_order_lane_valid[1] = false;
 		if ((rc = c->em_order.upload(order.data(), order.size(), c->stream))) return rc;
 		// gene names for span-start ties against named reads
 		std::string blob;
@@ -603,6 +604,8 @@ int lsq_debug_set_em_order(lsq_ctx *c, const uint32_t *order, unsigned n_small_p
 	if (rc) return rc;
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	c->em_small_places = n_small_places; c->em_places = n_places;
+	c->em_order_lane_valid[0] = c->em_order_lane_valid[1] = false;
+	c->opt_em_regroup = false;            // a placement given by hand stays
 	return LSQ_OK;
 }
 
@@ -620,6 +623,9 @@ int lsq_ctx_set_option(lsq_ctx *c, const char *name, double value) {
 	} else if (n == "snap_shares") {
 		c->opt_snap_shares = value != 0;
 		for (auto &r : c->reads) r.wg_grid = 0;
+	} else if (n == "em_regroup") {
+		c->opt_em_regroup = value != 0;
+		c->em_order_lane_valid[0] = c->em_order_lane_valid[1] = false;
 	} else if (n == "recount_every_read") {
 		c->opt_recount = value != 0;
 	} else if (n == "em_guard_band") {

@@ -116,6 +116,14 @@ struct lsq_ctx {
 	DevBuf<uint32_t> cls_base, iso_base, em_order, gene_name_off;
 	DevBuf<char> gene_names;                // device event order
 	DevBuf<uint32_t> pack_cls, pack_iso, pack_ev;      // lsq_results_pack_device: device index of every class / isoform / event of the shard, in output order
+	// Regrouping (option "em_regroup", on by default): a wave of the lean EM kernel runs until the slowest of its sixteen
+	// events has converged, so events that take about as many iterations should share waves.  After a solve, a small kernel
+	// on the same lane sorts the lean group's places by the iteration counts that solve just wrote; the lane's next solve
+	// (two steps later) and the fifteen after it use that order.  A prediction, nothing more: an event's numbers do not depend on its wave mates.
+	DevBuf<uint32_t> em_order_lane[2];
+	bool em_order_lane_valid[2] = {false, false};
+	unsigned em_regroup_age[2] = {0, 0};    // solves since the lane's order was last refreshed (every 16th solve refreshes it)
+	bool opt_em_regroup = true;
 	unsigned em_places = 0;
 	unsigned em_small_places = 0;           // the first of them: events of the lean EM kernel
 	DevBuf<double> G, theta2[2], logll2[2];

@@ -445,6 +445,31 @@ __global__ void __launch_bounds__(64) lsq_fim_kernel(FimArgs A) {
 	v[0] = by_diag; v[1] = by_inv;
 }
 
+// The lean group's places sorted by the iteration counts of the solve that has just finished on this lane, slowest
+// first (one workgroup: a counting sort over 256 iteration classes in LDS).  Empty places go to the end.
+__global__ void __launch_bounds__(1024) lsq_em_regroup_kernel(const unsigned *base_order, const unsigned *iters, unsigned n_places, unsigned *out) {
+	__shared__ unsigned hist[256], start[256];
+	const unsigned tid = threadIdx.x;
+	if (tid < 256) hist[tid] = 0;
+	__syncthreads();
+	for (unsigned p = tid; p < n_places; p += 1024) {
+		const unsigned e = base_order[p];
+		if (e != 0xFFFFFFFFu) atomicAdd(&hist[255u - min(iters[e], 255u)], 1u);
+	}
+	__syncthreads();
+	if (tid == 0) { unsigned run = 0; for (unsigned k = 0; k < 256; ++k) { start[k] = run; run += hist[k]; hist[k] = 0; } start[0] |= 0u; hist[0] = 0; out[n_places - 1] = 0xFFFFFFFFu; }
+	__syncthreads();
+	unsigned n_valid = 0;
+	for (unsigned p = tid; p < n_places; p += 1024) {
+		const unsigned e = base_order[p];
+		if (e != 0xFFFFFFFFu) { const unsigned k = 255u - min(iters[e], 255u); out[start[k] + atomicAdd(&hist[k], 1u)] = e; }
+	}
+	__syncthreads();
+	if (tid == 0) { for (unsigned k = 0; k < 256; ++k) n_valid += hist[k]; start[0] = n_valid; }
+	__syncthreads();
+	for (unsigned p = start[0] + tid; p < n_places; p += 1024) out[p] = 0xFFFFFFFFu;
+}
+
 } // namespace
 
 namespace lsq {
@@ -484,9 +509,18 @@ int run_solve(lsq_ctx *c) {
 		// registers back without waiting for three others (measured 0.259 -> 0.254 ms per pipelined step)
 		const unsigned blk = 64;
 		if (c->em_small_places) {
+			const int lane = c->flip;
 			A.place0 = 0; A.n_places = c->em_small_places;
+			if (c->opt_em_regroup && c->em_order_lane_valid[lane]) A.order = c->em_order_lane[lane].p;
 			hipLaunchKernelGGL(lsq_em_kernel<true>, dim3((c->em_small_places * EM_LANES + blk - 1) / blk), dim3(blk), 0, st, A);
 			HIP_TRY(hipGetLastError());
+			if (c->opt_em_regroup && (!c->em_order_lane_valid[lane] || ++c->em_regroup_age[lane] >= 16)) {
+				c->em_regroup_age[lane] = 0;
+				if (c->em_order_lane[lane].n != c->em_small_places) { int rc = c->em_order_lane[lane].alloc(c->em_small_places); if (rc) return rc; }
+				hipLaunchKernelGGL(lsq_em_regroup_kernel, dim3(1), dim3(1024), 0, st, c->em_order.p, c->iters.p, c->em_small_places, c->em_order_lane[lane].p);
+				HIP_TRY(hipGetLastError());
+				c->em_order_lane_valid[lane] = true;
+			}
 		}
 		if (c->em_places > c->em_small_places) {
 			A.order = c->em_order.p;

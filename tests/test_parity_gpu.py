@@ -643,6 +643,41 @@ def test_em_numbers_do_not_depend_on_which_events_share_a_wave(tmp_path):
     ctx.close()
 
 
+def test_em_regrouping_by_earlier_iteration_counts_keeps_every_number(tmp_path):
+    """option em_regroup (on by default): a lane's solves place the events by the iteration counts of one of its
+    earlier solves.  The placement learned on one read set is then used for another read set; every event must
+    still be solved (none dropped from the grid, none twice) with the numbers a fresh context without the option
+    gives, and the reference-order replay of flagged events still applies."""
+    specs = [L.SynthSpec(90 + i, 3000, 400000 + 150000 * i, 100, 3, L.EVENT_TYPES, bool(i)) for i in range(2)]
+    L.synth_write(specs[0], str(tmp_path), "g", write_mrf=False)
+    ann = L.Annotation(str(tmp_path / "g.interval"), str(tmp_path / "g.map"))
+    ev = L.Events(ann, ("SHORT_READ",), (100,))
+    reads = [L.Reads.synthetic(sp, ev) for sp in specs]
+    plain = L.Context(0)
+    plain.set_option("em_regroup", 0)
+    plain.upload_events(ev)
+    want = []
+    for r in reads:
+        plain.upload_reads(0, r); plain.count(); plain.solve()
+        want.append([x.copy() for x in plain.solution()])
+    plain.close()
+    assert not np.array_equal(want[0][2], want[1][2])          # the two read sets converge differently
+    ctx = L.Context(0)
+    ctx.upload_events(ev)
+    ctx.upload_reads(0, reads[0])
+    for k in range(40):                    # both lanes learn a placement, and refresh it at least once
+        ctx.count(); ctx.solve()
+        if k in (0, 1, 2, 3, 17, 18, 39):
+            for a, b, what in zip(want[0], ctx.solution(), ("theta", "logll", "iters", "flags")):
+                assert np.array_equal(a, b, equal_nan=True), "%s differs at step %d" % (what, k)
+    ctx.upload_reads(0, reads[1])          # the learned placement stays; the reads are others
+    for k in range(3):
+        ctx.count(); ctx.solve()
+        for a, b, what in zip(want[1], ctx.solution(), ("theta", "logll", "iters", "flags")):
+            assert np.array_equal(a, b, equal_nan=True), "%s differs on the second read set, step %d" % (what, k)
+    ctx.close()
+
+
 @pytest.mark.parametrize("name", ["toy", "multi_method", "events_s1", "readfmts", "formats"])
 def test_example_host_prints_the_reference_solve_table(name, tmp_path, monkeypatch):
     """examples/solve_host.c (plain C against include/lesseq_hip.h, the binding INTEGRATION.md describes) through the
