@@ -326,6 +326,20 @@ def main():
     ctx.set_timing(False)
     in_loop_gather = saved
     fence()
+    # The same loop with the EM placement fixed at upload (option em_regroup off): the timed loop repeats one read set,
+    # so the placement a lane learns from its earlier solve predicts the iteration counts exactly; a job whose read
+    # sets change from step to step gets less out of it, at worst this number.
+    ctx.set_option("em_regroup", 0)
+    n_off = min(a.steps, 100)
+    for k in range(10):
+        step(k)
+    fence()
+    t_off = time.perf_counter()
+    for k in range(n_off):
+        step(k)
+    fence()
+    ms_regroup_off = (time.perf_counter() - t_off) / n_off * 1e3
+    ctx.set_option("em_regroup", 1)
     # what the gather costs on its own (N > 1): submitted alone, timed on the host
     gather_ms = None
     if world > 1:
@@ -441,6 +455,9 @@ def main():
                 "count_stream_ms_alone": float(np.mean(count_ms)), "em_kernel_ms_alone": float(np.mean(solve_ms)),
                 "pipeline": "lsq_count on one HIP stream; exception pass (+ recount kernels that return at once unless the exception list overflowed), EM, record "
                             "packing and counter zeroing on a second one, beside the next step's count (two counter sets)",
+                "em_placement": "each step lane sorts the EM grid by the iteration counts of its own earlier solve (refreshed every 16th solve; the sort kernel "
+                                "runs inside the timed loop); the loop repeats one read set, so the prediction is exact here",
+                "ms_per_step_em_regroup_off_rank0": ms_regroup_off,
                 "valid_read_assignments": int(cnt_full.sum()), "exception_pairs": int(sum(exc)), "recounted": int(sum(recounted)),
                 "em_guard_band_events": int((flags_full & 1).sum()), "em_replayed_events": int(((flags_full >> 2) & 1).sum()),
                 "em_max_iters": int(iters_full.max()) if n_ev else 0,

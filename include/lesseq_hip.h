@@ -207,6 +207,14 @@ uint64_t lsq_reads_retained_blocks(const lsq_ctx *c, int method);
  * context.  Without a shard that is every retained read; with lsq_events_set_shard the slice's share (a read that starts
  * in no event of the slice is a candidate of none of them, count/count.cpp:429-432,463, and is dropped at ingest). */
 uint64_t lsq_reads_pooled(const lsq_ctx *c, int method);
+/* How the one- and two-block reads of a read file lie in HBM.  *compact = 1: 4 bytes a block -- 22 bits of offset (the
+ * first block's from the first base of its bucket of events minus 2 Mi, the second block's from the end of the first) and
+ * 10 bits of length; a read with a block of 1 024 bases or more, or an offset that does not fit, is kept with the
+ * many-block reads, blocks in full.  *compact = 0 (more than 1 in 16 one- and two-block reads would not fit, or option
+ * "compact_pools" 0): (start, end) per block, 8 bytes.  Either way every read takes part in lsq_count with its own
+ * coordinates.  *pool_bytes: bytes of block coordinates resident in HBM; pool_reads[3]: reads kept as one-block records,
+ * as two-block records, with the many-block reads.  Null: not wanted. */
+int lsq_reads_pool_format(const lsq_ctx *c, int method, int *compact, uint64_t *pool_bytes, uint64_t *pool_reads);
 
 /* Replaces the per-gene candidate scan + Read::build + compatibility + validity + counting
  * (count/count.cpp:420-482 == solve/solve.cpp:719-793; common/read.h:44-79,198-274): one
@@ -226,7 +234,8 @@ int lsq_count_status(lsq_ctx *c, uint32_t *exceptions, uint32_t *recounted);
  * file's exception list, 0 = a quarter of its reads and at least 65 536; applies to read sets uploaded
  * afterwards), "recount_every_read" (1: every count is redone by the one-lane-per-read kernel, a
  * self-check), "em_guard_band" (lsq_set_em_guard_band), "snap_shares" (0: the count kernel's workgroup
- * shares are cut at even read counts instead of at bucket ends), "em_regroup" (0: lsq_solve keeps the
+ * shares are cut at even read counts instead of at bucket ends), "compact_pools" (0: wide pool records for read sets
+ * uploaded afterwards, see lsq_reads_pool_format), "em_regroup" (0: lsq_solve keeps the
  * placement of events in its grid chosen at lsq_events_upload; default 1: each of the two step lanes
  * re-sorts the placement by the iteration counts of one of its own earlier solves, refreshed every
  * sixteenth solve, so that events of similar cost share a wavefront).  LSQ_E_ARG for an unknown name.  The executables

@@ -1,4 +1,5 @@
 """Thin object wrappers over the C ABI (include/lesseq_hip.h).  No compute lives here."""
+import os
 import ctypes as C
 
 import numpy as np
@@ -229,6 +230,11 @@ class Context:
         check(lib.lsq_ctx_create(device, C.byref(h)))
         self.h = h
         self.events = None
+        # LSQ_OPTIONS="name=value,...": the executables pass these to lsq_ctx_set_option (lsq_cli.cpp), so does this class
+        for item in filter(None, os.environ.get("LSQ_OPTIONS", "").split(",")):
+            if "=" in item:
+                name, value = item.split("=", 1)
+                self.set_option(name.strip(), float(value))
 
     def close(self):
         if getattr(self, "h", None):
@@ -266,6 +272,14 @@ class Context:
     def pooled(self, method):
         """retained reads kept in the pools: those that start in the span of an event planned on this context"""
         return lib.lsq_reads_pooled(self.h, method)
+
+    def pool_format(self, method):
+        """lsq_reads_pool_format: (compact records?, bytes of block coordinates in HBM,
+        reads kept as one-block / two-block records / with the many-block reads)"""
+        a, n = C.c_int(0), C.c_uint64(0)
+        k = (C.c_uint64 * 3)()
+        check(lib.lsq_reads_pool_format(self.h, method, C.byref(a), C.byref(n), k))
+        return bool(a.value), n.value, tuple(int(x) for x in k)
 
     def retained_blocks(self, method):
         return lib.lsq_reads_retained_blocks(self.h, method)

@@ -47,8 +47,12 @@ struct CountArgs {
 	unsigned n_buckets;
 	unsigned ablate;                   // developer switch (LSQ_ABLATE): 1 skip per-read work, 2 skip LDS atomics, 4 skip flush, 8 skip record look
 	unsigned tables_lds_bytes;         // LDS bytes reserved for the bucket image + histogram (16-byte multiple)
-	const int2 *p1; const unsigned char *p1_strand; const unsigned *p1_line;
-	const int4 *p2; const unsigned char *p2_strand; const unsigned *p2_line;
+	// Pools of one- and two-block reads, bucket by bucket.  Wide records: (start, end) and (start, end, start, end), 8 bytes
+	// a block.  Compact records (lsq_device.hpp COMPACT_*): 4 bytes a block, relative to the bucket; reads that do not fit
+	// sit with the many-block reads.
+	const void *p1; const unsigned char *p1_strand; const unsigned *p1_line;
+	const void *p2; const unsigned char *p2_strand; const unsigned *p2_line;
+	unsigned compact;
 	const unsigned *pn_blk_off; const unsigned *pn_nblk; const int2 *pn_se; const unsigned char *pn_strand; const unsigned *pn_line; const unsigned *pn_bucket;
 	const unsigned long long *p1_off, *p2_off, *pn_off, *slot_off;    // n_buckets + 1 each
 	const unsigned *wg_first;          // per workgroup of the fast kernel's grid: the bucket its slot range starts in
@@ -62,6 +66,27 @@ struct CountArgs {
 	unsigned exc_cap;
 	unsigned long long *dbg;            // developer counters (LSQ_ABLATE & 256): parked one-block, parked two-block, walk steps, walk lanes
 };
+
+// compact records to coordinates; base = the bucket's first base minus COMPACT_BIAS
+__device__ inline int2 unpack_one_block(const unsigned a, const int base) {
+	const int s = base + (int)(a & lsq::COMPACT_OFF_MASK);
+	return make_int2(s, s + (int)(a >> lsq::COMPACT_OFF_BITS));
+}
+__device__ inline int4 unpack_two_block(const unsigned a, const unsigned b, const int base) {
+	const int s1 = base + (int)(a & lsq::COMPACT_OFF_MASK), e1 = s1 + (int)(a >> lsq::COMPACT_OFF_BITS);
+	const int s2 = e1 + (int)(b & lsq::COMPACT_OFF_MASK);
+	return make_int4(s1, e1, s2, s2 + (int)(b >> lsq::COMPACT_OFF_BITS));
+}
+// a read of bucket `lo`'s slice of the pools (the slow paths: exception pass, recount, generic buckets)
+__device__ inline int2 pool1_read(const CountArgs &A, const unsigned long long g, const int lo) {
+	if (!A.compact) return reinterpret_cast<const int2 *>(A.p1)[g];
+	return unpack_one_block(reinterpret_cast<const unsigned *>(A.p1)[g], lo - lsq::COMPACT_BIAS);
+}
+__device__ inline int4 pool2_read(const CountArgs &A, const unsigned long long g, const int lo) {
+	if (!A.compact) return reinterpret_cast<const int4 *>(A.p2)[g];
+	const uint2 v = reinterpret_cast<const uint2 *>(A.p2)[g];
+	return unpack_two_block(v.x, v.y, lo - lsq::COMPACT_BIAS);
+}
 
 struct LdsView {
 	const unsigned short *bins;
@@ -222,11 +247,11 @@ __global__ void __launch_bounds__(COUNT_BLOCK) lsq_count_generic_kernel(CountArg
 		for (unsigned long long i = l0 + tid; i < l1; i += COUNT_BLOCK) {
 			if (i < n1) {
 				const unsigned long long g = A.p1_off[b] + i;
-				const int2 rd = A.p1[g];
+				const int2 rd = pool1_read(A, g, d.lo);
 				process_read<1>(L, d, A, make_int4(rd.x, rd.y, 0, 0), nullptr, 1, rd.y - rd.x, A.p1_strand, A.p1_line, g);
 			} else if (i < n1 + n2) {
 				const unsigned long long g = A.p2_off[b] + (i - n1);
-				const int4 rd = A.p2[g];
+				const int4 rd = pool2_read(A, g, d.lo);
 				process_read<2>(L, d, A, rd, nullptr, 2, (rd.y - rd.x) + (rd.w - rd.z), A.p2_strand, A.p2_line, g);
 			} else {
 				const unsigned long long g = A.pn_off[b] + (i - n1 - n2);
@@ -465,8 +490,9 @@ __device__ inline void walk_parked(const FastCtx &C, Ring<NB> &R, const bool to_
 	}
 }
 
-// RPW = reads per 16-byte word: 2 (pool 1: one block) or 1 (pool 2: two blocks)
-template <int RPW>
+// RPW = reads per 16-byte word of a wide pool: 2 (pool 1: one block) or 1 (pool 2: two blocks); a lane's words are
+// numbered that way for compact pools too (the fetch unpacks one compact word into two of them)
+template <int RPW, bool COMPACT>
 __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uint4 *cells, const unsigned *cell_info, const unsigned n_cells, const BucketDesc &d,
                                         const CountArgs &A, uint4 *queue, const uint4 *src_generic,
                                         const unsigned long long g0, const unsigned long long g1) {
@@ -482,13 +508,32 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 	// words [w0, w1) of the workgroup, dealt to its waves a step at a time (wave, wave + 4, ...): the
 	// reads that need the general walk sit together in the start-ordered pool, and a contiguous
 	// quarter per wave would leave three waves waiting for the one that got them
-	const unsigned long long w0 = g0 / RPW, w1 = (g1 + RPW - 1) / RPW;
+	// (compact pools: a 16-byte word of the pool holds the reads of two of these words, so the range starts on an even one)
+	const unsigned long long w0 = COMPACT ? ((g0 / RPW) & ~1ull) : g0 / RPW, w1 = (g1 + RPW - 1) / RPW;
 	const unsigned n_words = (unsigned)(w1 - w0);                                   // a workgroup's range stays below 2^21 reads
 	const unsigned ww0 = min(wave * TILE, n_words), ww1 = n_words;                   // relative to w0
-	const unsigned first_rel = (unsigned)(g0 - w0 * RPW);                            // 0 or 1: reads of word w0 before the range
+	const unsigned first_rel = (unsigned)(g0 - w0 * RPW);                            // reads of word w0 (and, compact, w0 + 1) before the range
 	const unsigned n_rel = (unsigned)(g1 - g0);
 	uint4 nxt[SW];
+	static_assert(!COMPACT || SW == 2, "a compact 16-byte word unpacks into two words of a lane");
+	const int base = d.lo - lsq::COMPACT_BIAS;
 	auto fetch_into = [&](uint4 (&dst)[SW], unsigned wt) {
+		if (COMPACT) {
+			// one 16-byte load per lane and step: four one-block records or two two-block ones; unpacked when the
+			// step that uses them begins (not here: the load is to stay in flight during the step before)
+			const unsigned w = min((wt >> 1) + lane, (ww1 - 1u) >> 1);
+			const u32x4 t = src[(w0 >> 1) + w];
+			dst[0] = make_uint4(t.x, t.y, t.z, t.w);
+			return;
+		}
+		if (ABL(A, RPW == 2 ? 131072u : 262144u)) {      // developer switch: half the words loaded (what a pool of half-size records would cost to stream)
+			const unsigned w = min((wt >> 1) + lane, ww1 - 1u);
+			const u32x4 t = src[w0 + w];
+			dst[0] = make_uint4(t.x, t.y, t.z, t.w);
+#pragma unroll
+			for (int k = 1; k < SW; ++k) dst[k] = make_uint4(t.x + 1u, t.y + 1u, t.z + 1u, t.w + 1u);
+			return;
+		}
 #pragma unroll
 		for (int k = 0; k < SW; ++k) {
 			// a lane's words are neighbours in the pool; past the end of the range the last word is read again
@@ -717,8 +762,21 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 	if (ww0 < ww1) fetch(ww0);
 	for (unsigned wt = ww0; wt < ww1; wt += WAVES * TILE) {
 		uint4 cur[SW];
+		if (COMPACT) {
+			const uint4 t = nxt[0];
+			if (RPW == 2) {
+				const int2 r0 = unpack_one_block(t.x, base), r1 = unpack_one_block(t.y, base), r2 = unpack_one_block(t.z, base), r3 = unpack_one_block(t.w, base);
+				cur[0] = make_uint4((unsigned)r0.x, (unsigned)r0.y, (unsigned)r1.x, (unsigned)r1.y);
+				cur[1] = make_uint4((unsigned)r2.x, (unsigned)r2.y, (unsigned)r3.x, (unsigned)r3.y);
+			} else {
+				const int4 a = unpack_two_block(t.x, t.y, base), b = unpack_two_block(t.z, t.w, base);
+				cur[0] = make_uint4((unsigned)a.x, (unsigned)a.y, (unsigned)a.z, (unsigned)a.w);
+				cur[1] = make_uint4((unsigned)b.x, (unsigned)b.y, (unsigned)b.z, (unsigned)b.w);
+			}
+		} else {
 #pragma unroll
-		for (int k = 0; k < SW; ++k) cur[k] = nxt[k];
+			for (int k = 0; k < SW; ++k) cur[k] = nxt[k];
+		}
 		if (wt + WAVES * TILE < ww1) fetch(wt + WAVES * TILE);
 		do_step(cur, wt);
 	}
@@ -865,6 +923,7 @@ __device__ inline void stage_bucket(const CountArgs &A, const unsigned b, unsign
 	}
 }
 
+template <bool COMPACT>
 __global__ void __launch_bounds__(COUNT_BLOCK, LSQ_FAST_WAVES) lsq_count_fast_kernel(CountArgs A) {
 	// LDS: the bucket's tables (image, histograms, visit record), then the waves' rings
 	extern __shared__ __align__(16) unsigned char lds[];
@@ -912,10 +971,10 @@ __global__ void __launch_bounds__(COUNT_BLOCK, LSQ_FAST_WAVES) lsq_count_fast_ke
 		const unsigned long long n1 = V.p1n, n2 = V.p2n;
 		// ---- pool 1
 		if (l0 < n1 && !ABL(A, 1024u))
-			stream_pool_fast<2>(C, bins, cells, cell_info, d.iso_off, d, A, wave_queue, reinterpret_cast<const uint4 *>(A.p1), V.p1o + l0, V.p1o + (l1 < n1 ? l1 : n1));
+			stream_pool_fast<2, COMPACT>(C, bins, cells, cell_info, d.iso_off, d, A, wave_queue, reinterpret_cast<const uint4 *>(A.p1), V.p1o + l0, V.p1o + (l1 < n1 ? l1 : n1));
 		// ---- pool 2
 		if (l1 > n1 && l0 < n1 + n2 && !ABL(A, 2048u))
-			stream_pool_fast<1>(C, bins, cells, cell_info, d.iso_off, d, A, wave_queue, reinterpret_cast<const uint4 *>(A.p2), V.p2o + ((l0 > n1 ? l0 : n1) - n1),
+			stream_pool_fast<1, COMPACT>(C, bins, cells, cell_info, d.iso_off, d, A, wave_queue, reinterpret_cast<const uint4 *>(A.p2), V.p2o + ((l0 > n1 ? l0 : n1) - n1),
 			                    V.p2o + ((l1 < n1 + n2 ? l1 : n1 + n2) - n1));
 		// (reads with three or more blocks are the workers')
 		__syncthreads();
@@ -1028,8 +1087,8 @@ __global__ void __launch_bounds__(256) lsq_count_cleanup_kernel(const CountArgs 
 		const bool scan = (e.ev_pool_scan >> 31) != 0;
 		int2 blk[2];
 		if (pool == 2) { const unsigned o0 = A.pn_blk_off[e.slot]; eval_read_global(A, G, A.pn_se + o0, (int)A.pn_nblk[e.slot], i, scan, A.pn_strand[e.slot], A.pn_line[e.slot]); }
-		else if (pool == 0) { blk[0] = A.p1[e.slot]; eval_read_global(A, G, blk, 1, i, scan, A.p1_strand[e.slot], A.p1_line[e.slot]); }
-		else { const int4 v = A.p2[e.slot]; blk[0] = make_int2(v.x, v.y); blk[1] = make_int2(v.z, v.w); eval_read_global(A, G, blk, 2, i, scan, A.p2_strand[e.slot], A.p2_line[e.slot]); }
+		else if (pool == 0) { blk[0] = pool1_read(A, e.slot, A.buckets[e.bucket].lo); eval_read_global(A, G, blk, 1, i, scan, A.p1_strand[e.slot], A.p1_line[e.slot]); }
+		else { const int4 v = pool2_read(A, e.slot, A.buckets[e.bucket].lo); blk[0] = make_int2(v.x, v.y); blk[1] = make_int2(v.z, v.w); eval_read_global(A, G, blk, 2, i, scan, A.p2_strand[e.slot], A.p2_line[e.slot]); }
 	}
 }
 
@@ -1059,11 +1118,11 @@ __global__ void __launch_bounds__(256) lsq_count_recount_kernel(const CountArgs 
 		if (A.buckets[b].kind != 1) continue;
 		const GlobalBucket G = global_bucket(A, b);
 		for (unsigned long long g = A.p1_off[b] + lane; g < A.p1_off[b + 1]; g += 64u) {
-			int2 blk[1] = {A.p1[g]};
+			int2 blk[1] = {pool1_read(A, g, A.buckets[b].lo)};
 			eval_read_global(A, G, blk, 1, first_event_for(G, blk[0].x), true, A.p1_strand[g], A.p1_line[g]);
 		}
 		for (unsigned long long g = A.p2_off[b] + lane; g < A.p2_off[b + 1]; g += 64u) {
-			const int4 v = A.p2[g];
+			const int4 v = pool2_read(A, g, A.buckets[b].lo);
 			int2 blk[2] = {make_int2(v.x, v.y), make_int2(v.z, v.w)};
 			eval_read_global(A, G, blk, 2, first_event_for(G, v.x), true, A.p2_strand[g], A.p2_line[g]);
 		}
@@ -1102,7 +1161,8 @@ int run_count(lsq_ctx *c) {
 	const unsigned lds_bytes = tables_bytes + WAVES * WAVE_QUEUE_WORDS * 16;
 	if (lds_bytes > 160 * 1024) return fail(LSQ_E_UNSUPPORTED, "bucket tables + read tile exceed the CU's LDS");
 	if (lds_bytes > 64 * 1024) {
-		HIP_TRY(hipFuncSetAttribute((const void *)lsq_count_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+		HIP_TRY(hipFuncSetAttribute((const void *)lsq_count_fast_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+		HIP_TRY(hipFuncSetAttribute((const void *)lsq_count_fast_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
 		HIP_TRY(hipFuncSetAttribute((const void *)lsq_count_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
 	}
 	// resident workgroups per CU as the runtime sees them (registers, LDS, wave slots): the grid is a whole number of rounds
@@ -1110,8 +1170,10 @@ int run_count(lsq_ctx *c) {
 	{
 		if (c->occ_lds_bytes != lds_bytes) {             // asked once per table size
 			int nb = 0;
-			HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)lsq_count_fast_kernel, (int)COUNT_BLOCK, (size_t)lds_bytes));
-			c->occ_lds_bytes = lds_bytes; c->occ_blocks = nb;
+			int nb2 = 0;
+			HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)lsq_count_fast_kernel<false>, (int)COUNT_BLOCK, (size_t)lds_bytes));
+			HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb2, (const void *)lsq_count_fast_kernel<true>, (int)COUNT_BLOCK, (size_t)lds_bytes));
+			c->occ_lds_bytes = lds_bytes; c->occ_blocks = std::min(nb, nb2);
 		}
 		if (c->occ_blocks >= 1) per_cu = std::min(per_cu, (unsigned)c->occ_blocks);
 	}
@@ -1169,8 +1231,9 @@ int run_count(lsq_ctx *c) {
 		A.n_buckets = (unsigned)E.buckets.size();
 		A.tables_lds_bytes = tables_bytes;
 		A.ablate = c->dev_ablate;
-		A.p1 = reinterpret_cast<const int2 *>(mr.p1.p); A.p1_strand = mr.p1_strand.p; A.p1_line = mr.p1_line.p;
-		A.p2 = reinterpret_cast<const int4 *>(mr.p2.p); A.p2_strand = mr.p2_strand.p; A.p2_line = mr.p2_line.p;
+		A.compact = mr.compact ? 1u : 0u;
+		A.p1 = mr.p1.p; A.p1_strand = mr.p1_strand.p; A.p1_line = mr.p1_line.p;
+		A.p2 = mr.p2.p; A.p2_strand = mr.p2_strand.p; A.p2_line = mr.p2_line.p;
 		A.pn_blk_off = mr.pn_blk_off.p; A.pn_nblk = mr.pn_nblk.p; A.pn_se = reinterpret_cast<const int2 *>(mr.pn_se.p);
 		A.pn_strand = mr.pn_strand.p; A.pn_line = mr.pn_line.p; A.pn_bucket = mr.pn_bucket.p;
 		A.p1_off = mr.p1_off.p; A.p2_off = mr.p2_off.p; A.pn_off = mr.pn_off.p; A.slot_off = mr.slot_off.p;
@@ -1191,11 +1254,13 @@ int run_count(lsq_ctx *c) {
 			// the last streaming kernel of the step carries ev_counted as its own completion signal: a separate
 			// event record is one more packet between this kernel and the next count's (measured ~5 us each)
 			const bool last_streaming = m == M - 1 && !c->has_generic && !c->time_events;
+			const dim3 fgrid((unsigned)grid + A.n_workers);
 			if (last_streaming) {
-				hipExtLaunchKernelGGL(lsq_count_fast_kernel, dim3((unsigned)grid + A.n_workers), dim3(COUNT_BLOCK), lds_bytes, st, nullptr, c->ev_counted2[set], 0, A);
+				if (mr.compact) hipExtLaunchKernelGGL(lsq_count_fast_kernel<true>, fgrid, dim3(COUNT_BLOCK), lds_bytes, st, nullptr, c->ev_counted2[set], 0, A);
+				else hipExtLaunchKernelGGL(lsq_count_fast_kernel<false>, fgrid, dim3(COUNT_BLOCK), lds_bytes, st, nullptr, c->ev_counted2[set], 0, A);
 				counted_signalled = true;
-			} else
-				hipLaunchKernelGGL(lsq_count_fast_kernel, dim3((unsigned)grid + A.n_workers), dim3(COUNT_BLOCK), lds_bytes, st, A);
+			} else if (mr.compact) hipLaunchKernelGGL(lsq_count_fast_kernel<true>, fgrid, dim3(COUNT_BLOCK), lds_bytes, st, A);
+			else hipLaunchKernelGGL(lsq_count_fast_kernel<false>, fgrid, dim3(COUNT_BLOCK), lds_bytes, st, A);
 			HIP_TRY(hipGetLastError());
 			if (c->time_events) HIP_TRY(hipEventRecord(c->evf1[m], st));
 			c->fast_launched |= 1 << m;

@@ -29,6 +29,14 @@ constexpr int EM_LANES = 4;          // lanes that share one event in the EM ker
 
 namespace lsq {
 
+// Compact pool records.  A block is (offset | length << 22): 22 bits of offset, 10 bits of length.  The offset of a read's
+// first block counts from the bucket's first base minus COMPACT_BIAS (the first bin of a bucket also holds reads that start
+// before it), that of its second block from the end of the first (the bases between them).  One-block reads take one
+// such word, two-block reads two.  Reads with a longer block or a larger offset are kept with the many-block reads.
+constexpr unsigned COMPACT_OFF_BITS = 22, COMPACT_OFF_MASK = (1u << COMPACT_OFF_BITS) - 1u, COMPACT_MAX_LEN = 1u << 10;
+constexpr int COMPACT_BIAS = 1 << 21;
+__host__ __device__ inline bool compact_block_fits(long long off, long long len) { return off >= 0 && off <= (long long)COMPACT_OFF_MASK && len > 0 && len < (long long)COMPACT_MAX_LEN; }
+
 // A (read, event) pair the fast kernel does not settle itself: span-start ties that need the
 // strand/name order, two-block reads whose blocks touch, second looks that did not fit the LDS
 // queue.  pool 0 = one-block pool, 1 = two-block pool; scan: continue with the following events.
@@ -65,7 +73,10 @@ struct MethodReads {
 	size_t exc_cap = 0;
 	bool present = false;
 	uint64_t n_retained = 0, n_retained_blocks = 0, total_slots = 0;
+	// one- and two-block pools: wide records (2 / 4 ints a read), or compact ones (1 / 2 ints a read, see COMPACT_*) when
+	// at least 15 of 16 such reads fit them; compact pools are padded to whole 16-byte words
 	DevBuf<int32_t> p1, p2, pn_se;
+	bool compact = false;
 	DevBuf<uint8_t> p1_strand, p2_strand, pn_strand;
 	DevBuf<uint32_t> p1_line, p2_line, pn_line, pn_blk_off, pn_nblk, pn_bucket;
 	DevBuf<unsigned long long> p1_off, p2_off, pn_off, pnb_off, slot_off;
@@ -151,6 +162,7 @@ struct lsq_ctx {
 	// (0 = a quarter of its reads, at least 64 Ki), recount every read with the one-lane-per-read kernel (self-check)
 	int opt_grid_mult = 0;
 	size_t opt_exc_cap = 0;
+	bool opt_compact_pools = true;          // "compact_pools": 0 keeps wide pool records whatever the reads look like
 	bool opt_recount = false;
 	bool opt_snap_shares = true;            // workgroup shares cut on bucket boundaries where one is near
 	unsigned dev_ablate = 0;                // developer build only (LSQ_ABLATE)

@@ -78,7 +78,8 @@ struct IngestWork {
 	unsigned *cnt1, *cnt2;         // [n_fine]: one- / two-block reads per (bucket, bin)
 	unsigned *cntn, *cntnb;        // [n_buckets]: n-block reads, and their blocks
 	unsigned *cur1, *cur2, *curn, *curnb;   // scatter cursors, same shapes
-	unsigned long long *totals;    // [0] retained reads, [1] retained blocks, [2] error flag
+	unsigned long long *totals;    // [0] retained reads, [1] retained blocks, [2] error flag, [3] one- and two-block reads that do not fit compact records
+	unsigned compact;              // compact pool records: one- and two-block reads that do not fit them go with the many-block reads
 };
 
 // interval_list::add_interval on a small sorted array (see lsq::IntervalList::add)
@@ -116,7 +117,7 @@ __device__ inline bool covered_contains(const IngestTables &T, unsigned chrom, i
 
 __global__ void __launch_bounds__(256) lsq_ingest_classify_kernel(IngestTables T, IngestRaw R, IngestWork W) {
 	const unsigned long long gsz = (unsigned long long)gridDim.x * blockDim.x;
-	unsigned long long kept_reads = 0, kept_blocks = 0;
+	unsigned long long kept_reads = 0, kept_blocks = 0, misfits = 0;
 	for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < R.n_reads; i += gsz) {
 		const unsigned long long b0 = R.blk_off[i], b1 = R.blk_off[i + 1];
 		int s[INGEST_MAX_BLOCKS], e[INGEST_MAX_BLOCKS];
@@ -155,9 +156,14 @@ __global__ void __launch_bounds__(256) lsq_ingest_classify_kernel(IngestTables T
 						in_cluster = ul > u0 && s[0] <= T.clu_e[ul - 1];
 					}
 					if (in_cluster && s[0] <= T.buckets[b].hi) {
-						const unsigned pool = n == 1 ? 0u : (n == 2 ? 1u : 2u);
-						key = b * 4u + pool;
 						const BucketDesc &d = T.buckets[b];
+						unsigned pool = n == 1 ? 0u : (n == 2 ? 1u : 2u);
+						if (pool < 2u && W.compact) {
+							bool fits = lsq::compact_block_fits((long long)s[0] - d.lo + lsq::COMPACT_BIAS, (long long)e[0] - s[0]);
+							if (n == 2) fits = fits && lsq::compact_block_fits((long long)s[1] - e[0], (long long)e[1] - s[1]);
+							if (!fits) { pool = 2u; ++misfits; }
+						}
+						key = b * 4u + pool;
 						const int rel = s[0] - d.lo;
 						const unsigned bin = rel <= 0 ? 0u : min((unsigned)rel >> d.shift, d.n_bins - 1u);
 						const unsigned fine = T.bin_base[b] + bin;
@@ -175,6 +181,7 @@ __global__ void __launch_bounds__(256) lsq_ingest_classify_kernel(IngestTables T
 		W.strand[i] = (unsigned char)strand;
 	}
 	if (kept_reads) { atomicAdd(&W.totals[0], kept_reads); atomicAdd(&W.totals[1], kept_blocks); }
+	if (misfits) atomicAdd(&W.totals[3], misfits);
 }
 
 // one workgroup: out[i] = sum of in[0..i), out[n] = total
@@ -258,10 +265,21 @@ __device__ inline unsigned binsort_key(const int4 r, int bin_lo, unsigned W) {
 	return (((unsigned)r.y * 2654435761u) ^ ((unsigned)r.z * 2246822519u)) >> 21 & (W - 1u);      // W is a power of two
 }
 
-template <class ReadT>
+// a read into the pool: the wide record as it is, or the compact one (CountArgs)
+template <bool COMPACT> __device__ inline void pool_store(void *out, const unsigned long long at, const int2 r, const int base) {
+	if (COMPACT) reinterpret_cast<unsigned *>(out)[at] = (unsigned)(r.x - base) | ((unsigned)(r.y - r.x) << lsq::COMPACT_OFF_BITS);
+	else reinterpret_cast<int2 *>(out)[at] = r;
+}
+template <bool COMPACT> __device__ inline void pool_store(void *out, const unsigned long long at, const int4 r, const int base) {
+	if (COMPACT) reinterpret_cast<uint2 *>(out)[at] = make_uint2((unsigned)(r.x - base) | ((unsigned)(r.y - r.x) << lsq::COMPACT_OFF_BITS),
+	                                                              (unsigned)(r.z - r.y) | ((unsigned)(r.w - r.z) << lsq::COMPACT_OFF_BITS));
+	else reinterpret_cast<int4 *>(out)[at] = r;
+}
+
+template <class ReadT, bool COMPACT>
 __global__ void __launch_bounds__(256) lsq_ingest_binsort_kernel(const BucketDesc *buckets, const unsigned *bin_base, unsigned n_buckets, unsigned n_fine,
                                                                  const unsigned long long *off, const ReadT *in, const unsigned char *in_strand,
-                                                                 const unsigned *in_line, ReadT *out, unsigned char *out_strand, unsigned *out_line) {
+                                                                 const unsigned *in_line, void *out, unsigned char *out_strand, unsigned *out_line) {
 	__shared__ unsigned cnt_all[4][BINSORT_MAX_W];
 	const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	unsigned *cnt = cnt_all[wave];
@@ -273,8 +291,9 @@ __global__ void __launch_bounds__(256) lsq_ingest_binsort_kernel(const BucketDes
 		while (hi_b - lo_b > 1) { const unsigned mid = (lo_b + hi_b) >> 1; if (bin_base[mid] <= fine) lo_b = mid; else hi_b = mid; }
 		const BucketDesc &d = buckets[lo_b];
 		const unsigned W = d.shift < 31u ? (1u << d.shift) : 0x80000000u;
+		const int base = d.lo - lsq::COMPACT_BIAS;
 		if (W > BINSORT_MAX_W || n < 3) {
-			for (unsigned i = lane; i < n; i += 64u) { out[o0 + i] = in[o0 + i]; out_strand[o0 + i] = in_strand[o0 + i]; out_line[o0 + i] = in_line[o0 + i]; }
+			for (unsigned i = lane; i < n; i += 64u) { pool_store<COMPACT>(out, o0 + i, in[o0 + i], base); out_strand[o0 + i] = in_strand[o0 + i]; out_line[o0 + i] = in_line[o0 + i]; }
 			continue;
 		}
 		const int bin_lo = d.lo + (int)((fine - bin_base[lo_b]) << d.shift);
@@ -294,7 +313,7 @@ __global__ void __launch_bounds__(256) lsq_ingest_binsort_kernel(const BucketDes
 		for (unsigned i = lane; i < n; i += 64u) {
 			const ReadT r = in[o0 + i];
 			const unsigned pos = atomicAdd(&cnt[binsort_key(r, bin_lo, W)], 1u);
-			out[o0 + pos] = r; out_strand[o0 + pos] = in_strand[o0 + i]; out_line[o0 + pos] = in_line[o0 + i];
+			pool_store<COMPACT>(out, o0 + pos, r, base); out_strand[o0 + pos] = in_strand[o0 + i]; out_line[o0 + pos] = in_line[o0 + i];
 		}
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
 	}
@@ -324,8 +343,6 @@ static int ingest_device(lsq_ctx *c, int method, const IngestRaw &Rw, uint64_t n
 	const size_t n_cnt = 2 * F + 2 * (size_t)B;
 	if ((rc = d_ms.alloc(nblk)) || (rc = d_me.alloc(nblk)) || (rc = d_nb.alloc(n)) || (rc = d_strand.alloc(n)) || (rc = d_key.alloc(n)) || (rc = d_fine.alloc(n))) return rc;
 	if ((rc = d_cnt.alloc(2 * n_cnt)) || (rc = d_off1.alloc(F + 1)) || (rc = d_off2.alloc(F + 1)) || (rc = d_totals.alloc(4))) return rc;
-	HIP_TRY(hipMemsetAsync(d_cnt.p, 0, std::max<size_t>(2 * n_cnt, 1) * 4, st));
-	HIP_TRY(hipMemsetAsync(d_totals.p, 0, 4 * 8, st));
 	IngestTables T{};
 	T.cov_off = c->cov_off.p; T.cov_s = c->cov_s.p; T.cov_e = c->cov_e.p;
 	T.cut_off = c->cut_off.p; T.cut_lo = c->cut_lo.p; T.chrom_first_bucket = c->chrom_first_bucket.p;
@@ -336,34 +353,49 @@ static int ingest_device(lsq_ctx *c, int method, const IngestRaw &Rw, uint64_t n
 	W.cnt1 = d_cnt.p; W.cnt2 = W.cnt1 + F; W.cntn = W.cnt2 + F; W.cntnb = W.cntn + B;
 	W.cur1 = d_cnt.p + n_cnt; W.cur2 = W.cur1 + F; W.curn = W.cur2 + F; W.curnb = W.curn + B;
 	W.totals = d_totals.p;
+	W.compact = c->opt_compact_pools ? 1u : 0u;
 	const unsigned igrid = (unsigned)std::min<unsigned long long>((n + 255) / 256 + 1, (unsigned long long)c->n_cu * 16);
-	if (n) {
-		hipLaunchKernelGGL(lsq_ingest_classify_kernel, dim3(igrid), dim3(256), 0, st, T, Rw, W);
-		HIP_TRY(hipGetLastError());
-	}
 	if ((rc = mr.p1_off.alloc(B + 1)) || (rc = mr.p2_off.alloc(B + 1)) || (rc = mr.pn_off.alloc(B + 1)) || (rc = mr.pnb_off.alloc(B + 1)) || (rc = mr.slot_off.alloc(B + 1))) return rc;
-	hipLaunchKernelGGL(lsq_scan_u32_kernel, dim3(1), dim3(1024), 0, st, W.cnt1, (unsigned long long)F, d_off1.p);
-	hipLaunchKernelGGL(lsq_scan_u32_kernel, dim3(1), dim3(1024), 0, st, W.cnt2, (unsigned long long)F, d_off2.p);
-	hipLaunchKernelGGL(lsq_scan_u32_kernel, dim3(1), dim3(1024), 0, st, W.cntn, (unsigned long long)B, mr.pn_off.p);
-	hipLaunchKernelGGL(lsq_scan_u32_kernel, dim3(1), dim3(1024), 0, st, W.cntnb, (unsigned long long)B, mr.pnb_off.p);
-	hipLaunchKernelGGL(lsq_ingest_offsets_kernel, dim3(B / 256 + 1), dim3(256), 0, st, c->bin_base.p, B, d_off1.p, d_off2.p, mr.pn_off.p,
-	                   mr.p1_off.p, mr.p2_off.p, mr.slot_off.p);
-	HIP_TRY(hipGetLastError());
-	SW.mark("ingest: allocs + classify launch");
 	unsigned long long tot[4] = {0, 0, 0, 0}, sums[4] = {0, 0, 0, 0};
-	HIP_TRY(hipMemcpyAsync(tot, d_totals.p, 4 * 8, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(&sums[0], mr.p1_off.p + B, 8, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(&sums[1], mr.p2_off.p + B, 8, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(&sums[2], mr.pn_off.p + B, 8, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(&sums[3], mr.pnb_off.p + B, 8, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipStreamSynchronize(st));
-	SW.mark("ingest: classify + scans done");
+	for (;;) {
+		HIP_TRY(hipMemsetAsync(d_cnt.p, 0, std::max<size_t>(2 * n_cnt, 1) * 4, st));
+		HIP_TRY(hipMemsetAsync(d_totals.p, 0, 4 * 8, st));
+		if (n) {
+			hipLaunchKernelGGL(lsq_ingest_classify_kernel, dim3(igrid), dim3(256), 0, st, T, Rw, W);
+			HIP_TRY(hipGetLastError());
+		}
+		hipLaunchKernelGGL(lsq_scan_u32_kernel, dim3(1), dim3(1024), 0, st, W.cnt1, (unsigned long long)F, d_off1.p);
+		hipLaunchKernelGGL(lsq_scan_u32_kernel, dim3(1), dim3(1024), 0, st, W.cnt2, (unsigned long long)F, d_off2.p);
+		hipLaunchKernelGGL(lsq_scan_u32_kernel, dim3(1), dim3(1024), 0, st, W.cntn, (unsigned long long)B, mr.pn_off.p);
+		hipLaunchKernelGGL(lsq_scan_u32_kernel, dim3(1), dim3(1024), 0, st, W.cntnb, (unsigned long long)B, mr.pnb_off.p);
+		hipLaunchKernelGGL(lsq_ingest_offsets_kernel, dim3(B / 256 + 1), dim3(256), 0, st, c->bin_base.p, B, d_off1.p, d_off2.p, mr.pn_off.p,
+		                   mr.p1_off.p, mr.p2_off.p, mr.slot_off.p);
+		HIP_TRY(hipGetLastError());
+		SW.mark("ingest: allocs + classify launch");
+		HIP_TRY(hipMemcpyAsync(tot, d_totals.p, 4 * 8, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipMemcpyAsync(&sums[0], mr.p1_off.p + B, 8, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipMemcpyAsync(&sums[1], mr.p2_off.p + B, 8, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipMemcpyAsync(&sums[2], mr.pn_off.p + B, 8, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipMemcpyAsync(&sums[3], mr.pnb_off.p + B, 8, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
+		SW.mark("ingest: classify + scans done");
+		// compact records pay when nearly every one- and two-block read fits them (the others are counted a lane a read, tables
+		// in L2); a read set of long blocks -- more than 1 in 16 does not fit -- is classified again for wide records
+		if (W.compact && tot[3] * 16 > sums[0] + sums[1] + tot[3]) { W.compact = 0; continue; }
+		break;
+	}
 	if (tot[2]) return fail(LSQ_E_RANGE, "a read covers 2^18 or more bases or keeps more than %d separate blocks: outside the device tables' range", INGEST_MAX_BLOCKS);
 	if (sums[3] > 0xFFFFFFF0ull) return fail(LSQ_E_RANGE, "too many blocks in multi-block reads");
 	if (n > 0xFFFFFFF0ull) return fail(LSQ_E_RANGE, "more than 2^32 reads in one file");
 	const size_t n1 = (size_t)sums[0], n2 = (size_t)sums[1], nn = (size_t)sums[2], nnb = (size_t)sums[3];
-	if ((rc = mr.p1.alloc(2 * n1)) || (rc = mr.p1_strand.alloc(n1)) || (rc = mr.p1_line.alloc(n1))) return rc;
-	if ((rc = mr.p2.alloc(4 * n2)) || (rc = mr.p2_strand.alloc(n2)) || (rc = mr.p2_line.alloc(n2))) return rc;
+	mr.compact = W.compact != 0;
+	// (compact pools: whole 16-byte words, the count kernel loads the word a range ends in)
+	if ((rc = mr.p1.alloc(mr.compact ? ((n1 + 3) & ~(size_t)3) : 2 * n1)) || (rc = mr.p1_strand.alloc(n1)) || (rc = mr.p1_line.alloc(n1))) return rc;
+	if ((rc = mr.p2.alloc(mr.compact ? 2 * ((n2 + 1) & ~(size_t)1) : 4 * n2)) || (rc = mr.p2_strand.alloc(n2)) || (rc = mr.p2_line.alloc(n2))) return rc;
+	if (mr.compact) {           // the padding is read (and ignored) by the kernel: keep it defined
+		if (n1 & 3) HIP_TRY(hipMemsetAsync(mr.p1.p + n1, 0, (4 - (n1 & 3)) * 4, st));
+		if (n2 & 1) HIP_TRY(hipMemsetAsync(mr.p2.p + 2 * n2, 0, 2 * 4, st));
+	}
 	if ((rc = mr.pn_se.alloc(2 * nnb)) || (rc = mr.pn_blk_off.alloc(nn)) || (rc = mr.pn_nblk.alloc(nn)) || (rc = mr.pn_strand.alloc(nn)) ||
 	    (rc = mr.pn_line.alloc(nn)) || (rc = mr.pn_bucket.alloc(nn))) return rc;
 	if (n) {
@@ -382,10 +414,15 @@ static int ingest_device(lsq_ctx *c, int method, const IngestRaw &Rw, uint64_t n
 		hipLaunchKernelGGL(lsq_ingest_scatter_kernel, dim3(igrid), dim3(256), 0, st, Rw, W, O);
 		HIP_TRY(hipGetLastError());
 		const unsigned sgrid = (unsigned)std::min<size_t>(F / 4 + 1, (size_t)c->n_cu * 32);
-		if (n1) hipLaunchKernelGGL(lsq_ingest_binsort_kernel<int2>, dim3(sgrid), dim3(256), 0, st, c->buckets.p, c->bin_base.p, B, (unsigned)F, d_off1.p,
-		                           reinterpret_cast<const int2 *>(t_p1.p), t_p1_strand.p, t_p1_line.p, reinterpret_cast<int2 *>(mr.p1.p), mr.p1_strand.p, mr.p1_line.p);
-		if (n2) hipLaunchKernelGGL(lsq_ingest_binsort_kernel<int4>, dim3(sgrid), dim3(256), 0, st, c->buckets.p, c->bin_base.p, B, (unsigned)F, d_off2.p,
-		                           reinterpret_cast<const int4 *>(t_p2.p), t_p2_strand.p, t_p2_line.p, reinterpret_cast<int4 *>(mr.p2.p), mr.p2_strand.p, mr.p2_line.p);
+		auto sort_pool = [&](auto kernel, const auto *in, const unsigned long long *off, const uint8_t *in_strand, const uint32_t *in_line, void *out, uint8_t *out_strand, uint32_t *out_line) {
+			hipLaunchKernelGGL(kernel, dim3(sgrid), dim3(256), 0, st, c->buckets.p, c->bin_base.p, B, (unsigned)F, off, in, in_strand, in_line, out, out_strand, out_line);
+		};
+		const int2 *in1 = reinterpret_cast<const int2 *>(t_p1.p);
+		const int4 *in2 = reinterpret_cast<const int4 *>(t_p2.p);
+		if (n1 && mr.compact) sort_pool(lsq_ingest_binsort_kernel<int2, true>, in1, d_off1.p, t_p1_strand.p, t_p1_line.p, mr.p1.p, mr.p1_strand.p, mr.p1_line.p);
+		if (n1 && !mr.compact) sort_pool(lsq_ingest_binsort_kernel<int2, false>, in1, d_off1.p, t_p1_strand.p, t_p1_line.p, mr.p1.p, mr.p1_strand.p, mr.p1_line.p);
+		if (n2 && mr.compact) sort_pool(lsq_ingest_binsort_kernel<int4, true>, in2, d_off2.p, t_p2_strand.p, t_p2_line.p, mr.p2.p, mr.p2_strand.p, mr.p2_line.p);
+		if (n2 && !mr.compact) sort_pool(lsq_ingest_binsort_kernel<int4, false>, in2, d_off2.p, t_p2_strand.p, t_p2_line.p, mr.p2.p, mr.p2_strand.p, mr.p2_line.p);
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(hipStreamSynchronize(st));            // the temporaries go out of scope here
 		SW.mark("ingest: scatter + bin sort done");
@@ -553,5 +590,15 @@ int lsq_last_mrf_timing(lsq_ctx *c, float *h2d_ms, float *parse_ms) {
 uint64_t lsq_reads_retained(const lsq_ctx *c, int method) { return (c && method >= 0 && method < LSQ_MAX_METHODS) ? c->reads[method].n_retained : 0; }
 uint64_t lsq_reads_pooled(const lsq_ctx *c, int method) { return (c && method >= 0 && method < LSQ_MAX_METHODS) ? c->reads[method].total_slots : 0; }
 uint64_t lsq_reads_retained_blocks(const lsq_ctx *c, int method) { return (c && method >= 0 && method < LSQ_MAX_METHODS) ? c->reads[method].n_retained_blocks : 0; }
+
+int lsq_reads_pool_format(const lsq_ctx *c, int method, int *compact, uint64_t *pool_bytes, uint64_t *pool_reads) {
+	if (!c || method < 0 || method >= LSQ_MAX_METHODS) return fail(LSQ_E_ARG, "bad context or method");
+	const MethodReads &mr = c->reads[method];
+	if (!mr.present) return fail(LSQ_E_STATE, "no reads uploaded for method %d", method);
+	if (compact) *compact = mr.compact ? 1 : 0;
+	if (pool_bytes) *pool_bytes = 4ull * (mr.p1.n + mr.p2.n + mr.pn_se.n);
+	if (pool_reads) { pool_reads[0] = mr.p1_line.n; pool_reads[1] = mr.p2_line.n; pool_reads[2] = mr.pn_line.n; }
+	return LSQ_OK;
+}
 
 } // extern "C"

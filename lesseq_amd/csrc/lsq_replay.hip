@@ -186,7 +186,7 @@ struct BucketReads {                       // one read file's reads of one bucke
 	unsigned long long pnb0 = 0, pnb1 = 0;
 };
 
-int fetch_bucket(const lsq::MethodReads &mr, size_t b, BucketReads &R) {
+int fetch_bucket(const lsq::MethodReads &mr, size_t b, int32_t lo, BucketReads &R) {
 	unsigned long long o1[2], o2[2], on[2], ob[2];
 	HIP_TRY(hipMemcpy(o1, mr.p1_off.p + b, sizeof o1, hipMemcpyDeviceToHost));
 	HIP_TRY(hipMemcpy(o2, mr.p2_off.p + b, sizeof o2, hipMemcpyDeviceToHost));
@@ -194,12 +194,25 @@ int fetch_bucket(const lsq::MethodReads &mr, size_t b, BucketReads &R) {
 	HIP_TRY(hipMemcpy(ob, mr.pnb_off.p + b, sizeof ob, hipMemcpyDeviceToHost));
 	const size_t n1 = (size_t)(o1[1] - o1[0]), n2 = (size_t)(o2[1] - o2[0]), nn = (size_t)(on[1] - on[0]);
 	int rc;
-	if ((rc = fetch(R.p1, mr.p1.p, 2 * (size_t)o1[0], 2 * n1)) || (rc = fetch(R.p1_strand, mr.p1_strand.p, (size_t)o1[0], n1)) || (rc = fetch(R.p1_line, mr.p1_line.p, (size_t)o1[0], n1)) ||
-	    (rc = fetch(R.p2, mr.p2.p, 4 * (size_t)o2[0], 4 * n2)) || (rc = fetch(R.p2_strand, mr.p2_strand.p, (size_t)o2[0], n2)) || (rc = fetch(R.p2_line, mr.p2_line.p, (size_t)o2[0], n2)) ||
+	const size_t w1 = mr.compact ? 1 : 2, w2 = mr.compact ? 2 : 4;       // ints per pool record
+	if ((rc = fetch(R.p1, mr.p1.p, w1 * (size_t)o1[0], w1 * n1)) || (rc = fetch(R.p1_strand, mr.p1_strand.p, (size_t)o1[0], n1)) || (rc = fetch(R.p1_line, mr.p1_line.p, (size_t)o1[0], n1)) ||
+	    (rc = fetch(R.p2, mr.p2.p, w2 * (size_t)o2[0], w2 * n2)) || (rc = fetch(R.p2_strand, mr.p2_strand.p, (size_t)o2[0], n2)) || (rc = fetch(R.p2_line, mr.p2_line.p, (size_t)o2[0], n2)) ||
 	    (rc = fetch(R.pn_blk_off, mr.pn_blk_off.p, (size_t)on[0], nn)) || (rc = fetch(R.pn_nblk, mr.pn_nblk.p, (size_t)on[0], nn)) ||
 	    (rc = fetch(R.pn_strand, mr.pn_strand.p, (size_t)on[0], nn)) || (rc = fetch(R.pn_line, mr.pn_line.p, (size_t)on[0], nn)) ||
 	    (rc = fetch(R.pn_se, mr.pn_se.p, 2 * (size_t)ob[0], 2 * (size_t)(ob[1] - ob[0])))) return rc;
 	R.pnb0 = ob[0]; R.pnb1 = ob[1];
+	if (mr.compact) {         // to wide records (lsq_device.hpp COMPACT_*)
+		std::vector<int32_t> a(2 * n1), b2(4 * n2);
+		const int32_t base = lo - lsq::COMPACT_BIAS;
+		auto off = [](int32_t w) { return (int32_t)((uint32_t)w & lsq::COMPACT_OFF_MASK); };
+		auto len = [](int32_t w) { return (int32_t)((uint32_t)w >> lsq::COMPACT_OFF_BITS); };
+		for (size_t i = 0; i < n1; ++i) { a[2 * i] = base + off(R.p1[i]); a[2 * i + 1] = a[2 * i] + len(R.p1[i]); }
+		for (size_t i = 0; i < n2; ++i) {
+			const int32_t s1 = base + off(R.p2[2 * i]), e1 = s1 + len(R.p2[2 * i]), s2 = e1 + off(R.p2[2 * i + 1]);
+			b2[4 * i] = s1; b2[4 * i + 1] = e1; b2[4 * i + 2] = s2; b2[4 * i + 3] = s2 + len(R.p2[2 * i + 1]);
+		}
+		R.p1.swap(a); R.p2.swap(b2);
+	}
 	return LSQ_OK;
 }
 
@@ -293,7 +306,7 @@ int replay_flagged(lsq_ctx *c, unsigned *n_done) {
 			const MethodReads &mr = c->reads[m];
 			if (!mr.present) return fail(LSQ_E_STATE, "the exact-order EM replay needs the reads of method %zu on the device", m);
 			BucketReads R;
-			{ int rc = fetch_bucket(mr, b, R); if (rc) return rc; }
+			{ int rc = fetch_bucket(mr, b, E.buckets[b].lo, R); if (rc) return rc; }
 			for (size_t t = t0; t < t1; ++t) {
 				const size_t d = todo[t];
 				const Event &ev = E.ev[(size_t)E.dev2out[d]];
@@ -340,7 +353,7 @@ int host_count(lsq_ctx *c) {
 		for (size_t m = 0; m < M; ++m) {
 			const MethodReads &mr = c->reads[m];
 			BucketReads R;
-			{ int rc = fetch_bucket(mr, b, R); if (rc) return rc; }
+			{ int rc = fetch_bucket(mr, b, E.buckets[b].lo, R); if (rc) return rc; }
 			for (size_t d = bd.ev_base; d < (size_t)bd.ev_base + bd.n_events; ++d) {
 				const Event &ev = E.ev[(size_t)E.dev2out[d]];
 				std::vector<HostRead> valid;

@@ -16,6 +16,7 @@ ctx = L.Context(0)
 for kv in filter(None, os.environ.get("AB_OPTS", "").split(",")):
     k, v = kv.split("="); ctx.set_option(k, int(v))
 ctx.upload_events(ev); ctx.upload_reads(0, L.Reads.synthetic(spec, ev))
+print("pool format (compact, bytes, reads per pool):", ctx.pool_format(0), flush=True)
 blk = torch.zeros(ev.record_words(0, len(ev)), dtype=torch.int64, device="cuda:0"); torch.cuda.synchronize()
 def step():
     ctx.count(); ctx.solve(); ctx.pack_results_device(blk.data_ptr())
