@@ -519,6 +519,106 @@ def test_event_shaped_inputs_more_seeds_vs_oracle(seed, tmp_path):
     assert rc == 0 and ob.solve_text_close(text, otext)
 
 
+def _tables(ev, reads, options=()):
+    ctx = L.Context(0)
+    for k, v in options:
+        ctx.set_option(k, v)
+    ctx.upload_events(ev)
+    ctx.upload_reads(0, reads)
+    ctx.count(); ctx.solve()
+    out = [x.copy() for x in ctx.counts()] + [x.copy() for x in ctx.solution()], ctx.pool_format(0), ctx.count_status()
+    ctx.close()
+    return out
+
+
+@pytest.mark.parametrize("zipf", [False, True], ids=["even_depth", "zipf_depth"])
+def test_compact_and_wide_pool_records_give_the_same_tables(zipf, tmp_path):
+    """lsq_reads_pool_format: the same reads as 4-byte compact block records and as 8-byte wide ones -- every count,
+    base sum, theta, log-likelihood, iteration count and flag equal; also with the recount over every read (the
+    one-lane-per-read kernel unpacks the records on its own) and with a tiny exception list (overflow -> recount)"""
+    spec = L.SynthSpec(61, 3000, 700000, 100, 3, L.EVENT_TYPES, zipf)
+    L.synth_write(spec, str(tmp_path), "f", write_mrf=False)
+    ann = L.Annotation(str(tmp_path / "f.interval"), str(tmp_path / "f.map"))
+    ev = L.Events(ann, ("SHORT_READ",), (100,))
+    reads = L.Reads.synthetic(spec, ev)
+    wide, fmt_w, _ = _tables(ev, reads, [("compact_pools", 0)])
+    comp, fmt_c, _ = _tables(ev, reads)
+    assert fmt_w[0] is False and fmt_c[0] is True
+    assert fmt_c[2] == fmt_w[2] and fmt_c[2][0] > 100000 and fmt_c[2][1] > 10000          # the same reads in the same pools
+    assert fmt_c[1] < 0.52 * fmt_w[1]                                                     # in half the bytes
+    for a, b, what in zip(wide, comp, ("counts", "bases", "theta", "logll", "iters", "flags")):
+        assert np.array_equal(a, b, equal_nan=True), what
+    assert int(wide[0].sum()) > 500000
+    rec, _, st = _tables(ev, reads, [("recount_every_read", 1)])
+    assert st[1][0] == 1
+    ovf, _, st = _tables(ev, reads, [("exception_capacity", 2)])
+    for other, what in ((rec, "recount"), (ovf, "overflow")):
+        for a, b in zip(wide[:2], other[:2]):
+            assert np.array_equal(a, b), what
+
+
+def test_reads_that_do_not_fit_compact_records(tmp_path):
+    """Compact records hold blocks shorter than 1 024 bases that start within 2 Mi bases of their bucket's first base
+    (and second blocks within 4 Mi of the first).  Reads beyond that -- long blocks, a 5 Mb intron, a gene 3 Mb long --
+    are kept with the many-block reads and counted all the same; when more than 1 in 16 reads is like that the whole
+    read file falls back to wide records.  Both cases against the oracle."""
+    import random
+    import golden_inputs as gi
+    rng = random.Random(9)
+    iv, mp = [], []
+    # a gene with a 5 Mb intron, a gene with one 3 Mb exon and a far second one, a gene of long exons, and ordinary ones
+    genes = {"FAR": [[(10_000, 10_400), (5_010_400, 5_010_900)], [(10_000, 10_400), (12_000, 12_300), (5_010_400, 5_010_900)]],
+             "WIDE": [[(6_000_000, 9_000_000), (9_100_000, 9_100_500)], [(6_000_000, 6_000_600), (9_100_000, 9_100_500)]],
+             "LONG": [[(12_000_000, 12_003_000), (12_004_000, 12_006_500)], [(12_000_000, 12_003_000)]]}
+    for g in range(30):
+        s = 13_000_000 + 9_000 * g
+        genes["N%d" % g] = [[(s, s + 200), (s + 500, s + 650), (s + 1200, s + 1500)], [(s, s + 200), (s + 1200, s + 1500)]]
+    for name, forms in genes.items():
+        for k, ex in enumerate(forms):
+            iv.append(gi.interval_line("%s.%d" % (name, k), "c1", "+", ex))
+            mp.append("%s\t%s.%d\n" % (name, name, k))
+    _write(tmp_path / "g.interval", "".join(iv))
+    _write(tmp_path / "g.map", "".join(mp))
+
+    def read_set(path, n, long_share, special_share):
+        lines = ["AlignmentBlocks\n"]
+        names = list(genes)
+        for _ in range(n):
+            name = names[rng.randrange(3)] if rng.random() < special_share else names[3 + rng.randrange(30)]
+            f = genes[name][rng.randrange(len(genes[name]))]
+            tlen = sum(e - s for s, e in f)
+            ln = rng.choice([1024, 1500, 2200]) if rng.random() < long_share else rng.choice([100, 100, 100, 76, 1023])
+            ln = min(ln, tlen)
+            # near an exon junction half of the time, so that two-block reads are common
+            t0 = rng.randint(0, tlen - ln)
+            if rng.random() < 0.5 and len(f) > 1:
+                t0 = max(0, min(tlen - ln, (f[0][1] - f[0][0]) - rng.randint(1, ln - 1)))
+            lines.append(gi.mrf_line("c1", "+", gi.transcript_blocks(f, t0, ln)))
+        _write(path, "".join(lines))
+
+    for tag, long_share, special_share, want_compact in (("few", 0.02, 0.1, True), ("many", 0.6, 0.6, False)):
+        read_set(tmp_path / ("%s.mrf" % tag), 30000, long_share, special_share)
+        argv = ["0", "g", "./", "LH_GENE_TXT", str(tmp_path / "g.interval"), "UCSC_GENE2ISOFORM", str(tmp_path / "g.map"), "0", "1000",
+                "MRF_SINGLE", "MEDIUM_READ", "100", str(tmp_path / ("%s.mrf" % tag)), "3000000"]
+        rc, otext, exact = ob.run("solve", argv)
+        assert rc == 0
+        compare_exact(gpu_exact(argv), exact, tag)
+        a = L.Annotation(argv[4], argv[6])
+        ev = L.Events(a, ("MEDIUM_READ",), (100,))
+        reads = L.Reads.from_mrf(argv[12], ev)
+        tabs, fmt, _ = _tables(ev, reads)
+        assert fmt[0] is want_compact, (tag, fmt)
+        if want_compact:
+            assert fmt[2][2] > 300              # misfits (and the few many-block reads) sit in the third pool
+        wide, fmt_w, _ = _tables(ev, reads, [("compact_pools", 0)])
+        assert fmt_w[0] is False and sum(fmt_w[2]) == sum(fmt[2])
+        for x, y, what in zip(wide, tabs, ("counts", "bases", "theta", "logll", "iters", "flags")):
+            assert np.array_equal(x, y, equal_nan=True), (tag, what)
+        rc, text = L.cli_run("count", argv[:-1])
+        rc2, ctext, _ = ob.run("count", argv[:-1])
+        assert rc == rc2 == 0 and text == ctext, tag
+
+
 def test_steps_submitted_back_to_back_with_changing_reads(tmp_path):
     """The step pipeline (two streams, two counter sets): steps are only submitted, with another
     read set uploaded in between and the hand-off going to a buffer per step; every step's tables must be the ones
