@@ -625,7 +625,7 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 					} else asm volatile("" ::"v"(nA), "v"(sA), "v"(nL), "v"(sL));
 					if (ABL(A, 256u) && lane == 0) atomicAdd(&A.dbg[12], 1ull);
 					if (ABL(A, 256u) && lane == 0 && __any(lane_parks)) atomicAdd(&A.dbg[11], 1ull);
-					if (__any(lane_parks) && !ABL(A, 17u)) {
+					if (__any(lane_parks) && !ABL(A, 17u | 524288u)) {
 						// Some read of some lane is not settled by its lane's cell.  Second chance: its own cell (the lane's reads
 						// straddle a cell boundary); what that does not settle either is parked for the general walk.
 						const unsigned info = cell_info[min(ci, n_cells - 1u)];
@@ -721,7 +721,7 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 				const bool in = w0i < ww1 && rel < n_rel;
 				const Look L1 = look2(rd, in);
 				unsigned n_add = L1.add ? 1u : 0u, s_add = L1.add ? L1.matched : 0u;
-				park[0] = L1.park && !ABL(A, 17u);
+				park[0] = L1.park && !ABL(A, 17u | 1048576u);
 				pe0[0] = u;
 				pe1[0] = make_uint4(L1.hint, rel, 0u, 0u);
 #pragma unroll
@@ -737,7 +737,7 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 					s_add += (same && L1.add) ? (unsigned)((r2.y - r2.x) + (r2.w - r2.z)) : 0u;
 					// another junction (or none): parked -- a full look of its own for the second read cost more than the
 					// walk it saved (measured: 0.246 against 0.253 ms)
-					park[j] = in2 && !same && !ABL(A, 17u);
+					park[j] = in2 && !same && !ABL(A, 17u | 1048576u | 2097152u);
 					pe0[j] = v;
 					pe1[j] = make_uint4(PARK_EVENT_UNKNOWN, rel2, 0u, 0u);
 				}
@@ -1180,10 +1180,11 @@ int run_count(lsq_ctx *c) {
 	for (int m = 0; m < M; ++m) {
 		MethodReads &mr = c->reads[m];
 		if (mr.total_slots == 0 || E.buckets.empty()) continue;
-		// workgroups per resident slot: 2 for even read depth (fewest table stagings), more when a few buckets
-		// hold most of the reads (measured on the skewed workload: 2 -> 0.48 ms, 8 -> 0.30 ms); lsq_ctx_set_option
+		// workgroups per resident slot: 2 for even read depth and wide records (fewest table stagings), 4 with compact
+		// records (measured at C3: 2 -> 0.183, 4 -> 0.179, 6 -> 0.187 ms per step), more when a few buckets hold most
+		// of the reads (measured on the skewed workload: 2 -> 0.48 ms, 8 -> 0.30 ms); lsq_ctx_set_option
 		// "grid_multiplier" overrides
-		const unsigned mult = c->opt_grid_mult ? (unsigned)c->opt_grid_mult : (mr.skew >= 32.0 ? 8u : (mr.skew >= 4.0 ? 4u : 2u));
+		const unsigned mult = c->opt_grid_mult ? (unsigned)c->opt_grid_mult : (mr.skew >= 32.0 ? 8u : (mr.skew >= 4.0 || mr.compact ? 4u : 2u));
 		unsigned long long grid = (unsigned long long)c->n_cu * per_cu * mult;
 		// one workgroup's share must keep the packed LDS counters (24-bit count, 40-bit bases) exact
 		grid = std::max(grid, mr.total_slots / (1ull << 21) + 1);
