@@ -452,8 +452,9 @@ int plan_device(lsq_events &E) {
 	for (size_t i = 0; i < n; ++i)
 		if (i >= E.shard_first && i - E.shard_first < E.shard_count) per_chrom[E.ev[i].chrom_id].push_back((int32_t)i);
 	auto ev_bytes = [&](const Event &e) -> uint32_t {
-		// packed bucket: record 48 B, ~1.5 cells of 20 B per segment, 8 bin records of 16 B, class histogram
-		return std::max(48u + 40u * (uint32_t)e.N + 40u + 128u, 16u + 8u * (uint32_t)e.N + 4u * (uint32_t)e.K) + 8u * HIST_REPLICAS * ((1u << e.K) - 1u);
+		// packed bucket: record 48 B, ~2 cell records of 32 B per segment (the segment's stretches and the gap behind it),
+		// 8 bin records of 16 B, class histogram
+		return std::max(48u + 64u * (uint32_t)e.N + 40u + 128u, 16u + 8u * (uint32_t)e.N + 4u * (uint32_t)e.K) + 8u * HIST_REPLICAS * ((1u << e.K) - 1u);
 	};
 	for (size_t c = 0; c < per_chrom.size(); ++c) {
 		auto &lst = per_chrom[c];
@@ -561,8 +562,9 @@ int plan_device(lsq_events &E) {
 			uint32_t off = 0;
 			uint32_t bins_off = off; off = align16(off + (fast ? 16u : 2u) * d.n_bins);
 			// cells (packed buckets only): see struct Cell
-			std::vector<Cell> cells;
-			std::vector<uint32_t> cell_info;
+			std::vector<Cell> cells;             // the cells proper (start order), then the second owners' records
+			std::vector<CellX> cellx;
+			uint32_t n_main_cells = 0;
 			if (fast) {
 				struct SegRef { int64_t sx, sy; uint32_t ev, k, cls_off; };
 				std::vector<SegRef> segs_all;
@@ -589,14 +591,20 @@ int plan_device(lsq_events &E) {
 				bps.erase(std::unique(bps.begin(), bps.end()), bps.end());
 				std::sort(first_bases.begin(), first_bases.end());
 				std::sort(segs_all.begin(), segs_all.end(), [](const SegRef &x, const SegRef &y) { return x.sx < y.sx; });
-				struct Tmp { Cell c; uint32_t info; uint32_t ev, k; bool single; };
-				std::vector<Tmp> tmp;
+				auto slot_of = [&](const SegRef *sr, uint32_t mask) -> uint32_t {
+					const Event &e = E.ev[lst[b_begin + sr->ev]];
+					uint32_t cls = cls_of(e, mask);
+					return cls ? sr->cls_off + cls - 1 : CELL_NONE;
+				};
 				for (size_t q = 0; q + 1 < bps.size(); ++q) {
 					const int64_t x0 = bps[q], x1 = bps[q + 1];
 					const bool first_base = std::binary_search(first_bases.begin(), first_bases.end(), x0) && x1 == x0 + 1;   // first base of a span
 					const SegRef *own[3]; int n_own = 0;
 					for (size_t r = 0; r < segs_all.size() && segs_all[r].sx <= x0; ++r)
 						if (segs_all[r].sy >= x1) { if (n_own < 3) own[n_own] = &segs_all[r]; ++n_own; }
+					Cell c; CellX x;
+					c.lo = (int32_t)x0; c.hi = (int32_t)x1;
+					x.flags = 0; x.ev = 0;
 					if (first_base) {
 						// The first base of a span is no cell: a read that starts there is a candidate of the event only if
 						// it is not ordered before (gene_start, gene_end, strand, name) in the read index (count/count.cpp:64-85,
@@ -604,56 +612,44 @@ int plan_device(lsq_events &E) {
 						// event has a segment here -- such a read can match no other event either (its first block starts in
 						// none of their segments), so a read that ends before gene_end counts for nobody.  A start cell says so:
 						// one base wide, "runs into the next stretch" up to gene_end - 1, both slots empty; a read that reaches
-						// gene_end or beyond is parked with the event as its one candidate, as before.
+						// gene_end or beyond is parked with the event as its one candidate.
 						const auto fb = std::equal_range(first_bases.begin(), first_bases.end(), x0);
 						if (n_own != 1 || fb.second - fb.first != 1 || own[0]->sx != x0) continue;
 						const Event &e0 = E.ev[lst[b_begin + own[0]->ev]];
 						if (e0.gene_start != x0 || e0.gene_end - 1 < x1) continue;
-						Tmp t;
-						t.c.lo = (int32_t)x0; t.c.hi = (int32_t)x1; t.c.hi2 = (int32_t)(e0.gene_end - 1);
-						t.c.slots = CELL_NONE | (CELL_NONE << 16);
-						t.single = true; t.ev = own[0]->ev; t.k = CELL_K_START;
-						t.info = (own[0]->ev << 8) | (CELL_K_START << 2);
-						tmp.push_back(t);
-						continue;
-					}
-					if (n_own == 0 || n_own > 2) continue;
-					Tmp t;
-					t.c.lo = (int32_t)x0; t.c.hi = (int32_t)x1; t.c.hi2 = (int32_t)x1;
-					auto slot_of = [&](const SegRef *sr, uint32_t mask) -> uint32_t {
+						c.e1 = (int32_t)x1; c.e2 = (int32_t)(e0.gene_end - 1);
+						x.slots = CELL_NONE | (CELL_NONE << 16);
+						x.info = (own[0]->ev << 8) | (CELL_K_START << 2);
+						x.ev = own[0]->ev;
+					} else if (n_own == 0) {
+						// inside no segment of the bucket: a read that starts here matches nothing
+						c.e1 = c.e2 = INT32_MAX;
+						x.slots = CELL_NONE | (CELL_NONE << 16); x.info = CELL_INFO_EMPTY;
+					} else if (n_own == 1) {
+						const SegRef *sr = own[0];
 						const Event &e = E.ev[lst[b_begin + sr->ev]];
-						uint32_t cls = cls_of(e, mask);
-						return cls ? sr->cls_off + cls - 1 : CELL_NONE;
-					};
-					uint32_t sa = slot_of(own[0], 1u << own[0]->k);
-					uint32_t sb = n_own == 2 ? slot_of(own[1], 1u << own[1]->k) : CELL_NONE;
-					t.c.slots = sa | (sb << 16);
-					t.single = n_own == 1;
-					t.ev = own[0]->ev; t.k = own[0]->k;
-					t.info = n_own == 1 ? ((own[0]->ev << 8) | (own[0]->k << 2) | (own[0]->sy == x1 ? 2u : 0u) | (own[0]->sx == x0 ? 1u : 0u)) : CELL_INFO_SHARED;
-					tmp.push_back(t);
+						const int k = (int)sr->k;
+						c.e1 = (int32_t)sr->sy; c.e2 = c.e1;
+						uint32_t s2 = CELL_NONE;
+						if (k + 1 < e.N && e.seg_s[k + 1] == e.seg_e[k]) { c.e2 = (int32_t)e.seg_e[k + 1]; s2 = slot_of(sr, (1u << k) | (1u << (k + 1))); }
+						x.slots = slot_of(sr, 1u << k) | (s2 << 16);
+						x.info = (sr->ev << 8) | ((uint32_t)k << 2) | (sr->sx == x0 ? 1u : 0u);
+						x.ev = sr->ev;
+					} else if (n_own == 2) {
+						c.e1 = c.e2 = (int32_t)std::min(own[0]->sy, own[1]->sy);
+						x.slots = slot_of(own[0], 1u << own[0]->k) | (slot_of(own[1], 1u << own[1]->k) << 16);
+						x.info = CELL_INFO_SHARED; x.flags = CELLX_BOTH;
+					} else continue;
+					cells.push_back(c); cellx.push_back(x);
 				}
-				// a single-owner cell that reaches its segment's end, followed at once by a single-owner cell
-				// of the same event's next segment: reads may run from the one into the other
-				for (size_t q = 0; q + 1 < tmp.size(); ++q) {
-					Tmp &x = tmp[q]; const Tmp &y = tmp[q + 1];
-					if (x.single && y.single && (x.info & 2u) && (y.info & 1u) && x.ev == y.ev && y.k == x.k + 1 && y.c.lo == x.c.hi) {
-						const Event &e = E.ev[lst[b_begin + x.ev]];
-						uint32_t cls = cls_of(e, (1u << x.k) | (1u << y.k));
-						uint32_t co3 = 0;
-						for (size_t k3 = b_begin; k3 < b_begin + x.ev; ++k3) co3 += (1u << E.ev[lst[k3]].K) - 1u;
-						x.c.hi2 = y.c.hi;
-						x.c.slots = (x.c.slots & 0xFFFFu) | ((cls ? co3 + cls - 1 : CELL_NONE) << 16);
-					}
-				}
-				if (tmp.size() <= 65000)
-					for (const Tmp &t : tmp) { cells.push_back(t.c); cell_info.push_back(t.info); }
+				if (cells.size() > 65000) { cells.clear(); cellx.clear(); }
+				n_main_cells = (uint32_t)cells.size();
 			}
 			if (fast) {
 				d.ev_off = off; off = align16(off + (uint32_t)sizeof(FastRec) * d.n_events);
-				d.seg_off = off; off = align16(off + (uint32_t)sizeof(Cell) * (uint32_t)cells.size());   // cells, then their info words
-				off = align16(off + 4u * (uint32_t)cells.size());
-				d.iso_off = (uint32_t)cells.size();                                                       // cell count
+				d.seg_off = off; off = align16(off + (uint32_t)sizeof(Cell) * (uint32_t)cells.size());   // Cell records, then the CellX ones
+				off = align16(off + (uint32_t)sizeof(CellX) * (uint32_t)cells.size());
+				d.iso_off = n_main_cells | ((uint32_t)cells.size() << 16);                               // cells proper | all records
 			} else {
 				d.ev_off = off; off = align16(off + 16 * d.n_events);
 				d.seg_off = off; off = align16(off + 8 * nseg);
@@ -673,7 +669,7 @@ int plan_device(lsq_events &E) {
 			uint32_t *bins32 = reinterpret_cast<uint32_t *>(img + bins_off);
 			if (fast && !cells.empty()) {
 				memcpy(img + d.seg_off, cells.data(), cells.size() * sizeof(Cell));
-				memcpy(img + d.seg_off + ((cells.size() * sizeof(Cell) + 15u) & ~(size_t)15u), cell_info.data(), cell_info.size() * 4u);
+				memcpy(img + d.seg_off + cells.size() * sizeof(Cell), cellx.data(), cellx.size() * sizeof(CellX));
 			}
 			EventRec *recs = reinterpret_cast<EventRec *>(img + d.ev_off);
 			FastRec *frecs = reinterpret_cast<FastRec *>(img + d.ev_off);
@@ -742,10 +738,10 @@ int plan_device(lsq_events &E) {
 					// packed buckets: 16-byte bin record = first cell that can hold a base >= bin_lo | first event
 					// << 16, then the ends of that cell and the two after it: the cell that holds a base p of
 					// the bin is found by counting the ends that are <= p
-					while (first_cell < cells.size() && cells[first_cell].hi <= bin_lo) ++first_cell;
+					while (first_cell < n_main_cells && cells[first_cell].hi <= bin_lo) ++first_cell;
 					uint32_t *rec = bins32 + 4 * k;
 					rec[0] = (uint32_t)first_cell | (first << 16);
-					for (size_t q = 0; q < 3; ++q) rec[1 + q] = (uint32_t)(first_cell + q < cells.size() ? cells[first_cell + q].hi : INT32_MAX);
+					for (size_t q = 0; q < 3; ++q) rec[1 + q] = (uint32_t)(first_cell + q < n_main_cells ? cells[first_cell + q].hi : INT32_MAX);
 				} else bins[k] = (uint16_t)first;
 			}
 			if (E.chrom_first_bucket[c] < 0) E.chrom_first_bucket[c] = (int32_t)E.buckets.size();

@@ -446,6 +446,17 @@ struct Ring {
 		}
 		tail += (unsigned)__popcll(m);
 	}
+	// up to two one-word entries a lane (bit 0 / bit 1 of `bits`), the lanes' entries in lane order
+	__device__ inline void push2(const unsigned bits, const unsigned lane, const uint4 ea, const uint4 eb) {
+		static_assert(NB == 1 || NB == 2, "");
+		const unsigned long long m0 = __ballot((bits & 1u) != 0u), m1 = __ballot((bits & 2u) != 0u);
+		if (!(m0 | m1)) return;
+		const unsigned long long lt = (1ull << lane) - 1ull;
+		const unsigned at = tail + (unsigned)__popcll(m0 & lt) + (unsigned)__popcll(m1 & lt);
+		if (bits & 1u) q[at % CAP] = ea;
+		if (bits & 2u) q[(at + (bits & 1u)) % CAP] = eb;
+		tail += (unsigned)__popcll(m0) + (unsigned)__popcll(m1);
+	}
 };
 
 template <int NB>
@@ -493,7 +504,7 @@ __device__ inline void walk_parked(const FastCtx &C, Ring<NB> &R, const bool to_
 // RPW = reads per 16-byte word of a wide pool: 2 (pool 1: one block) or 1 (pool 2: two blocks); a lane's words are
 // numbered that way for compact pools too (the fetch unpacks one compact word into two of them)
 template <int RPW, bool COMPACT>
-__device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uint4 *cells, const unsigned *cell_info, const unsigned n_cells, const BucketDesc &d,
+__device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uint4 *cells, const uint4 *cellx, const unsigned n_cells, const BucketDesc &d,
                                         const CountArgs &A, uint4 *queue, const uint4 *src_generic,
                                         const unsigned long long g0, const unsigned long long g1) {
 	constexpr int NB = RPW == 2 ? 1 : 2;
@@ -559,6 +570,7 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 	};
 	Ring<NB> R;
 	R.q = queue;
+
 	// one step of the wave over the words in `cur` (the step's words, fetched a step ahead)
 	auto do_step = [&](const uint4 (&cur)[SW], const unsigned wt) {
 #pragma unroll
@@ -584,81 +596,74 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 				if (kg == 0) {
 					unsigned ci, evf;
 					locate((int)cur[k0].x, ci, evf);
-					const uint4 cw = cells[min(ci, n_cells - 1u)];           // lo, hi, hi2, slots
+					const unsigned cc = min(ci, n_cells - 1u);
+					const uint4 cw = cells[cc];           // lo, hi, e1, e2
+					const uint4 cx = cellx[cc];           // slots, info, flags, owner event
 					const bool has = ci < n_cells && !ABL(A, 8u);
-					const int lo = (int)cw.x, hi = (int)cw.y, hi2 = (int)cw.z;
-					const unsigned width = has ? (unsigned)(hi - lo) : 0u;
-					// reads that end inside the cell (A) and reads that end inside the cell or the abutting segment (L):
-					// counts and lengths; the run into the next segment is L minus A
-					unsigned nA = 0, sA = 0, nL = 0, sL = 0;
-					bool lane_parks = false;
+					const int lo = (int)cw.x, e1 = (int)cw.z, e2 = (int)cw.w;
+					const unsigned width = has ? (unsigned)((int)cw.y - lo) : 0u;
 					// all but the first and last steps of a workgroup's range lie wholly inside it: no per-read range test there
 					const bool interior = wt + TILE <= ww1 && (wt > 0u || first_rel == 0u) && (wt + TILE) * 2u - first_rel <= n_rel;
+					auto in_range = [&](const int j, unsigned &rel) {
+						const unsigned wj = wt + lane * (unsigned)SW + (unsigned)(k0 + j / 2);
+						rel = wj * 2u + (unsigned)(j & 1) - first_rel;      // position in the range (wraps above n_rel when outside)
+						return wj < ww1 && rel < n_rel;
+					};
+					// Reads that end inside the owner's segment (A) and reads that end inside it or the segment that abuts it (L):
+					// counts and lengths; the run into the next segment is L minus A.  open: a bit per read that the cell does
+					// not settle -- it lies in another cell or in none, or runs past e2.
+					unsigned nA = 0, sA = 0, nL = 0, sL = 0, open = 0;
 					auto decide = [&](auto whole_step) {
 #pragma unroll
 						for (int j = 0; j < N_READS; ++j) {
 							const int kk = k0 + j / 2;
 							const int ra = (j & 1) ? (int)cur[kk].z : (int)cur[kk].x, rb = (j & 1) ? (int)cur[kk].w : (int)cur[kk].y;
 							bool in = true;
-							if (!decltype(whole_step)::value) {
-								const unsigned wj = wt + lane * (unsigned)SW + (unsigned)kk;
-								const unsigned rel = wj * 2u + (unsigned)(j & 1) - first_rel;      // position in the range (wraps above n_rel when outside)
-								in = wj < ww1 && rel < n_rel;
-							}
+							if (!decltype(whole_step)::value) { unsigned rel; in = in_range(j, rel); }
 							const bool m = in && (unsigned)(ra - lo) < width;
-							const bool a = m && rb <= hi;
-							const bool l = m && rb <= hi2;
+							const bool a = m && rb <= e1;
+							const bool l = m && rb <= e2;
 							const unsigned len = (unsigned)(rb - ra);
 							nA += a ? 1u : 0u; sA += a ? len : 0u;
 							nL += l ? 1u : 0u; sL += l ? len : 0u;
-							lane_parks = lane_parks || (in && !l);
+							open |= (in && !l) ? 1u << j : 0u;
 						}
 					};
 					if (interior) decide(std::true_type{}); else decide(std::false_type{});
-					const unsigned sa = cw.w & 0xFFFFu, sb = cw.w >> 16;
+					const unsigned s1 = cx.x & 0xFFFFu, s2 = cx.x >> 16;
+					const bool both = (cx.z & CELLX_BOTH) != 0;          // two owners: s2 is the second owner's slot, e2 == e1
 					if (!ABL(A, (1u | 16384u))) {
 						const unsigned long long addA = ((unsigned long long)nA << 40) | sA;
 						const unsigned nX = nL - nA, sX = sL - sA;
-						if (nA && sa != CELL_NONE) atomicAdd(&C.hist[sa], addA);
-						if (nA && hi2 == hi && sb != CELL_NONE) atomicAdd(&C.hist[sb], addA);        // second owner of the cell
-						if (nX && sb != CELL_NONE) atomicAdd(&C.hist[sb], ((unsigned long long)nX << 40) | sX);
+						if (nA && s1 != CELL_NONE) atomicAdd(&C.hist[s1], addA);
+						if (nA && both && s2 != CELL_NONE) atomicAdd(&C.hist[s2], addA);
+						if (nX && s2 != CELL_NONE) atomicAdd(&C.hist[s2], ((unsigned long long)nX << 40) | sX);
 					} else asm volatile("" ::"v"(nA), "v"(sA), "v"(nL), "v"(sL));
-					if (ABL(A, 256u) && lane == 0) atomicAdd(&A.dbg[12], 1ull);
-					if (ABL(A, 256u) && lane == 0 && __any(lane_parks)) atomicAdd(&A.dbg[11], 1ull);
-					if (__any(lane_parks) && !ABL(A, 17u | 524288u)) {
-						// Some read of some lane is not settled by its lane's cell.  Second chance: its own cell (the lane's reads
-						// straddle a cell boundary); what that does not settle either is parked for the general walk.
-						const unsigned info = cell_info[min(ci, n_cells - 1u)];
+					if (ABL(A, 256u)) {
+						const bool any_open = __any(open != 0u);
+						if (lane == 0) { atomicAdd(&A.dbg[12], 1ull); atomicAdd(&A.dbg[11], any_open ? 1ull : 0ull); }
+					}
+					if (__any(open != 0u) && !ABL(A, 17u | 524288u)) {
+						// Some read of some lane is not settled by its lane's cell (a lane's reads straddle a cell boundary once per
+						// cell; the rest are reads past the owner's segments or in no cell).  They are parked for the general walk,
+						// two reads of every lane at a time: a read in a one-owner cell with that owner as the one event to look at,
+						// the others from the first event of their bin.
 #pragma unroll
-						for (int j = 0; j < N_READS; ++j) {
-							const int kk = k0 + j / 2;
-							const int ra = (j & 1) ? (int)cur[kk].z : (int)cur[kk].x, rb = (j & 1) ? (int)cur[kk].w : (int)cur[kk].y;
-							const unsigned wj = wt + lane * (unsigned)SW + (unsigned)kk;
-							const unsigned rel = wj * 2u + (unsigned)(j & 1) - first_rel;
-							const bool in = wj < ww1 && rel < n_rel;
-							const bool m = in && (unsigned)(ra - lo) < width;
-							bool pk = in && !(m && rb <= hi2);
-							unsigned own_info = info;
-							bool m_any = m;
-							if (__any(pk && !m)) {
-								unsigned c2, e2;
-								locate(ra, c2, e2);
-								const uint4 cv = cells[min(c2, n_cells - 1u)];
-								const bool m2 = pk && !m && c2 < n_cells && ra >= (int)cv.x && ra < (int)cv.y;
-								const bool a2 = m2 && rb <= (int)cv.y, l2 = m2 && rb <= (int)cv.z;
-								const unsigned long long add1 = (1ull << 40) | (unsigned long long)(unsigned)(rb - ra);
-								const unsigned sa2 = cv.w & 0xFFFFu, sb2 = cv.w >> 16;
-								if (a2 && sa2 != CELL_NONE) atomicAdd(&C.hist[sa2], add1);
-								if (a2 && (int)cv.z == (int)cv.y && sb2 != CELL_NONE) atomicAdd(&C.hist[sb2], add1);
-								if (l2 && !a2 && sb2 != CELL_NONE) atomicAdd(&C.hist[sb2], add1);
-								pk = pk && !l2;
-								if (m2) { own_info = cell_info[min(c2, n_cells - 1u)]; m_any = true; }
+						for (int h = 0; h < N_READS; h += 2) {
+							uint4 en[2];
+#pragma unroll
+							for (int j = h; j < h + 2; ++j) {
+								const int kk = k0 + j / 2;
+								const int ra = (j & 1) ? (int)cur[kk].z : (int)cur[kk].x, rb = (j & 1) ? (int)cur[kk].w : (int)cur[kk].y;
+								unsigned rel;
+								(void)in_range(j, rel);
+								const bool m = (unsigned)(ra - lo) < width;
+								en[j - h] = make_uint4((unsigned)ra, (unsigned)rb, (m && !both) ? (cx.w | PARK_ONE_EVENT) : PARK_EVENT_UNKNOWN, rel);
+								if (ABL(A, 256u) && ((open >> j) & 1u)) { atomicAdd(&A.dbg[5 + (m ? (both ? 2 : 1) : 0)], 1ull); atomicAdd(&A.dbg[0], 1ull); }
 							}
-							const unsigned owner_word = own_info == CELL_INFO_SHARED ? PARK_EVENT_UNKNOWN : ((own_info >> 8) | PARK_ONE_EVENT);
-							if (ABL(A, 256u) && pk) { atomicAdd(&A.dbg[5 + (m_any ? (own_info == CELL_INFO_SHARED ? 2 : 1) : 0)], 1ull); atomicAdd(&A.dbg[0], 1ull); }
-							R.push(pk, lane, make_uint4((unsigned)ra, (unsigned)rb, m_any ? owner_word : PARK_EVENT_UNKNOWN, rel), make_uint4(0, 0, 0, 0));
-							// the ring holds what one walk leaves behind (< 64) plus 128 entries
-							if ((j & 1) == 1 && R.live() >= 64u) {             // wave-uniform
+							R.push2((open >> h) & 3u, lane, en[0], en[1]);
+							// the ring holds what one walk leaves behind (< 64) plus these 128 entries
+							if (R.live() >= 64u) {             // wave-uniform
 								if (!ABL(A, 32u)) walk_parked<NB>(C, R, false);
 								else R.head = R.tail;
 							}
@@ -678,20 +683,23 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 				// Everything else -- shared cells, a run over abutting segments, touching blocks -- is parked for the general walk.
 				// The ingest groups the reads of a bin by junction, so a lane's second read mostly crosses the junction of its
 				// first and only needs its outer ends compared; when it does not, it is parked.
-				struct Look { bool add, park; unsigned slot, matched, hint; bool junction; int4 c; };       // c: lo of cell 1, end of block 1, start of block 2, end of block 2's segment
+				struct Look { bool add, park; unsigned slot, matched, hint; bool junction; int4 c; };       // c: the cell of block 1 (lo, hi), -, end of block 2's segment
 				auto look2 = [&](const int4 rd, const bool in) {
 					Look L;
 					unsigned c1, evf;
 					locate(rd.x, c1, evf);
-					const uint4 cw1 = cells[min(c1, n_cells - 1u)];
-					const unsigned i1 = cell_info[min(c1, n_cells - 1u)];
+					const unsigned c1c = min(c1, n_cells - 1u);
+					const uint4 cw1 = cells[c1c];          // lo, hi, e1, e2
+					const uint4 cx1 = cellx[c1c];          // slots, info, link, owner event
+					const unsigned i1 = cx1.y;
 					const unsigned k1 = (i1 >> 2) & 0x3Fu;
-					const bool v1 = c1 < n_cells && i1 != CELL_INFO_SHARED && (int)cw1.x <= rd.x && rd.x < (int)cw1.y && !ABL(A, 8u);   // block 1 starts in a one-owner cell
+					const bool here = c1 < n_cells && (int)cw1.x <= rd.x && rd.x < (int)cw1.y && !ABL(A, 8u);
+					const bool v1 = here && i1 < CELL_INFO_EMPTY;                                       // block 1 starts in a one-owner cell
 					const bool start1 = k1 == CELL_K_START;
-					const bool inside1 = v1 && !start1 && rd.y <= (int)cw1.y && rd.z != rd.y;         // (touching blocks: the exception pass decides)
-					const bool ends1 = inside1 && rd.y == (int)cw1.y && (i1 & 2u);                       // block 1 ends on its segment's end
+					const bool inside1 = v1 && !start1 && rd.y <= (int)cw1.z && rd.z != rd.y;            // block 1 ends inside its segment (touching blocks: the exception pass decides)
+					const bool ends1 = inside1 && rd.y == (int)cw1.z;                                      // ... on its end
 					// the owner's record: where its segments start and end (unused ones hold INT32_MAX, which no block reaches)
-					const unsigned ri = 3u * (v1 ? i1 >> 8 : 0u);
+					const unsigned ri = 3u * (v1 ? cx1.w : 0u);
 					const uint4 w0r = C.recs[ri], w1r = C.recs[ri + 1u], w2r = C.recs[ri + 2u];
 					// block 2 continues the match only from the first base of a later segment of the same event
 					const unsigned k2 = rd.z == (int)w1r.z ? 1u : (rd.z == (int)w2r.x ? 2u : (rd.z == (int)w2r.z ? 3u : 0u));
@@ -699,18 +707,19 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 					const bool cont = ends1 && k2 > k1;
 					const bool J = cont && rd.w <= end2;
 					const bool S = inside1 && !cont;
-					const bool drop = v1 && start1 && rd.w <= (int)cw1.z;
+					// counts for nobody: from a start cell and over before gene_end; or block 1 starts inside no segment at all
+					const bool drop = (v1 && start1 && rd.w <= (int)cw1.w) || (here && i1 == CELL_INFO_EMPTY);
 					const unsigned len1 = (unsigned)(rd.y - rd.x), total = len1 + (unsigned)(rd.w - rd.z);
 					const unsigned long long tbl = ((unsigned long long)w0r.w << 32) | w0r.z;
 					const unsigned cls = (unsigned)(tbl >> (4u * ((1u << (k1 & 3u)) | (1u << k2)))) & 0xFu;
-					const unsigned sa = cw1.w & 0xFFFFu;
+					const unsigned sa = cx1.x & 0xFFFFu;
 					L.junction = J;
 					L.add = in && ((J && cls != 0u) || (S && sa != CELL_NONE && 50u * len1 > 49u * total));
 					L.slot = J ? (w0r.y & 0xFFFFu) + cls - 1u : sa;
 					L.matched = J ? total : len1;
 					L.park = in && !(J || S || drop);
-					L.hint = v1 ? ((i1 >> 8) | PARK_ONE_EVENT) : evf;
-					L.c = make_int4((int)cw1.x, rd.y, rd.z, end2);
+					L.hint = v1 ? (cx1.w | PARK_ONE_EVENT) : evf;
+					L.c = make_int4((int)cw1.x, (int)cw1.y, 0, end2);
 					if (ABL(A, 256u) && L.park) atomicAdd(&A.dbg[8 + (v1 ? 1 : 0)], 1ull);       // parked: block 1 in no one-owner cell / in one
 					return L;
 				};
@@ -732,7 +741,7 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 					const unsigned rel2 = wj - first_rel;
 					const bool in2 = wj < ww1 && rel2 < n_rel;
 					// same junction: block 1 ends and block 2 starts where the first read's do; then only the outer ends matter
-					const bool same = in2 && in && L1.junction && r2.y == rd.y && r2.z == rd.z && L1.c.x <= r2.x && r2.x < r2.y && r2.w <= L1.c.w;
+					const bool same = in2 && in && L1.junction && r2.y == rd.y && r2.z == rd.z && L1.c.x <= r2.x && r2.x < L1.c.y && r2.w <= L1.c.w;
 					n_add += (same && L1.add) ? 1u : 0u;
 					s_add += (same && L1.add) ? (unsigned)((r2.y - r2.x) + (r2.w - r2.z)) : 0u;
 					// another junction (or none): parked -- a full look of its own for the second read cost more than the
@@ -746,10 +755,13 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 			}
 		}
 		if (RPW == 1) {
-#pragma unroll
+			static_assert(RPW != 1 || N_READS == 2, "two parked entries a step");
+#pragma unroll 1
 			for (int q = 0; q < N_READS; ++q) {
-				if (ABL(A, 256u) && park[q]) atomicAdd(&A.dbg[NB - 1], 1ull);
-				R.push(park[q], lane, pe0[q], pe1[q]);
+				const bool pq = q ? park[N_READS - 1] : park[0];
+				const uint4 q0 = q ? pe0[N_READS - 1] : pe0[0], q1 = q ? pe1[N_READS - 1] : pe1[0];
+				if (ABL(A, 256u) && pq) atomicAdd(&A.dbg[NB - 1], 1ull);
+				R.push(pq, lane, q0, q1);
 				// the ring holds what one walk leaves behind (< 64) plus 64 two-block entries
 				if (R.live() >= 64u) {             // wave-uniform
 					if (!ABL(A, 32u)) walk_parked<NB>(C, R, false);
@@ -958,7 +970,9 @@ __global__ void __launch_bounds__(COUNT_BLOCK, LSQ_FAST_WAVES) lsq_count_fast_ke
 		const unsigned b = V.b;
 		const uint4 *bins = reinterpret_cast<const uint4 *>(buf);
 		const uint4 *cells = reinterpret_cast<const uint4 *>(buf + d.seg_off);
-		const unsigned *cell_info = reinterpret_cast<const unsigned *>(buf + d.seg_off + 16u * d.iso_off);
+		// (iso_off of a packed bucket: cells proper | all owner records << 16; the CellX records follow the Cell ones)
+		const unsigned n_cells = d.iso_off & 0xFFFFu;
+		const uint4 *cellx = reinterpret_cast<const uint4 *>(buf + d.seg_off + 16u * (d.iso_off >> 16));
 		FastCtx C;
 		C.bins = bins; C.lo = d.lo; C.shift = d.shift; C.n_bins = d.n_bins;
 		C.recs = reinterpret_cast<const uint4 *>(buf + d.ev_off);
@@ -971,10 +985,10 @@ __global__ void __launch_bounds__(COUNT_BLOCK, LSQ_FAST_WAVES) lsq_count_fast_ke
 		const unsigned long long n1 = V.p1n, n2 = V.p2n;
 		// ---- pool 1
 		if (l0 < n1 && !ABL(A, 1024u))
-			stream_pool_fast<2, COMPACT>(C, bins, cells, cell_info, d.iso_off, d, A, wave_queue, reinterpret_cast<const uint4 *>(A.p1), V.p1o + l0, V.p1o + (l1 < n1 ? l1 : n1));
+			stream_pool_fast<2, COMPACT>(C, bins, cells, cellx, n_cells, d, A, wave_queue, reinterpret_cast<const uint4 *>(A.p1), V.p1o + l0, V.p1o + (l1 < n1 ? l1 : n1));
 		// ---- pool 2
 		if (l1 > n1 && l0 < n1 + n2 && !ABL(A, 2048u))
-			stream_pool_fast<1, COMPACT>(C, bins, cells, cell_info, d.iso_off, d, A, wave_queue, reinterpret_cast<const uint4 *>(A.p2), V.p2o + ((l0 > n1 ? l0 : n1) - n1),
+			stream_pool_fast<1, COMPACT>(C, bins, cells, cellx, n_cells, d, A, wave_queue, reinterpret_cast<const uint4 *>(A.p2), V.p2o + ((l0 > n1 ? l0 : n1) - n1),
 			                    V.p2o + ((l1 < n1 + n2 ? l1 : n1 + n2) - n1));
 		// (reads with three or more blocks are the workers')
 		__syncthreads();

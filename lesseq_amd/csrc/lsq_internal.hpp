@@ -103,34 +103,44 @@ constexpr uint32_t FAST_ABUT_SHIFT = 16;
 constexpr uint32_t FAST_FLAG_OVERLAPS_NEXT = 1u << 19;
 constexpr uint32_t FAST_NSEG_SHIFT = 24;
 
-// Shortcut table of a packed bucket.  A cell is a stretch of coordinates over which the set of
-// segments (of any event of the bucket) that cover it does not change, with one or two such
-// segments ("owners").  A one-block read that lies inside a cell is valid for exactly its owners'
-// events, with matched == its length and the class of the single segment; the first base of an
-// event's span is left out of every cell (the span-start tie rule decides there).
-//   lo, hi : the cell; hi2 > hi: the owner's next segment starts at hi and the stretch [hi, hi2)
-//            has that segment as only owner -- a read that starts in the cell and ends in
-//            (hi, hi2] matches both segments (slot2)
-//   slots  : low 16 bits owner A's histogram slot; high 16 bits owner B's (hi2 == hi) or the
-//            slot of the two-segment run (hi2 > hi); 0xFFFF = no compatible isoform / absent
+// Shortcut table of a packed bucket.  A cell is a stretch of coordinates over which the set of segments (of any event
+// of the bucket) that cover it does not change, with none, one or two such segments ("owners").  A read whose first base
+// lies in the cell can only ever count for the owners' events: every other event whose span covers the base has no
+// segment there, so the read's first block starts in none of its segments and nothing matches (common/read.h:204-274).
+// One owner -- segment k of its event: a one-block read [a, b) that starts in the cell is settled by where it ends:
+//   b <= e1              inside the segment: matched == its length, the class of {k}                          (slot 1)
+//   e1 < b <= e2         e2 > e1: segment k+1 starts where k ends, the read runs into it: class of {k, k+1}   (slot 2)
+//   b > e2               the general walk decides (a further abutting segment; the 98 % rule)
+// Two owners (CELLX_BOTH): e1 = e2 = the nearer of the two segments' ends, slot 1 / slot 2 = the owners' single-segment
+// classes; a read that ends at or before e1 counts for both, any other goes to the general walk.
+// No owner: a stretch inside no segment; both slots empty, e1 = e2 = INT32_MAX -- its reads count for nobody.
+// The first base of an event's span is left out of every cell (the span-start tie rule decides there), but see
+// CELL_K_START.  One record per cell in two arrays of 16-byte words: Cell and CellX.
 struct Cell {
-	int32_t lo, hi;
-	int32_t hi2;
-	uint32_t slots;
+	int32_t lo, hi;        // the cell
+	int32_t e1, e2;
 };
 static_assert(sizeof(Cell) == 16, "Cell layout");
+struct CellX {
+	uint32_t slots;        // low 16 bits: histogram slot 1; high 16 bits: slot 2; 0xFFFF = no compatible isoform / absent
+	uint32_t info;         // one owner: event << 8 | segment << 2 | lo is the segment's start; CELL_INFO_SHARED with two owners; CELL_INFO_EMPTY with none
+	uint32_t flags;        // CELLX_BOTH
+	uint32_t ev;           // one owner: its event (index in the bucket)
+};
+static_assert(sizeof(CellX) == 16, "CellX layout");
 constexpr uint32_t CELL_NONE = 0xFFFFu;
+constexpr uint32_t CELLX_BOTH = 1u << 16;
 // The LDS histogram of a bucket is kept HIST_REPLICAS times (lane & (R-1) picks the copy; copies
 // are (n_cls | 1) entries apart so that they start in different banks): neighbouring reads of the
 // start-ordered pools land in the same class, and atomics on one LDS address run one after the other.
 constexpr uint32_t HIST_REPLICAS = 4;
 inline uint32_t hist_stride(uint32_t n_cls) { return n_cls | 1u; }
-// per cell, for junction reads: owner event << 8 | segment << 2 | hi is the segment's end << 1 |
-// lo is the segment's start; CELL_INFO_SHARED for two-owner cells
 constexpr uint32_t CELL_INFO_SHARED = 0xFFFFFFFFu;
+constexpr uint32_t CELL_INFO_EMPTY = 0xFFFFFFFEu;          // a stretch inside no segment
 // segment number of a start cell (the first base of an event's span where that event's first segment is the only cover):
-// lo = gene_start, hi = lo + 1, hi2 = gene_end - 1, both slots CELL_NONE -- a one-block read from there that ends before
-// gene_end is ordered before the event in the read index and counts for nobody
+// lo = gene_start, hi = e1 = lo + 1, e2 = gene_end - 1, both slots CELL_NONE -- a one-block read from there that ends
+// before gene_end is ordered before the event in the read index and counts for nobody; one that reaches gene_end goes
+// to the general walk
 constexpr uint32_t CELL_K_START = 63u;
 
 struct TieRec {            // global memory, device event order; read only on start ties
