@@ -16,8 +16,12 @@ for name, d in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
             kn = kn.split("lsq_")[1].split("(")[0]
             a = acc[kn]; a[0] += float(row["Counter_Value"]); a[1] += 1
     res[name] = {k: {"mean_KiB": v / max(n, 1), "dispatches": n} for k, (v, n) in acc.items()}
-fetch = res["FETCH_SIZE"].get("count_fast_kernel", {}).get("mean_KiB", 0.0)
-write = res["WRITE_SIZE"].get("count_fast_kernel", {}).get("mean_KiB", 0.0)
+def fast(table):       # the kernel is a template over the pool record format: count_fast_kernel<true> / <false>
+    hits = [v for k, v in table.items() if k.startswith("count_fast_kernel")]
+    n = sum(h["dispatches"] for h in hits)
+    return sum(h["mean_KiB"] * h["dispatches"] for h in hits) / n if n else 0.0
+fetch = fast(res["FETCH_SIZE"])
+write = fast(res["WRITE_SIZE"])
 res["count_fast_kernel_hbm_bytes_per_launch"] = 2.0 * fetch * 1024 + write * 1024
 res["correction"] = "2 x FETCH_SIZE (gfx950 counts 128-B requests at 64 B) + WRITE_SIZE, KiB -> bytes"
 print(json.dumps(res, indent=1))
