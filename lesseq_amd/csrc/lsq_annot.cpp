@@ -623,7 +623,7 @@ int plan_device(lsq_events &E) {
 						x.ev = own[0]->ev;
 					} else if (n_own == 0) {
 						// inside no segment of the bucket: a read that starts here matches nothing
-						c.e1 = c.e2 = INT32_MAX;
+						c.e1 = c.e2 = CELL_NO_END;
 						x.slots = CELL_NONE | (CELL_NONE << 16); x.info = CELL_INFO_EMPTY;
 					} else if (n_own == 1) {
 						const SegRef *sr = own[0];

@@ -594,14 +594,16 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 				// once.  Everything else (a different cell, no cell, a longer run) is parked -- and only
 				// then is anything built for the ring: most steps park nothing in any lane.
 				if (kg == 0) {
+					// the loop's coordinates: the records' offsets from `base` (compact) or the reads' own (wide)
+					const int ws = COMPACT ? base : 0;
 					unsigned ci, evf;
-					locate((int)cur[k0].x, ci, evf);
+					locate((int)cur[k0].x + ws, ci, evf);
 					const unsigned cc = min(ci, n_cells - 1u);
 					const uint4 cw = cells[cc];           // lo, hi, e1, e2
 					const uint4 cx = cellx[cc];           // slots, info, flags, owner event
 					const bool has = ci < n_cells && !ABL(A, 8u);
-					const int lo = (int)cw.x, e1 = (int)cw.z, e2 = (int)cw.w;
-					const unsigned width = has ? (unsigned)((int)cw.y - lo) : 0u;
+					const int lo = (int)cw.x - ws, e1 = (int)cw.z - ws, e2 = (int)cw.w - ws;
+					const unsigned width = has ? (unsigned)((int)cw.y - (int)cw.x) : 0u;
 					// all but the first and last steps of a workgroup's range lie wholly inside it: no per-read range test there
 					const bool interior = wt + TILE <= ww1 && (wt > 0u || first_rel == 0u) && (wt + TILE) * 2u - first_rel <= n_rel;
 					auto in_range = [&](const int j, unsigned &rel) {
@@ -609,41 +611,50 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 						rel = wj * 2u + (unsigned)(j & 1) - first_rel;      // position in the range (wraps above n_rel when outside)
 						return wj < ww1 && rel < n_rel;
 					};
+					// read j of the lane: first base (in the loop's coordinates) and length
+					auto read_of = [&](const int j, int &s, unsigned &len) {
+						const int kk = k0 + j / 2;
+						const unsigned a = (j & 1) ? cur[kk].z : cur[kk].x, b = (j & 1) ? cur[kk].w : cur[kk].y;
+						s = (int)a; len = COMPACT ? b : b - a;
+					};
 					// Reads that end inside the owner's segment (A) and reads that end inside it or the segment that abuts it (L):
-					// counts and lengths; the run into the next segment is L minus A.  open: a bit per read that the cell does
-					// not settle -- it lies in another cell or in none, or runs past e2.
-					unsigned nA = 0, sA = 0, nL = 0, sL = 0, open = 0;
+					// count and matched bases of each kind in one word (count << 24 | bases: four reads of < 2^18 bases); the run
+					// into the next segment is L minus A.  A read that the cell does not settle -- it lies in another cell or in
+					// none, or runs past e2 -- shows as a count short of the reads in the range.
+					unsigned accA = 0, accL = 0, n_in = N_READS;
 					auto decide = [&](auto whole_step) {
+						if (!decltype(whole_step)::value) n_in = 0;
 #pragma unroll
 						for (int j = 0; j < N_READS; ++j) {
-							const int kk = k0 + j / 2;
-							const int ra = (j & 1) ? (int)cur[kk].z : (int)cur[kk].x, rb = (j & 1) ? (int)cur[kk].w : (int)cur[kk].y;
+							int s; unsigned len;
+							read_of(j, s, len);
 							bool in = true;
-							if (!decltype(whole_step)::value) { unsigned rel; in = in_range(j, rel); }
-							const bool m = in && (unsigned)(ra - lo) < width;
-							const bool a = m && rb <= e1;
-							const bool l = m && rb <= e2;
-							const unsigned len = (unsigned)(rb - ra);
-							nA += a ? 1u : 0u; sA += a ? len : 0u;
-							nL += l ? 1u : 0u; sL += l ? len : 0u;
-							open |= (in && !l) ? 1u << j : 0u;
+							if (!decltype(whole_step)::value) { unsigned rel; in = in_range(j, rel); n_in += in ? 1u : 0u; }
+							const int e = s + (int)len;
+							const bool m = in && (unsigned)(s - lo) < width;
+							const bool a = m && e <= e1;
+							const bool l = m && e <= e2;
+							const unsigned p = len | (1u << 24);
+							accA += a ? p : 0u;
+							accL += l ? p : 0u;
 						}
 					};
 					if (interior) decide(std::true_type{}); else decide(std::false_type{});
 					const unsigned s1 = cx.x & 0xFFFFu, s2 = cx.x >> 16;
 					const bool both = (cx.z & CELLX_BOTH) != 0;          // two owners: s2 is the second owner's slot, e2 == e1
 					if (!ABL(A, (1u | 16384u))) {
-						const unsigned long long addA = ((unsigned long long)nA << 40) | sA;
-						const unsigned nX = nL - nA, sX = sL - sA;
-						if (nA && s1 != CELL_NONE) atomicAdd(&C.hist[s1], addA);
-						if (nA && both && s2 != CELL_NONE) atomicAdd(&C.hist[s2], addA);
-						if (nX && s2 != CELL_NONE) atomicAdd(&C.hist[s2], ((unsigned long long)nX << 40) | sX);
-					} else asm volatile("" ::"v"(nA), "v"(sA), "v"(nL), "v"(sL));
+						const unsigned long long addA = ((unsigned long long)(accA >> 24) << 40) | (accA & 0xFFFFFFu);
+						const unsigned accX = accL - accA;
+						if (accA && s1 != CELL_NONE) atomicAdd(&C.hist[s1], addA);
+						if (accA && both && s2 != CELL_NONE) atomicAdd(&C.hist[s2], addA);
+						if (accX && s2 != CELL_NONE) atomicAdd(&C.hist[s2], ((unsigned long long)(accX >> 24) << 40) | (accX & 0xFFFFFFu));
+					} else asm volatile("" ::"v"(accA), "v"(accL));
+					const bool lane_open = (accL >> 24) != n_in;
 					if (ABL(A, 256u)) {
-						const bool any_open = __any(open != 0u);
+						const bool any_open = __any(lane_open);
 						if (lane == 0) { atomicAdd(&A.dbg[12], 1ull); atomicAdd(&A.dbg[11], any_open ? 1ull : 0ull); }
 					}
-					if (__any(open != 0u) && !ABL(A, 17u | 524288u)) {
+					if (__any(lane_open) && !ABL(A, 17u | 524288u)) {
 						// Some read of some lane is not settled by its lane's cell (a lane's reads straddle a cell boundary once per
 						// cell; the rest are reads past the owner's segments or in no cell).  They are parked for the general walk,
 						// two reads of every lane at a time: a read in a one-owner cell with that owner as the one event to look at,
@@ -651,17 +662,19 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 #pragma unroll
 						for (int h = 0; h < N_READS; h += 2) {
 							uint4 en[2];
+							unsigned open = 0;
 #pragma unroll
 							for (int j = h; j < h + 2; ++j) {
-								const int kk = k0 + j / 2;
-								const int ra = (j & 1) ? (int)cur[kk].z : (int)cur[kk].x, rb = (j & 1) ? (int)cur[kk].w : (int)cur[kk].y;
-								unsigned rel;
-								(void)in_range(j, rel);
-								const bool m = (unsigned)(ra - lo) < width;
-								en[j - h] = make_uint4((unsigned)ra, (unsigned)rb, (m && !both) ? (cx.w | PARK_ONE_EVENT) : PARK_EVENT_UNKNOWN, rel);
-								if (ABL(A, 256u) && ((open >> j) & 1u)) { atomicAdd(&A.dbg[5 + (m ? (both ? 2 : 1) : 0)], 1ull); atomicAdd(&A.dbg[0], 1ull); }
+								int s; unsigned len, rel;
+								read_of(j, s, len);
+								const bool in = in_range(j, rel);
+								const bool m = (unsigned)(s - lo) < width;
+								const bool op = in && !(m && s + (int)len <= e2);
+								open |= op ? 1u << (j - h) : 0u;
+								en[j - h] = make_uint4((unsigned)(s + ws), (unsigned)(s + ws) + len, (m && !both) ? (cx.w | PARK_ONE_EVENT) : PARK_EVENT_UNKNOWN, rel);
+								if (ABL(A, 256u) && op) { atomicAdd(&A.dbg[5 + (m ? (both ? 2 : 1) : 0)], 1ull); atomicAdd(&A.dbg[0], 1ull); }
 							}
-							R.push2((open >> h) & 3u, lane, en[0], en[1]);
+							R.push2(open, lane, en[0], en[1]);
 							// the ring holds what one walk leaves behind (< 64) plus these 128 entries
 							if (R.live() >= 64u) {             // wave-uniform
 								if (!ABL(A, 32u)) walk_parked<NB>(C, R, false);
@@ -777,9 +790,9 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 		if (COMPACT) {
 			const uint4 t = nxt[0];
 			if (RPW == 2) {
-				const int2 r0 = unpack_one_block(t.x, base), r1 = unpack_one_block(t.y, base), r2 = unpack_one_block(t.z, base), r3 = unpack_one_block(t.w, base);
-				cur[0] = make_uint4((unsigned)r0.x, (unsigned)r0.y, (unsigned)r1.x, (unsigned)r1.y);
-				cur[1] = make_uint4((unsigned)r2.x, (unsigned)r2.y, (unsigned)r3.x, (unsigned)r3.y);
+				// one-block reads stay in the records' own terms: (offset from `base`, length); the loop compares there
+				cur[0] = make_uint4(t.x & lsq::COMPACT_OFF_MASK, t.x >> lsq::COMPACT_OFF_BITS, t.y & lsq::COMPACT_OFF_MASK, t.y >> lsq::COMPACT_OFF_BITS);
+				cur[1] = make_uint4(t.z & lsq::COMPACT_OFF_MASK, t.z >> lsq::COMPACT_OFF_BITS, t.w & lsq::COMPACT_OFF_MASK, t.w >> lsq::COMPACT_OFF_BITS);
 			} else {
 				const int4 a = unpack_two_block(t.x, t.y, base), b = unpack_two_block(t.z, t.w, base);
 				cur[0] = make_uint4((unsigned)a.x, (unsigned)a.y, (unsigned)a.z, (unsigned)a.w);
@@ -792,6 +805,8 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 		if (wt + WAVES * TILE < ww1) fetch(wt + WAVES * TILE);
 		do_step(cur, wt);
 	}
+	// (the waves drain their own rings: handing the leftovers of four waves to one, so that fewer partly filled walk steps
+	// run, was measured -- 116 000 -> 87 000 walk steps on C3 -- and lost more at the two barriers it needs: 0.174 -> 0.180 ms)
 	if (R.live() && !ABL(A, 32u)) walk_parked<NB>(C, R, true);
 }
 

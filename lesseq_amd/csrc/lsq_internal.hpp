@@ -113,7 +113,7 @@ constexpr uint32_t FAST_NSEG_SHIFT = 24;
 //   b > e2               the general walk decides (a further abutting segment; the 98 % rule)
 // Two owners (CELLX_BOTH): e1 = e2 = the nearer of the two segments' ends, slot 1 / slot 2 = the owners' single-segment
 // classes; a read that ends at or before e1 counts for both, any other goes to the general walk.
-// No owner: a stretch inside no segment; both slots empty, e1 = e2 = INT32_MAX -- its reads count for nobody.
+// No owner: a stretch inside no segment; both slots empty, e1 = e2 = CELL_NO_END -- its reads count for nobody.
 // The first base of an event's span is left out of every cell (the span-start tie rule decides there), but see
 // CELL_K_START.  One record per cell in two arrays of 16-byte words: Cell and CellX.
 struct Cell {
@@ -129,6 +129,7 @@ struct CellX {
 };
 static_assert(sizeof(CellX) == 16, "CellX layout");
 constexpr uint32_t CELL_NONE = 0xFFFFu;
+constexpr int32_t CELL_NO_END = 0x7F000000;     // beyond every coordinate (< 2^30), and still so after the kernel has taken a bucket's base (> -2^22) off it
 constexpr uint32_t CELLX_BOTH = 1u << 16;
 // The LDS histogram of a bucket is kept HIST_REPLICAS times (lane & (R-1) picks the copy; copies
 // are (n_cls | 1) entries apart so that they start in different banks): neighbouring reads of the
