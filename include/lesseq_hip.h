@@ -355,6 +355,12 @@ void lsq_free(void *p);
  * "count", "solve" or "classify".  stdout text is returned in *out_text (malloc'd), the
  * return value is the process exit status the reference would give (0, 1). */
 int lsq_cli_run(const char *tool, int argc, const char *const *argv, char **out_text);
+/* The same for an executable's main(): writes the table to stdout itself and returns the exit status.  A successful
+ * count / solve run leaves the process (_exit) as soon as its table is written and flushed -- the pools, the helper
+ * threads and the runtime are the operating system's to reclaim, which takes it a fraction of the time an orderly
+ * teardown of several gigabytes of HBM takes (0.1-0.2 s of a 0.7 s run); LSQ_CLI_TEARDOWN=1 in the environment keeps
+ * the orderly way.  Not for use inside a host process: call lsq_cli_run there. */
+int lsq_cli_main(const char *tool, int argc, const char *const *argv);
 
 /* ------------------------------------------------------------------------------------
  * Synthetic workload; deterministic in (seed, sizes).  Host-only.

@@ -1,6 +1,7 @@
 // Host side of the path, part 3: output rows (count/count.cpp:486-492, solve/solve.cpp:808-847)
 // and the three executables' argv handling, exit codes and stderr log.
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cctype>
@@ -155,6 +156,8 @@ int run_classify(int argc, const char *const *argv) {
 	logf(2, "Built isoform structures for the %zu selected gene(s)", written);
 	return 0;
 }
+
+bool g_exit_after_output = false;       // set by lsq_cli_main
 
 // developer aid: LSQ_CLI_TIMING=1 prints the seconds each phase took on stderr
 struct PhaseTimer {
@@ -496,6 +499,13 @@ int run_count_solve(bool solve, int argc, const char *const *argv, std::string &
 	}
 	T.mark("format rows");
 	logf(2, "Processed %lld genes... Done", (long long)n_ev);
+	if (g_exit_after_output) {
+		// an executable (lsq_cli_main): the table is complete -- write it and leave.  Freeing gigabytes of HBM pools buffer by
+		// buffer, joining the helper threads and unloading the runtime is work the end of the process does for nothing.
+		fwrite(out.data(), 1, out.size(), stdout);
+		fflush(stdout); fflush(stderr);
+		_exit(0);
+	}
 	return 0;
 }
 
@@ -565,6 +575,14 @@ int lsq_format_solve(const lsq_events *E, int M, const uint64_t *cnt, const uint
 	}
 	*out_text = dup_text(o);
 	return *out_text ? LSQ_OK : fail(LSQ_E_ARG, "out of memory");
+}
+
+int lsq_cli_main(const char *tool, int argc, const char *const *argv) {
+	g_exit_after_output = getenv("LSQ_CLI_TEARDOWN") == nullptr;
+	char *text = nullptr;
+	const int rc = lsq_cli_run(tool, argc, argv, &text);
+	if (text) { fputs(text, stdout); fflush(stdout); free(text); }
+	return rc;
 }
 
 int lsq_cli_run(const char *tool, int argc, const char *const *argv, char **out_text) {

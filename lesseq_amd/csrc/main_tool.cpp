@@ -11,8 +11,5 @@ int main(int argc, char **argv) {
 	const char *base = strrchr(argv[0], '/');
 	base = base ? base + 1 : argv[0];
 	const char *tool = strstr(base, "solve") ? "solve" : (strstr(base, "classify") ? "classify" : "count");
-	char *text = nullptr;
-	int rc = lsq_cli_run(tool, argc, argv, &text);
-	if (text) { fputs(text, stdout); fflush(stdout); free(text); }
-	return rc;
+	return lsq_cli_main(tool, argc, argv);
 }
