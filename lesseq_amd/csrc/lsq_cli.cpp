@@ -509,6 +509,27 @@ int run_count_solve(bool solve, int argc, const char *const *argv, std::string &
 	return 0;
 }
 
+// The rows of the events [0, n), event by event in order: formatted by a few threads over contiguous runs of events
+// (100 000 rows through the reference's six-digit formatting take 0.05 s on one core), joined in order.
+template <class F>
+std::string format_events_parallel(size_t n, F &&one) {
+	const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+	const size_t T = n < 8192 ? 1 : std::min<size_t>({8, hw, n / 4096});
+	std::vector<std::string> parts(T);
+	auto run = [&](size_t k) { for (size_t i = n * k / T; i < n * (k + 1) / T; ++i) one(parts[k], i); };
+	std::vector<std::thread> th;
+	for (size_t k = 1; k < T; ++k) th.emplace_back(run, k);
+	run(0);
+	for (auto &x : th) x.join();
+	if (T == 1) return std::move(parts[0]);
+	size_t total = 0;
+	for (const auto &s : parts) total += s.size();
+	std::string o;
+	o.reserve(total);
+	for (const auto &s : parts) o += s;
+	return o;
+}
+
 } // namespace
 
 extern "C" {
@@ -516,8 +537,7 @@ extern "C" {
 int lsq_format_count(const lsq_events *E, int M, const uint64_t *cnt, char **out_text) {
 	if (!E || !cnt || !out_text || M != E->n_methods) return fail(LSQ_E_ARG, "bad argument");
 	const size_t n_cls = E->class_off.back();
-	std::string o;
-	for (size_t i = 0; i < E->ev.size(); ++i) {
+	const std::string o = format_events_parallel(E->ev.size(), [&](std::string &o, size_t i) {
 		const Event &e = E->ev[i];
 		const size_t nc = (1u << e.K) - 1u;
 		std::vector<double> supports(M, 0.0), iso_count(e.K, 0.0);
@@ -532,7 +552,7 @@ int lsq_format_count(const lsq_events *E, int M, const uint64_t *cnt, char **out
 			for (int m = 0; m < M; ++m) { put_g(o, supports[m]); o += '\t'; }
 			o += e.iso_names[j]; o += '\t'; put_g(o, iso_count[j]); o += '\n';
 		}
-	}
+	});
 	*out_text = dup_text(o);
 	return *out_text ? LSQ_OK : fail(LSQ_E_ARG, "out of memory");
 }
@@ -541,8 +561,7 @@ int lsq_format_solve(const lsq_events *E, int M, const uint64_t *cnt, const uint
                      const double *theta, const double *logll, const double *total_read_bases, char **out_text) {
 	if (!E || !cnt || !bases || !theta || !logll || !total_read_bases || !out_text || M != E->n_methods) return fail(LSQ_E_ARG, "bad argument");
 	const size_t n_cls = E->class_off.back();
-	std::string o;
-	for (size_t i = 0; i < E->ev.size(); ++i) {
+	const std::string o = format_events_parallel(E->ev.size(), [&](std::string &o, size_t i) {
 		const Event &e = E->ev[i];
 		const size_t nc = (1u << e.K) - 1u;
 		std::vector<double> supports(M, 0.0), support_bases(M, 0.0);
@@ -572,7 +591,7 @@ int lsq_format_solve(const lsq_events *E, int M, const uint64_t *cnt, const uint
 			if (sum_supports > 1E-5) { o += '\t'; put_g(o, logll[i] / sum_supports); o += '\n'; }
 			else o += "\t0\n";
 		}
-	}
+	});
 	*out_text = dup_text(o);
 	return *out_text ? LSQ_OK : fail(LSQ_E_ARG, "out of memory");
 }
