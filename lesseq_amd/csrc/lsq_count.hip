@@ -1209,11 +1209,11 @@ int run_count(lsq_ctx *c) {
 	for (int m = 0; m < M; ++m) {
 		MethodReads &mr = c->reads[m];
 		if (mr.total_slots == 0 || E.buckets.empty()) continue;
-		// workgroups per resident slot: 2 for even read depth and wide records (fewest table stagings), 4 with compact
-		// records (measured at C3: 2 -> 0.183, 4 -> 0.179, 6 -> 0.187 ms per step), more when a few buckets hold most
+		// workgroups per resident slot: 2 for even read depth and wide records (fewest table stagings), 3 with compact
+		// records (measured at C3: 2 -> 0.175, 3 -> 0.172, 4 -> 0.174, 6 -> 0.187 ms per step), more when a few buckets hold most
 		// of the reads (measured on the skewed workload: 2 -> 0.48 ms, 8 -> 0.30 ms); lsq_ctx_set_option
 		// "grid_multiplier" overrides
-		const unsigned mult = c->opt_grid_mult ? (unsigned)c->opt_grid_mult : (mr.skew >= 32.0 ? 8u : (mr.skew >= 4.0 || mr.compact ? 4u : 2u));
+		const unsigned mult = c->opt_grid_mult ? (unsigned)c->opt_grid_mult : (mr.skew >= 32.0 ? 8u : (mr.skew >= 4.0 ? 4u : (mr.compact ? 3u : 2u)));
 		unsigned long long grid = (unsigned long long)c->n_cu * per_cu * mult;
 		// one workgroup's share must keep the packed LDS counters (24-bit count, 40-bit bases) exact
 		grid = std::max(grid, mr.total_slots / (1ull << 21) + 1);
