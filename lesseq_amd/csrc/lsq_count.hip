@@ -248,6 +248,7 @@ __global__ void __launch_bounds__(COUNT_BLOCK) lsq_count_generic_kernel(CountArg
 			if (i < n1) {
 				const unsigned long long g = A.p1_off[b] + i;
 				const int2 rd = pool1_read(A, g, d.lo);
+				if (rd.y == rd.x) continue;          // padding of a cell's group
 				process_read<1>(L, d, A, make_int4(rd.x, rd.y, 0, 0), nullptr, 1, rd.y - rd.x, A.p1_strand, A.p1_line, g);
 			} else if (i < n1 + n2) {
 				const unsigned long long g = A.p2_off[b] + (i - n1);
@@ -519,8 +520,9 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 	// words [w0, w1) of the workgroup, dealt to its waves a step at a time (wave, wave + 4, ...): the
 	// reads that need the general walk sit together in the start-ordered pool, and a contiguous
 	// quarter per wave would leave three waves waiting for the one that got them
-	// (compact pools: a 16-byte word of the pool holds the reads of two of these words, so the range starts on an even one)
-	const unsigned long long w0 = COMPACT ? ((g0 / RPW) & ~1ull) : g0 / RPW, w1 = (g1 + RPW - 1) / RPW;
+	// (compact pools: a 16-byte word of the pool holds the reads of two of these words, so the range starts on an even one;
+	// one-block reads: a lane's four records are one of the quadruples the pool's cell groups are padded to)
+	const unsigned long long w0 = (COMPACT || RPW == 2) ? ((g0 / RPW) & ~1ull) : g0 / RPW, w1 = (g1 + RPW - 1) / RPW;
 	const unsigned n_words = (unsigned)(w1 - w0);                                   // a workgroup's range stays below 2^21 reads
 	const unsigned ww0 = min(wave * TILE, n_words), ww1 = n_words;                   // relative to w0
 	const unsigned first_rel = (unsigned)(g0 - w0 * RPW);                            // reads of word w0 (and, compact, w0 + 1) before the range
@@ -619,22 +621,23 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 					};
 					// Reads that end inside the owner's segment (A) and reads that end inside it or the segment that abuts it (L):
 					// count and matched bases of each kind in one word (count << 24 | bases: four reads of < 2^18 bases); the run
-					// into the next segment is L minus A.  A read that the cell does not settle -- it lies in another cell or in
-					// none, or runs past e2 -- shows as a count short of the reads in the range.
-					unsigned accA = 0, accL = 0, n_in = N_READS;
+					// into the next segment is L minus A.  lane_open: a read that the cell does not settle -- it lies in another
+					// cell or in none, or runs past e2.
+					unsigned accA = 0, accL = 0;
+					bool lane_open = false;
 					auto decide = [&](auto whole_step) {
-						if (!decltype(whole_step)::value) n_in = 0;
 #pragma unroll
 						for (int j = 0; j < N_READS; ++j) {
 							int s; unsigned len;
 							read_of(j, s, len);
 							bool in = true;
-							if (!decltype(whole_step)::value) { unsigned rel; in = in_range(j, rel); n_in += in ? 1u : 0u; }
+							if (!decltype(whole_step)::value) { unsigned rel; in = in_range(j, rel); }
 							const int e = s + (int)len;
 							const bool m = in && (unsigned)(s - lo) < width;
 							const bool a = m && e <= e1;
 							const bool l = m && e <= e2;
-							const unsigned p = len | (1u << 24);
+							lane_open = lane_open || (in && !l);
+							const unsigned p = len | (min(len, 1u) << 24);           // (an empty record -- the padding of a cell's group -- counts for nothing)
 							accA += a ? p : 0u;
 							accL += l ? p : 0u;
 						}
@@ -649,7 +652,6 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 						if (accA && both && s2 != CELL_NONE) atomicAdd(&C.hist[s2], addA);
 						if (accX && s2 != CELL_NONE) atomicAdd(&C.hist[s2], ((unsigned long long)(accX >> 24) << 40) | (accX & 0xFFFFFFu));
 					} else asm volatile("" ::"v"(accA), "v"(accL));
-					const bool lane_open = (accL >> 24) != n_in;
 					if (ABL(A, 256u)) {
 						const bool any_open = __any(lane_open);
 						if (lane == 0) { atomicAdd(&A.dbg[12], 1ull); atomicAdd(&A.dbg[11], any_open ? 1ull : 0ull); }
@@ -669,7 +671,7 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 								read_of(j, s, len);
 								const bool in = in_range(j, rel);
 								const bool m = (unsigned)(s - lo) < width;
-								const bool op = in && !(m && s + (int)len <= e2);
+								const bool op = in && len != 0u && !(m && s + (int)len <= e2);
 								open |= op ? 1u << (j - h) : 0u;
 								en[j - h] = make_uint4((unsigned)(s + ws), (unsigned)(s + ws) + len, (m && !both) ? (cx.w | PARK_ONE_EVENT) : PARK_EVENT_UNKNOWN, rel);
 								if (ABL(A, 256u) && op) { atomicAdd(&A.dbg[5 + (m ? (both ? 2 : 1) : 0)], 1ull); atomicAdd(&A.dbg[0], 1ull); }
@@ -1148,6 +1150,7 @@ __global__ void __launch_bounds__(256) lsq_count_recount_kernel(const CountArgs 
 		const GlobalBucket G = global_bucket(A, b);
 		for (unsigned long long g = A.p1_off[b] + lane; g < A.p1_off[b + 1]; g += 64u) {
 			int2 blk[1] = {pool1_read(A, g, A.buckets[b].lo)};
+			if (blk[0].y == blk[0].x) continue;      // padding of a cell's group
 			eval_read_global(A, G, blk, 1, first_event_for(G, blk[0].x), true, A.p1_strand[g], A.p1_line[g]);
 		}
 		for (unsigned long long g = A.p2_off[b] + lane; g < A.p2_off[b + 1]; g += 64u) {

@@ -220,6 +220,10 @@ int lsq_events_upload(lsq_ctx *c, lsq_events *E) {
 		for (size_t b = 0; b < E->buckets.size(); ++b) bb[b + 1] = bb[b] + E->buckets[b].n_bins;
 		c->n_fine = bb.back();
 		if ((rc = c->bin_base.upload(bb.data(), bb.size(), c->stream))) return rc;
+		std::vector<unsigned> cb(E->buckets.size() + 1, 0);
+		for (size_t b = 0; b < E->buckets.size(); ++b) cb[b + 1] = cb[b] + (E->buckets[b].kind == 1 ? (E->buckets[b].iso_off & 0xFFFFu) : 0u) + 1u;
+		c->n_cell_groups = cb.back();
+		if ((rc = c->cell_base.upload(cb.data(), cb.size(), c->stream))) return rc;
 	}
 	if ((rc = upload_strand_ranks(c))) return rc;
 	HIP_TRY(hipStreamSynchronize(c->stream));

@@ -231,7 +231,11 @@ int valid_reads(const lsq_events &E, const lsq::Event &ev, const BucketReads &R,
 		const unsigned cls = eval_read(ev, blk, nblk, first, &matched);
 		if (cls) valid.push_back({p, q, line, matched, (unsigned short)cls, strand});
 	};
-	for (size_t i = 0; i < R.p1_line.size(); ++i) { const int2 blk = make_int2(R.p1[2 * i], R.p1[2 * i + 1]); consider(&blk, 1, R.p1_strand[i], R.p1_line[i]); }
+	for (size_t i = 0; i < R.p1_line.size(); ++i) {
+		const int2 blk = make_int2(R.p1[2 * i], R.p1[2 * i + 1]);
+		if (blk.y == blk.x) continue;            // padding of a cell's group
+		consider(&blk, 1, R.p1_strand[i], R.p1_line[i]);
+	}
 	for (size_t i = 0; i < R.p2_line.size(); ++i) {
 		const int2 blk[2] = {make_int2(R.p2[4 * i], R.p2[4 * i + 1]), make_int2(R.p2[4 * i + 2], R.p2[4 * i + 3])};
 		consider(blk, 2, R.p2_strand[i], R.p2_line[i]);

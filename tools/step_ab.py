@@ -6,8 +6,8 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 import lesseq_amd as L
 from bench import WORKLOADS
-W = WORKLOADS["c3"]
-spec = L.SynthSpec(W["seed"], W["n_events"], W["n_reads"], W["R"], W["n_chrom"], L.EVENT_TYPES)
+W = WORKLOADS[os.environ.get("AB_WL", "c3")]
+spec = L.SynthSpec(W["seed"], W["n_events"], W["n_reads"], W["R"], W["n_chrom"], W["types"] or L.EVENT_TYPES, W.get("zipf", False))
 tmp = tempfile.mkdtemp()
 L.synth_write(spec, tmp, "w", write_mrf=False)
 ann = L.Annotation(tmp + "/w.interval", tmp + "/w.map")
