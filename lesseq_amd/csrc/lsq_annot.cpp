@@ -439,6 +439,7 @@ int plan_device(lsq_events &E) {
 	const size_t n = E.ev.size();
 	E.lds_budget = lds_budget_bytes();
 	E.buckets.clear(); E.images.clear(); E.dev2out.clear(); E.ties.clear();
+	E.jg_keys.clear(); E.jg_base.clear();
 	E.dev_cls_base.clear(); E.dev_iso_base.clear(); E.dev_K.clear();
 	E.cut_lo.assign(E.chroms.names.size(), {});
 	E.clu_s.assign(E.chroms.names.size(), {});
@@ -546,6 +547,7 @@ int plan_device(lsq_events &E) {
 				E.n_cls_total += ncls; E.n_iso_total += niso;
 				if (E.chrom_first_bucket[c] < 0) E.chrom_first_bucket[c] = (int32_t)E.buckets.size();
 				E.cut_lo[c].push_back((int32_t)lo);
+				E.jg_base.push_back((uint32_t)E.jg_keys.size());
 				E.buckets.push_back(d);
 				continue;
 			}
@@ -746,9 +748,19 @@ int plan_device(lsq_events &E) {
 			}
 			if (E.chrom_first_bucket[c] < 0) E.chrom_first_bucket[c] = (int32_t)E.buckets.size();
 			E.cut_lo[c].push_back((int32_t)lo);
+			E.jg_base.push_back((uint32_t)E.jg_keys.size());
+			if (fast)
+				for (uint32_t ci = 0; ci < n_main_cells; ++ci) {
+					const CellX &x = cellx[ci];
+					const uint32_t k = (x.info >> 2) & 0x3Fu;
+					if (x.info >= CELL_INFO_EMPTY || k == CELL_K_START) continue;
+					const Event &e = E.ev[lst[b_begin + x.ev]];
+					for (int k2 = (int)k + 1; k2 < e.N; ++k2) E.jg_keys.push_back(((uint64_t)ci << 32) | (uint32_t)(int32_t)e.seg_s[k2]);
+				}
 			E.buckets.push_back(d);
 		}
 	}
+	E.jg_base.push_back((uint32_t)E.jg_keys.size());
 	return LSQ_OK;
 }
 

@@ -253,6 +253,7 @@ __global__ void __launch_bounds__(COUNT_BLOCK) lsq_count_generic_kernel(CountArg
 			} else if (i < n1 + n2) {
 				const unsigned long long g = A.p2_off[b] + (i - n1);
 				const int4 rd = pool2_read(A, g, d.lo);
+				if (rd.y == rd.x) continue;          // padding of a junction group
 				process_read<2>(L, d, A, rd, nullptr, 2, (rd.y - rd.x) + (rd.w - rd.z), A.p2_strand, A.p2_line, g);
 			} else {
 				const unsigned long long g = A.pn_off[b] + (i - n1 - n2);
@@ -520,9 +521,9 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 	// words [w0, w1) of the workgroup, dealt to its waves a step at a time (wave, wave + 4, ...): the
 	// reads that need the general walk sit together in the start-ordered pool, and a contiguous
 	// quarter per wave would leave three waves waiting for the one that got them
-	// (compact pools: a 16-byte word of the pool holds the reads of two of these words, so the range starts on an even one;
-	// one-block reads: a lane's four records are one of the quadruples the pool's cell groups are padded to)
-	const unsigned long long w0 = (COMPACT || RPW == 2) ? ((g0 / RPW) & ~1ull) : g0 / RPW, w1 = (g1 + RPW - 1) / RPW;
+	// (the range starts on an even word: a lane's two words -- four one-block records, two two-block records -- are one of
+	// the quadruples / pairs the pools' groups are padded to, and one 16-byte word of a compact pool)
+	const unsigned long long w0 = (g0 / RPW) & ~1ull, w1 = (g1 + RPW - 1) / RPW;
 	const unsigned n_words = (unsigned)(w1 - w0);                                   // a workgroup's range stays below 2^21 reads
 	const unsigned ww0 = min(wave * TILE, n_words), ww1 = n_words;                   // relative to w0
 	const unsigned first_rel = (unsigned)(g0 - w0 * RPW);                            // reads of word w0 (and, compact, w0 + 1) before the range
@@ -698,7 +699,9 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 				// Everything else -- shared cells, a run over abutting segments, touching blocks -- is parked for the general walk.
 				// The ingest groups the reads of a bin by junction, so a lane's second read mostly crosses the junction of its
 				// first and only needs its outer ends compared; when it does not, it is parked.
-				struct Look { bool add, park; unsigned slot, matched, hint; bool junction; int4 c; };       // c: the cell of block 1 (lo, hi), -, end of block 2's segment
+				// junction: block 1 ends on its segment's end and block 2 starts a later segment of the same event (whether or not it
+				// also ends inside that segment); jslot: the histogram slot of that two-segment class, CELL_NONE without one
+				struct Look { bool add, park; unsigned slot, matched, hint; bool junction; unsigned jslot; int4 c; };       // c: the cell of block 1 (lo, hi), -, end of block 2's segment
 				auto look2 = [&](const int4 rd, const bool in) {
 					Look L;
 					unsigned c1, evf;
@@ -728,7 +731,8 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 					const unsigned long long tbl = ((unsigned long long)w0r.w << 32) | w0r.z;
 					const unsigned cls = (unsigned)(tbl >> (4u * ((1u << (k1 & 3u)) | (1u << k2)))) & 0xFu;
 					const unsigned sa = cx1.x & 0xFFFFu;
-					L.junction = J;
+					L.junction = cont;
+					L.jslot = cls != 0u ? (w0r.y & 0xFFFFu) + cls - 1u : CELL_NONE;
 					L.add = in && ((J && cls != 0u) || (S && sa != CELL_NONE && 50u * len1 > 49u * total));
 					L.slot = J ? (w0r.y & 0xFFFFu) + cls - 1u : sa;
 					L.matched = J ? total : len1;
@@ -744,7 +748,9 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 				const unsigned rel = w0i - first_rel;
 				const bool in = w0i < ww1 && rel < n_rel;
 				const Look L1 = look2(rd, in);
-				unsigned n_add = L1.add ? 1u : 0u, s_add = L1.add ? L1.matched : 0u;
+				// (the first read adds to its own slot -- the junction's or, for a read that stops after block 1, its segment's; the
+				// second, when it crosses the first one's junction, to the junction's)
+				unsigned n_add = L1.add ? 1u : 0u, s_add = L1.add ? L1.matched : 0u, n_add2 = 0, s_add2 = 0;
 				park[0] = L1.park && !ABL(A, 17u | 1048576u);
 				pe0[0] = u;
 				pe1[0] = make_uint4(L1.hint, rel, 0u, 0u);
@@ -756,17 +762,23 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 					const unsigned rel2 = wj - first_rel;
 					const bool in2 = wj < ww1 && rel2 < n_rel;
 					// same junction: block 1 ends and block 2 starts where the first read's do; then only the outer ends matter
-					const bool same = in2 && in && L1.junction && r2.y == rd.y && r2.z == rd.z && L1.c.x <= r2.x && r2.x < L1.c.y && r2.w <= L1.c.w;
-					n_add += (same && L1.add) ? 1u : 0u;
-					s_add += (same && L1.add) ? (unsigned)((r2.y - r2.x) + (r2.w - r2.z)) : 0u;
-					// another junction (or none): parked -- a full look of its own for the second read cost more than the
-					// walk it saved (measured: 0.246 against 0.253 ms)
-					park[j] = in2 && !same && !ABL(A, 17u | 1048576u | 2097152u);
+					const bool same = in2 && L1.junction && r2.y == rd.y && r2.z == rd.z && L1.c.x <= r2.x && r2.x < L1.c.y && r2.w <= L1.c.w;
+					n_add2 += (same && L1.jslot != CELL_NONE) ? 1u : 0u;
+					s_add2 += (same && L1.jslot != CELL_NONE) ? (unsigned)((r2.y - r2.x) + (r2.w - r2.z)) : 0u;
+					// Not the first read's junction (an empty record, the padding of a junction group, aside).  The pool is laid out
+					// by junction group, so that is a pair of the bucket's last group -- the reads that cross no junction of the
+					// annotation -- or a read that runs past its second segment: parked.  (A look of its own for such a second
+					// read, in the steps that hold such pairs only, was measured twice: 0.246 against 0.253 ms before the groups,
+					// 0.1627 against 0.1677 with them -- it costs more than the walk it saves.)
+					park[j] = in2 && !same && r2.y != r2.x && !ABL(A, 17u | 1048576u | 2097152u);
 					pe0[j] = v;
 					pe1[j] = make_uint4(PARK_EVENT_UNKNOWN, rel2, 0u, 0u);
 				}
-				if (!ABL(A, 1u)) { if (n_add) atomicAdd(&C.hist[L1.slot], ((unsigned long long)n_add << 40) | s_add); }
-				else asm volatile("" ::"v"(n_add), "v"(s_add));
+				if (!ABL(A, 1u)) {
+					if (n_add && n_add2 && L1.slot == L1.jslot) { n_add += n_add2; s_add += s_add2; n_add2 = 0; }
+					if (n_add) atomicAdd(&C.hist[L1.slot], ((unsigned long long)n_add << 40) | s_add);
+					if (n_add2) atomicAdd(&C.hist[L1.jslot], ((unsigned long long)n_add2 << 40) | s_add2);
+				} else asm volatile("" ::"v"(n_add), "v"(s_add), "v"(n_add2), "v"(s_add2));
 			}
 		}
 		if (RPW == 1) {
@@ -1155,6 +1167,7 @@ __global__ void __launch_bounds__(256) lsq_count_recount_kernel(const CountArgs 
 		}
 		for (unsigned long long g = A.p2_off[b] + lane; g < A.p2_off[b + 1]; g += 64u) {
 			const int4 v = pool2_read(A, g, A.buckets[b].lo);
+			if (v.y == v.x) continue;                // padding of a junction group
 			int2 blk[2] = {make_int2(v.x, v.y), make_int2(v.z, v.w)};
 			eval_read_global(A, G, blk, 2, first_event_for(G, v.x), true, A.p2_strand[g], A.p2_line[g]);
 		}

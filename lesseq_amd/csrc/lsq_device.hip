@@ -224,6 +224,13 @@ int lsq_events_upload(lsq_ctx *c, lsq_events *E) {
 		for (size_t b = 0; b < E->buckets.size(); ++b) cb[b + 1] = cb[b] + (E->buckets[b].kind == 1 ? (E->buckets[b].iso_off & 0xFFFFu) : 0u) + 1u;
 		c->n_cell_groups = cb.back();
 		if ((rc = c->cell_base.upload(cb.data(), cb.size(), c->stream))) return rc;
+		std::vector<unsigned> jb(E->buckets.size() + 1, 0);
+		for (size_t b = 0; b <= E->buckets.size(); ++b) jb[b] = E->jg_base[b] + (unsigned)b;       // the bucket's junction groups, then its "other" group
+		c->n_junction_groups = jb.back();
+		const unsigned long long none = 0;
+		if ((rc = c->jg_keys.upload(E->jg_keys.empty() ? &none : (const unsigned long long *)E->jg_keys.data(), std::max<size_t>(E->jg_keys.size(), 1), c->stream))) return rc;
+		if ((rc = c->jg_base.upload(E->jg_base.data(), E->jg_base.size(), c->stream))) return rc;
+		if ((rc = c->jgroup_base.upload(jb.data(), jb.size(), c->stream))) return rc;
 	}
 	if ((rc = upload_strand_ranks(c))) return rc;
 	HIP_TRY(hipStreamSynchronize(c->stream));

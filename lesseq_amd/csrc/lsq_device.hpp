@@ -77,7 +77,7 @@ struct MethodReads {
 	// at least 15 of 16 such reads fit them; compact pools are padded to whole 16-byte words
 	DevBuf<int32_t> p1, p2, pn_se;
 	bool compact = false;
-	uint64_t n1_reads = 0;                  // one-block reads in the pool (its slots also hold the groups' padding)
+	uint64_t n1_reads = 0, n2_reads = 0;    // one- and two-block reads in the pools (their slots also hold the groups' padding)
 	DevBuf<uint8_t> p1_strand, p2_strand, pn_strand;
 	DevBuf<uint32_t> p1_line, p2_line, pn_line, pn_blk_off, pn_nblk, pn_bucket;
 	DevBuf<unsigned long long> p1_off, p2_off, pn_off, pnb_off, slot_off;
@@ -163,6 +163,11 @@ struct lsq_ctx {
 	// neighbouring records and decides them against one cell.  cell_base: per bucket the first of its groups (n_buckets + 1).
 	DevBuf<unsigned> cell_base;
 	size_t n_cell_groups = 0;
+	// The two-block pool is laid out by junction group (lsq_events::jg_keys), every group padded to two records, and per
+	// bucket one more group for the reads that cross no known junction.  jgroup_base: per bucket the first of its groups.
+	DevBuf<unsigned long long> jg_keys;
+	DevBuf<unsigned> jg_base, jgroup_base;
+	size_t n_junction_groups = 0;
 	unsigned n_chrom_tables = 0;
 	// lsq_ctx_set_option: grid multiplier (0 = by the read set's skew), entries of a method's exception list
 	// (0 = a quarter of its reads, at least 64 Ki), recount every read with the one-lane-per-read kernel (self-check)

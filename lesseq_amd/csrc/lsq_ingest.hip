@@ -58,6 +58,7 @@ struct IngestTables {
 	const BucketDesc *buckets;
 	const unsigned *bin_base;
 	const unsigned *cell_base;      // per bucket: first of its one-block groups (its cells, then "no cell")
+	const unsigned long long *jg_keys; const unsigned *jg_base, *jgroup_base;      // junction groups of the two-block pool (lsq_events::jg_keys)
 	const unsigned char *images;    // the buckets' LDS images (bin records and cells of packed buckets)      // per bucket: first of its bins in the fine counters (n_buckets + 1)
 	unsigned n_chrom;
 };
@@ -73,14 +74,14 @@ struct IngestRaw {
 
 struct IngestWork {
 	unsigned *key;                 // per read: bucket * 4 + pool, or INGEST_NO_KEY
-	unsigned *fine;                // per read: two-block reads bin_base[bucket] + bin of the first base; one-block reads cell_base[bucket] + cell (or the bucket's "no cell" group)
+	unsigned *fine;                // per read: its group -- one-block reads cell_base[bucket] + cell (or the bucket's "no cell" group), two-block reads jgroup_base[bucket] + junction group (or the bucket's last)
 	unsigned char *nb;             // per read: merged blocks
 	unsigned char *strand;         // per read: strand id of the last kept block
 	int *ms, *me;                  // merged blocks, at the read's original block offset
-	unsigned *cnt1, *cnt2;         // one-block reads per group [n_cell_groups]; two-block reads per (bucket, bin) [n_fine]
+	unsigned *cnt1, *cnt2;         // one-block reads per group [n_cell_groups]; two-block reads per group [n_junction_groups]
 	unsigned *cntn, *cntnb;        // [n_buckets]: n-block reads, and their blocks
 	unsigned *cur1, *cur2, *curn, *curnb;   // scatter cursors, same shapes
-	unsigned long long *totals;    // [0] retained reads, [1] retained blocks, [2] error flag, [3] one- and two-block reads that do not fit compact records, [4] one-block reads pooled
+	unsigned long long *totals;    // [0] retained reads, [1] retained blocks, [2] error flag, [3] one- and two-block reads that do not fit compact records, [4] / [5] one- / two-block reads pooled
 	unsigned compact;              // compact pool records: one- and two-block reads that do not fit them go with the many-block reads
 };
 
@@ -119,7 +120,7 @@ __device__ inline bool covered_contains(const IngestTables &T, unsigned chrom, i
 
 __global__ void __launch_bounds__(256) lsq_ingest_classify_kernel(IngestTables T, IngestRaw R, IngestWork W) {
 	const unsigned long long gsz = (unsigned long long)gridDim.x * blockDim.x;
-	unsigned long long kept_reads = 0, kept_blocks = 0, misfits = 0, pooled1 = 0;
+	unsigned long long kept_reads = 0, kept_blocks = 0, misfits = 0, pooled1 = 0, pooled2 = 0;
 	for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < R.n_reads; i += gsz) {
 		const unsigned long long b0 = R.blk_off[i], b1 = R.blk_off[i + 1];
 		int s[INGEST_MAX_BLOCKS], e[INGEST_MAX_BLOCKS];
@@ -168,8 +169,8 @@ __global__ void __launch_bounds__(256) lsq_ingest_classify_kernel(IngestTables T
 						key = b * 4u + pool;
 						const int rel = s[0] - d.lo;
 						const unsigned bin = rel <= 0 ? 0u : min((unsigned)rel >> d.shift, d.n_bins - 1u);
-						unsigned fine = T.bin_base[b] + bin;
-						if (pool == 0) {
+						unsigned fine = 0;
+						if (pool < 2u) {
 							// the read's cell, found as the count kernel finds it (bin record: first cell | first event << 16, the
 							// ends of that cell and the next two; then on through the cell table)
 							unsigned n_cells = 0, cell = 0;
@@ -182,12 +183,25 @@ __global__ void __launch_bounds__(256) lsq_ingest_classify_kernel(IngestTables T
 								cell = (br.x & 0xFFFFu) + (unsigned)(p >= (int)br.y) + (unsigned)(p >= (int)br.z) + (unsigned)(p >= (int)br.w);
 								if (p >= (int)br.w) while (cell + 1u < n_cells && p >= cells[cell + 1u].lo) ++cell;
 								if (!(cell < n_cells && cells[cell].lo <= p && p < cells[cell].hi)) cell = n_cells;
-							}
-							fine = T.cell_base[b] + cell;
+								if (pool == 1u) {
+									// the junction group: block 1 ends on the end of the cell owner's segment, block 2 starts where a
+									// later segment of that event does (the keys hold exactly those starts); else the bucket's last group
+									const unsigned k0 = T.jg_base[b], k1 = T.jg_base[b + 1];
+									unsigned g = k1;
+									if (cell < n_cells && e[0] == cells[cell].e1) {
+										const unsigned long long want = ((unsigned long long)cell << 32) | (unsigned)s[1];
+										unsigned lo_k = k0, hi_k = k1;
+										while (lo_k < hi_k) { const unsigned mid = (lo_k + hi_k) >> 1; if (T.jg_keys[mid] < want) lo_k = mid + 1; else hi_k = mid; }
+										if (lo_k < k1 && T.jg_keys[lo_k] == want) g = lo_k;
+									}
+									fine = T.jgroup_base[b] + (g - k0);
+								}
+							} else if (pool == 1u) fine = T.jgroup_base[b] + (T.jg_base[b + 1] - T.jg_base[b]);
+							if (pool == 0u) fine = T.cell_base[b] + cell;
 						}
 						W.fine[i] = fine;
 						if (pool == 0) { atomicAdd(&W.cnt1[fine], 1u); ++pooled1; }
-						else if (pool == 1) atomicAdd(&W.cnt2[fine], 1u);
+						else if (pool == 1) { atomicAdd(&W.cnt2[fine], 1u); ++pooled2; }
 						else { atomicAdd(&W.cntn[b], 1u); atomicAdd(&W.cntnb[b], (unsigned)n); }
 					}
 				}
@@ -201,12 +215,13 @@ __global__ void __launch_bounds__(256) lsq_ingest_classify_kernel(IngestTables T
 	if (kept_reads) { atomicAdd(&W.totals[0], kept_reads); atomicAdd(&W.totals[1], kept_blocks); }
 	if (misfits) atomicAdd(&W.totals[3], misfits);
 	if (pooled1) atomicAdd(&W.totals[4], pooled1);
+	if (pooled2) atomicAdd(&W.totals[5], pooled2);
 }
 
-// one workgroup: out[i] = sum of in[0..i), out[n] = total; PAD4: every value rounded up to a multiple of four first
-template <bool PAD4>
+// one workgroup: out[i] = sum of in[0..i), out[n] = total; every value rounded up to a multiple of PAD (a power of two) first
+template <unsigned PAD>
 __global__ void __launch_bounds__(1024) lsq_scan_u32_kernel(const unsigned *in_raw, unsigned long long n, unsigned long long *out) {
-	auto in = [&](unsigned long long b) { const unsigned v = in_raw[b]; return PAD4 ? ((v + 3u) & ~3u) : v; };
+	auto in = [&](unsigned long long b) { const unsigned v = in_raw[b]; return (v + (PAD - 1u)) & ~(PAD - 1u); };
 	__shared__ unsigned long long part[1024];
 	const unsigned tid = threadIdx.x;
 	const unsigned long long per = (n + 1023ull) / 1024ull;
@@ -223,12 +238,12 @@ __global__ void __launch_bounds__(1024) lsq_scan_u32_kernel(const unsigned *in_r
 }
 
 // per-bucket pool offsets out of the per-bin ones
-__global__ void __launch_bounds__(256) lsq_ingest_offsets_kernel(const unsigned *cell_base, const unsigned *bin_base, unsigned n_buckets, const unsigned long long *off1,
+__global__ void __launch_bounds__(256) lsq_ingest_offsets_kernel(const unsigned *cell_base, const unsigned *jgroup_base, unsigned n_buckets, const unsigned long long *off1,
                                                                  const unsigned long long *off2, const unsigned long long *pn_off,
                                                                  unsigned long long *p1_off, unsigned long long *p2_off, unsigned long long *slot_off) {
 	const unsigned b = blockIdx.x * blockDim.x + threadIdx.x;
 	if (b > n_buckets) return;
-	const unsigned long long a1 = off1[cell_base[b]], a2 = off2[bin_base[b]];
+	const unsigned long long a1 = off1[cell_base[b]], a2 = off2[jgroup_base[b]];
 	p1_off[b] = a1; p2_off[b] = a2;
 	slot_off[b] = a1 + a2 + pn_off[b];
 }
@@ -247,7 +262,7 @@ template <bool COMPACT> __device__ inline void pool_store(void *out, const unsig
 struct IngestOut {
 	void *p1; unsigned char *p1_strand; unsigned *p1_line;           // the one-block pool itself (groups by cell: no sort follows)
 	unsigned compact; const BucketDesc *buckets;
-	int4 *p2; unsigned char *p2_strand; unsigned *p2_line;
+	void *p2; unsigned char *p2_strand; unsigned *p2_line;           // the two-block pool itself (groups by junction)
 	unsigned *pn_blk_off, *pn_nblk, *pn_line, *pn_bucket; unsigned char *pn_strand; int2 *pn_se;
 	const unsigned long long *off1, *off2, *pn_off, *pnb_off;       // per one-block group / per (bucket, bin) / per bucket
 };
@@ -267,9 +282,11 @@ __global__ void __launch_bounds__(256) lsq_ingest_scatter_kernel(IngestRaw R, In
 			if (O.compact) pool_store<true>(O.p1, w, r, base); else pool_store<false>(O.p1, w, r, base);
 			O.p1_strand[w] = W.strand[i]; O.p1_line[w] = R.line_no[i];
 		} else if (pool == 1) {
-			const unsigned fine = W.fine[i];
-			const unsigned long long w = O.off2[fine] + atomicAdd(&W.cur2[fine], 1u);
-			O.p2[w] = make_int4(W.ms[b0], W.me[b0], W.ms[b0 + 1], W.me[b0 + 1]);
+			const unsigned group = W.fine[i];
+			const unsigned long long w = O.off2[group] + atomicAdd(&W.cur2[group], 1u);
+			const int4 r = make_int4(W.ms[b0], W.me[b0], W.ms[b0 + 1], W.me[b0 + 1]);
+			const int base = O.buckets[b].lo - lsq::COMPACT_BIAS;
+			if (O.compact) pool_store<true>(O.p2, w, r, base); else pool_store<false>(O.p2, w, r, base);
 			O.p2_strand[w] = W.strand[i]; O.p2_line[w] = R.line_no[i];
 		} else {
 			const unsigned n = W.nb[i];
@@ -282,21 +299,34 @@ __global__ void __launch_bounds__(256) lsq_ingest_scatter_kernel(IngestRaw R, In
 	}
 }
 
-// The padding of the one-block groups (up to three records each): empty reads -- length 0 -- that start on the cell's
-// first base, so that the count kernel's loop sees them as inside the cell and adding nothing.
-__global__ void __launch_bounds__(256) lsq_ingest_pad_kernel(const BucketDesc *buckets, const unsigned *cell_base, unsigned n_buckets, unsigned n_groups,
-                                                             const unsigned *cnt1, const unsigned long long *off1, const unsigned char *images,
-                                                             void *p1, unsigned compact, unsigned char *p1_strand, unsigned *p1_line) {
-	for (unsigned g = blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += gridDim.x * blockDim.x) {
-		const unsigned n = cnt1[g], pad = ((n + 3u) & ~3u) - n;
+// The padding of the groups (up to three records in a one-block group, one in a two-block group): empty reads.  A
+// one-block one starts on its cell's first base, so that the count kernel's loop sees it as inside the cell and adding
+// nothing; a two-block one is always the second of a lane's pair and is passed over there.
+__global__ void __launch_bounds__(256) lsq_ingest_pad_kernel(const BucketDesc *buckets, const unsigned *cell_base, const unsigned *jgroup_base, unsigned n_buckets,
+                                                             unsigned n_groups1, unsigned n_groups2, const unsigned *cnt1, const unsigned long long *off1,
+                                                             const unsigned *cnt2, const unsigned long long *off2, const unsigned char *images,
+                                                             void *p1, void *p2, unsigned compact, unsigned char *p1_strand, unsigned *p1_line,
+                                                             unsigned char *p2_strand, unsigned *p2_line) {
+	for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < n_groups1 + n_groups2; t += gridDim.x * blockDim.x) {
+		const bool one = t < n_groups1;
+		const unsigned g = one ? t : t - n_groups1;
+		const unsigned n = one ? cnt1[g] : cnt2[g], pad = one ? ((n + 3u) & ~3u) - n : (n & 1u);
 		if (!pad) continue;
-		unsigned lo_b = 0, hi_b = n_buckets;                 // bucket of the group: last b with cell_base[b] <= g
-		while (hi_b - lo_b > 1) { const unsigned mid = (lo_b + hi_b) >> 1; if (cell_base[mid] <= g) lo_b = mid; else hi_b = mid; }
+		const unsigned *gbase = one ? cell_base : jgroup_base;
+		unsigned lo_b = 0, hi_b = n_buckets;                 // bucket of the group: last b with gbase[b] <= g
+		while (hi_b - lo_b > 1) { const unsigned mid = (lo_b + hi_b) >> 1; if (gbase[mid] <= g) lo_b = mid; else hi_b = mid; }
 		const BucketDesc &d = buckets[lo_b];
+		const int base = d.lo - lsq::COMPACT_BIAS;
+		if (!one) {
+			const unsigned long long w = off2[g] + n;
+			if (compact) reinterpret_cast<uint2 *>(p2)[w] = make_uint2((unsigned)lsq::COMPACT_BIAS, 0u);
+			else reinterpret_cast<int4 *>(p2)[w] = make_int4(d.lo, d.lo, d.lo, d.lo);
+			p2_strand[w] = 0; p2_line[w] = 0;
+			continue;
+		}
 		const unsigned cell = g - cell_base[lo_b];
 		int at = d.lo;
 		if (d.kind == 1u && cell < (d.iso_off & 0xFFFFu)) at = reinterpret_cast<const lsq::Cell *>(images + d.img_off + d.seg_off)[cell].lo;
-		const int base = d.lo - lsq::COMPACT_BIAS;
 		if (compact && !lsq::compact_block_fits((long long)at - base, 1)) at = base;       // (a cell 2 Mi bases into its bucket: the loop then parks nothing for it all the same, the record is empty)
 		for (unsigned q = 0; q < pad; ++q) {
 			const unsigned long long w = off1[g] + n + q;
@@ -304,62 +334,6 @@ __global__ void __launch_bounds__(256) lsq_ingest_pad_kernel(const BucketDesc *b
 			else reinterpret_cast<int2 *>(p1)[w] = make_int2(at, at);
 			p1_strand[w] = 0; p1_line[w] = 0;
 		}
-	}
-}
-
-// Orders the two-block reads of every (bucket, bin) by their junction (end of block 1, start of block 2 -- the count
-// kernel decides a lane's second read against the junction of its first): a counting sort in LDS over a hash of the
-// pair (only "equal keys sit together" matters), one wave per bin (the scatter above left the bin's reads together, in
-// the order its atomics gave).  One-block reads need no such pass: the scatter puts them into their cell's group, the
-// device form of the reference's read index (a std::set ordered by start, count/count.cpp:348-364) at the grain the
-// count kernel works at.  Bins wider than BINSORT_MAX_W coordinates are copied as they are -- the order only matters for
-// speed.
-constexpr unsigned BINSORT_MAX_W = 2048;
-__device__ inline unsigned binsort_key(const int4 r, int bin_lo, unsigned W) {
-	(void)bin_lo;
-	return (((unsigned)r.y * 2654435761u) ^ ((unsigned)r.z * 2246822519u)) >> 21 & (W - 1u);      // W is a power of two
-}
-
-template <class ReadT, bool COMPACT>
-__global__ void __launch_bounds__(256) lsq_ingest_binsort_kernel(const BucketDesc *buckets, const unsigned *bin_base, unsigned n_buckets, unsigned n_fine,
-                                                                 const unsigned long long *off, const ReadT *in, const unsigned char *in_strand,
-                                                                 const unsigned *in_line, void *out, unsigned char *out_strand, unsigned *out_line) {
-	__shared__ unsigned cnt_all[4][BINSORT_MAX_W];
-	const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-	unsigned *cnt = cnt_all[wave];
-	for (unsigned fine = blockIdx.x * 4u + wave; fine < n_fine; fine += gridDim.x * 4u) {
-		const unsigned long long o0 = off[fine], o1 = off[fine + 1];
-		if (o0 == o1) continue;
-		const unsigned n = (unsigned)(o1 - o0);
-		unsigned lo_b = 0, hi_b = n_buckets;                 // bucket of the bin: last b with bin_base[b] <= fine
-		while (hi_b - lo_b > 1) { const unsigned mid = (lo_b + hi_b) >> 1; if (bin_base[mid] <= fine) lo_b = mid; else hi_b = mid; }
-		const BucketDesc &d = buckets[lo_b];
-		const unsigned W = d.shift < 31u ? (1u << d.shift) : 0x80000000u;
-		const int base = d.lo - lsq::COMPACT_BIAS;
-		if (W > BINSORT_MAX_W || n < 3) {
-			for (unsigned i = lane; i < n; i += 64u) { pool_store<COMPACT>(out, o0 + i, in[o0 + i], base); out_strand[o0 + i] = in_strand[o0 + i]; out_line[o0 + i] = in_line[o0 + i]; }
-			continue;
-		}
-		const int bin_lo = d.lo + (int)((fine - bin_base[lo_b]) << d.shift);
-		for (unsigned k = lane; k < W; k += 64u) cnt[k] = 0;
-		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-		for (unsigned i = lane; i < n; i += 64u) atomicAdd(&cnt[binsort_key(in[o0 + i], bin_lo, W)], 1u);
-		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-		// exclusive prefix over the W counters: W/64 consecutive ones per lane
-		const unsigned per = (W + 63u) / 64u, k0 = min(lane * per, W), k1 = min(k0 + per, W);
-		unsigned acc = 0;
-		for (unsigned k = k0; k < k1; ++k) acc += cnt[k];
-		unsigned inc = acc;
-		for (unsigned dd = 1; dd < 64; dd <<= 1) { const unsigned t = __shfl_up(inc, dd); if (lane >= dd) inc += t; }
-		unsigned run = inc - acc;
-		for (unsigned k = k0; k < k1; ++k) { const unsigned v = cnt[k]; cnt[k] = run; run += v; }
-		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-		for (unsigned i = lane; i < n; i += 64u) {
-			const ReadT r = in[o0 + i];
-			const unsigned pos = atomicAdd(&cnt[binsort_key(r, bin_lo, W)], 1u);
-			pool_store<COMPACT>(out, o0 + pos, r, base); out_strand[o0 + pos] = in_strand[o0 + i]; out_line[o0 + pos] = in_line[o0 + i];
-		}
-		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
 	}
 }
 
@@ -383,21 +357,22 @@ static int ingest_device(lsq_ctx *c, int method, const IngestRaw &Rw, uint64_t n
 	DevBuf<unsigned> d_key, d_fine;
 	DevBuf<unsigned> d_cnt;                      // cnt1 | cnt2 | cntn | cntnb, then the four cursor arrays
 	DevBuf<unsigned long long> d_off1, d_off2, d_totals;
-	const size_t F = c->n_fine;                  // bins of all buckets
 	const size_t FC = c->n_cell_groups;          // one-block groups of all buckets
-	const size_t n_cnt = FC + F + 2 * (size_t)B;
+	const size_t FJ = c->n_junction_groups;      // two-block groups of all buckets
+	const size_t n_cnt = FC + FJ + 2 * (size_t)B;
 	if ((rc = d_ms.alloc(nblk)) || (rc = d_me.alloc(nblk)) || (rc = d_nb.alloc(n)) || (rc = d_strand.alloc(n)) || (rc = d_key.alloc(n)) || (rc = d_fine.alloc(n))) return rc;
-	if ((rc = d_cnt.alloc(2 * n_cnt)) || (rc = d_off1.alloc(FC + 1)) || (rc = d_off2.alloc(F + 1)) || (rc = d_totals.alloc(8))) return rc;
+	if ((rc = d_cnt.alloc(2 * n_cnt)) || (rc = d_off1.alloc(FC + 1)) || (rc = d_off2.alloc(FJ + 1)) || (rc = d_totals.alloc(8))) return rc;
 	IngestTables T{};
 	T.cov_off = c->cov_off.p; T.cov_s = c->cov_s.p; T.cov_e = c->cov_e.p;
 	T.cut_off = c->cut_off.p; T.cut_lo = c->cut_lo.p; T.chrom_first_bucket = c->chrom_first_bucket.p;
 	T.clu_off = c->clu_off.p; T.clu_s = c->clu_s.p; T.clu_e = c->clu_e.p;
 	T.buckets = c->buckets.p; T.bin_base = c->bin_base.p; T.n_chrom = c->n_chrom_tables;
 	T.cell_base = c->cell_base.p; T.images = c->images.p;
+	T.jg_keys = c->jg_keys.p; T.jg_base = c->jg_base.p; T.jgroup_base = c->jgroup_base.p;
 	IngestWork W{};
 	W.key = d_key.p; W.fine = d_fine.p; W.nb = d_nb.p; W.strand = d_strand.p; W.ms = d_ms.p; W.me = d_me.p;
-	W.cnt1 = d_cnt.p; W.cnt2 = W.cnt1 + FC; W.cntn = W.cnt2 + F; W.cntnb = W.cntn + B;
-	W.cur1 = d_cnt.p + n_cnt; W.cur2 = W.cur1 + FC; W.curn = W.cur2 + F; W.curnb = W.curn + B;
+	W.cnt1 = d_cnt.p; W.cnt2 = W.cnt1 + FC; W.cntn = W.cnt2 + FJ; W.cntnb = W.cntn + B;
+	W.cur1 = d_cnt.p + n_cnt; W.cur2 = W.cur1 + FC; W.curn = W.cur2 + FJ; W.curnb = W.curn + B;
 	W.totals = d_totals.p;
 	W.compact = c->opt_compact_pools ? 1u : 0u;
 	const unsigned igrid = (unsigned)std::min<unsigned long long>((n + 255) / 256 + 1, (unsigned long long)c->n_cu * 16);
@@ -410,11 +385,11 @@ static int ingest_device(lsq_ctx *c, int method, const IngestRaw &Rw, uint64_t n
 			hipLaunchKernelGGL(lsq_ingest_classify_kernel, dim3(igrid), dim3(256), 0, st, T, Rw, W);
 			HIP_TRY(hipGetLastError());
 		}
-		hipLaunchKernelGGL(lsq_scan_u32_kernel<true>, dim3(1), dim3(1024), 0, st, W.cnt1, (unsigned long long)FC, d_off1.p);      // groups padded to four records
-		hipLaunchKernelGGL(lsq_scan_u32_kernel<false>, dim3(1), dim3(1024), 0, st, W.cnt2, (unsigned long long)F, d_off2.p);
-		hipLaunchKernelGGL(lsq_scan_u32_kernel<false>, dim3(1), dim3(1024), 0, st, W.cntn, (unsigned long long)B, mr.pn_off.p);
-		hipLaunchKernelGGL(lsq_scan_u32_kernel<false>, dim3(1), dim3(1024), 0, st, W.cntnb, (unsigned long long)B, mr.pnb_off.p);
-		hipLaunchKernelGGL(lsq_ingest_offsets_kernel, dim3(B / 256 + 1), dim3(256), 0, st, c->cell_base.p, c->bin_base.p, B, d_off1.p, d_off2.p, mr.pn_off.p,
+		hipLaunchKernelGGL(lsq_scan_u32_kernel<4>, dim3(1), dim3(1024), 0, st, W.cnt1, (unsigned long long)FC, d_off1.p);      // groups padded to four records
+		hipLaunchKernelGGL(lsq_scan_u32_kernel<2>, dim3(1), dim3(1024), 0, st, W.cnt2, (unsigned long long)FJ, d_off2.p);     // ... to two
+		hipLaunchKernelGGL(lsq_scan_u32_kernel<1>, dim3(1), dim3(1024), 0, st, W.cntn, (unsigned long long)B, mr.pn_off.p);
+		hipLaunchKernelGGL(lsq_scan_u32_kernel<1>, dim3(1), dim3(1024), 0, st, W.cntnb, (unsigned long long)B, mr.pnb_off.p);
+		hipLaunchKernelGGL(lsq_ingest_offsets_kernel, dim3(B / 256 + 1), dim3(256), 0, st, c->cell_base.p, c->jgroup_base.p, B, d_off1.p, d_off2.p, mr.pn_off.p,
 		                   mr.p1_off.p, mr.p2_off.p, mr.slot_off.p);
 		HIP_TRY(hipGetLastError());
 		SW.mark("ingest: allocs + classify launch");
@@ -427,7 +402,7 @@ static int ingest_device(lsq_ctx *c, int method, const IngestRaw &Rw, uint64_t n
 		SW.mark("ingest: classify + scans done");
 		// compact records pay when nearly every one- and two-block read fits them (the others are counted a lane a read, tables
 		// in L2); a read set of long blocks -- more than 1 in 16 does not fit -- is classified again for wide records
-		if (W.compact && tot[3] * 16 > tot[4] + sums[1] + tot[3]) { W.compact = 0; continue; }
+		if (W.compact && tot[3] * 16 > tot[4] + tot[5] + tot[3]) { W.compact = 0; continue; }
 		break;
 	}
 	if (tot[2]) return fail(LSQ_E_RANGE, "a read covers 2^18 or more bases or keeps more than %d separate blocks: outside the device tables' range", INGEST_MAX_BLOCKS);
@@ -435,45 +410,29 @@ static int ingest_device(lsq_ctx *c, int method, const IngestRaw &Rw, uint64_t n
 	if (n > 0xFFFFFFF0ull) return fail(LSQ_E_RANGE, "more than 2^32 reads in one file");
 	const size_t n1 = (size_t)sums[0], n2 = (size_t)sums[1], nn = (size_t)sums[2], nnb = (size_t)sums[3];
 	mr.compact = W.compact != 0;
-	mr.n1_reads = tot[4];
-	// (n1: the one-block pool's slots, the groups' padding among them.  Compact pools: whole 16-byte words, the count kernel
-	// loads the word a range ends in)
+	mr.n1_reads = tot[4]; mr.n2_reads = tot[5];
+	// (n1, n2: the pools' slots, the groups' padding among them: multiples of four and of two, so compact pools are whole
+	// 16-byte words)
 	if ((rc = mr.p1.alloc(mr.compact ? ((n1 + 3) & ~(size_t)3) : 2 * n1)) || (rc = mr.p1_strand.alloc(n1)) || (rc = mr.p1_line.alloc(n1))) return rc;
 	if ((rc = mr.p2.alloc(mr.compact ? 2 * ((n2 + 1) & ~(size_t)1) : 4 * n2)) || (rc = mr.p2_strand.alloc(n2)) || (rc = mr.p2_line.alloc(n2))) return rc;
-	if (mr.compact) {           // the padding is read (and ignored) by the kernel: keep it defined
-		if (n1 & 3) HIP_TRY(hipMemsetAsync(mr.p1.p + n1, 0, (4 - (n1 & 3)) * 4, st));
-		if (n2 & 1) HIP_TRY(hipMemsetAsync(mr.p2.p + 2 * n2, 0, 2 * 4, st));
-	}
 	if ((rc = mr.pn_se.alloc(2 * nnb)) || (rc = mr.pn_blk_off.alloc(nn)) || (rc = mr.pn_nblk.alloc(nn)) || (rc = mr.pn_strand.alloc(nn)) ||
 	    (rc = mr.pn_line.alloc(nn)) || (rc = mr.pn_bucket.alloc(nn))) return rc;
 	if (n) {
-		// the scatter writes the one-block pool itself (its groups need no order inside) and a temporary for the two-block
-		// reads, which the per-bin sort turns into their pool
-		DevBuf<int32_t> t_p2;
-		DevBuf<uint8_t> t_p2_strand;
-		DevBuf<uint32_t> t_p2_line;
-		if ((rc = t_p2.alloc(4 * n2)) || (rc = t_p2_strand.alloc(n2)) || (rc = t_p2_line.alloc(n2))) return rc;
+		// the scatter writes the pools themselves: their groups need no order inside
 		IngestOut O{};
 		O.p1 = mr.p1.p; O.p1_strand = mr.p1_strand.p; O.p1_line = mr.p1_line.p;
 		O.compact = mr.compact ? 1u : 0u; O.buckets = c->buckets.p;
-		O.p2 = reinterpret_cast<int4 *>(t_p2.p); O.p2_strand = t_p2_strand.p; O.p2_line = t_p2_line.p;
+		O.p2 = mr.p2.p; O.p2_strand = mr.p2_strand.p; O.p2_line = mr.p2_line.p;
 		O.pn_blk_off = mr.pn_blk_off.p; O.pn_nblk = mr.pn_nblk.p; O.pn_line = mr.pn_line.p; O.pn_bucket = mr.pn_bucket.p;
 		O.pn_strand = mr.pn_strand.p; O.pn_se = reinterpret_cast<int2 *>(mr.pn_se.p);
 		O.off1 = d_off1.p; O.off2 = d_off2.p; O.pn_off = mr.pn_off.p; O.pnb_off = mr.pnb_off.p;
 		hipLaunchKernelGGL(lsq_ingest_scatter_kernel, dim3(igrid), dim3(256), 0, st, Rw, W, O);
-		hipLaunchKernelGGL(lsq_ingest_pad_kernel, dim3((unsigned)std::min<size_t>(FC / 256 + 1, (size_t)c->n_cu * 8)), dim3(256), 0, st, c->buckets.p, c->cell_base.p, B, (unsigned)FC,
-		                   W.cnt1, d_off1.p, c->images.p, (void *)mr.p1.p, O.compact, mr.p1_strand.p, mr.p1_line.p);
+		const unsigned pgrid = (unsigned)std::min<size_t>((FC + FJ) / 256 + 1, (size_t)c->n_cu * 8);
+		hipLaunchKernelGGL(lsq_ingest_pad_kernel, dim3(pgrid), dim3(256), 0, st, c->buckets.p, c->cell_base.p, c->jgroup_base.p, B, (unsigned)FC, (unsigned)FJ,
+		                   W.cnt1, d_off1.p, W.cnt2, d_off2.p, c->images.p, (void *)mr.p1.p, (void *)mr.p2.p, O.compact, mr.p1_strand.p, mr.p1_line.p, mr.p2_strand.p, mr.p2_line.p);
 		HIP_TRY(hipGetLastError());
-		const unsigned sgrid = (unsigned)std::min<size_t>(F / 4 + 1, (size_t)c->n_cu * 32);
-		auto sort_pool = [&](auto kernel, const auto *in, const unsigned long long *off, const uint8_t *in_strand, const uint32_t *in_line, void *out, uint8_t *out_strand, uint32_t *out_line) {
-			hipLaunchKernelGGL(kernel, dim3(sgrid), dim3(256), 0, st, c->buckets.p, c->bin_base.p, B, (unsigned)F, off, in, in_strand, in_line, out, out_strand, out_line);
-		};
-		const int4 *in2 = reinterpret_cast<const int4 *>(t_p2.p);
-		if (n2 && mr.compact) sort_pool(lsq_ingest_binsort_kernel<int4, true>, in2, d_off2.p, t_p2_strand.p, t_p2_line.p, mr.p2.p, mr.p2_strand.p, mr.p2_line.p);
-		if (n2 && !mr.compact) sort_pool(lsq_ingest_binsort_kernel<int4, false>, in2, d_off2.p, t_p2_strand.p, t_p2_line.p, mr.p2.p, mr.p2_strand.p, mr.p2_line.p);
-		HIP_TRY(hipGetLastError());
-		HIP_TRY(hipStreamSynchronize(st));            // the temporaries go out of scope here
-		SW.mark("ingest: scatter + bin sort done");
+		HIP_TRY(hipStreamSynchronize(st));            // the work arrays go out of scope at the end of this function
+		SW.mark("ingest: scatter done");
 	}
 	SW.mark("ingest: pool temporaries freed");
 	{
@@ -639,7 +598,7 @@ uint64_t lsq_reads_retained(const lsq_ctx *c, int method) { return (c && method 
 uint64_t lsq_reads_pooled(const lsq_ctx *c, int method) {
 	if (!c || method < 0 || method >= LSQ_MAX_METHODS) return 0;
 	const MethodReads &mr = c->reads[method];
-	return mr.n1_reads + mr.p2_line.n + mr.pn_line.n;          // (total_slots also counts the padding of the one-block groups)
+	return mr.n1_reads + mr.n2_reads + mr.pn_line.n;          // (total_slots also counts the padding of the groups)
 }
 uint64_t lsq_reads_retained_blocks(const lsq_ctx *c, int method) { return (c && method >= 0 && method < LSQ_MAX_METHODS) ? c->reads[method].n_retained_blocks : 0; }
 
@@ -649,7 +608,7 @@ int lsq_reads_pool_format(const lsq_ctx *c, int method, int *compact, uint64_t *
 	if (!mr.present) return fail(LSQ_E_STATE, "no reads uploaded for method %d", method);
 	if (compact) *compact = mr.compact ? 1 : 0;
 	if (pool_bytes) *pool_bytes = 4ull * (mr.p1.n + mr.p2.n + mr.pn_se.n);
-	if (pool_reads) { pool_reads[0] = mr.n1_reads; pool_reads[1] = mr.p2_line.n; pool_reads[2] = mr.pn_line.n; }
+	if (pool_reads) { pool_reads[0] = mr.n1_reads; pool_reads[1] = mr.n2_reads; pool_reads[2] = mr.pn_line.n; }
 	return LSQ_OK;
 }
 

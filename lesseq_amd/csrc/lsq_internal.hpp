@@ -180,6 +180,12 @@ struct lsq_events {
 	uint32_t lds_budget = 0;
 	std::vector<lsq::BucketDesc> buckets;          // sorted by (chrom_id, lo)
 	std::vector<uint8_t> images;                   // all bucket images
+	// Junction groups of the two-block pool: per bucket the sorted keys (cell << 32 | start of block 2) of the reads the
+	// count kernel settles as junction reads -- block 1 starts in a one-owner cell, ends on the end of that owner's segment,
+	// block 2 starts on the first base of a later segment of the same event.  The ingest lays the two-block reads out by
+	// these groups (and one group per bucket for all others), padded to two records: a lane's two reads cross one junction.
+	std::vector<uint64_t> jg_keys;
+	std::vector<uint32_t> jg_base;                 // per bucket: first of its keys (n_buckets + 1)
 	std::vector<int32_t> dev2out;                  // device event index -> output index
 	std::vector<uint32_t> dev_cls_base;            // per device event
 	std::vector<uint32_t> dev_iso_base;            // per device event

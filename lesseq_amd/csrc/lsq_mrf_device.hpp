@@ -314,7 +314,7 @@ static int scan_newlines(lsq_ctx *c, lsq_text &T) {
 		if ((rc = d_tile_cnt.alloc(n_tiles)) || (rc = d_tile_base.alloc(n_tiles + 1))) return rc;
 		hipLaunchKernelGGL(lsq_mrf_newline_count_kernel, dim3((unsigned)n_tiles), dim3(256), 0, st, T.d_text.p, len, d_tile_cnt.p);
 		HIP_TRY(hipGetLastError());
-		hipLaunchKernelGGL(lsq_scan_u32_kernel<false>, dim3(1), dim3(1024), 0, st, d_tile_cnt.p, n_tiles, d_tile_base.p);
+		hipLaunchKernelGGL(lsq_scan_u32_kernel<1>, dim3(1), dim3(1024), 0, st, d_tile_cnt.p, n_tiles, d_tile_base.p);
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(hipMemcpyAsync(&T.n_nl, d_tile_base.p + n_tiles, 8, hipMemcpyDeviceToHost, st));
 		HIP_TRY(hipStreamSynchronize(st));
@@ -368,8 +368,8 @@ static int parse_staged_text(lsq_ctx *c, const char *read_format, lsq_text &T, u
 	hipLaunchKernelGGL(lsq_mrf_count_kernel, dim3((unsigned)n_wg), dim3(256), 0, st, d_text.p, d_nl_pos.p, n_lines, has_header, first_line,
 	                   d_line_nb.p, d_wg_reads.p, d_wg_blocks.p, d_err.p);
 	HIP_TRY(hipGetLastError());
-	hipLaunchKernelGGL(lsq_scan_u32_kernel<false>, dim3(1), dim3(1024), 0, st, d_wg_reads.p, n_wg, d_rd_base.p);
-	hipLaunchKernelGGL(lsq_scan_u32_kernel<false>, dim3(1), dim3(1024), 0, st, d_wg_blocks.p, n_wg, d_bk_base.p);
+	hipLaunchKernelGGL(lsq_scan_u32_kernel<1>, dim3(1), dim3(1024), 0, st, d_wg_reads.p, n_wg, d_rd_base.p);
+	hipLaunchKernelGGL(lsq_scan_u32_kernel<1>, dim3(1), dim3(1024), 0, st, d_wg_blocks.p, n_wg, d_bk_base.p);
 	HIP_TRY(hipGetLastError());
 	unsigned long long n_reads = 0, n_blocks = 0;
 	HIP_TRY(hipMemcpyAsync(err, d_err.p, sizeof(err), hipMemcpyDeviceToHost, st));

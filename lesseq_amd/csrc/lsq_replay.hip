@@ -238,6 +238,7 @@ int valid_reads(const lsq_events &E, const lsq::Event &ev, const BucketReads &R,
 	}
 	for (size_t i = 0; i < R.p2_line.size(); ++i) {
 		const int2 blk[2] = {make_int2(R.p2[4 * i], R.p2[4 * i + 1]), make_int2(R.p2[4 * i + 2], R.p2[4 * i + 3])};
+		if (blk[0].y == blk[0].x) continue;      // padding of a junction group
 		consider(blk, 2, R.p2_strand[i], R.p2_line[i]);
 	}
 	for (size_t i = 0; i < R.pn_line.size(); ++i) {
