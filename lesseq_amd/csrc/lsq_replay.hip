@@ -420,4 +420,64 @@ int lsq_solve_finalize(lsq_ctx *c, uint32_t *n_replayed) {
 	return rc;
 }
 
+// Developer check of the pools' layout (tests): every aligned quadruple of one-block records starts in one cell (or all
+// in none), every aligned pair of two-block records of a junction group crosses one junction, and the records that are
+// not padding number what the ingest counted.  out: [0] one-block records, [1] of them padding, [2] quadruples over more
+// than one cell, [3] two-block records, [4] of them padding, [5] pairs whose first read crosses a junction of the
+// annotation and whose second crosses another or none.
+int lsq_debug_check_pool_layout(lsq_ctx *c, int method, unsigned long long *out) {
+	if (!c || !c->E || !out || method < 0 || method >= c->E->n_methods) return fail(LSQ_E_ARG, "bad argument");
+	HIP_TRY(hipSetDevice(c->device));
+	{ int rc = lsq::sync_all(c); if (rc) return rc; }
+	const lsq_events &E = *c->E;
+	const lsq::MethodReads &mr = c->reads[method];
+	if (!mr.present) return fail(LSQ_E_STATE, "no reads uploaded for method %d", method);
+	for (int q = 0; q < 6; ++q) out[q] = 0;
+	for (size_t b = 0; b < E.buckets.size(); ++b) {
+		const lsq::BucketDesc &d = E.buckets[b];
+		BucketReads R;
+		{ int rc = fetch_bucket(mr, b, d.lo, R); if (rc) return rc; }
+		const lsq::Cell *cells = d.kind == 1 ? reinterpret_cast<const lsq::Cell *>(E.images.data() + d.img_off + d.seg_off) : nullptr;
+		const unsigned n_cells = d.kind == 1 ? (d.iso_off & 0xFFFFu) : 0u;
+		auto cell_of = [&](int p) -> long {
+			for (unsigned q = 0; q < n_cells; ++q) if (cells[q].lo <= p && p < cells[q].hi) return (long)q;
+			return -1;
+		};
+		const size_t n1 = R.p1_line.size(), n2 = R.p2_line.size();
+		if ((n1 & 3u) || (n2 & 1u)) return fail(LSQ_E_STATE, "bucket %zu: pool slices of %zu and %zu records are not whole quadruples / pairs", b, n1, n2);
+		out[0] += n1; out[3] += n2;
+		for (size_t q = 0; q < n1; q += 4) {
+			long first = -2;
+			bool mixed = false;
+			for (size_t k = q; k < q + 4; ++k) {
+				const int s = R.p1[2 * k], e = R.p1[2 * k + 1];
+				if (s == e) { ++out[1]; continue; }
+				const long cl = cell_of(s);
+				if (first == -2) first = cl; else if (cl != first) mixed = true;
+			}
+			if (mixed) ++out[2];
+		}
+		const uint64_t *k0 = E.jg_keys.data() + E.jg_base[b], *k1 = E.jg_keys.data() + E.jg_base[b + 1];
+		auto group_of = [&](const int32_t *r) -> long {          // index of the read's junction key, -1: the bucket's last group
+			const long cl = cell_of(r[0]);
+			if (cl < 0 || r[1] != cells[cl].e1) return -1;
+			const uint64_t want = ((uint64_t)cl << 32) | (uint32_t)r[2];
+			const uint64_t *it = std::lower_bound(k0, k1, want);
+			return (it != k1 && *it == want) ? (long)(it - k0) : -1;
+		};
+		for (size_t q = 0; q < n2; q += 2) {
+			const int32_t *ra = &R.p2[4 * q], *rb = &R.p2[4 * (q + 1)];
+			const bool ea = ra[0] == ra[1], eb = rb[0] == rb[1];
+			out[4] += (ea ? 1u : 0u) + (eb ? 1u : 0u);
+			if (ea) { if (!eb) ++out[5]; continue; }           // padding never comes first
+			const long ga = group_of(ra);
+			if (ga >= 0 && !eb && group_of(rb) != ga) ++out[5];
+		}
+	}
+	if (out[0] - out[1] != mr.n1_reads || out[3] - out[4] != mr.n2_reads)
+		return fail(LSQ_E_STATE, "the pools hold %llu + %llu reads, the ingest counted %llu + %llu", out[0] - out[1], out[3] - out[4],
+		            (unsigned long long)mr.n1_reads, (unsigned long long)mr.n2_reads);
+	return LSQ_OK;
+}
+
 } // extern "C"

@@ -619,6 +619,34 @@ def test_reads_that_do_not_fit_compact_records(tmp_path):
         assert rc == rc2 == 0 and text == ctext, tag
 
 
+@pytest.mark.parametrize("compact", [1, 0], ids=["compact_records", "wide_records"])
+def test_pools_are_laid_out_by_cell_and_by_junction(compact, tmp_path):
+    """the ingest's layout, which the count kernel's speed rests on (its results do not): every aligned quadruple of
+    one-block records starts in one cell of the annotation, every aligned pair of two-block records of a junction group
+    crosses one junction, padding is empty records only, and the records that are not padding are the reads counted"""
+    import ctypes as C
+    spec = L.SynthSpec(71, 2500, 500000, 100, 3, L.EVENT_TYPES, True)
+    L.synth_write(spec, str(tmp_path), "q", write_mrf=False)
+    ann = L.Annotation(str(tmp_path / "q.interval"), str(tmp_path / "q.map"))
+    ev = L.Events(ann, ("SHORT_READ",), (100,))
+    ctx = L.Context(0)
+    ctx.set_option("compact_pools", compact)
+    ctx.upload_events(ev)
+    ctx.upload_reads(0, L.Reads.synthetic(spec, ev))
+    out = (C.c_ulonglong * 6)()
+    L.lib.lsq_debug_check_pool_layout.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_ulonglong)]
+    L.lib.lsq_debug_check_pool_layout.restype = C.c_int
+    assert L.lib.lsq_debug_check_pool_layout(ctx.h, 0, out) == 0, L.lib.lsq_last_error()
+    n1, pad1, mixed1, n2, pad2, mixed2 = [int(x) for x in out]
+    fmt = ctx.pool_format(0)
+    assert fmt[0] is bool(compact)
+    assert (n1 - pad1, n2 - pad2) == fmt[2][:2] and n1 - pad1 > 200000 and n2 - pad2 > 30000
+    assert mixed1 == 0 and mixed2 == 0
+    assert 0 < pad1 < 0.05 * n1 and 0 < pad2 < 0.2 * n2          # a few records per cell / junction
+    assert ctx.pooled(0) == sum(fmt[2]) == ctx.retained(0)
+    ctx.close()
+
+
 def test_steps_submitted_back_to_back_with_changing_reads(tmp_path):
     """The step pipeline (two streams, two counter sets): steps are only submitted, with another
     read set uploaded in between and the hand-off going to a buffer per step; every step's tables must be the ones
