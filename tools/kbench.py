@@ -62,9 +62,8 @@ for bud in budgets:
             import ctypes as C
             buf = (C.c_ulonglong * 16)()
             L.lib.lsq_debug_counters(ctx.h, buf)
-            print("   dbg: two-block parks: first read no simple junction %d, junction but ends outside %d; second read same junction outside %d, other junction %d, first had none %d" % (buf[8], buf[9], buf[10], buf[13], buf[14]))
-            print("   dbg: one-block wave steps %d, of which with a parked read %d, with a two-owner cell %d, with a read past its segments %d" % (buf[12], buf[11], buf[10], buf[13]))
-            print("   dbg: waves with such steps %d, most of them in one wave %d" % (buf[15], buf[14]))
+            print("   dbg: two-block looks that ended in a park: block 1 in no one-owner cell %d, in one %d" % (buf[8], buf[9]))
+            print("   dbg: one-block wave steps %d, of which with a parked read %d" % (buf[12], buf[11]))
             print("   dbg: parked1=%d parked2=%d walk_steps=%d walk_lanes=%d exceptions=%d  (retained %d)" % (buf[0], buf[1], buf[2], buf[3], buf[4], ctx.retained(0)))
             print("   dbg: parked one-block reads: not in the lane's cell %d, one-owner cell %d, two-owner cell %d" % (buf[5], buf[6], buf[7]))
         print("abl=%d " % abl, end="")
