@@ -638,9 +638,10 @@ int plan_device(lsq_events &E) {
 						x.info = (sr->ev << 8) | ((uint32_t)k << 2) | (sr->sx == x0 ? 1u : 0u);
 						x.ev = sr->ev;
 					} else if (n_own == 2) {
-						c.e1 = c.e2 = (int32_t)std::min(own[0]->sy, own[1]->sy);
-						x.slots = slot_of(own[0], 1u << own[0]->k) | (slot_of(own[1], 1u << own[1]->k) << 16);
-						x.info = CELL_INFO_SHARED; x.flags = CELLX_BOTH;
+						const SegRef *sh = own[0]->sy <= own[1]->sy ? own[0] : own[1], *lg = sh == own[0] ? own[1] : own[0];      // the segment that ends first, the other
+						c.e1 = (int32_t)sh->sy; c.e2 = (int32_t)lg->sy;
+						x.slots = slot_of(sh, 1u << sh->k) | (slot_of(lg, 1u << lg->k) << 16);
+						x.info = CELL_INFO_SHARED; x.flags = CELLX_BOTH; x.ev = sh->ev;
 					} else continue;
 					cells.push_back(c); cellx.push_back(x);
 				}

@@ -624,6 +624,7 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 					// count and matched bases of each kind in one word (count << 24 | bases: four reads of < 2^18 bases); the run
 					// into the next segment is L minus A.  lane_open: a read that the cell does not settle -- it lies in another
 					// cell or in none, or runs past e2.
+					const bool both = (cx.z & CELLX_BOTH) != 0;          // two owners: e1 / e2 the ends of their segments, slot 1 / slot 2 theirs
 					unsigned accA = 0, accL = 0;
 					bool lane_open = false;
 					auto decide = [&](auto whole_step) {
@@ -637,7 +638,7 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 							const bool m = in && (unsigned)(s - lo) < width;
 							const bool a = m && e <= e1;
 							const bool l = m && e <= e2;
-							lane_open = lane_open || (in && !l);
+							lane_open = lane_open || (in && !(both ? a : l));
 							const unsigned p = len | (min(len, 1u) << 24);           // (an empty record -- the padding of a cell's group -- counts for nothing)
 							accA += a ? p : 0u;
 							accL += l ? p : 0u;
@@ -645,7 +646,6 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 					};
 					if (interior) decide(std::true_type{}); else decide(std::false_type{});
 					const unsigned s1 = cx.x & 0xFFFFu, s2 = cx.x >> 16;
-					const bool both = (cx.z & CELLX_BOTH) != 0;          // two owners: s2 is the second owner's slot, e2 == e1
 					if (!ABL(A, (1u | 16384u))) {
 						const unsigned long long addA = ((unsigned long long)(accA >> 24) << 40) | (accA & 0xFFFFFFu);
 						const unsigned accX = accL - accA;
@@ -672,9 +672,12 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 								read_of(j, s, len);
 								const bool in = in_range(j, rel);
 								const bool m = (unsigned)(s - lo) < width;
-								const bool op = in && len != 0u && !(m && s + (int)len <= e2);
+								const int e = s + (int)len;
+								const bool op = in && len != 0u && !(m && e <= (both ? e1 : e2));
 								open |= op ? 1u << (j - h) : 0u;
-								en[j - h] = make_uint4((unsigned)(s + ws), (unsigned)(s + ws) + len, (m && !both) ? (cx.w | PARK_ONE_EVENT) : PARK_EVENT_UNKNOWN, rel);
+								// in a one-owner cell: that owner; in a two-owner cell and inside the farther segment: the owner of the
+								// nearer one (the loop has counted the read for the other); else from the first event of the bin
+								en[j - h] = make_uint4((unsigned)(s + ws), (unsigned)(s + ws) + len, (m && (!both || e <= e2)) ? (cx.w | PARK_ONE_EVENT) : PARK_EVENT_UNKNOWN, rel);
 								if (ABL(A, 256u) && op) { atomicAdd(&A.dbg[5 + (m ? (both ? 2 : 1) : 0)], 1ull); atomicAdd(&A.dbg[0], 1ull); }
 							}
 							R.push2(open, lane, en[0], en[1]);

@@ -111,8 +111,10 @@ constexpr uint32_t FAST_NSEG_SHIFT = 24;
 //   b <= e1              inside the segment: matched == its length, the class of {k}                          (slot 1)
 //   e1 < b <= e2         e2 > e1: segment k+1 starts where k ends, the read runs into it: class of {k, k+1}   (slot 2)
 //   b > e2               the general walk decides (a further abutting segment; the 98 % rule)
-// Two owners (CELLX_BOTH): e1 = e2 = the nearer of the two segments' ends, slot 1 / slot 2 = the owners' single-segment
-// classes; a read that ends at or before e1 counts for both, any other goes to the general walk.
+// Two owners (CELLX_BOTH): e1 = the nearer of the two segments' ends, e2 = the farther, slot 1 / slot 2 = the single-
+// segment classes of the owner that ends first / of the other, CellX.ev = the owner that ends first.  A read that ends at
+// or before e1 counts for both; one that ends in (e1, e2] counts for the second owner and goes to the general walk for the
+// first alone; one beyond e2 goes to the walk for both.
 // No owner: a stretch inside no segment; both slots empty, e1 = e2 = CELL_NO_END -- its reads count for nobody.
 // The first base of an event's span is left out of every cell (the span-start tie rule decides there), but see
 // CELL_K_START.  One record per cell in two arrays of 16-byte words: Cell and CellX.
@@ -125,7 +127,7 @@ struct CellX {
 	uint32_t slots;        // low 16 bits: histogram slot 1; high 16 bits: slot 2; 0xFFFF = no compatible isoform / absent
 	uint32_t info;         // one owner: event << 8 | segment << 2 | lo is the segment's start; CELL_INFO_SHARED with two owners; CELL_INFO_EMPTY with none
 	uint32_t flags;        // CELLX_BOTH
-	uint32_t ev;           // one owner: its event (index in the bucket)
+	uint32_t ev;           // one owner: its event (index in the bucket); two owners: the one whose segment ends first
 };
 static_assert(sizeof(CellX) == 16, "CellX layout");
 constexpr uint32_t CELL_NONE = 0xFFFFu;
