@@ -410,6 +410,9 @@ __device__ inline bool fast_trip(const FastCtx &C, const int4 v, const int total
 #ifndef LSQ_STREAM_WORDS
 #define LSQ_STREAM_WORDS 2
 #endif
+#ifndef LSQ_P2_COMPACT_WORDS
+#define LSQ_P2_COMPACT_WORDS 2         // two-block reads a lane takes per step from a compact pool (2 or 4; 4 -- one table look for four reads -- measured 3 % slower: the one-block path of the same kernel loses more registers than the look saves)
+#endif
 constexpr int STREAM_WORDS = LSQ_STREAM_WORDS;                // 16-byte words per lane in flight
 #ifndef LSQ_GROUP_WORDS
 #define LSQ_GROUP_WORDS 2
@@ -461,8 +464,10 @@ struct Ring {
 	}
 };
 
-template <int NB>
-__device__ inline void walk_parked(const FastCtx &C, Ring<NB> &R, const bool to_empty) {
+// PACKED2: two-block reads parked as their compact record (one ring word: record, event to look at, position) -- `base` unpacks them
+template <int NB, bool PACKED2 = false>
+__device__ inline void walk_parked(const FastCtx &C, Ring<(NB == 1 || PACKED2) ? 1 : 2> &R, const bool to_empty, const int base = 0) {
+	constexpr int RW = (NB == 1 || PACKED2) ? 1 : 2;
 	const unsigned lane = threadIdx.x & 63u;
 	wave_sync_lds();
 #pragma unroll 1
@@ -470,18 +475,25 @@ __device__ inline void walk_parked(const FastCtx &C, Ring<NB> &R, const bool to_
 		const unsigned n = min(R.live(), 64u);
 		const bool on = lane < n;
 		if (ABL(C, 256u) && lane == 0) { atomicAdd(&C.dbg[2], 1ull); atomicAdd(&C.dbg[3], (unsigned long long)n); }
-		const unsigned at = (R.head + (on ? lane : 0u)) % Ring<NB>::CAP;
+		const unsigned at = (R.head + (on ? lane : 0u)) % Ring<RW>::CAP;
 		uint4 e0, e1 = make_uint4(0, 0, 0, 0);
-		if (NB == 1) e0 = R.q[at];
+		if (RW == 1) e0 = R.q[at];
 		else { e0 = R.q[2 * at]; e1 = R.q[2 * at + 1]; }
 		R.head += n;
 		int4 rd; unsigned i, rel;
-		const unsigned ev_word = NB == 1 ? e0.z : e1.x;
+		const unsigned ev_word = RW == 1 ? e0.z : e1.x;
 		const bool one_event = (ev_word & PARK_ONE_EVENT) != 0;
-		if (NB == 1) { e0.z &= ~PARK_ONE_EVENT; } else { e1.x &= ~PARK_ONE_EVENT; }
+		if (RW == 1) { e0.z &= ~PARK_ONE_EVENT; } else { e1.x &= ~PARK_ONE_EVENT; }
 		if (NB == 1) {
 			rd = make_int4((int)e0.x, (int)e0.y, (int)e0.x, (int)e0.y); i = e0.z; rel = e0.w;
 			// parked without a look at the bin directory: the first event of the read's bin
+			const int brel = rd.x - C.lo;
+			const unsigned bin = brel <= 0 ? 0u : min((unsigned)brel >> C.shift, C.n_bins - 1u);
+			const unsigned first = reinterpret_cast<const unsigned *>(C.bins)[4u * bin] >> 16;
+			if (i == PARK_EVENT_UNKNOWN) { i = first; e0.z = first; }
+		}
+		else if (PACKED2) {
+			rd = unpack_two_block(e0.x, e0.y, base); i = e0.z; rel = e0.w;
 			const int brel = rd.x - C.lo;
 			const unsigned bin = brel <= 0 ? 0u : min((unsigned)brel >> C.shift, C.n_bins - 1u);
 			const unsigned first = reinterpret_cast<const unsigned *>(C.bins)[4u * bin] >> 16;
@@ -497,7 +509,7 @@ __device__ inline void walk_parked(const FastCtx &C, Ring<NB> &R, const bool to_
 		const int total = NB == 1 ? rd.y - rd.x : (rd.y - rd.x) + (rd.w - rd.z);
 		const bool more = fast_trip<NB>(C, rd, total, rel, i, on) && !one_event && !ABL(C, 64u);
 		wave_sync_lds();
-		if (NB == 1) e0.z = i + 1u; else e1.x = i + 1u;     // (i is the resolved event)
+		if (RW == 1) e0.z = i + 1u; else e1.x = i + 1u;     // (i is the resolved event)
 		R.push(more, lane, e0, e1);
 		wave_sync_lds();
 	}
@@ -510,8 +522,13 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
                                         const CountArgs &A, uint4 *queue, const uint4 *src_generic,
                                         const unsigned long long g0, const unsigned long long g1) {
 	constexpr int NB = RPW == 2 ? 1 : 2;
-	// words per lane in flight, and looked up together: two-block reads take the whole step as one group
-	constexpr int SW = RPW == 2 ? STREAM_WORDS : LSQ_STREAM_WORDS_P2, GW = RPW == 2 ? GROUP_WORDS : SW;
+	// Words (16 bytes of a wide pool: two one-block reads, one two-block read) per lane in flight, and looked up together:
+	// two-block reads take the whole step as one group -- two of them with wide records, four with compact ones (one table
+	// look serves the four: the pool's junction groups are padded to quadruples)
+	constexpr int SW = RPW == 2 ? STREAM_WORDS : (COMPACT ? LSQ_P2_COMPACT_WORDS : LSQ_STREAM_WORDS_P2), GW = RPW == 2 ? GROUP_WORDS : SW;
+	constexpr int CW = COMPACT ? SW / 2 : SW;          // 16-byte loads a lane issues per step
+	constexpr bool PACKED2 = COMPACT && RPW == 1;      // two-block reads are parked as their compact records
+	constexpr int RW = (NB == 1 || PACKED2) ? 1 : 2;   // ring words per parked read
 	constexpr unsigned TILE = 64u * SW;        // words per wave step
 	C.pool = RPW == 2 ? 0u : 1u;
 	C.slot0 = g0;
@@ -521,23 +538,26 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 	// words [w0, w1) of the workgroup, dealt to its waves a step at a time (wave, wave + 4, ...): the
 	// reads that need the general walk sit together in the start-ordered pool, and a contiguous
 	// quarter per wave would leave three waves waiting for the one that got them
-	// (the range starts on an even word: a lane's two words -- four one-block records, two two-block records -- are one of
-	// the quadruples / pairs the pools' groups are padded to, and one 16-byte word of a compact pool)
-	const unsigned long long w0 = (g0 / RPW) & ~1ull, w1 = (g1 + RPW - 1) / RPW;
+	// (the range starts on a multiple of a lane's words: they are one of the quadruples / pairs the pools' groups are padded
+	// to, and whole 16-byte words of a compact pool)
+	const unsigned long long w0 = (g0 / RPW) & ~(unsigned long long)(SW - 1), w1 = (g1 + RPW - 1) / RPW;
 	const unsigned n_words = (unsigned)(w1 - w0);                                   // a workgroup's range stays below 2^21 reads
 	const unsigned ww0 = min(wave * TILE, n_words), ww1 = n_words;                   // relative to w0
 	const unsigned first_rel = (unsigned)(g0 - w0 * RPW);                            // reads of word w0 (and, compact, w0 + 1) before the range
 	const unsigned n_rel = (unsigned)(g1 - g0);
 	uint4 nxt[SW];
-	static_assert(!COMPACT || SW == 2, "a compact 16-byte word unpacks into two words of a lane");
+	static_assert(!COMPACT || (SW & 1) == 0, "a compact 16-byte word unpacks into two words of a lane");
 	const int base = d.lo - lsq::COMPACT_BIAS;
 	auto fetch_into = [&](uint4 (&dst)[SW], unsigned wt) {
 		if (COMPACT) {
 			// one 16-byte load per lane and step: four one-block records or two two-block ones; unpacked when the
 			// step that uses them begins (not here: the load is to stay in flight during the step before)
-			const unsigned w = min((wt >> 1) + lane, (ww1 - 1u) >> 1);
-			const u32x4 t = src[(w0 >> 1) + w];
-			dst[0] = make_uint4(t.x, t.y, t.z, t.w);
+#pragma unroll
+			for (int cq = 0; cq < CW; ++cq) {
+				const unsigned w = min((wt >> 1) + lane * (unsigned)CW + (unsigned)cq, (ww1 - 1u) >> 1);
+				const u32x4 t = src[(w0 >> 1) + w];
+				dst[cq] = make_uint4(t.x, t.y, t.z, t.w);
+			}
 			return;
 		}
 		if (ABL(A, RPW == 2 ? 131072u : 262144u)) {      // developer switch: half the words loaded (what a pool of half-size records would cost to stream)
@@ -571,10 +591,11 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 			while (cell + 1u < n_cells && p >= (int)cells[cell + 1u].x) ++cell;
 		}
 	};
-	Ring<NB> R;
+	Ring<RW> R;
 	R.q = queue;
 
 	// one step of the wave over the words in `cur` (the step's words, fetched a step ahead)
+	uint4 raw2[PACKED2 ? CW : 1];        // the step's two-block records as loaded (what is parked of them)
 	auto do_step = [&](const uint4 (&cur)[SW], const unsigned wt) {
 #pragma unroll
 		for (int k0 = 0; k0 < SW; k0 += GW) {
@@ -683,7 +704,7 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 							R.push2(open, lane, en[0], en[1]);
 							// the ring holds what one walk leaves behind (< 64) plus these 128 entries
 							if (R.live() >= 64u) {             // wave-uniform
-								if (!ABL(A, 32u)) walk_parked<NB>(C, R, false);
+								if (!ABL(A, 32u)) walk_parked<NB, PACKED2>(C, R, false, base);
 								else R.head = R.tail;
 							}
 						}
@@ -755,7 +776,8 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 				// second, when it crosses the first one's junction, to the junction's)
 				unsigned n_add = L1.add ? 1u : 0u, s_add = L1.add ? L1.matched : 0u, n_add2 = 0, s_add2 = 0;
 				park[0] = L1.park && !ABL(A, 17u | 1048576u);
-				pe0[0] = u;
+				// a parked read: its blocks and (event to look at, position) -- or, PACKED2, its compact record with those two in one word
+				pe0[0] = PACKED2 ? make_uint4(raw2[0].x, raw2[0].y, L1.hint, rel) : u;
 				pe1[0] = make_uint4(L1.hint, rel, 0u, 0u);
 #pragma unroll
 				for (int j = 1; j < N_READS; ++j) {
@@ -774,7 +796,8 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 					// read, in the steps that hold such pairs only, was measured twice: 0.246 against 0.253 ms before the groups,
 					// 0.1627 against 0.1677 with them -- it costs more than the walk it saves.)
 					park[j] = in2 && !same && r2.y != r2.x && !ABL(A, 17u | 1048576u | 2097152u);
-					pe0[j] = v;
+					const uint4 rq = raw2[PACKED2 ? j / 2 : 0];
+					pe0[j] = PACKED2 ? make_uint4((j & 1) ? rq.z : rq.x, (j & 1) ? rq.w : rq.y, PARK_EVENT_UNKNOWN, rel2) : v;
 					pe1[j] = make_uint4(PARK_EVENT_UNKNOWN, rel2, 0u, 0u);
 				}
 				if (!ABL(A, 1u)) {
@@ -784,17 +807,31 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 				} else asm volatile("" ::"v"(n_add), "v"(s_add), "v"(n_add2), "v"(s_add2));
 			}
 		}
-		if (RPW == 1) {
-			static_assert(RPW != 1 || N_READS == 2, "two parked entries a step");
+		if (RPW == 1 && PACKED2) {
+			static_assert(!PACKED2 || N_READS == 4 || N_READS == 2, "two or four parked entries a step, two per push");
 #pragma unroll 1
-			for (int q = 0; q < N_READS; ++q) {
+			for (int h = 0; h < N_READS / 2; ++h) {
+				const bool pa = h ? park[N_READS - 2] : park[0], pb = h ? park[N_READS - 1] : park[1];
+				const uint4 qa = h ? pe0[N_READS - 2] : pe0[0], qb = h ? pe0[N_READS - 1] : pe0[1];
+				if (ABL(A, 256u)) atomicAdd(&A.dbg[NB - 1], (pa ? 1ull : 0ull) + (pb ? 1ull : 0ull));
+				R.push2((pa ? 1u : 0u) | (pb ? 2u : 0u), lane, qa, qb);
+				// the ring holds what one walk leaves behind (< 64) plus these 128 one-word entries
+				if (R.live() >= 64u) {             // wave-uniform
+					if (!ABL(A, 32u)) walk_parked<NB, PACKED2>(C, R, false, base);
+					else R.head = R.tail;
+				}
+			}
+		} else if (RPW == 1) {
+			static_assert(RPW != 1 || PACKED2 || N_READS == 2, "two parked entries a step");
+#pragma unroll 1
+			for (int q = 0; q < 2; ++q) {
 				const bool pq = q ? park[N_READS - 1] : park[0];
 				const uint4 q0 = q ? pe0[N_READS - 1] : pe0[0], q1 = q ? pe1[N_READS - 1] : pe1[0];
 				if (ABL(A, 256u) && pq) atomicAdd(&A.dbg[NB - 1], 1ull);
 				R.push(pq, lane, q0, q1);
 				// the ring holds what one walk leaves behind (< 64) plus 64 two-block entries
 				if (R.live() >= 64u) {             // wave-uniform
-					if (!ABL(A, 32u)) walk_parked<NB>(C, R, false);
+					if (!ABL(A, 32u)) walk_parked<NB, PACKED2>(C, R, false, base);
 					else R.head = R.tail;
 				}
 			}
@@ -811,9 +848,14 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 				cur[0] = make_uint4(t.x & lsq::COMPACT_OFF_MASK, t.x >> lsq::COMPACT_OFF_BITS, t.y & lsq::COMPACT_OFF_MASK, t.y >> lsq::COMPACT_OFF_BITS);
 				cur[1] = make_uint4(t.z & lsq::COMPACT_OFF_MASK, t.z >> lsq::COMPACT_OFF_BITS, t.w & lsq::COMPACT_OFF_MASK, t.w >> lsq::COMPACT_OFF_BITS);
 			} else {
-				const int4 a = unpack_two_block(t.x, t.y, base), b = unpack_two_block(t.z, t.w, base);
-				cur[0] = make_uint4((unsigned)a.x, (unsigned)a.y, (unsigned)a.z, (unsigned)a.w);
-				cur[1] = make_uint4((unsigned)b.x, (unsigned)b.y, (unsigned)b.z, (unsigned)b.w);
+#pragma unroll
+				for (int cq = 0; cq < CW; ++cq) {
+					const uint4 tq = nxt[cq];
+					const int4 a = unpack_two_block(tq.x, tq.y, base), b = unpack_two_block(tq.z, tq.w, base);
+					cur[2 * cq] = make_uint4((unsigned)a.x, (unsigned)a.y, (unsigned)a.z, (unsigned)a.w);
+					cur[2 * cq + 1] = make_uint4((unsigned)b.x, (unsigned)b.y, (unsigned)b.z, (unsigned)b.w);
+					raw2[cq] = tq;
+				}
 			}
 		} else {
 #pragma unroll
@@ -824,7 +866,7 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 	}
 	// (the waves drain their own rings: handing the leftovers of four waves to one, so that fewer partly filled walk steps
 	// run, was measured -- 116 000 -> 87 000 walk steps on C3 -- and lost more at the two barriers it needs: 0.174 -> 0.180 ms)
-	if (R.live() && !ABL(A, 32u)) walk_parked<NB>(C, R, true);
+	if (R.live() && !ABL(A, 32u)) walk_parked<NB, PACKED2>(C, R, true, base);
 }
 
 // Global count/bases adds of a whole wave, merged by class before they reach L2: with skewed read

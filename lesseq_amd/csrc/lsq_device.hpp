@@ -163,7 +163,7 @@ struct lsq_ctx {
 	// neighbouring records and decides them against one cell.  cell_base: per bucket the first of its groups (n_buckets + 1).
 	DevBuf<unsigned> cell_base;
 	size_t n_cell_groups = 0;
-	// The two-block pool is laid out by junction group (lsq_events::jg_keys), every group padded to two records, and per
+	// The two-block pool is laid out by junction group (lsq_events::jg_keys), every group padded to four records, and per
 	// bucket one more group for the reads that cross no known junction.  jgroup_base: per bucket the first of its groups.
 	DevBuf<unsigned long long> jg_keys;
 	DevBuf<unsigned> jg_base, jgroup_base;

@@ -299,9 +299,9 @@ __global__ void __launch_bounds__(256) lsq_ingest_scatter_kernel(IngestRaw R, In
 	}
 }
 
-// The padding of the groups (up to three records in a one-block group, one in a two-block group): empty reads.  A
-// one-block one starts on its cell's first base, so that the count kernel's loop sees it as inside the cell and adding
-// nothing; a two-block one is always the second of a lane's pair and is passed over there.
+// The padding of the groups (up to three records each): empty reads.  A one-block one starts on its cell's first base, so
+// that the count kernel's loop sees it as inside the cell and adding nothing; a two-block one never comes first among a
+// lane's records and is passed over there.
 __global__ void __launch_bounds__(256) lsq_ingest_pad_kernel(const BucketDesc *buckets, const unsigned *cell_base, const unsigned *jgroup_base, unsigned n_buckets,
                                                              unsigned n_groups1, unsigned n_groups2, const unsigned *cnt1, const unsigned long long *off1,
                                                              const unsigned *cnt2, const unsigned long long *off2, const unsigned char *images,
@@ -310,7 +310,7 @@ __global__ void __launch_bounds__(256) lsq_ingest_pad_kernel(const BucketDesc *b
 	for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < n_groups1 + n_groups2; t += gridDim.x * blockDim.x) {
 		const bool one = t < n_groups1;
 		const unsigned g = one ? t : t - n_groups1;
-		const unsigned n = one ? cnt1[g] : cnt2[g], pad = one ? ((n + 3u) & ~3u) - n : (n & 1u);
+		const unsigned n = one ? cnt1[g] : cnt2[g], pad = ((n + 3u) & ~3u) - n;
 		if (!pad) continue;
 		const unsigned *gbase = one ? cell_base : jgroup_base;
 		unsigned lo_b = 0, hi_b = n_buckets;                 // bucket of the group: last b with gbase[b] <= g
@@ -318,10 +318,12 @@ __global__ void __launch_bounds__(256) lsq_ingest_pad_kernel(const BucketDesc *b
 		const BucketDesc &d = buckets[lo_b];
 		const int base = d.lo - lsq::COMPACT_BIAS;
 		if (!one) {
-			const unsigned long long w = off2[g] + n;
-			if (compact) reinterpret_cast<uint2 *>(p2)[w] = make_uint2((unsigned)lsq::COMPACT_BIAS, 0u);
-			else reinterpret_cast<int4 *>(p2)[w] = make_int4(d.lo, d.lo, d.lo, d.lo);
-			p2_strand[w] = 0; p2_line[w] = 0;
+			for (unsigned q = 0; q < pad; ++q) {
+				const unsigned long long w = off2[g] + n + q;
+				if (compact) reinterpret_cast<uint2 *>(p2)[w] = make_uint2((unsigned)lsq::COMPACT_BIAS, 0u);
+				else reinterpret_cast<int4 *>(p2)[w] = make_int4(d.lo, d.lo, d.lo, d.lo);
+				p2_strand[w] = 0; p2_line[w] = 0;
+			}
 			continue;
 		}
 		const unsigned cell = g - cell_base[lo_b];
@@ -386,7 +388,7 @@ static int ingest_device(lsq_ctx *c, int method, const IngestRaw &Rw, uint64_t n
 			HIP_TRY(hipGetLastError());
 		}
 		hipLaunchKernelGGL(lsq_scan_u32_kernel<4>, dim3(1), dim3(1024), 0, st, W.cnt1, (unsigned long long)FC, d_off1.p);      // groups padded to four records
-		hipLaunchKernelGGL(lsq_scan_u32_kernel<2>, dim3(1), dim3(1024), 0, st, W.cnt2, (unsigned long long)FJ, d_off2.p);     // ... to two
+		hipLaunchKernelGGL(lsq_scan_u32_kernel<4>, dim3(1), dim3(1024), 0, st, W.cnt2, (unsigned long long)FJ, d_off2.p);
 		hipLaunchKernelGGL(lsq_scan_u32_kernel<1>, dim3(1), dim3(1024), 0, st, W.cntn, (unsigned long long)B, mr.pn_off.p);
 		hipLaunchKernelGGL(lsq_scan_u32_kernel<1>, dim3(1), dim3(1024), 0, st, W.cntnb, (unsigned long long)B, mr.pnb_off.p);
 		hipLaunchKernelGGL(lsq_ingest_offsets_kernel, dim3(B / 256 + 1), dim3(256), 0, st, c->cell_base.p, c->jgroup_base.p, B, d_off1.p, d_off2.p, mr.pn_off.p,

@@ -421,10 +421,10 @@ int lsq_solve_finalize(lsq_ctx *c, uint32_t *n_replayed) {
 }
 
 // Developer check of the pools' layout (tests): every aligned quadruple of one-block records starts in one cell (or all
-// in none), every aligned pair of two-block records of a junction group crosses one junction, and the records that are
+// in none), every aligned quadruple of two-block records of a junction group crosses one junction, and the records that are
 // not padding number what the ingest counted.  out: [0] one-block records, [1] of them padding, [2] quadruples over more
-// than one cell, [3] two-block records, [4] of them padding, [5] pairs whose first read crosses a junction of the
-// annotation and whose second crosses another or none.
+// than one cell, [3] two-block records, [4] of them padding, [5] quadruples whose first read crosses a junction of the
+// annotation and another of whose reads crosses another or none.
 int lsq_debug_check_pool_layout(lsq_ctx *c, int method, unsigned long long *out) {
 	if (!c || !c->E || !out || method < 0 || method >= c->E->n_methods) return fail(LSQ_E_ARG, "bad argument");
 	HIP_TRY(hipSetDevice(c->device));
@@ -444,7 +444,7 @@ int lsq_debug_check_pool_layout(lsq_ctx *c, int method, unsigned long long *out)
 			return -1;
 		};
 		const size_t n1 = R.p1_line.size(), n2 = R.p2_line.size();
-		if ((n1 & 3u) || (n2 & 1u)) return fail(LSQ_E_STATE, "bucket %zu: pool slices of %zu and %zu records are not whole quadruples / pairs", b, n1, n2);
+		if ((n1 & 3u) || (n2 & 3u)) return fail(LSQ_E_STATE, "bucket %zu: pool slices of %zu and %zu records are not whole quadruples / pairs", b, n1, n2);
 		out[0] += n1; out[3] += n2;
 		for (size_t q = 0; q < n1; q += 4) {
 			long first = -2;
@@ -465,13 +465,20 @@ int lsq_debug_check_pool_layout(lsq_ctx *c, int method, unsigned long long *out)
 			const uint64_t *it = std::lower_bound(k0, k1, want);
 			return (it != k1 && *it == want) ? (long)(it - k0) : -1;
 		};
-		for (size_t q = 0; q < n2; q += 2) {
-			const int32_t *ra = &R.p2[4 * q], *rb = &R.p2[4 * (q + 1)];
-			const bool ea = ra[0] == ra[1], eb = rb[0] == rb[1];
-			out[4] += (ea ? 1u : 0u) + (eb ? 1u : 0u);
-			if (ea) { if (!eb) ++out[5]; continue; }           // padding never comes first
-			const long ga = group_of(ra);
-			if (ga >= 0 && !eb && group_of(rb) != ga) ++out[5];
+		for (size_t q = 0; q < n2; q += 4) {
+			const int32_t *ra = &R.p2[4 * q];
+			const bool ea = ra[0] == ra[1];
+			const long ga = ea ? -1 : group_of(ra);
+			bool bad = false;
+			out[4] += ea ? 1u : 0u;
+			for (size_t k = q + 1; k < q + 4; ++k) {
+				const int32_t *rb = &R.p2[4 * k];
+				const bool eb = rb[0] == rb[1];
+				out[4] += eb ? 1u : 0u;
+				if (ea) bad = bad || !eb;                       // padding never comes first
+				else if (ga >= 0 && !eb && group_of(rb) != ga) bad = true;
+			}
+			if (bad) ++out[5];
 		}
 	}
 	if (out[0] - out[1] != mr.n1_reads || out[3] - out[4] != mr.n2_reads)
