@@ -29,9 +29,11 @@ struct EmArgs {
 // plain VALU moves with no trip through the LDS crossbar
 template <int CTRL>
 __device__ inline double quad_perm_f64(double x) {
+	// (every lane of the quad is read by one of its lanes and all of them are enabled: no value is needed for a lane
+	// whose source is missing, so none is set up -- with a 0 there the compiler spent a move per half and permute on it)
 	int lo = __double2loint(x), hi = __double2hiint(x);
-	lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
-	hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+	lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+	hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
 	return __hiloint2double(hi, lo);
 }
 __device__ inline double group_sum(double x) {
@@ -174,9 +176,10 @@ __device__ inline void em_pass_lean(const double (&kd)[SLOTS], const double (&gm
 	bool on_t[SLOTS], far_t[SLOTS], far = false;
 #pragma unroll
 	for (int t = 0; t < SLOTS; ++t) {
-		sm[t] = 0;
+		// (sums of non-negative terms start from their first term: 0 + x is x for them, and without -ffast-math the add of
+		// the zero stays in the chain)
 #pragma unroll
-		for (int j = 0; j < KK; ++j) { local[t][j] = th[j] * gm[t][j]; sm[t] += local[t][j]; }
+		for (int j = 0; j < KK; ++j) { local[t][j] = th[j] * gm[t][j]; sm[t] = j == 0 ? local[t][0] : sm[t] + local[t][j]; }
 		on_t[t] = on && kd[t] != 0;
 		safe[t] = (on_t[t] && sm[t] > 0) ? sm[t] : 1.0;     // an empty pair slot must not send the wave down the library path
 		r[t] = fast_recip(safe[t]);
@@ -194,7 +197,7 @@ __device__ inline void em_pass_lean(const double (&kd)[SLOTS], const double (&gm
 	for (int t = 0; t < SLOTS; ++t) {
 		const double kr = (on_t[t] && sm[t] > 0) ? kd[t] * r[t] : 0.0;
 #pragma unroll
-		for (int j = 0; j < KK; ++j) zz[j] += local[t][j] * kr;
+		for (int j = 0; j < KK; ++j) zz[j] = t == 0 ? local[t][j] * kr : zz[j] + local[t][j] * kr;
 	}
 #pragma unroll
 	for (int j = 0; j < KK; ++j) z[j] = group_sum(zz[j]);
