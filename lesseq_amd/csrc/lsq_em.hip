@@ -246,8 +246,11 @@ __device__ inline void em_lean(const EmArgs &A, const EmCache &C, const unsigned
 #pragma unroll
 	for (int j = 0; j < KK; ++j) c3[j] = z3[j] * inv_n;
 	em_pass_lean<SLOTS, KK>(kd, gm, c3, run, P, cll, cz3);
-	while (__any(run)) {
-		double n3[KK], nll, nz3[KK];
+	// One turn of the loop: the candidate c = theta(t+1) with its log-likelihood and numerators exists; the pass for
+	// n = theta(t+2) starts from c's numerators at once, and beside it c is tested against the accepted theta(t) and, for
+	// the events still running, accepted.  The loop body is written out twice with c and n in swapped roles, so that
+	// nothing has to be copied from "next" to "candidate" between two turns.
+	auto turn = [&](const double (&c3)[KK], const double cll, const double (&cz3)[KK], double (&n3)[KK], double &nll, double (&nz3)[KK]) {
 #pragma unroll
 		for (int j = 0; j < KK; ++j) n3[j] = cz3[j] * inv_n;
 		em_pass_lean<SLOTS, KK>(kd, gm, n3, run, P, nll, nz3);         // speculative: theta(t+2)
@@ -256,15 +259,20 @@ __device__ inline void em_lean(const EmArgs &A, const EmCache &C, const unsigned
 		const double crit = (cll_ex - 1u < 0x7FEu) ? fabs(1.0 - ll * fast_recip(cll)) : fabs(1.0 - ll / cll);
 		const bool go = run;
 #pragma unroll
-		for (int j = 0; j < KK; ++j) { t3[j] = go ? c3[j] : t3[j]; z3[j] = go ? cz3[j] : z3[j]; }
+		for (int j = 0; j < KK; ++j) t3[j] = go ? c3[j] : t3[j];
 		ll = go ? cll : ll;
 		iters += go ? 1u : 0u;
 		if (go && fabs(crit - 1E-6) < A.band) flag |= 1;
 		if (go && !(crit > 1E-6)) run = false;
 		else if (go && iters >= A.max_iters) { flag |= 2; run = false; }
-#pragma unroll
-		for (int j = 0; j < KK; ++j) { c3[j] = n3[j]; cz3[j] = nz3[j]; }
-		cll = nll;
+	};
+	{
+		double n3[KK], nll, nz3[KK];
+		while (__any(run)) {
+			turn(c3, cll, cz3, n3, nll, nz3);
+			if (!__any(run)) break;
+			turn(n3, nll, nz3, c3, cll, cz3);
+		}
 	}
 	if (ev_ok && sub == 0) {
 #pragma unroll
