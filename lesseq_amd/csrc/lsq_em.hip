@@ -256,7 +256,13 @@ __device__ inline void em_lean(const EmArgs &A, const EmCache &C, const unsigned
 		em_pass_lean<SLOTS, KK>(kd, gm, n3, run, P, nll, nz3);         // speculative: theta(t+2)
 		const unsigned cll_ex = (unsigned)((unsigned long long)__double_as_longlong(cll) >> 52) & 0x7FFu;
 		// read.h:659, floating abs; -inf, nan, zero keep the division's own answers
-		const double crit = (cll_ex - 1u < 0x7FEu) ? fabs(1.0 - ll * fast_recip(cll)) : fabs(1.0 - ll / cll);
+		const bool plain = cll_ex - 1u < 0x7FEu;
+		double crit = fabs(1.0 - ll * fast_recip(plain ? cll : 1.0));
+		if (__any(!plain)) {                         // wave-uniform and rare: the division proper (a select between the two
+			asm volatile("" ::: "memory");           // forms made every turn compute both)
+			const double by_division = fabs(1.0 - ll / cll);
+			crit = plain ? crit : by_division;
+		}
 		const bool go = run;
 #pragma unroll
 		for (int j = 0; j < KK; ++j) t3[j] = go ? c3[j] : t3[j];
