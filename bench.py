@@ -222,20 +222,26 @@ def main():
             rccl.lsq_comm_init_rank.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
             rccl.lsq_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
             rccl.lsq_comm_destroy.argtypes = [C.c_void_p]
-            uid = torch.zeros(128, dtype=torch.uint8)
-            if rank == 0:
-                buf = (C.c_ubyte * 128)()
-                ok = 1 if rccl.lsq_comm_unique_id(buf) == 0 else 0
-                uid = torch.tensor(list(buf), dtype=torch.uint8)
-            if world > 1:
-                uid_d = uid.to(dev)
-                dist.broadcast(uid_d, 0)
-                uid = uid_d.cpu()
-            idb = (C.c_ubyte * 128)(*uid.tolist())
-            if ok and rccl.lsq_comm_init_rank(world, rank, idb, local_rank, C.byref(comm)) != 0:
-                ok = 0
         except Exception:
-            ok = 0
+            ok, rccl = 0, None
+        # every rank takes part in the two exchanges below whatever happened above (a rank that skipped one would leave the
+        # others waiting); the communicator is only set up when every rank has the library AND rank 0 has an id
+        uid = torch.zeros(129, dtype=torch.uint8)
+        if rank == 0 and ok:
+            buf = (C.c_ubyte * 128)()
+            ok = 1 if rccl.lsq_comm_unique_id(buf) == 0 else 0
+            uid = torch.tensor(list(buf) + [ok], dtype=torch.uint8)
+        have = torch.tensor([ok], dtype=torch.int32, device=dev)
+        if world > 1:
+            uid_d = uid.to(dev)
+            dist.broadcast(uid_d, 0)
+            uid = uid_d.cpu()
+            dist.all_reduce(have, op=dist.ReduceOp.MIN)
+        ok = 1 if (int(have.item()) == 1 and int(uid[128]) == 1) or (world == 1 and ok) else 0
+        if ok:
+            idb = (C.c_ubyte * 128)(*uid[:128].tolist())
+            if rccl.lsq_comm_init_rank(world, rank, idb, local_rank, C.byref(comm)) != 0:
+                ok = 0
         flag = torch.tensor([ok], dtype=torch.int32, device=dev)
         if world > 1:
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
