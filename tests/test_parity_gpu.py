@@ -642,7 +642,7 @@ def test_pools_are_laid_out_by_cell_and_by_junction(compact, tmp_path):
     assert fmt[0] is bool(compact)
     assert (n1 - pad1, n2 - pad2) == fmt[2][:2] and n1 - pad1 > 200000 and n2 - pad2 > 30000
     assert mixed1 == 0 and mixed2 == 0
-    assert 0 < pad1 < 0.05 * n1 and 0 < pad2 < 0.3 * n2          # a few records per cell / junction
+    assert 0 < pad1 < 0.1 * n1 and 0 < pad2 < 0.6 * n2           # a few records per cell / junction
     assert ctx.pooled(0) == sum(fmt[2]) == ctx.retained(0)
     ctx.close()
 
