@@ -221,6 +221,7 @@ def main():
             rccl.lsq_comm_unique_id.argtypes = [C.c_void_p]
             rccl.lsq_comm_init_rank.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
             rccl.lsq_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+            rccl.lsq_step_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
             rccl.lsq_comm_destroy.argtypes = [C.c_void_p]
         except Exception:
             ok, rccl = 0, None
@@ -257,15 +258,14 @@ def main():
 
     def step(k):
         b = k & 1
+        if in_loop_gather and use_lsq_gather:
+            # count + solve + pack + gather in one call.  Block b is always this lane's (lanes and blocks both alternate): the
+            # gather that read it two steps ago sits ahead of this pack on the same stream
+            if rccl.lsq_step_gather(ctx.h, comm, blocks[b].data_ptr(), gathered[b].data_ptr(), stride) != 0:
+                raise RuntimeError("lsq_step_gather failed")
+            return
         ctx.count()
         ctx.solve()
-        if in_loop_gather and use_lsq_gather:
-            # block b is always this lane's (lanes and blocks both alternate): the gather that read it two steps ago sits
-            # ahead of this pack on the same stream
-            ctx.pack_results_device(blocks[b].data_ptr())
-            if rccl.lsq_gather(ctx.h, comm, blocks[b].data_ptr(), gathered[b].data_ptr(), stride) != 0:
-                raise RuntimeError("lsq_gather failed")
-            return
         if in_loop_gather and not on_host:
             ptr = ctx.result_stream               # this step's lane
             ext = ext_streams.get(ptr)

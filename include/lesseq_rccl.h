@@ -42,6 +42,9 @@ int lsq_comm_size(const lsq_comm *comm);
  * ncclAllGather on the context's result stream, behind the pack -- asynchronous, like the rest of a step.
  * lsq_ctx_synchronize, then lsq_gathered_unpack on a host copy, gives the whole job's tables. */
 int lsq_gather(lsq_ctx *c, lsq_comm *comm, const void *d_block, void *d_gathered, uint64_t stride_words);
+/* lsq_count + lsq_solve + lsq_results_pack_device(d_block) + lsq_gather in one call: a step of a loop over batches
+ * (reads uploaded beforehand).  Asynchronous like its parts; the status of the first part that fails. */
+int lsq_step_gather(lsq_ctx *c, lsq_comm *comm, void *d_block, void *d_gathered, uint64_t stride_words);
 
 #ifdef __cplusplus
 }

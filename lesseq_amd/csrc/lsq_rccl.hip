@@ -103,4 +103,12 @@ int lsq_gather(lsq_ctx *c, lsq_comm *comm, const void *d_block, void *d_gathered
 	return LSQ_OK;
 }
 
+// One step of an event-sharded job in one call: count, solve, pack, gather (what a loop over batches does per batch;
+// four calls through a binding's foreign-function layer cost more host time than the launches themselves).
+int lsq_step_gather(lsq_ctx *c, lsq_comm *comm, void *d_block, void *d_gathered, uint64_t stride_words) {
+	int rc;
+	if ((rc = lsq_count(c)) || (rc = lsq_solve(c)) || (rc = lsq_results_pack_device(c, d_block))) return fail(rc, "%s", lsq_last_error());
+	return lsq_gather(c, comm, d_block, d_gathered, stride_words);
+}
+
 } // extern "C"
