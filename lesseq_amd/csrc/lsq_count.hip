@@ -823,10 +823,11 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 			}
 		} else if (RPW == 1) {
 			static_assert(RPW != 1 || PACKED2 || N_READS == 2, "two parked entries a step");
-#pragma unroll 1
+			// (written out twice: as a loop over q the compiler kept the entries in scratch memory and indexed them there)
+#pragma unroll
 			for (int q = 0; q < 2; ++q) {
-				const bool pq = q ? park[N_READS - 1] : park[0];
-				const uint4 q0 = q ? pe0[N_READS - 1] : pe0[0], q1 = q ? pe1[N_READS - 1] : pe1[0];
+				const bool pq = park[q ? N_READS - 1 : 0];
+				const uint4 q0 = pe0[q ? N_READS - 1 : 0], q1 = pe1[q ? N_READS - 1 : 0];
 				if (ABL(A, 256u) && pq) atomicAdd(&A.dbg[NB - 1], 1ull);
 				R.push(pq, lane, q0, q1);
 				// the ring holds what one walk leaves behind (< 64) plus 64 two-block entries
