@@ -488,6 +488,11 @@ def main():
                 # the same kernel on an otherwise idle device (steps synchronised one by one, no EM beside it)
                 "frac_alone": alg_bytes / (float(np.mean(alone_fast_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "plain_read_GBps_this_device": plain_read, "frac_of_plain_read": (achieved / plain_read if plain_read else None),
+                # the same kernel time against the bytes the pools actually hold (compact records: 4 B per block) -- what the
+                # HBM has to deliver at least; `achieved` above counts SURVEY 8(d)'s 8 B per block
+                "resident_bytes_per_launch": float(pool_fmt[1] + ev_bytes),
+                "achieved_on_resident_bytes": (pool_fmt[1] + ev_bytes) / (fk * 1e-3) / 1e9,
+                "frac_on_resident_bytes": (pool_fmt[1] + ev_bytes) / (fk * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "traffic": None,
                 "traffic_from_committed_profile": committed,
                 "algorithmic_bytes_per_launch": alg_bytes,
