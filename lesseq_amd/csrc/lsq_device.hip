@@ -138,6 +138,8 @@ int lsq_events_upload(lsq_ctx *c, lsq_events *E) {
 		}
 		c->em_places = (unsigned)order.size();
 		c->em_order_lane_valid[0] = c->em_order_lane_valid[1] = false;
+		if (c->em_split.n != 3) { if ((rc = c->em_split.alloc(3))) return rc; }
+		HIP_TRY(hipMemsetAsync(c->em_split.p, 0xFF, 3 * sizeof(uint32_t), c->stream));
 		if ((rc = c->em_order.upload(order.data(), order.size(), c->stream))) return rc;
 		// gene names for span-start ties against named reads
 		std::string blob;

@@ -133,6 +133,7 @@ struct lsq_ctx {
 	// on the same lane sorts the lean group's places by the iteration counts that solve just wrote; the lane's next solve
 	// (two steps later) and the fifteen after it use that order.  A prediction, nothing more: an event's numbers do not depend on its wave mates.
 	DevBuf<uint32_t> em_order_lane[2];
+	DevBuf<uint32_t> em_split;             // per lane the first place of the one-lane-per-event kernel (lsq_em.hip), then a word that says "none"
 	bool em_order_lane_valid[2] = {false, false};
 	unsigned em_regroup_age[2] = {0, 0};    // solves since the lane's order was last refreshed (every 16th solve refreshes it)
 	bool opt_em_regroup = true;

@@ -11,6 +11,7 @@ struct EmArgs {
 	double band;                       // guard band around the 1e-6 stop threshold (lsq_set_em_guard_band)
 	unsigned max_iters;                // read.h has no cap; 1000000 flags the event (developer switch LSQ_EM_CAP lowers it for timing experiments)
 	const unsigned *order;             // device event per place of the EM grid
+	const unsigned *split;             // lean group: places below *split run four lanes an event, the others one (lsq_em_lean_kernel)
 	const unsigned char *K;
 	const unsigned *cls_base, *iso_base;
 	const unsigned long long *cnt;     // [method][n_cls]
@@ -166,10 +167,14 @@ __device__ inline double log1p_small(double d) {
 	return d * fma(w4, b2, fma(w2, b1, b0));
 }
 
-template <int SLOTS, int KK>
+// FLAT: one lane holds a whole event -- its four (method, class) pairs in the four slots, where the other form has them
+// in the four lanes of a quad -- and sums the slots in the order the quad's two permutes do, (0 + 1) + (2 + 3): the same
+// numbers bit for bit, four times the events per wave and no permutes.
+template <int SLOTS, int KK, bool FLAT = false>
 __device__ inline void em_pass_lean(const double (&kd)[SLOTS], const double (&gm)[SLOTS][KK], const double (&th)[KK],
                                     const bool on, EmPairState<SLOTS> &P, double &ll, double (&z)[KK]) {
-	double l = 0, zz[KK];
+	static_assert(!FLAT || SLOTS == 4 || SLOTS == 3, "a flat event has the quad's four slots (three when no event uses the fourth)");
+	double l = 0, zz[KK], part[FLAT ? SLOTS : 1][KK], lpart[FLAT ? SLOTS : 1];
 #pragma unroll
 	for (int j = 0; j < KK; ++j) zz[j] = 0;
 	double local[SLOTS][KK], sm[SLOTS], safe[SLOTS], r[SLOTS], d[SLOTS];
@@ -197,10 +202,17 @@ __device__ inline void em_pass_lean(const double (&kd)[SLOTS], const double (&gm
 	for (int t = 0; t < SLOTS; ++t) {
 		const double kr = (on_t[t] && sm[t] > 0) ? kd[t] * r[t] : 0.0;
 #pragma unroll
-		for (int j = 0; j < KK; ++j) zz[j] = t == 0 ? local[t][j] * kr : zz[j] + local[t][j] * kr;
+		for (int j = 0; j < KK; ++j) {
+			if (FLAT) part[t][j] = local[t][j] * kr;
+			else zz[j] = t == 0 ? local[t][j] * kr : zz[j] + local[t][j] * kr;
+		}
 	}
 #pragma unroll
-	for (int j = 0; j < KK; ++j) z[j] = group_sum(zz[j]);
+	for (int j = 0; j < KK; ++j) {
+		// (three slots: the quad's idle fourth lane adds an exact zero to the third's non-negative product)
+		if (FLAT) z[j] = SLOTS == 4 ? (part[0][j] + part[1][j]) + (part[2][j] + part[SLOTS - 1][j]) : (part[0][j] + part[1][j]) + part[2][j];
+		else z[j] = group_sum(zz[j]);
+	}
 	const bool full = __any(far);
 #pragma unroll
 	for (int t = 0; t < SLOTS; ++t) {
@@ -214,17 +226,19 @@ __device__ inline void em_pass_lean(const double (&kd)[SLOTS], const double (&gm
 		}
 		P.s[t] = safe[t]; P.r[t] = r[t]; P.lg[t] = lg;
 		const double term = kd[t] * lg;
-		l += on_t[t] ? term : 0.0;
+		if (FLAT) lpart[t] = 0.0 + (on_t[t] ? term : 0.0);          // (a lane of the quad form starts its sum at 0)
+		else l += on_t[t] ? term : 0.0;
 	}
-	ll = group_sum(l);
+	if (FLAT) ll = SLOTS == 4 ? (lpart[0] + lpart[1]) + (lpart[2] + lpart[SLOTS - 1]) : (lpart[0] + lpart[1]) + (lpart[2] + 0.0);
+	else ll = group_sum(l);
 }
 
 // The whole EM of a wave whose events all fit SLOTS (method, class) pairs per lane and KK isoforms,
 // in registers.  The pass for theta(t+2) starts from z(t+1) as soon as that exists, without waiting
 // for the stop test on ll(t+1): the test (a reciprocal, a compare, a ballot) runs beside the next
 // pass instead of between two passes.  One pass per event is thrown away.
-template <int SLOTS, int KK>
-__device__ inline void em_lean(const EmArgs &A, const EmCache &C, const unsigned e, const unsigned sub, const bool ev_ok, const int K, const unsigned ib,
+template <int SLOTS, int KK, bool FLAT = false, class CacheT = EmCache>
+__device__ inline void em_lean(const EmArgs &A, const CacheT &C, const unsigned e, const unsigned sub, const bool ev_ok, const int K, const unsigned ib,
                                const double inv_n, const bool any_reads, bool run) {
 	double kd[SLOTS], gm[SLOTS][KK], t3[KK], z3[KK];
 #pragma unroll
@@ -241,11 +255,11 @@ __device__ inline void em_lean(const EmArgs &A, const EmCache &C, const unsigned
 	unsigned iters = 0;
 	unsigned char flag = 0;
 	double ll = 0;
-	em_pass_lean<SLOTS, KK>(kd, gm, t3, any_reads, P, ll, z3);
+	em_pass_lean<SLOTS, KK, FLAT>(kd, gm, t3, any_reads, P, ll, z3);
 	double c3[KK], cll, cz3[KK];           // candidate: theta(t+1), its log-likelihood and numerators
 #pragma unroll
 	for (int j = 0; j < KK; ++j) c3[j] = z3[j] * inv_n;
-	em_pass_lean<SLOTS, KK>(kd, gm, c3, run, P, cll, cz3);
+	em_pass_lean<SLOTS, KK, FLAT>(kd, gm, c3, run, P, cll, cz3);
 	// One turn of the loop: the candidate c = theta(t+1) with its log-likelihood and numerators exists; the pass for
 	// n = theta(t+2) starts from c's numerators at once, and beside it c is tested against the accepted theta(t) and, for
 	// the events still running, accepted.  The loop body is written out twice with c and n in swapped roles, so that
@@ -253,7 +267,7 @@ __device__ inline void em_lean(const EmArgs &A, const EmCache &C, const unsigned
 	auto turn = [&](const double (&c3)[KK], const double cll, const double (&cz3)[KK], double (&n3)[KK], double &nll, double (&nz3)[KK]) {
 #pragma unroll
 		for (int j = 0; j < KK; ++j) n3[j] = cz3[j] * inv_n;
-		em_pass_lean<SLOTS, KK>(kd, gm, n3, run, P, nll, nz3);         // speculative: theta(t+2)
+		em_pass_lean<SLOTS, KK, FLAT>(kd, gm, n3, run, P, nll, nz3);         // speculative: theta(t+2)
 		const unsigned cll_ex = (unsigned)((unsigned long long)__double_as_longlong(cll) >> 52) & 0x7FFu;
 		// read.h:659, floating abs; -inf, nan, zero keep the division's own answers
 		const bool plain = cll_ex - 1u < 0x7FEu;
@@ -293,17 +307,19 @@ __device__ inline void em_lean(const EmArgs &A, const EmCache &C, const unsigned
 // (LESSeq's local events with one read file): only the lean loop, a third of the registers -- the
 // kernel shares the compute units with the next count's streaming kernel (lsq_device.hpp).
 template <bool SMALL>
-__global__ void __launch_bounds__(256) lsq_em_kernel(EmArgs A) {
+__device__ inline void em_quad_body(const EmArgs &A, const unsigned block) {
 	// The next count's streaming kernel may share the SIMDs (lsq_device.hpp: the result stream); this
 	// kernel is a few dependent chains, that one thousands of independent ones: these waves go first.
 #ifndef LSQ_EM_NO_PRIO
 	__builtin_amdgcn_s_setprio(3);
 #endif
-	const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
+	const unsigned gid = block * blockDim.x + threadIdx.x;
 	const unsigned place = A.place0 + gid / EM_LANES, sub = gid % EM_LANES;
 	// events in the order of A.order: the small ones (two isoforms, one pair per lane) first, then the
 	// rest, each group filling whole waves (0xFFFFFFFF = empty place)
-	const unsigned e = place < A.n_places ? A.order[place] : 0xFFFFFFFFu;
+	const unsigned mine = SMALL ? min(A.n_places, *A.split) : A.n_places;          // (the lean group is shared with lsq_em_flat_kernel)
+	if (SMALL && A.place0 + block * blockDim.x / EM_LANES >= mine) return;
+	const unsigned e = place < mine ? A.order[place] : 0xFFFFFFFFu;
 	const bool ev_ok = e != 0xFFFFFFFFu;
 	const int K = ev_ok ? A.K[e] : 1;
 	const unsigned cb = ev_ok ? A.cls_base[e] : 0, ib = ev_ok ? A.iso_base[e] : 0;
@@ -382,6 +398,55 @@ __global__ void __launch_bounds__(256) lsq_em_kernel(EmArgs A) {
 		A.flags[e] = flag;
 	}
 }
+
+// The lean group (two isoforms, at most four (method, class) pairs: LESSeq's local events with one read file) with one
+// LANE per event: 64 events a wave instead of 16, a third of the instructions per event and pass -- what the next count's
+// streaming kernel, which shares the vector pipes with this one, gets back -- and the same numbers (em_pass_lean FLAT).
+template <int FS> struct EmCacheFlat { double kd[FS]; double g[FS][2]; int cls[FS]; };
+// FS: slots of an event -- 3 when every event of the group has at most three pairs (one read file), else 4
+template <int FS>
+__device__ inline void em_flat_body(const EmArgs &A, const unsigned block) {
+#ifndef LSQ_EM_NO_PRIO
+	__builtin_amdgcn_s_setprio(3);
+#endif
+	const unsigned place = A.place0 + block * blockDim.x + threadIdx.x;
+	const unsigned first = *A.split;                  // a multiple of 64: the places below it are the four-lane form's
+	if (A.place0 + (block + 1u) * blockDim.x <= first) return;
+	const unsigned e = (place < A.n_places && place >= first) ? A.order[place] : 0xFFFFFFFFu;
+	const bool ev_ok = e != 0xFFFFFFFFu;
+	const int K = ev_ok ? A.K[e] : 1;
+	const unsigned cb = ev_ok ? A.cls_base[e] : 0, ib = ev_ok ? A.iso_base[e] : 0;
+	const int nc = (1 << K) - 1;
+	const int n_pairs = (int)A.n_methods * nc;        // <= FS for every event of this group
+	EmCacheFlat<FS> C;
+#pragma unroll
+	for (int q = 0; q < FS; ++q) {
+		const bool has = ev_ok && q < n_pairs;
+		const int m = has ? q / nc : 0, c = has ? q - m * nc : 0;
+		C.kd[q] = has ? (double)A.cnt[(size_t)m * A.n_cls + cb + (unsigned)c] : 0.0;      // exact: counts are far below 2^53
+		C.cls[q] = has ? c + 1 : 0;
+#pragma unroll
+		for (int j = 0; j < 2; ++j) C.g[q][j] = (has && j < K) ? A.G[(size_t)m * A.n_iso + ib + j] : 0.0;
+	}
+	const double n_total = ((0.0 + C.kd[0]) + (0.0 + C.kd[1])) + ((0.0 + C.kd[2]) + (0.0 + (FS == 4 ? C.kd[FS - 1] : 0.0)));
+	const double inv_n = 1.0 / n_total;
+	// no reads: theta stays 1/K, log-likelihood 0; one isoform: theta = 1 (solve/solve.cpp:798-802)
+	const bool run = ev_ok && n_total > 0 && K > 1, any_reads = ev_ok && n_total > 0;
+	em_lean<FS, 2, true, EmCacheFlat<FS>>(A, C, e, 0u, ev_ok, K, ib, inv_n, any_reads, run);
+}
+
+// The lean group in one launch (two on one stream would run one after the other): the first n_quad workgroups take the
+// places below *A.split four lanes an event, the others the places from there on one lane an event; workgroups of 64.
+template <int FS>
+__global__ void __launch_bounds__(64) lsq_em_lean_kernel(EmArgs A, unsigned n_quad) {
+	if (blockIdx.x < n_quad) em_quad_body<true>(A, blockIdx.x);
+	else em_flat_body<FS>(A, blockIdx.x - n_quad);
+}
+// ... and before a placement by iteration counts exists (or with option em_regroup off): four lanes an event throughout,
+// in a kernel of its own (the one-lane form's registers would come on top: 128 against 104 a wave)
+__global__ void __launch_bounds__(64) lsq_em_lean_quad_kernel(EmArgs A) { em_quad_body<true>(A, blockIdx.x); }
+// the other events: more than two isoforms or more than one (method, class) pair per lane
+__global__ void __launch_bounds__(256) lsq_em_kernel(EmArgs A) { em_quad_body<false>(A, blockIdx.x); }
 
 // ---- expected Fisher information and the variance estimates made from it (fim.h, linalg.h) ------------
 // PARITY UNPINNED: no translation unit of the reference includes these headers.  fim.h:115-158 sums, over
@@ -464,7 +529,11 @@ __global__ void __launch_bounds__(64) lsq_fim_kernel(FimArgs A) {
 
 // The lean group's places sorted by the iteration counts of the solve that has just finished on this lane, slowest
 // first (one workgroup: a counting sort over 256 iteration classes in LDS).  Empty places go to the end.
-__global__ void __launch_bounds__(1024) lsq_em_regroup_kernel(const unsigned *base_order, const unsigned *iters, unsigned n_places, unsigned *out) {
+// *split: the first place (a multiple of 64) from which on the events took fewer than EM_FLAT_BELOW iterations: those go to
+// the one-lane-per-event kernel next time -- a third of the instructions per event and pass, twice the time per pass --,
+// the slow ones before them stay with four lanes an event, where the time of a pass is what counts.
+constexpr unsigned EM_FLAT_BELOW = 32;
+__global__ void __launch_bounds__(1024) lsq_em_regroup_kernel(const unsigned *base_order, const unsigned *iters, unsigned n_places, unsigned *out, unsigned *split) {
 	__shared__ unsigned hist[256], start[256];
 	const unsigned tid = threadIdx.x;
 	if (tid < 256) hist[tid] = 0;
@@ -474,7 +543,12 @@ __global__ void __launch_bounds__(1024) lsq_em_regroup_kernel(const unsigned *ba
 		if (e != 0xFFFFFFFFu) atomicAdd(&hist[255u - min(iters[e], 255u)], 1u);
 	}
 	__syncthreads();
-	if (tid == 0) { unsigned run = 0; for (unsigned k = 0; k < 256; ++k) { start[k] = run; run += hist[k]; hist[k] = 0; } start[0] |= 0u; hist[0] = 0; out[n_places - 1] = 0xFFFFFFFFu; }
+	if (tid == 0) {
+		unsigned run = 0;
+		for (unsigned k = 0; k < 256; ++k) { start[k] = run; run += hist[k]; hist[k] = 0; }
+		out[n_places - 1] = 0xFFFFFFFFu;
+		*split = (start[256u - EM_FLAT_BELOW] + 63u) & ~63u;       // events with EM_FLAT_BELOW iterations or more come first
+	}
 	__syncthreads();
 	unsigned n_valid = 0;
 	for (unsigned p = tid; p < n_places; p += 1024) {
@@ -528,13 +602,18 @@ int run_solve(lsq_ctx *c) {
 		if (c->em_small_places) {
 			const int lane = c->flip;
 			A.place0 = 0; A.n_places = c->em_small_places;
-			if (c->opt_em_regroup && c->em_order_lane_valid[lane]) A.order = c->em_order_lane[lane].p;
-			hipLaunchKernelGGL(lsq_em_kernel<true>, dim3((c->em_small_places * EM_LANES + blk - 1) / blk), dim3(blk), 0, st, A);
+			const bool regrouped = c->opt_em_regroup && c->em_order_lane_valid[lane];
+			if (regrouped) A.order = c->em_order_lane[lane].p;
+			A.split = c->em_split.p + (regrouped ? lane : 2);          // (word 2: every place to the four-lane kernel)
+			const unsigned n_quad = (c->em_small_places * EM_LANES + blk - 1) / blk, n_flat = regrouped ? (c->em_small_places + 63u) / 64u : 0u;
+			if (!n_flat) hipLaunchKernelGGL(lsq_em_lean_quad_kernel, dim3(n_quad), dim3(blk), 0, st, A);
+			else if (E.n_methods == 1) hipLaunchKernelGGL(lsq_em_lean_kernel<3>, dim3(n_quad + n_flat), dim3(blk), 0, st, A, n_quad);
+			else hipLaunchKernelGGL(lsq_em_lean_kernel<4>, dim3(n_quad + n_flat), dim3(blk), 0, st, A, n_quad);
 			HIP_TRY(hipGetLastError());
 			if (c->opt_em_regroup && (!c->em_order_lane_valid[lane] || ++c->em_regroup_age[lane] >= 16)) {
 				c->em_regroup_age[lane] = 0;
 				if (c->em_order_lane[lane].n != c->em_small_places) { int rc = c->em_order_lane[lane].alloc(c->em_small_places); if (rc) return rc; }
-				hipLaunchKernelGGL(lsq_em_regroup_kernel, dim3(1), dim3(1024), 0, st, c->em_order.p, c->iters.p, c->em_small_places, c->em_order_lane[lane].p);
+				hipLaunchKernelGGL(lsq_em_regroup_kernel, dim3(1), dim3(1024), 0, st, c->em_order.p, c->iters.p, c->em_small_places, c->em_order_lane[lane].p, c->em_split.p + lane);
 				HIP_TRY(hipGetLastError());
 				c->em_order_lane_valid[lane] = true;
 			}
@@ -542,7 +621,7 @@ int run_solve(lsq_ctx *c) {
 		if (c->em_places > c->em_small_places) {
 			A.order = c->em_order.p;
 			A.place0 = c->em_small_places; A.n_places = c->em_places;
-			hipLaunchKernelGGL(lsq_em_kernel<false>, dim3(((c->em_places - c->em_small_places) * EM_LANES + 255) / 256), dim3(256), 0, st, A);
+			hipLaunchKernelGGL(lsq_em_kernel, dim3(((c->em_places - c->em_small_places) * EM_LANES + 255) / 256), dim3(256), 0, st, A);
 			HIP_TRY(hipGetLastError());
 		}
 	}
