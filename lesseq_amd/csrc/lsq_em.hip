@@ -532,7 +532,10 @@ __global__ void __launch_bounds__(64) lsq_fim_kernel(FimArgs A) {
 // *split: the first place (a multiple of 64) from which on the events took fewer than EM_FLAT_BELOW iterations: those go to
 // the one-lane-per-event kernel next time -- a third of the instructions per event and pass, twice the time per pass --,
 // the slow ones before them stay with four lanes an event, where the time of a pass is what counts.
-constexpr unsigned EM_FLAT_BELOW = 32;
+#ifndef LSQ_EM_FLAT_BELOW
+#define LSQ_EM_FLAT_BELOW 32
+#endif
+constexpr unsigned EM_FLAT_BELOW = LSQ_EM_FLAT_BELOW;
 __global__ void __launch_bounds__(1024) lsq_em_regroup_kernel(const unsigned *base_order, const unsigned *iters, unsigned n_places, unsigned *out, unsigned *split) {
 	__shared__ unsigned hist[256], start[256];
 	const unsigned tid = threadIdx.x;
