@@ -292,7 +292,7 @@ class Context:
 
     def set_option(self, name, value):
         """lsq_ctx_set_option: grid_multiplier, exception_capacity, recount_every_read, em_guard_band,
-        snap_shares, em_regroup"""
+        snap_shares, em_regroup, em_flat_min_events, compact_pools"""
         check(lib.lsq_ctx_set_option(self.h, _b(name), float(value)))
 
     def count_status(self):

@@ -638,6 +638,8 @@ int lsq_ctx_set_option(lsq_ctx *c, const char *name, double value) {
 		for (auto &r : c->reads) r.wg_grid = 0;
 	} else if (n == "compact_pools") {
 		c->opt_compact_pools = value != 0;        // takes effect with the next upload of a read set
+	} else if (n == "em_flat_min_events") {
+		c->opt_em_flat_min = value < 0 ? 0u : (unsigned)value;
 	} else if (n == "em_regroup") {
 		c->opt_em_regroup = value != 0;
 		c->em_order_lane_valid[0] = c->em_order_lane_valid[1] = false;

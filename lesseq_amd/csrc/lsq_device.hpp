@@ -137,6 +137,7 @@ struct lsq_ctx {
 	bool em_order_lane_valid[2] = {false, false};
 	unsigned em_regroup_age[2] = {0, 0};    // solves since the lane's order was last refreshed (every 16th solve refreshes it)
 	bool opt_em_regroup = true;
+	unsigned opt_em_flat_min = 16384;      // "em_flat_min_events": lean events from which on the fast ones run one lane per event
 	unsigned em_places = 0;
 	unsigned em_small_places = 0;           // the first of them: events of the lean EM kernel
 	DevBuf<double> G, theta2[2], logll2[2];

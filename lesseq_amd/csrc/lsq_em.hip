@@ -547,10 +547,14 @@ __global__ void __launch_bounds__(1024) lsq_em_regroup_kernel(const unsigned *ba
 	}
 	__syncthreads();
 	if (tid == 0) {
-		unsigned run = 0;
-		for (unsigned k = 0; k < 256; ++k) { start[k] = run; run += hist[k]; hist[k] = 0; }
+		unsigned run = 0, slowest = 0;
+		for (unsigned k = 0; k < 256; ++k) { if (hist[k] && !slowest) slowest = 255u - k; start[k] = run; run += hist[k]; hist[k] = 0; }
 		out[n_places - 1] = 0xFFFFFFFFu;
-		*split = (start[256u - EM_FLAT_BELOW] + 63u) & ~63u;       // events with EM_FLAT_BELOW iterations or more come first
+		// one lane per event below EM_FLAT_BELOW iterations -- and below 0.45 of the slowest event's count when that is
+		// less: a pass of that form takes twice the time, and its longest chain is not to outlast the four-lane form's
+		// (configs[1]: slowest event 35 iterations; with the fixed threshold its EM took 0.021 ms instead of 0.015)
+		const unsigned below = min(EM_FLAT_BELOW, max(4u, slowest * 29u / 64u));
+		*split = (start[256u - below] + 63u) & ~63u;       // the events with that many iterations or more come first
 	}
 	__syncthreads();
 	unsigned n_valid = 0;
@@ -607,8 +611,11 @@ int run_solve(lsq_ctx *c) {
 			A.place0 = 0; A.n_places = c->em_small_places;
 			const bool regrouped = c->opt_em_regroup && c->em_order_lane_valid[lane];
 			if (regrouped) A.order = c->em_order_lane[lane].p;
-			A.split = c->em_split.p + (regrouped ? lane : 2);          // (word 2: every place to the four-lane kernel)
-			const unsigned n_quad = (c->em_small_places * EM_LANES + blk - 1) / blk, n_flat = regrouped ? (c->em_small_places + 63u) / 64u : 0u;
+			// one lane per event only for a job's worth of events: with a few thousand (configs[1], a rank's eighth of configs[2])
+			// a step waits for the EM's chain, not for its instructions (C2: 0.0485 ms per step without, 0.0497 with)
+			const bool flat = regrouped && c->em_small_places >= c->opt_em_flat_min;
+			A.split = c->em_split.p + (flat ? lane : 2);          // (word 2: every place to the four-lane kernel)
+			const unsigned n_quad = (c->em_small_places * EM_LANES + blk - 1) / blk, n_flat = flat ? (c->em_small_places + 63u) / 64u : 0u;
 			if (!n_flat) hipLaunchKernelGGL(lsq_em_lean_quad_kernel, dim3(n_quad), dim3(blk), 0, st, A);
 			else if (E.n_methods == 1) hipLaunchKernelGGL(lsq_em_lean_kernel<3>, dim3(n_quad + n_flat), dim3(blk), 0, st, A, n_quad);
 			else hipLaunchKernelGGL(lsq_em_lean_kernel<4>, dim3(n_quad + n_flat), dim3(blk), 0, st, A, n_quad);

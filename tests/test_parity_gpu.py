@@ -773,7 +773,7 @@ def test_em_numbers_do_not_depend_on_which_events_share_a_wave(tmp_path):
 
 def test_em_regrouping_by_earlier_iteration_counts_keeps_every_number(tmp_path):
     """option em_regroup (on by default): a lane's solves place the events by the iteration counts of one of its
-    earlier solves.  The placement learned on one read set is then used for another read set; every event must
+    earlier solves, and (em_flat_min_events) solve the fast ones one lane per event, the slow ones four lanes per event.  The placement learned on one read set is then used for another read set; every event must
     still be solved (none dropped from the grid, none twice) with the numbers a fresh context without the option
     gives, and the reference-order replay of flagged events still applies."""
     specs = [L.SynthSpec(90 + i, 3000, 400000 + 150000 * i, 100, 3, L.EVENT_TYPES, bool(i)) for i in range(2)]
@@ -791,6 +791,7 @@ def test_em_regrouping_by_earlier_iteration_counts_keeps_every_number(tmp_path):
     plain.close()
     assert not np.array_equal(want[0][2], want[1][2])          # the two read sets converge differently
     ctx = L.Context(0)
+    ctx.set_option("em_flat_min_events", 0)        # the one-lane-per-event form for the fast events, on this small job too
     ctx.upload_events(ev)
     ctx.upload_reads(0, reads[0])
     for k in range(40):                    # both lanes learn a placement, and refresh it at least once
