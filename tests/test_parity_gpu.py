@@ -31,9 +31,10 @@ def test_cli_matches_reference_golden(name, tmp_path, monkeypatch):
             assert ob.solve_text_close(text, exp), (name, r["argv"], text, exp)
 
 
-def gpu_exact(argv, tool="solve", want_fim=False, band=None):
+def gpu_exact(argv, tool="solve", want_fim=False, band=None, repeat=1):
     """runs the library pipeline step by step; returns per-gene dicts like the oracle's exact output.
-    band: lsq_set_em_guard_band (None = the library's 1e-11)"""
+    band: lsq_set_em_guard_band (None = the library's 1e-11); repeat: count + solve that many times (from the third
+    time on a lane's solve uses the placement, and the one-lane form, it learned from its first)"""
     per = 5 if tool == "solve" else 4
     groups = [argv[9 + i * per: 9 + (i + 1) * per] for i in range((len(argv) - 9) // per)]
     a = L.Annotation(argv[4], argv[6], int(argv[7]), int(argv[8]), argv[3], argv[5])
@@ -44,8 +45,9 @@ def gpu_exact(argv, tool="solve", want_fim=False, band=None):
     ctx.upload_events(ev)
     for m, g in enumerate(groups):
         ctx.upload_reads(m, L.Reads.from_mrf(g[3], ev, read_format=g[0]))
-    ctx.count()
-    ctx.solve()
+    for _ in range(repeat):
+        ctx.count()
+        ctx.solve()
     cnt, bases = ctx.counts()
     theta, ll, iters, flags = ctx.solution()
     off = ev.class_offsets()

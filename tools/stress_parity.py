@@ -27,9 +27,9 @@ for seed in range(first, first + n):
             rc1, _ = L.cli_run("solve", argv)
             assert rc1 != 0, (seed, rc1, rc)      # (in a host process the library reports the error; the executables abort like the reference)
             continue
-        for opts in ("", "compact_pools=0"):
+        for opts in ("em_flat_min_events=0", "compact_pools=0"):
             os.environ["LSQ_OPTIONS"] = opts
-            compare_exact(gpu_exact(argv), exact, "seed %d %s" % (seed, opts))
+            compare_exact(gpu_exact(argv, repeat=4 if opts.startswith("em_flat") else 1), exact, "seed %d %s" % (seed, opts))
             rc1, text = L.cli_run("count", argv[:-1])
             rc2, ctext, _ = ob.run("count", argv[:-1])
             assert rc1 == rc2 == 0 and text == ctext, (seed, opts)
