@@ -1228,7 +1228,6 @@ int run_count(lsq_ctx *c) {
 	const lsq_events &E = *c->E;
 	const size_t n_cls = E.n_cls_total;
 	const int M = E.n_methods;
-	hipStream_t st = c->stream;
 	hipStream_t st_em = nullptr;
 	// This count writes the counter set the solve before last read; the previous count had it
 	// zeroed on the result stream, behind those readers, and recorded ev_mark after that.  Now the
@@ -1236,6 +1235,7 @@ int run_count(lsq_ctx *c) {
 	// (Lanes: this count takes lane `set`; the lane of the count before -- its result stream carries that step's EM and
 	// hand-off -- gets the zeroing of its counters and its mark queued behind them now.)
 	const int set = c->flip ^ 1, other = c->flip;
+	hipStream_t st = c->opt_two_count_streams ? c->stream_count2[set] : c->stream;      // (lsq_device.hpp: a count stream per lane)
 	if (c->mark_recorded2[set]) HIP_TRY(hipStreamWaitEvent(st, c->ev_mark2[set], 0));
 	HIP_TRY(hipMemsetAsync(c->counters.p + (size_t)other * c->counters_per_set, 0, c->counters_per_set * sizeof(unsigned long long), c->stream_em2[other]));
 	HIP_TRY(hipEventRecord(c->ev_mark2[other], c->stream_em2[other]));

@@ -20,6 +20,8 @@ int upload_strand_ranks(lsq_ctx *c) {
 
 int sync_all(lsq_ctx *c) {
 	HIP_TRY(hipStreamSynchronize(c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream_count2[0]));
+	HIP_TRY(hipStreamSynchronize(c->stream_count2[1]));
 	HIP_TRY(hipStreamSynchronize(c->stream_em2[0]));
 	HIP_TRY(hipStreamSynchronize(c->stream_em2[1]));
 	return LSQ_OK;
@@ -61,6 +63,7 @@ int lsq_ctx_create(int device_id, lsq_ctx **out) {
 	HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 	for (int l = 0; l < 2; ++l) {
 		HIP_TRY(hipStreamCreateWithFlags(&c->stream_em2[l], hipStreamNonBlocking));      // (a higher stream priority changed nothing measurable)
+		HIP_TRY(hipStreamCreateWithFlags(&c->stream_count2[l], hipStreamNonBlocking));
 		HIP_TRY(hipEventCreateWithFlags(&c->ev_counted2[l], hipEventDisableTiming));
 		HIP_TRY(hipEventCreateWithFlags(&c->ev_mark2[l], hipEventDisableTiming));
 	}
@@ -79,6 +82,7 @@ void lsq_ctx_destroy(lsq_ctx *c) {
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	for (int l = 0; l < 2; ++l) {
 		if (c->stream_em2[l]) (void)hipStreamSynchronize(c->stream_em2[l]);
+		if (c->stream_count2[l]) (void)hipStreamSynchronize(c->stream_count2[l]);
 		if (c->ev_counted2[l]) (void)hipEventDestroy(c->ev_counted2[l]);
 		if (c->ev_mark2[l]) (void)hipEventDestroy(c->ev_mark2[l]);
 	}
@@ -90,7 +94,7 @@ void lsq_ctx_destroy(lsq_ctx *c) {
 	if (c->evt1) (void)hipEventDestroy(c->evt1);
 	for (int m = 0; m < LSQ_MAX_METHODS; ++m) { if (c->evf0[m]) (void)hipEventDestroy(c->evf0[m]); if (c->evf1[m]) (void)hipEventDestroy(c->evf1[m]); }
 	if (c->stream) (void)hipStreamDestroy(c->stream);
-	for (int l = 0; l < 2; ++l) if (c->stream_em2[l]) (void)hipStreamDestroy(c->stream_em2[l]);
+	for (int l = 0; l < 2; ++l) { if (c->stream_em2[l]) (void)hipStreamDestroy(c->stream_em2[l]); if (c->stream_count2[l]) (void)hipStreamDestroy(c->stream_count2[l]); }
 	delete c;
 }
 
@@ -638,6 +642,9 @@ int lsq_ctx_set_option(lsq_ctx *c, const char *name, double value) {
 		for (auto &r : c->reads) r.wg_grid = 0;
 	} else if (n == "compact_pools") {
 		c->opt_compact_pools = value != 0;        // takes effect with the next upload of a read set
+	} else if (n == "count_streams") {
+		{ int rc = sync_all(c); if (rc) return rc; }
+		c->opt_two_count_streams = value >= 2;
 	} else if (n == "em_flat_min_events") {
 		c->opt_em_flat_min = value < 0 ? 0u : (unsigned)value;
 	} else if (n == "em_regroup") {

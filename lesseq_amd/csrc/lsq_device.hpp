@@ -110,6 +110,11 @@ struct lsq_ctx {
 	// shards (a rank of an event-sharded job) the result stream's chain, not the count kernel, bounded the step.
 	hipStream_t stream_em = nullptr;        // the latest count's lane (= stream_em2[flip])
 	hipStream_t stream_em2[2] = {nullptr, nullptr};
+	// A lane's counts run on a stream of the lane's own: consecutive counts write different counter sets and share only
+	// what they read, so the next count's workgroups may fill the compute units the tail of this one leaves idle, and no
+	// dispatch waits for the kernel before it (option "count_streams" 1: every count on `stream`, one after the other).
+	hipStream_t stream_count2[2] = {nullptr, nullptr};
+	bool opt_two_count_streams = true;
 	hipEvent_t ev_counted2[2] = {nullptr, nullptr}, ev_mark2[2] = {nullptr, nullptr};
 	bool mark_recorded2[2] = {false, false};
 	int flip = 0;                           // counter set of the latest count

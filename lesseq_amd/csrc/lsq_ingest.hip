@@ -354,6 +354,8 @@ static int ingest_device(lsq_ctx *c, int method, const IngestRaw &Rw, uint64_t n
 	// the pools of this method are rewritten below: an exception pass of an earlier count may still read them on the result stream
 	HIP_TRY(hipStreamSynchronize(c->stream_em2[0]));
 	HIP_TRY(hipStreamSynchronize(c->stream_em2[1]));
+	HIP_TRY(hipStreamSynchronize(c->stream_count2[0]));      // ... and a count of an earlier read set on a lane's count stream
+	HIP_TRY(hipStreamSynchronize(c->stream_count2[1]));
 	DevBuf<int> d_ms, d_me;
 	DevBuf<unsigned char> d_nb, d_strand;
 	DevBuf<unsigned> d_key, d_fine;
