@@ -487,6 +487,9 @@ def main():
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 # the same kernel on an otherwise idle device (steps synchronised one by one, no EM beside it)
                 "frac_alone": alg_bytes / (float(np.mean(alone_fast_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                # consecutive counts run on two streams and overlap at their ends (the next one fills the tail of this one), so a
+                # launch's own duration is longer than the time the loop spends per launch: the same bytes over the step time
+                "frac_at_step_rate": (alg_bytes / (1e-3 * 1e3 * elapsed / a.steps) / 1e9 / HBM_PEAK_GBS) if world == 1 else None,
                 "plain_read_GBps_this_device": plain_read, "frac_of_plain_read": (achieved / plain_read if plain_read else None),
                 # the same kernel time against the bytes the pools actually hold (compact records: 4 B per block) -- what the
                 # HBM has to deliver at least; `achieved` above counts SURVEY 8(d)'s 8 B per block

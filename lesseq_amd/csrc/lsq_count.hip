@@ -1271,11 +1271,12 @@ int run_count(lsq_ctx *c) {
 	for (int m = 0; m < M; ++m) {
 		MethodReads &mr = c->reads[m];
 		if (mr.total_slots == 0 || E.buckets.empty()) continue;
-		// workgroups per resident slot: 2 for even read depth and wide records (fewest table stagings), 3 with compact
-		// records (measured at C3: 2 -> 0.175, 3 -> 0.172, 4 -> 0.174, 6 -> 0.187 ms per step), more when a few buckets hold most
-		// of the reads (measured on the skewed workload: 2 -> 0.48 ms, 8 -> 0.30 ms); lsq_ctx_set_option
-		// "grid_multiplier" overrides
-		const unsigned mult = c->opt_grid_mult ? (unsigned)c->opt_grid_mult : (mr.skew >= 32.0 ? 8u : (mr.skew >= 4.0 ? 4u : (mr.compact ? 3u : 2u)));
+		// workgroups per resident slot: 2 for even read depth (fewest table stagings), more when a few buckets hold most of the
+		// reads and shares differ in cost.  Measured with a count stream per lane, where the next count fills the tail of this
+		// one (before that the tail made more and smaller shares pay: 3 and 8): C3 1 -> 0.150, 2 -> 0.143, 3 -> 0.148, 4 ->
+		// 0.151 ms per step; the skewed c5s 3 -> 0.179, 4 -> 0.176, 6 -> 0.178, 8 -> 0.183; C2 1 -> 0.046, 2 -> 0.044, 3 -> 0.044.
+		// lsq_ctx_set_option "grid_multiplier" overrides
+		const unsigned mult = c->opt_grid_mult ? (unsigned)c->opt_grid_mult : (mr.skew >= 32.0 ? 4u : (mr.skew >= 4.0 ? 3u : 2u));
 		unsigned long long grid = (unsigned long long)c->n_cu * per_cu * mult;
 		// one workgroup's share must keep the packed LDS counters (24-bit count, 40-bit bases) exact
 		grid = std::max(grid, mr.total_slots / (1ull << 21) + 1);
