@@ -1249,7 +1249,14 @@ int run_count(lsq_ctx *c) {
 	if (c->time_events) HIP_TRY(hipEventRecord(c->ev0, st));      // ev0..ev1 brackets the count kernel launches only
 	const unsigned generic_tables_bytes = (std::max<unsigned>(E.max_lds_bytes, 16) + 15u) & ~15u;
 	const unsigned tables_bytes = generic_tables_bytes + VISIT_LDS_BYTES;            // fast kernel: + the visit record
-	const unsigned lds_bytes = tables_bytes + WAVES * WAVE_QUEUE_WORDS * 16;
+	// Five workgroups a compute unit, not the six that registers and tables would allow: 5 x 80 registers a SIMD leave
+	// room for a wave of the EM kernel (104) beside them, so the EM of the step before runs without displacing count waves
+	// (measured with LDS padding at the same tables: 6 -> 0.1429, 5 -> 0.1366, 4 -> 0.1433 ms per step on C3).  The LDS
+	// request is what holds the number down.  Only where the EM is that kernel, i.e. with a job's worth of events: with a few
+	// thousand (configs[1]) the small EM kernel fits anyway and the sixth workgroup is worth 10 % (0.0443 -> 0.0400 ms).
+	// Option "workgroups_per_cu": -1 = this rule, 0 = as many as fit, n = n.
+	const unsigned cap = c->opt_wg_per_cu >= 0 ? (unsigned)c->opt_wg_per_cu : (c->em_small_places >= c->opt_em_flat_min ? 5u : 0u);
+	const unsigned lds_bytes = std::max(tables_bytes + WAVES * WAVE_QUEUE_WORDS * 16, cap ? 160u * 1024u / (cap + 1u) + 16u : 0u);
 	if (lds_bytes > 160 * 1024) return fail(LSQ_E_UNSUPPORTED, "bucket tables + read tile exceed the CU's LDS");
 	if (lds_bytes > 64 * 1024) {
 		HIP_TRY(hipFuncSetAttribute((const void *)lsq_count_fast_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -1276,8 +1283,8 @@ int run_count(lsq_ctx *c) {
 		// one (before that the tail made more and smaller shares pay: 3 and 8): C3 1 -> 0.150, 2 -> 0.143, 3 -> 0.148, 4 ->
 		// 0.151 ms per step; the skewed c5s 3 -> 0.179, 4 -> 0.176, 6 -> 0.178, 8 -> 0.183; C2 1 -> 0.046, 2 -> 0.044, 3 -> 0.044.
 		// lsq_ctx_set_option "grid_multiplier" overrides
-		const unsigned mult = c->opt_grid_mult ? (unsigned)c->opt_grid_mult : (mr.skew >= 32.0 ? 4u : (mr.skew >= 4.0 ? 3u : 2u));
-		unsigned long long grid = (unsigned long long)c->n_cu * per_cu * mult;
+		const double mult = c->opt_grid_mult > 0 ? c->opt_grid_mult : (mr.skew >= 32.0 ? 4.0 : (mr.skew >= 4.0 ? 3.0 : 2.0));
+		unsigned long long grid = (unsigned long long)((double)c->n_cu * per_cu * mult);
 		// one workgroup's share must keep the packed LDS counters (24-bit count, 40-bit bases) exact
 		grid = std::max(grid, mr.total_slots / (1ull << 21) + 1);
 		grid = std::min<unsigned long long>(grid, std::max<unsigned long long>(mr.total_slots / 64, 1));

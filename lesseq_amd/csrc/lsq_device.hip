@@ -632,7 +632,7 @@ int lsq_ctx_set_option(lsq_ctx *c, const char *name, double value) {
 	const std::string n(name);
 	if (n == "grid_multiplier") {
 		if (!(value >= 0 && value <= 64)) return fail(LSQ_E_ARG, "grid_multiplier must lie in 0..64 (0 = automatic)");
-		c->opt_grid_mult = (int)value;
+		c->opt_grid_mult = value;
 		for (auto &r : c->reads) r.wg_grid = 0;
 	} else if (n == "exception_capacity") {
 		if (!(value >= 0 && value <= 4e9)) return fail(LSQ_E_ARG, "exception_capacity must lie in 0..4e9 (0 = automatic)");
@@ -642,6 +642,9 @@ int lsq_ctx_set_option(lsq_ctx *c, const char *name, double value) {
 		for (auto &r : c->reads) r.wg_grid = 0;
 	} else if (n == "compact_pools") {
 		c->opt_compact_pools = value != 0;        // takes effect with the next upload of a read set
+	} else if (n == "workgroups_per_cu") {
+		c->opt_wg_per_cu = value < 0 ? -1 : (int)value;
+		c->occ_lds_bytes = 0;          // the occupancy is asked again
 	} else if (n == "count_streams") {
 		{ int rc = sync_all(c); if (rc) return rc; }
 		c->opt_two_count_streams = value >= 2;

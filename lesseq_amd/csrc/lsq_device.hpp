@@ -115,6 +115,7 @@ struct lsq_ctx {
 	// dispatch waits for the kernel before it (option "count_streams" 1: every count on `stream`, one after the other).
 	hipStream_t stream_count2[2] = {nullptr, nullptr};
 	bool opt_two_count_streams = true;
+	int opt_wg_per_cu = -1;                 // "workgroups_per_cu": resident workgroups of the count kernel per compute unit (lsq_count.hip)
 	hipEvent_t ev_counted2[2] = {nullptr, nullptr}, ev_mark2[2] = {nullptr, nullptr};
 	bool mark_recorded2[2] = {false, false};
 	int flip = 0;                           // counter set of the latest count
@@ -178,7 +179,7 @@ struct lsq_ctx {
 	unsigned n_chrom_tables = 0;
 	// lsq_ctx_set_option: grid multiplier (0 = by the read set's skew), entries of a method's exception list
 	// (0 = a quarter of its reads, at least 64 Ki), recount every read with the one-lane-per-read kernel (self-check)
-	int opt_grid_mult = 0;
+	double opt_grid_mult = 0;               // "grid_multiplier" (fractions allowed)
 	size_t opt_exc_cap = 0;
 	bool opt_compact_pools = true;          // "compact_pools": 0 keeps wide pool records whatever the reads look like
 	bool opt_recount = false;

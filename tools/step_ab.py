@@ -14,7 +14,7 @@ ann = L.Annotation(tmp + "/w.interval", tmp + "/w.map")
 ev = L.Events(ann, ("SHORT_READ",), (100,))
 ctx = L.Context(0)
 for kv in filter(None, os.environ.get("AB_OPTS", "").split(",")):
-    k, v = kv.split("="); ctx.set_option(k, int(v))
+    k, v = kv.split("="); ctx.set_option(k, float(v))
 ctx.upload_events(ev); ctx.upload_reads(0, L.Reads.synthetic(spec, ev))
 print("pool format (compact, bytes, reads per pool):", ctx.pool_format(0), flush=True)
 blk = torch.zeros(ev.record_words(0, len(ev)), dtype=torch.int64, device="cuda:0"); torch.cuda.synchronize()
