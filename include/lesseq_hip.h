@@ -241,7 +241,7 @@ int lsq_count_status(lsq_ctx *c, uint32_t *exceptions, uint32_t *recounted);
  * sixteenth solve, so that events of similar cost share a wavefront), "count_streams" (1: every lsq_count on one
  * stream; default 2: a stream per step lane, so that a count may begin while the tail of the one before still runs),
  * "workgroups_per_cu" (resident workgroups of the count kernel per compute unit: 0 = as many as fit, default -1 = five
- * when the EM runs its one-lane-per-event kernel beside it, else as many as fit), "em_flat_min_events" (default 16 384: with at
+ * when the EM runs its one-lane-per-event kernel beside it and the read set is evenly deep, else as many as fit), "em_flat_min_events" (default 16 384: with at
  * least that many two-isoform events the ones that converged within 32 iterations last time are solved one lane per
  * event instead of four -- fewer instructions, longer passes).  LSQ_E_ARG for an unknown name.  The executables
  * pass LSQ_OPTIONS="name=value,..." from the environment through this call. */

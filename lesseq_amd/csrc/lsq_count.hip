@@ -1253,9 +1253,13 @@ int run_count(lsq_ctx *c) {
 	// room for a wave of the EM kernel (104) beside them, so the EM of the step before runs without displacing count waves
 	// (measured with LDS padding at the same tables: 6 -> 0.1429, 5 -> 0.1366, 4 -> 0.1433 ms per step on C3).  The LDS
 	// request is what holds the number down.  Only where the EM is that kernel, i.e. with a job's worth of events: with a few
-	// thousand (configs[1]) the small EM kernel fits anyway and the sixth workgroup is worth 10 % (0.0443 -> 0.0400 ms).
-	// Option "workgroups_per_cu": -1 = this rule, 0 = as many as fit, n = n.
-	const unsigned cap = c->opt_wg_per_cu >= 0 ? (unsigned)c->opt_wg_per_cu : (c->em_small_places >= c->opt_em_flat_min ? 5u : 0u);
+	// thousand (configs[1]) the small EM kernel fits anyway and the sixth workgroup is worth 10 % (0.0443 -> 0.0400 ms).  And
+	// only for evenly deep read sets: with a few hot buckets (c5s) the step is the same either way (0.178 / 0.176-0.184 ms)
+	// and the kernel alone wants the sixth (0.219 -> 0.256 ms).  Option "workgroups_per_cu": -1 = this rule, 0 = as many as
+	// fit, n = n.
+	double max_skew = 0.0;
+	for (int m = 0; m < M; ++m) max_skew = std::max(max_skew, c->reads[m].skew);
+	const unsigned cap = c->opt_wg_per_cu >= 0 ? (unsigned)c->opt_wg_per_cu : (c->em_small_places >= c->opt_em_flat_min && max_skew < 4.0 ? 5u : 0u);
 	const unsigned lds_bytes = std::max(tables_bytes + WAVES * WAVE_QUEUE_WORDS * 16, cap ? 160u * 1024u / (cap + 1u) + 16u : 0u);
 	if (lds_bytes > 160 * 1024) return fail(LSQ_E_UNSUPPORTED, "bucket tables + read tile exceed the CU's LDS");
 	if (lds_bytes > 64 * 1024) {
