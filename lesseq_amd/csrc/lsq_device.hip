@@ -643,13 +643,15 @@ int lsq_ctx_set_option(lsq_ctx *c, const char *name, double value) {
 	} else if (n == "compact_pools") {
 		c->opt_compact_pools = value != 0;        // takes effect with the next upload of a read set
 	} else if (n == "workgroups_per_cu") {
-		c->opt_wg_per_cu = value < 0 ? -1 : (int)value;
+		if (!(value >= -1 && value <= 32)) return fail(LSQ_E_ARG, "workgroups_per_cu must lie in -1..32 (-1 = automatic, 0 = as many as fit)");
+		c->opt_wg_per_cu = (int)value;
 		c->occ_lds_bytes = 0;          // the occupancy is asked again
 	} else if (n == "count_streams") {
 		{ int rc = sync_all(c); if (rc) return rc; }
 		c->opt_two_count_streams = value >= 2;
 	} else if (n == "em_flat_min_events") {
-		c->opt_em_flat_min = value < 0 ? 0u : (unsigned)value;
+		if (!(value >= 0 && value <= 4e9)) return fail(LSQ_E_ARG, "em_flat_min_events must lie in 0..4e9");
+		c->opt_em_flat_min = (unsigned)value;
 	} else if (n == "em_regroup") {
 		c->opt_em_regroup = value != 0;
 		c->em_order_lane_valid[0] = c->em_order_lane_valid[1] = false;

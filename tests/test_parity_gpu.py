@@ -169,17 +169,20 @@ def test_gene_range_and_unknown_read_type(tmp_path, monkeypatch):
 
 
 def test_results_do_not_depend_on_launch_geometry(tmp_path, monkeypatch):
-    """bucket size (LDS budget) and grid size change the work split, never the integers"""
+    """bucket size (LDS budget), grid size and resident workgroups change the work split, never the integers"""
     spec = L.SynthSpec(11, 3000, 500000, 100, 3, L.EVENT_TYPES)
     a_dir = str(tmp_path)
     L.synth_write(spec, a_dir, "g", write_mrf=False)
     results = []
-    for budget, mult in (("8192", "2"), ("1024", "1"), ("65536", "7"), ("90000", "16")):
+    for budget, mult, per_cu in (("8192", "2", -1), ("1024", "1", 0), ("65536", "7", 5), ("90000", "16", 3)):
         monkeypatch.setenv("LSQ_LDS_BUDGET", budget)
         a = L.Annotation(os.path.join(a_dir, "g.interval"), os.path.join(a_dir, "g.map"))
         ev = L.Events(a, ("SHORT_READ",), (100,))
         ctx = L.Context(0)
         ctx.set_option("grid_multiplier", int(mult))
+        ctx.set_option("workgroups_per_cu", per_cu)
+        with pytest.raises(L.LsqError):
+            ctx.set_option("workgroups_per_cu", 1000)
         ctx.upload_events(ev)
         ctx.upload_reads(0, L.Reads.synthetic(spec, ev))
         ctx.count()
