@@ -367,6 +367,7 @@ def main():
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=cmp_dev)
     retained_mine, blocks_mine = ctx.retained(0), ctx.retained_blocks(0)
     pool_fmt = ctx.pool_format(0)
+    launch_info = ctx.launch_info()
     per_rank = torch.tensor([float(np.mean(fast_ms)), float(np.mean(alone_fast_ms)), float(np.mean(solve_ms)), my_weight, float(n_ev_mine),
                              float(job_retained), float(job_blocks)], dtype=torch.float64, device=cmp_dev)
     if world > 1:
@@ -456,6 +457,7 @@ def main():
                 "workload": W["desc"] + ("; BASELINE configs[3]: the same job sharded by event index over %d GPUs with an RCCL gather" % world if strong and a.workload == "c3" else ""),
                 "events": n_ev * (1 if strong or world == 1 else world), "mrf_reads": total_mrf, "retained_reads": total_retained,
                 "retained_blocks": total_blocks, "buckets_rank0": ev.num_buckets,
+                "count_launch_rank0": {"one_block_reads_per_lane_and_look": launch_info[0], "workgroups_per_cu": launch_info[1]},
                 "pool_records_rank0": {"compact": pool_fmt[0], "resident_bytes_of_block_coordinates": pool_fmt[1],
                                        "reads_as_one_block_two_block_many_block_records": list(pool_fmt[2]),
                                        "note": "compact: 4 bytes a block in HBM (22-bit offset from the bucket, 10-bit length); the roofline's algorithmic bytes stay "
@@ -483,7 +485,7 @@ def main():
                 "parallelism": par,
             },
             "roofline": {
-                "bound": "hbm", "kernel": "lsq_count_fast_kernel<%s>" % ("true" if pool_fmt[0] else "false") + (" (rank 0's launch)" if world > 1 else ""),
+                "bound": "hbm", "kernel": "lsq_count_fast_kernel<%s, %d>" % ("true" if pool_fmt[0] else "false", launch_info[0] // 2) + (" (rank 0's launch)" if world > 1 else ""),
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 # the same kernel on an otherwise idle device (steps synchronised one by one, no EM beside it)
                 "frac_alone": alg_bytes / (float(np.mean(alone_fast_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS,

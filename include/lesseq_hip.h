@@ -229,6 +229,10 @@ int lsq_count(lsq_ctx *c);
  * device, so every table that leaves the context -- also through lsq_results_copy_device in a loop
  * that never synchronises -- is whole. */
 int lsq_count_status(lsq_ctx *c, uint32_t *exceptions, uint32_t *recounted);
+/* How the latest lsq_count launched its streaming kernel: one-block reads a lane settles per look at the tables (4:
+ * lsq_count_fast_kernel<.., 2>, 8: lsq_count_fast_kernel<true, 4>) and resident workgroups per compute unit.  Either
+ * pointer may be null. */
+int lsq_count_launch_info(lsq_ctx *c, uint32_t *reads_per_look, uint32_t *workgroups_per_cu);
 /* Tuning knobs; results never depend on them.  "grid_multiplier" (workgroups per resident slot of the
  * count kernel's grid, 0 = chosen from the read set's skew), "exception_capacity" (entries of a read
  * file's exception list, 0 = a quarter of its reads and at least 65 536; applies to read sets uploaded
@@ -240,7 +244,8 @@ int lsq_count_status(lsq_ctx *c, uint32_t *exceptions, uint32_t *recounted);
  * re-sorts the placement by the iteration counts of one of its own earlier solves, refreshed every
  * sixteenth solve, so that events of similar cost share a wavefront), "count_streams" (1: every lsq_count on one
  * stream; default 2: a stream per step lane, so that a count may begin while the tail of the one before still runs),
- * "workgroups_per_cu" (resident workgroups of the count kernel per compute unit: 0 = as many as fit, default -1 = five
+ * "reads_per_look" (0 = automatic: eight one-block reads per lane and table look where the count kernel is held to five
+ * workgroups a compute unit and the pools are compact, else four; 4; 8), "workgroups_per_cu" (resident workgroups of the count kernel per compute unit: 0 = as many as fit, default -1 = five
  * when the EM runs its one-lane-per-event kernel beside it and the read set is evenly deep, else as many as fit), "em_flat_min_events" (default 16 384: with at
  * least that many two-isoform events the ones that converged within 32 iterations last time are solved one lane per
  * event instead of four -- fewer instructions, longer passes).  LSQ_E_ARG for an unknown name.  The executables

@@ -99,6 +99,7 @@ _sig("lsq_results_class_offsets", C.c_int, vp, P(u64))
 _sig("lsq_results_counts", C.c_int, vp, P(u64), P(u64))
 _sig("lsq_results_solve", C.c_int, vp, P(C.c_double), P(C.c_double), P(u32), P(u8))
 _sig("lsq_count_status", C.c_int, vp, P(u32), P(u32))
+_sig("lsq_count_launch_info", C.c_int, vp, P(u32), P(u32))
 _sig("lsq_ctx_set_option", C.c_int, vp, cs, C.c_double)
 _sig("lsq_solve_finalize", C.c_int, vp, P(u32))
 _sig("lsq_set_em_guard_band", C.c_int, vp, C.c_double)

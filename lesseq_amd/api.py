@@ -302,6 +302,12 @@ class Context:
         check(lib.lsq_count_status(self.h, e, r))
         return list(e)[:self.events.n_methods], list(r)[:self.events.n_methods]
 
+    def launch_info(self):
+        """(one-block reads a lane settles per table look, resident workgroups per compute unit) of the latest count()"""
+        a, b = u32(), u32()
+        check(lib.lsq_count_launch_info(self.h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def set_em_guard_band(self, band):
         """events whose EM stop test comes within `band` of its threshold are replayed in the reference's per-read order"""
         check(lib.lsq_set_em_guard_band(self.h, float(band)))

@@ -517,7 +517,9 @@ __device__ inline void walk_parked(const FastCtx &C, Ring<(NB == 1 || PACKED2) ?
 
 // RPW = reads per 16-byte word of a wide pool: 2 (pool 1: one block) or 1 (pool 2: two blocks); a lane's words are
 // numbered that way for compact pools too (the fetch unpacks one compact word into two of them)
-template <int RPW, bool COMPACT>
+// P1W: words a lane takes from the one-block pool per step, all of them settled by one look at the tables (2 or 4, i.e. four
+// or eight reads: the pool's cell groups are padded to eight)
+template <int RPW, bool COMPACT, int P1W>
 __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uint4 *cells, const uint4 *cellx, const unsigned n_cells, const BucketDesc &d,
                                         const CountArgs &A, uint4 *queue, const uint4 *src_generic,
                                         const unsigned long long g0, const unsigned long long g1) {
@@ -525,7 +527,8 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 	// Words (16 bytes of a wide pool: two one-block reads, one two-block read) per lane in flight, and looked up together:
 	// two-block reads take the whole step as one group -- two of them with wide records, four with compact ones (one table
 	// look serves the four: the pool's junction groups are padded to quadruples)
-	constexpr int SW = RPW == 2 ? STREAM_WORDS : (COMPACT ? LSQ_P2_COMPACT_WORDS : LSQ_STREAM_WORDS_P2), GW = RPW == 2 ? GROUP_WORDS : SW;
+	constexpr int SW = RPW == 2 ? P1W : (COMPACT ? LSQ_P2_COMPACT_WORDS : LSQ_STREAM_WORDS_P2), GW = RPW == 2 ? (P1W == STREAM_WORDS ? GROUP_WORDS : P1W) : SW;
+	static_assert(RPW != 2 || (unsigned)(SW * RPW) <= P1_GROUP_PAD, "a lane's reads of a step lie in one cell group");
 	constexpr int CW = COMPACT ? SW / 2 : SW;          // 16-byte loads a lane issues per step
 	constexpr bool PACKED2 = COMPACT && RPW == 1;      // two-block reads are parked as their compact records
 	constexpr int RW = (NB == 1 || PACKED2) ? 1 : 2;   // ring words per parked read
@@ -843,11 +846,14 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 	for (unsigned wt = ww0; wt < ww1; wt += WAVES * TILE) {
 		uint4 cur[SW];
 		if (COMPACT) {
-			const uint4 t = nxt[0];
 			if (RPW == 2) {
 				// one-block reads stay in the records' own terms: (offset from `base`, length); the loop compares there
-				cur[0] = make_uint4(t.x & lsq::COMPACT_OFF_MASK, t.x >> lsq::COMPACT_OFF_BITS, t.y & lsq::COMPACT_OFF_MASK, t.y >> lsq::COMPACT_OFF_BITS);
-				cur[1] = make_uint4(t.z & lsq::COMPACT_OFF_MASK, t.z >> lsq::COMPACT_OFF_BITS, t.w & lsq::COMPACT_OFF_MASK, t.w >> lsq::COMPACT_OFF_BITS);
+#pragma unroll
+				for (int cq = 0; cq < CW; ++cq) {
+					const uint4 t = nxt[cq];
+					cur[2 * cq] = make_uint4(t.x & lsq::COMPACT_OFF_MASK, t.x >> lsq::COMPACT_OFF_BITS, t.y & lsq::COMPACT_OFF_MASK, t.y >> lsq::COMPACT_OFF_BITS);
+					cur[2 * cq + 1] = make_uint4(t.z & lsq::COMPACT_OFF_MASK, t.z >> lsq::COMPACT_OFF_BITS, t.w & lsq::COMPACT_OFF_MASK, t.w >> lsq::COMPACT_OFF_BITS);
+				}
 			} else {
 #pragma unroll
 				for (int cq = 0; cq < CW; ++cq) {
@@ -1010,8 +1016,11 @@ __device__ inline void stage_bucket(const CountArgs &A, const unsigned b, unsign
 	}
 }
 
-template <bool COMPACT>
-__global__ void __launch_bounds__(COUNT_BLOCK, LSQ_FAST_WAVES) lsq_count_fast_kernel(CountArgs A) {
+// <COMPACT, 2>: four one-block reads per lane and look, six waves a SIMD (80 registers); <true, 4>: eight, five waves (96
+// registers) -- for the launches that are held to five workgroups a compute unit anyway (run_count), where the longer
+// step of a lane costs no occupancy and the look is shared by twice the reads
+template <bool COMPACT, int P1W>
+__global__ void __launch_bounds__(COUNT_BLOCK, P1W == 4 ? 5 : LSQ_FAST_WAVES) lsq_count_fast_kernel(CountArgs A) {
 	// LDS: the bucket's tables (image, histograms, visit record), then the waves' rings
 	extern __shared__ __align__(16) unsigned char lds[];
 	const unsigned tid = threadIdx.x;
@@ -1060,10 +1069,10 @@ __global__ void __launch_bounds__(COUNT_BLOCK, LSQ_FAST_WAVES) lsq_count_fast_ke
 		const unsigned long long n1 = V.p1n, n2 = V.p2n;
 		// ---- pool 1
 		if (l0 < n1 && !ABL(A, 1024u))
-			stream_pool_fast<2, COMPACT>(C, bins, cells, cellx, n_cells, d, A, wave_queue, reinterpret_cast<const uint4 *>(A.p1), V.p1o + l0, V.p1o + (l1 < n1 ? l1 : n1));
+			stream_pool_fast<2, COMPACT, P1W>(C, bins, cells, cellx, n_cells, d, A, wave_queue, reinterpret_cast<const uint4 *>(A.p1), V.p1o + l0, V.p1o + (l1 < n1 ? l1 : n1));
 		// ---- pool 2
 		if (l1 > n1 && l0 < n1 + n2 && !ABL(A, 2048u))
-			stream_pool_fast<1, COMPACT>(C, bins, cells, cellx, n_cells, d, A, wave_queue, reinterpret_cast<const uint4 *>(A.p2), V.p2o + ((l0 > n1 ? l0 : n1) - n1),
+			stream_pool_fast<1, COMPACT, P1W>(C, bins, cells, cellx, n_cells, d, A, wave_queue, reinterpret_cast<const uint4 *>(A.p2), V.p2o + ((l0 > n1 ? l0 : n1) - n1),
 			                    V.p2o + ((l1 < n1 + n2 ? l1 : n1 + n2) - n1));
 		// (reads with three or more blocks are the workers')
 		__syncthreads();
@@ -1262,23 +1271,33 @@ int run_count(lsq_ctx *c) {
 	const unsigned cap = c->opt_wg_per_cu >= 0 ? (unsigned)c->opt_wg_per_cu : (c->em_small_places >= c->opt_em_flat_min && max_skew < 4.0 ? 5u : 0u);
 	const unsigned lds_bytes = std::max(tables_bytes + WAVES * WAVE_QUEUE_WORDS * 16, cap ? 160u * 1024u / (cap + 1u) + 16u : 0u);
 	if (lds_bytes > 160 * 1024) return fail(LSQ_E_UNSUPPORTED, "bucket tables + read tile exceed the CU's LDS");
+	// Eight reads per look (lsq_count_fast_kernel<true, 4>) where the launch is held to five workgroups a compute unit anyway
+	// and every pool is compact (C3, same box, developer builds: 0.1465 -> 0.1418 ms per step; the skewed c5s, which runs six
+	// workgroups: 0.189 -> 0.191).  Option "reads_per_look": 0 = this rule, 4, 8.
+	bool all_compact = true;
+	for (int m = 0; m < M; ++m) if (c->reads[m].total_slots && !c->reads[m].compact) all_compact = false;
+	const int p1w = !all_compact ? 2 : (c->opt_reads_per_look ? (c->opt_reads_per_look == 8 ? 4 : 2) : (cap != 0 && cap <= 5 ? 4 : 2));
+	const void *const fn_wide = (const void *)lsq_count_fast_kernel<false, 2>;
+	const void *const fn_compact = p1w == 4 ? (const void *)lsq_count_fast_kernel<true, 4> : (const void *)lsq_count_fast_kernel<true, 2>;
+	c->last_reads_per_look = 2u * (unsigned)p1w;
 	if (lds_bytes > 64 * 1024) {
-		HIP_TRY(hipFuncSetAttribute((const void *)lsq_count_fast_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-		HIP_TRY(hipFuncSetAttribute((const void *)lsq_count_fast_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+		HIP_TRY(hipFuncSetAttribute(fn_wide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+		HIP_TRY(hipFuncSetAttribute(fn_compact, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
 		HIP_TRY(hipFuncSetAttribute((const void *)lsq_count_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
 	}
 	// resident workgroups per CU as the runtime sees them (registers, LDS, wave slots): the grid is a whole number of rounds
 	unsigned per_cu = std::max(1u, std::min(2048u / COUNT_BLOCK, (160u * 1024u) / lds_bytes));
 	{
-		if (c->occ_lds_bytes != lds_bytes) {             // asked once per table size
+		if (c->occ_lds_bytes != lds_bytes || c->occ_p1w != p1w) {             // asked once per table size and kernel
 			int nb = 0;
 			int nb2 = 0;
-			HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)lsq_count_fast_kernel<false>, (int)COUNT_BLOCK, (size_t)lds_bytes));
-			HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb2, (const void *)lsq_count_fast_kernel<true>, (int)COUNT_BLOCK, (size_t)lds_bytes));
-			c->occ_lds_bytes = lds_bytes; c->occ_blocks = std::min(nb, nb2);
+			HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn_wide, (int)COUNT_BLOCK, (size_t)lds_bytes));
+			HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb2, fn_compact, (int)COUNT_BLOCK, (size_t)lds_bytes));
+			c->occ_lds_bytes = lds_bytes; c->occ_p1w = p1w; c->occ_blocks = all_compact ? nb2 : std::min(nb, nb2);
 		}
 		if (c->occ_blocks >= 1) per_cu = std::min(per_cu, (unsigned)c->occ_blocks);
 	}
+	c->last_wg_per_cu = per_cu;
 	for (int m = 0; m < M; ++m) {
 		MethodReads &mr = c->reads[m];
 		if (mr.total_slots == 0 || E.buckets.empty()) continue;
@@ -1359,13 +1378,9 @@ int run_count(lsq_ctx *c) {
 			// event record is one more packet between this kernel and the next count's (measured ~5 us each)
 			const bool last_streaming = m == M - 1 && !c->has_generic && !c->time_events;
 			const dim3 fgrid((unsigned)grid + A.n_workers);
-			if (last_streaming) {
-				if (mr.compact) hipExtLaunchKernelGGL(lsq_count_fast_kernel<true>, fgrid, dim3(COUNT_BLOCK), lds_bytes, st, nullptr, c->ev_counted2[set], 0, A);
-				else hipExtLaunchKernelGGL(lsq_count_fast_kernel<false>, fgrid, dim3(COUNT_BLOCK), lds_bytes, st, nullptr, c->ev_counted2[set], 0, A);
-				counted_signalled = true;
-			} else if (mr.compact) hipLaunchKernelGGL(lsq_count_fast_kernel<true>, fgrid, dim3(COUNT_BLOCK), lds_bytes, st, A);
-			else hipLaunchKernelGGL(lsq_count_fast_kernel<false>, fgrid, dim3(COUNT_BLOCK), lds_bytes, st, A);
-			HIP_TRY(hipGetLastError());
+			void *kargs[] = {(void *)&A};
+			HIP_TRY(hipExtLaunchKernel(mr.compact ? fn_compact : fn_wide, fgrid, dim3(COUNT_BLOCK), kargs, lds_bytes, st, nullptr, last_streaming ? c->ev_counted2[set] : nullptr, 0));
+			if (last_streaming) counted_signalled = true;
 			if (c->time_events) HIP_TRY(hipEventRecord(c->evf1[m], st));
 			c->fast_launched |= 1 << m;
 			cleanups.push_back({A, n_pn, m});
@@ -1419,6 +1434,15 @@ int lsq_count_status(lsq_ctx *c, uint32_t *exceptions, uint32_t *recounted) {
 		if (exceptions) exceptions[m] = h[2 * (size_t)m];
 		if (recounted) recounted[m] = h[2 * (size_t)m + 1];
 	}
+	return LSQ_OK;
+}
+
+// how the latest lsq_count launched its streaming kernel
+int lsq_count_launch_info(lsq_ctx *c, uint32_t *reads_per_look, uint32_t *workgroups_per_cu) {
+	if (!c) return fail(LSQ_E_ARG, "null context");
+	if (!c->counted) return fail(LSQ_E_STATE, "lsq_count must come first");
+	if (reads_per_look) *reads_per_look = c->last_reads_per_look;
+	if (workgroups_per_cu) *workgroups_per_cu = c->last_wg_per_cu;
 	return LSQ_OK;
 }
 

@@ -646,6 +646,9 @@ int lsq_ctx_set_option(lsq_ctx *c, const char *name, double value) {
 		if (!(value >= -1 && value <= 32)) return fail(LSQ_E_ARG, "workgroups_per_cu must lie in -1..32 (-1 = automatic, 0 = as many as fit)");
 		c->opt_wg_per_cu = (int)value;
 		c->occ_lds_bytes = 0;          // the occupancy is asked again
+	} else if (n == "reads_per_look") {
+		if (!(value == 0 || value == 4 || value == 8)) return fail(LSQ_E_ARG, "reads_per_look must be 0 (automatic), 4 or 8");
+		c->opt_reads_per_look = (int)value;
 	} else if (n == "count_streams") {
 		{ int rc = sync_all(c); if (rc) return rc; }
 		c->opt_two_count_streams = value >= 2;

@@ -25,6 +25,10 @@ using namespace lsq;
 	} while (0)
 
 
+#ifndef LSQ_P1_PAD
+#define LSQ_P1_PAD 8
+#endif
+constexpr unsigned P1_GROUP_PAD = LSQ_P1_PAD;      // records a cell's group of the one-block pool is padded to: what a lane of the count kernel takes per look
 constexpr int EM_LANES = 4;          // lanes that share one event in the EM kernel (and one place of its grid)
 
 namespace lsq {
@@ -124,6 +128,9 @@ struct lsq_ctx {
 	hipEvent_t evt0 = nullptr, evt1 = nullptr;      // around a text copy (lsq_text_stage may run beside other host work)
 	hipEvent_t evf0[LSQ_MAX_METHODS] = {}, evf1[LSQ_MAX_METHODS] = {};   // around each method's lsq_count_fast_kernel launch
 	int fast_launched = 0;
+	int occ_p1w = 0;
+	int opt_reads_per_look = 0;             // "reads_per_look": 0 = by the launch (lsq_count.hip), 4, 8
+	unsigned last_reads_per_look = 4, last_wg_per_cu = 0;       // what the latest lsq_count ran with
 	unsigned occ_lds_bytes = 0; int occ_blocks = 0;      // the runtime's occupancy answer for the fast kernel at that LDS size
 	bool time_events = false;               // lsq_set_timing: event records around the kernels cost ~4 us each in the queue
 	bool count_timed = false, solve_timed = false;      // the last lsq_count / lsq_solve ran with them

@@ -310,7 +310,7 @@ __global__ void __launch_bounds__(256) lsq_ingest_pad_kernel(const BucketDesc *b
 	for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < n_groups1 + n_groups2; t += gridDim.x * blockDim.x) {
 		const bool one = t < n_groups1;
 		const unsigned g = one ? t : t - n_groups1;
-		const unsigned n = one ? cnt1[g] : cnt2[g], pad = ((n + 3u) & ~3u) - n;
+		const unsigned n = one ? cnt1[g] : cnt2[g], gp = one ? P1_GROUP_PAD : 4u, pad = ((n + gp - 1u) & ~(gp - 1u)) - n;
 		if (!pad) continue;
 		const unsigned *gbase = one ? cell_base : jgroup_base;
 		unsigned lo_b = 0, hi_b = n_buckets;                 // bucket of the group: last b with gbase[b] <= g
@@ -389,7 +389,7 @@ static int ingest_device(lsq_ctx *c, int method, const IngestRaw &Rw, uint64_t n
 			hipLaunchKernelGGL(lsq_ingest_classify_kernel, dim3(igrid), dim3(256), 0, st, T, Rw, W);
 			HIP_TRY(hipGetLastError());
 		}
-		hipLaunchKernelGGL(lsq_scan_u32_kernel<4>, dim3(1), dim3(1024), 0, st, W.cnt1, (unsigned long long)FC, d_off1.p);      // groups padded to four records
+		hipLaunchKernelGGL(lsq_scan_u32_kernel<P1_GROUP_PAD>, dim3(1), dim3(1024), 0, st, W.cnt1, (unsigned long long)FC, d_off1.p);      // groups padded to four records
 		hipLaunchKernelGGL(lsq_scan_u32_kernel<4>, dim3(1), dim3(1024), 0, st, W.cnt2, (unsigned long long)FJ, d_off2.p);
 		hipLaunchKernelGGL(lsq_scan_u32_kernel<1>, dim3(1), dim3(1024), 0, st, W.cntn, (unsigned long long)B, mr.pn_off.p);
 		hipLaunchKernelGGL(lsq_scan_u32_kernel<1>, dim3(1), dim3(1024), 0, st, W.cntnb, (unsigned long long)B, mr.pnb_off.p);

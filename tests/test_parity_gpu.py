@@ -174,13 +174,14 @@ def test_results_do_not_depend_on_launch_geometry(tmp_path, monkeypatch):
     a_dir = str(tmp_path)
     L.synth_write(spec, a_dir, "g", write_mrf=False)
     results = []
-    for budget, mult, per_cu in (("8192", "2", -1), ("1024", "1", 0), ("65536", "7", 5), ("90000", "16", 3)):
+    for budget, mult, per_cu, per_look in (("8192", "2", -1, 0), ("1024", "1", 0, 8), ("65536", "7", 5, 4), ("90000", "16", 3, 8), ("8192", "2", 5, 0)):
         monkeypatch.setenv("LSQ_LDS_BUDGET", budget)
         a = L.Annotation(os.path.join(a_dir, "g.interval"), os.path.join(a_dir, "g.map"))
         ev = L.Events(a, ("SHORT_READ",), (100,))
         ctx = L.Context(0)
         ctx.set_option("grid_multiplier", int(mult))
         ctx.set_option("workgroups_per_cu", per_cu)
+        ctx.set_option("reads_per_look", per_look)
         with pytest.raises(L.LsqError):
             ctx.set_option("workgroups_per_cu", 1000)
         ctx.upload_events(ev)
@@ -188,6 +189,7 @@ def test_results_do_not_depend_on_launch_geometry(tmp_path, monkeypatch):
         ctx.count()
         cnt, bases = ctx.counts()
         results.append((ev.num_buckets, cnt.copy(), bases.copy()))
+        assert ctx.launch_info()[0] == (per_look if per_look else (8 if per_cu == 5 else 4))
         ctx.close()
     assert len({r[0] for r in results}) > 1
     for r in results[1:]:
