@@ -413,6 +413,9 @@ __device__ inline bool fast_trip(const FastCtx &C, const int4 v, const int total
 #ifndef LSQ_P2_COMPACT_WORDS
 #define LSQ_P2_COMPACT_WORDS 2         // two-block reads a lane takes per step from a compact pool (2 or 4; 4 -- one table look for four reads -- measured 3 % slower: the one-block path of the same kernel loses more registers than the look saves)
 #endif
+#ifndef LSQ_P2_COMPACT_WORDS_W5
+#define LSQ_P2_COMPACT_WORDS_W5 4      // the same in the five-wave kernel: with 96 registers the one look for four reads pays (C3, developer builds, same box: 0.1401 -> 0.1364 ms per step)
+#endif
 constexpr int STREAM_WORDS = LSQ_STREAM_WORDS;                // 16-byte words per lane in flight
 #ifndef LSQ_GROUP_WORDS
 #define LSQ_GROUP_WORDS 2
@@ -527,7 +530,7 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 	// Words (16 bytes of a wide pool: two one-block reads, one two-block read) per lane in flight, and looked up together:
 	// two-block reads take the whole step as one group -- two of them with wide records, four with compact ones (one table
 	// look serves the four: the pool's junction groups are padded to quadruples)
-	constexpr int SW = RPW == 2 ? P1W : (COMPACT ? LSQ_P2_COMPACT_WORDS : LSQ_STREAM_WORDS_P2), GW = RPW == 2 ? (P1W == STREAM_WORDS ? GROUP_WORDS : P1W) : SW;
+	constexpr int SW = RPW == 2 ? P1W : (COMPACT ? (P1W == 4 ? LSQ_P2_COMPACT_WORDS_W5 : LSQ_P2_COMPACT_WORDS) : LSQ_STREAM_WORDS_P2), GW = RPW == 2 ? (P1W == STREAM_WORDS ? GROUP_WORDS : P1W) : SW;
 	static_assert(RPW != 2 || (unsigned)(SW * RPW) <= P1_GROUP_PAD, "a lane's reads of a step lie in one cell group");
 	constexpr int CW = COMPACT ? SW / 2 : SW;          // 16-byte loads a lane issues per step
 	constexpr bool PACKED2 = COMPACT && RPW == 1;      // two-block reads are parked as their compact records
