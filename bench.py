@@ -417,7 +417,8 @@ def main():
         for i in range(lo_e, lo_e + n_e):
             K, N = ev.K(i), ev.N(i)
             ev_bytes += 8 * N + 8 * K + 16 + 8 * ((1 << K) - 1) + 8
-        alg_bytes = 8.0 * blocks_mine + ev_bytes            # of rank 0's launch
+        # of rank 0's launch: a rank of an event-sharded job streams the blocks of its slice's reads, not the job's
+        alg_bytes = 8.0 * (ctx.pooled_blocks(0) if (world > 1 and strong) else blocks_mine) + ev_bytes
         achieved = alg_bytes / (fk * 1e-3) / 1e9
         # HBM bytes per launch of the same kernel from the committed rocprofv3 PMC passes (tools/bench_prof.sh): not measured by this run
         committed = None

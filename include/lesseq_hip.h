@@ -207,6 +207,7 @@ uint64_t lsq_reads_retained_blocks(const lsq_ctx *c, int method);
  * context.  Without a shard that is every retained read; with lsq_events_set_shard the slice's share (a read that starts
  * in no event of the slice is a candidate of none of them, count/count.cpp:429-432,463, and is dropped at ingest). */
 uint64_t lsq_reads_pooled(const lsq_ctx *c, int method);
+uint64_t lsq_reads_pooled_blocks(const lsq_ctx *c, int method);      /* ... and their blocks: what one lsq_count streams */
 /* How the one- and two-block reads of a read file lie in HBM.  *compact = 1: 4 bytes a block -- 22 bits of offset (the
  * first block's from the first base of its bucket of events minus 2 Mi, the second block's from the end of the first) and
  * 10 bits of length; a read with a block of 1 024 bases or more, or an offset that does not fit, is kept with the

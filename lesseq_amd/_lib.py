@@ -91,6 +91,7 @@ _sig("lsq_last_mrf_timing", C.c_int, vp, P(C.c_float), P(C.c_float))
 _sig("lsq_reads_retained", u64, vp, C.c_int)
 _sig("lsq_reads_retained_blocks", u64, vp, C.c_int)
 _sig("lsq_reads_pooled", u64, vp, C.c_int)
+_sig("lsq_reads_pooled_blocks", u64, vp, C.c_int)
 _sig("lsq_reads_pool_format", C.c_int, vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
 _sig("lsq_count", C.c_int, vp)
 _sig("lsq_solve", C.c_int, vp)

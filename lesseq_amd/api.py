@@ -273,6 +273,10 @@ class Context:
         """retained reads kept in the pools: those that start in the span of an event planned on this context"""
         return lib.lsq_reads_pooled(self.h, method)
 
+    def pooled_blocks(self, method):
+        """blocks of the pooled reads: what one count() streams"""
+        return lib.lsq_reads_pooled_blocks(self.h, method)
+
     def pool_format(self, method):
         """lsq_reads_pool_format: (compact records?, bytes of block coordinates in HBM,
         reads kept as one-block / two-block records / with the many-block reads)"""

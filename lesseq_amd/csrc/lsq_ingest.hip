@@ -604,6 +604,11 @@ uint64_t lsq_reads_pooled(const lsq_ctx *c, int method) {
 	const MethodReads &mr = c->reads[method];
 	return mr.n1_reads + mr.n2_reads + mr.pn_line.n;          // (total_slots also counts the padding of the groups)
 }
+uint64_t lsq_reads_pooled_blocks(const lsq_ctx *c, int method) {
+	if (!c || method < 0 || method >= LSQ_MAX_METHODS) return 0;
+	const MethodReads &mr = c->reads[method];
+	return mr.n1_reads + 2 * mr.n2_reads + mr.pn_se.n / 2;
+}
 uint64_t lsq_reads_retained_blocks(const lsq_ctx *c, int method) { return (c && method >= 0 && method < LSQ_MAX_METHODS) ? c->reads[method].n_retained_blocks : 0; }
 
 int lsq_reads_pool_format(const lsq_ctx *c, int method, int *compact, uint64_t *pool_bytes, uint64_t *pool_reads) {
