@@ -16,7 +16,7 @@ for name, d in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
             kn = kn.split("lsq_")[1].split("(")[0]
             a = acc[kn]; a[0] += float(row["Counter_Value"]); a[1] += 1
     res[name] = {k: {"mean_KiB": v / max(n, 1), "dispatches": n} for k, (v, n) in acc.items()}
-def fast(table):       # the kernel is a template over the pool record format: count_fast_kernel<true> / <false>
+def fast(table):       # the kernel is a template over the pool record format: count_fast_kernel<true, 4> / <true, 2> / <false, 2>
     hits = [v for k, v in table.items() if k.startswith("count_fast_kernel")]
     n = sum(h["dispatches"] for h in hits)
     return sum(h["mean_KiB"] * h["dispatches"] for h in hits) / n if n else 0.0
