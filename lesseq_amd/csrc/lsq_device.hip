@@ -1,6 +1,7 @@
 // Device group of the C ABI: context, event tables, count / solve entry points, result fetch (gfx950).
 // The kernels live in lsq_count.hip, lsq_em.hip and lsq_ingest.hip.
 #include "lsq_device.hpp"
+#include <chrono>
 
 namespace lsq {
 
@@ -18,12 +19,23 @@ int upload_strand_ranks(lsq_ctx *c) {
 	return LSQ_OK;
 }
 
+// A blocking wait wakes up tens of microseconds after the stream has drained; a step is 0.04-0.14 ms.  So the stream is
+// polled for its first two milliseconds (a few steps' worth) and only a longer wait goes to sleep.
+static hipError_t wait_for_stream(hipStream_t s) {
+	const auto t0 = std::chrono::steady_clock::now();
+	for (;;) {
+		const hipError_t e = hipStreamQuery(s);
+		if (e != hipErrorNotReady) return e;
+		if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) return hipStreamSynchronize(s);
+	}
+}
+
 int sync_all(lsq_ctx *c) {
-	HIP_TRY(hipStreamSynchronize(c->stream));
-	HIP_TRY(hipStreamSynchronize(c->stream_count2[0]));
-	HIP_TRY(hipStreamSynchronize(c->stream_count2[1]));
-	HIP_TRY(hipStreamSynchronize(c->stream_em2[0]));
-	HIP_TRY(hipStreamSynchronize(c->stream_em2[1]));
+	HIP_TRY(wait_for_stream(c->stream_count2[0]));
+	HIP_TRY(wait_for_stream(c->stream_count2[1]));
+	HIP_TRY(wait_for_stream(c->stream_em2[0]));
+	HIP_TRY(wait_for_stream(c->stream_em2[1]));
+	HIP_TRY(wait_for_stream(c->stream));
 	return LSQ_OK;
 }
 
