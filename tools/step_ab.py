@@ -20,9 +20,13 @@ print("pool format (compact, bytes, reads per pool):", ctx.pool_format(0), flush
 blk = torch.zeros(ev.record_words(0, len(ev)), dtype=torch.int64, device="cuda:0"); torch.cuda.synchronize()
 def step():
     ctx.count(); ctx.solve(); ctx.pack_results_device(blk.data_ptr())
-TOGGLE = os.environ.get("AB_TOGGLE")          # an option flipped 0/1 between repetitions of the same process
+TOGGLE = os.environ.get("AB_TOGGLE")          # an option flipped 0/1 (or "name:a:b": between a and b) between repetitions of the same process
+TVALS = (0.0, 1.0)
+if TOGGLE and ":" in TOGGLE:
+    TOGGLE, va, vb = TOGGLE.split(":")
+    TVALS = (float(va), float(vb))
 for rep in range(8 if TOGGLE else 3):
-    if TOGGLE: ctx.set_option(TOGGLE, rep & 1)
+    if TOGGLE: ctx.set_option(TOGGLE, TVALS[rep & 1])
     for _ in range(40): step()
     ctx.synchronize(); t0 = time.perf_counter()
     for _ in range(300): step()
@@ -30,4 +34,4 @@ for rep in range(8 if TOGGLE else 3):
     ctx.set_timing(True)
     for _ in range(3): step()
     ctx.synchronize(); fk = ctx.fast_kernel_ms(); ctx.set_timing(False)
-    print("%s: %.4f ms per step, count kernel in the pipeline %.4f" % (os.environ.get("LSQ_LIB", "release").split("_")[-1] + " " + os.environ.get("AB_OPTS", "") + (" %s=%d" % (TOGGLE, rep & 1) if TOGGLE else ""), dt, fk), flush=True)
+    print("%s: %.4f ms per step, count kernel in the pipeline %.4f" % (os.environ.get("LSQ_LIB", "release").split("_")[-1] + " " + os.environ.get("AB_OPTS", "") + (" %s=%g" % (TOGGLE, TVALS[rep & 1]) if TOGGLE else ""), dt, fk), flush=True)
