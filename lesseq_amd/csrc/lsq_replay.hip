@@ -444,12 +444,12 @@ int lsq_debug_check_pool_layout(lsq_ctx *c, int method, unsigned long long *out)
 			return -1;
 		};
 		const size_t n1 = R.p1_line.size(), n2 = R.p2_line.size();
-		if ((n1 & 3u) || (n2 & 3u)) return fail(LSQ_E_STATE, "bucket %zu: pool slices of %zu and %zu records are not whole quadruples / pairs", b, n1, n2);
+		if ((n1 % P1_GROUP_PAD) || (n2 & 3u)) return fail(LSQ_E_STATE, "bucket %zu: pool slices of %zu and %zu records are not whole groups of %u / quadruples", b, n1, n2, P1_GROUP_PAD);
 		out[0] += n1; out[3] += n2;
-		for (size_t q = 0; q < n1; q += 4) {
+		for (size_t q = 0; q < n1; q += P1_GROUP_PAD) {          // what a lane of lsq_count_fast_kernel<true, 4> settles with one look
 			long first = -2;
 			bool mixed = false;
-			for (size_t k = q; k < q + 4; ++k) {
+			for (size_t k = q; k < q + P1_GROUP_PAD; ++k) {
 				const int s = R.p1[2 * k], e = R.p1[2 * k + 1];
 				if (s == e) { ++out[1]; continue; }
 				const long cl = cell_of(s);

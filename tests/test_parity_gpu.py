@@ -628,7 +628,7 @@ def test_reads_that_do_not_fit_compact_records(tmp_path):
 
 @pytest.mark.parametrize("compact", [1, 0], ids=["compact_records", "wide_records"])
 def test_pools_are_laid_out_by_cell_and_by_junction(compact, tmp_path):
-    """the ingest's layout, which the count kernel's speed rests on (its results do not): every aligned quadruple of
+    """the ingest's layout, which the count kernel's speed rests on (its results do not): every aligned group of eight
     one-block records starts in one cell of the annotation, every aligned pair of two-block records of a junction group
     crosses one junction, padding is empty records only, and the records that are not padding are the reads counted"""
     import ctypes as C
@@ -649,8 +649,9 @@ def test_pools_are_laid_out_by_cell_and_by_junction(compact, tmp_path):
     assert fmt[0] is bool(compact)
     assert (n1 - pad1, n2 - pad2) == fmt[2][:2] and n1 - pad1 > 200000 and n2 - pad2 > 30000
     assert mixed1 == 0 and mixed2 == 0
-    assert 0 < pad1 < 0.1 * n1 and 0 < pad2 < 0.6 * n2           # a few records per cell / junction
+    assert 0 < pad1 < 0.2 * n1 and 0 < pad2 < 0.6 * n2           # a few records per cell / junction
     assert ctx.pooled(0) == sum(fmt[2]) == ctx.retained(0)
+    assert fmt[2][0] + 2 * fmt[2][1] + 3 * fmt[2][2] <= ctx.pooled_blocks(0) <= ctx.retained_blocks(0)
     ctx.close()
 
 
