@@ -544,7 +544,7 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 	// words [w0, w1) of the workgroup, dealt to its waves a step at a time (wave, wave + 4, ...): the
 	// reads that need the general walk sit together in the start-ordered pool, and a contiguous
 	// quarter per wave would leave three waves waiting for the one that got them
-	// (the range starts on a multiple of a lane's words: they are one of the quadruples / pairs the pools' groups are padded
+	// (the range starts on a multiple of a lane's words: they are one of the octuples / quadruples the pools' groups are padded
 	// to, and whole 16-byte words of a compact pool)
 	const unsigned long long w0 = (g0 / RPW) & ~(unsigned long long)(SW - 1), w1 = (g1 + RPW - 1) / RPW;
 	const unsigned n_words = (unsigned)(w1 - w0);                                   // a workgroup's range stays below 2^21 reads

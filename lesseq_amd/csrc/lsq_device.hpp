@@ -174,7 +174,7 @@ struct lsq_ctx {
 	DevBuf<unsigned> bin_base;             // per bucket: first of its bins among all bins (n_buckets + 1)
 	size_t n_fine = 0;
 	// The one-block pool is laid out by cell (lsq_internal.hpp: Cell), not by bin: per bucket its cells in order and one more
-	// group for the reads that start in no cell, every group padded to four records -- a lane of the count kernel takes four
+	// group for the reads that start in no cell, every group padded to eight records (P1_GROUP_PAD) -- a lane of the count kernel takes four or eight
 	// neighbouring records and decides them against one cell.  cell_base: per bucket the first of its groups (n_buckets + 1).
 	DevBuf<unsigned> cell_base;
 	size_t n_cell_groups = 0;

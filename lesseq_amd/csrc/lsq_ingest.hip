@@ -299,7 +299,7 @@ __global__ void __launch_bounds__(256) lsq_ingest_scatter_kernel(IngestRaw R, In
 	}
 }
 
-// The padding of the groups (up to three records each): empty reads.  A one-block one starts on its cell's first base, so
+// The padding of the groups (up to seven one-block, three two-block records each): empty reads.  A one-block one starts on its cell's first base, so
 // that the count kernel's loop sees it as inside the cell and adding nothing; a two-block one never comes first among a
 // lane's records and is passed over there.
 __global__ void __launch_bounds__(256) lsq_ingest_pad_kernel(const BucketDesc *buckets, const unsigned *cell_base, const unsigned *jgroup_base, unsigned n_buckets,
@@ -389,7 +389,7 @@ static int ingest_device(lsq_ctx *c, int method, const IngestRaw &Rw, uint64_t n
 			hipLaunchKernelGGL(lsq_ingest_classify_kernel, dim3(igrid), dim3(256), 0, st, T, Rw, W);
 			HIP_TRY(hipGetLastError());
 		}
-		hipLaunchKernelGGL(lsq_scan_u32_kernel<P1_GROUP_PAD>, dim3(1), dim3(1024), 0, st, W.cnt1, (unsigned long long)FC, d_off1.p);      // groups padded to four records
+		hipLaunchKernelGGL(lsq_scan_u32_kernel<P1_GROUP_PAD>, dim3(1), dim3(1024), 0, st, W.cnt1, (unsigned long long)FC, d_off1.p);      // groups padded to eight records, and to four
 		hipLaunchKernelGGL(lsq_scan_u32_kernel<4>, dim3(1), dim3(1024), 0, st, W.cnt2, (unsigned long long)FJ, d_off2.p);
 		hipLaunchKernelGGL(lsq_scan_u32_kernel<1>, dim3(1), dim3(1024), 0, st, W.cntn, (unsigned long long)B, mr.pn_off.p);
 		hipLaunchKernelGGL(lsq_scan_u32_kernel<1>, dim3(1), dim3(1024), 0, st, W.cntnb, (unsigned long long)B, mr.pnb_off.p);

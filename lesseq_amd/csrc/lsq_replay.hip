@@ -420,9 +420,9 @@ int lsq_solve_finalize(lsq_ctx *c, uint32_t *n_replayed) {
 	return rc;
 }
 
-// Developer check of the pools' layout (tests): every aligned quadruple of one-block records starts in one cell (or all
+// Developer check of the pools' layout (tests): every aligned group of eight one-block records starts in one cell (or all
 // in none), every aligned quadruple of two-block records of a junction group crosses one junction, and the records that are
-// not padding number what the ingest counted.  out: [0] one-block records, [1] of them padding, [2] quadruples over more
+// not padding number what the ingest counted.  out: [0] one-block records, [1] of them padding, [2] groups of eight over more
 // than one cell, [3] two-block records, [4] of them padding, [5] quadruples whose first read crosses a junction of the
 // annotation and another of whose reads crosses another or none.
 int lsq_debug_check_pool_layout(lsq_ctx *c, int method, unsigned long long *out) {
