@@ -1308,8 +1308,10 @@ int run_count(lsq_ctx *c) {
 		// reads and shares differ in cost.  Measured with a count stream per lane, where the next count fills the tail of this
 		// one (before that the tail made more and smaller shares pay: 3 and 8): C3 1 -> 0.150, 2 -> 0.143, 3 -> 0.148, 4 ->
 		// 0.151 ms per step; the skewed c5s 3 -> 0.179, 4 -> 0.176, 6 -> 0.178, 8 -> 0.183; C2 1 -> 0.046, 2 -> 0.044, 3 -> 0.044.
+		// The five-wave kernel's steps are twice as long, and its shares pay for being smaller: C3 1.6 -> 0.137, 2 -> 0.133,
+		// 2.4 -> 0.1335, 3 -> 0.129, 3.5 -> 0.132, 4 -> 0.133, 5 -> 0.137, 6 -> 0.1355.
 		// lsq_ctx_set_option "grid_multiplier" overrides
-		const double mult = c->opt_grid_mult > 0 ? c->opt_grid_mult : (mr.skew >= 32.0 ? 4.0 : (mr.skew >= 4.0 ? 3.0 : 2.0));
+		const double mult = c->opt_grid_mult > 0 ? c->opt_grid_mult : (mr.skew >= 32.0 ? 4.0 : (mr.skew >= 4.0 || p1w == 4 ? 3.0 : 2.0));
 		unsigned long long grid = (unsigned long long)((double)c->n_cu * per_cu * mult);
 		// one workgroup's share must keep the packed LDS counters (24-bit count, 40-bit bases) exact
 		grid = std::max(grid, mr.total_slots / (1ull << 21) + 1);
