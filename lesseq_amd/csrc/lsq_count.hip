@@ -1274,6 +1274,8 @@ int run_count(lsq_ctx *c) {
 	const unsigned cap = c->opt_wg_per_cu >= 0 ? (unsigned)c->opt_wg_per_cu : (c->em_small_places >= c->opt_em_flat_min && max_skew < 4.0 ? 5u : 0u);
 	const unsigned lds_bytes = std::max(tables_bytes + WAVES * WAVE_QUEUE_WORDS * 16, cap ? 160u * 1024u / (cap + 1u) + 16u : 0u);
 	if (lds_bytes > 160 * 1024) return fail(LSQ_E_UNSUPPORTED, "bucket tables + read tile exceed the CU's LDS");
+	// (That is how the rule was found, with the 80-register kernel.  The launches it holds to five now run the 96-register
+	// kernel below, which fills the SIMD's registers at five waves by itself and still gains: fewer instructions per read.)
 	// Eight reads per look (lsq_count_fast_kernel<true, 4>) where the launch is held to five workgroups a compute unit anyway
 	// and every pool is compact (C3, same box, developer builds: 0.1465 -> 0.1418 ms per step; the skewed c5s, which runs six
 	// workgroups: 0.189 -> 0.191).  Option "reads_per_look": 0 = this rule, 4, 8.
