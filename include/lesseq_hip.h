@@ -275,6 +275,14 @@ int lsq_results_counts(lsq_ctx *c, uint64_t *class_count, uint64_t *class_bases)
 /* The inverse: class counts and matched bases in that layout become the context's counts (e.g. the
  * sums over several processes that each counted a slice of the reads); lsq_solve then runs on them. */
 int lsq_results_set_counts(lsq_ctx *c, const uint64_t *class_count, const uint64_t *class_bases);
+/* The same exchange without the host: lsq_counts_export_device copies the latest count's class counts and matched bases
+ * as they lie on the device -- lsq_counts_device_words() 8-byte words, the same order on every context that holds the
+ * same events -- into a device buffer, on the result stream; lsq_counts_import_device takes such a buffer (the sum over
+ * the ranks of a read-sharded job, count/count.cpp:378,467-482 add reads in any order) as the counts lsq_solve and the
+ * getters work on.  The caller orders its collective against the result stream (lsq_ctx_result_stream). */
+uint64_t lsq_counts_device_words(const lsq_ctx *c);
+int lsq_counts_export_device(lsq_ctx *c, void *d_words);
+int lsq_counts_import_device(lsq_ctx *c, const void *d_words);
 int lsq_results_solve(lsq_ctx *c, double *theta, double *logll, uint32_t *em_iters, uint8_t *em_flags);
 /* The exact-order replay on its own, for callers that take the results through lsq_results_copy_device:
  * waits for the latest lsq_solve, redoes every flagged event as described above and writes theta, logll,
@@ -333,6 +341,7 @@ int lsq_results_pack_device(lsq_ctx *c, void *d_block);
 int lsq_device_alloc(lsq_ctx *c, uint64_t bytes, void **out);
 void lsq_device_free(lsq_ctx *c, void *p);
 int lsq_device_read(lsq_ctx *c, void *host_dst, const void *device_src, uint64_t bytes);
+int lsq_device_write(lsq_ctx *c, void *device_dst, const void *host_src, uint64_t bytes);      /* blocking, after the context's streams */
 int lsq_gathered_unpack(const lsq_events *e, int world, const uint64_t *first, const uint64_t *count,
                         const uint64_t *blocks, uint64_t stride_words,
                         uint64_t *class_count, uint64_t *class_bases, double *theta, double *logll);

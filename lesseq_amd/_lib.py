@@ -16,6 +16,18 @@ if not os.path.exists(LIB_PATH):
     raise ImportError("%s is missing: build it with `make -C lesseq_amd/csrc` (or __graft_entry__.build()); "
                       "there is no fallback implementation" % LIB_PATH)
 
+# One HIP runtime per process.  PyTorch-ROCm brings libamdhip64 of its own; if this library came first it would bind the
+# system's copy, torch would then load its own beside it, and whichever of the two opens the device second finds none
+# (measured: torch.cuda.is_available() False after a Context, or LSQ_E_DEVICE after torch.cuda's start-up).  With torch
+# loaded first the library's libamdhip64 dependency resolves to the copy already in the process.  bench.py, the multi-GPU
+# drivers (dist.py under torchrun) and the distributed tests all hold both; a host without torch skips this.
+# (LSQ_NO_TORCH=1: leave torch out, for a process that will never use it.)
+if os.environ.get("LSQ_NO_TORCH") != "1":
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+
 lib = C.CDLL(LIB_PATH)
 
 u64, i64, u32, i32, u16, u8 = C.c_uint64, C.c_int64, C.c_uint32, C.c_int32, C.c_uint16, C.c_uint8
@@ -101,6 +113,9 @@ _sig("lsq_results_counts", C.c_int, vp, P(u64), P(u64))
 _sig("lsq_results_solve", C.c_int, vp, P(C.c_double), P(C.c_double), P(u32), P(u8))
 _sig("lsq_count_status", C.c_int, vp, P(u32), P(u32))
 _sig("lsq_count_launch_info", C.c_int, vp, P(u32), P(u32))
+_sig("lsq_counts_device_words", u64, vp)
+_sig("lsq_counts_export_device", C.c_int, vp, vp)
+_sig("lsq_counts_import_device", C.c_int, vp, vp)
 _sig("lsq_ctx_set_option", C.c_int, vp, cs, C.c_double)
 _sig("lsq_solve_finalize", C.c_int, vp, P(u32))
 _sig("lsq_set_em_guard_band", C.c_int, vp, C.c_double)
@@ -113,6 +128,7 @@ _sig("lsq_gathered_unpack", C.c_int, vp, C.c_int, P(u64), P(u64), P(u64), u64, P
 _sig("lsq_device_alloc", C.c_int, vp, u64, P(vp))
 _sig("lsq_device_free", None, vp, vp)
 _sig("lsq_device_read", C.c_int, vp, vp, vp, u64)
+_sig("lsq_device_write", C.c_int, vp, vp, vp, u64)
 _sig("lsq_results_device_order", C.c_int, vp, P(i32))
 _sig("lsq_fim", C.c_int, vp)
 _sig("lsq_results_fim_size", C.c_int64, vp)

@@ -306,6 +306,17 @@ class Context:
         check(lib.lsq_count_status(self.h, e, r))
         return list(e)[:self.events.n_methods], list(r)[:self.events.n_methods]
 
+    def counts_device_words(self):
+        return int(lib.lsq_counts_device_words(self.h))
+
+    def export_counts_device(self, d_ptr):
+        """the latest count's class counts and matched bases, device order, into a device buffer (result stream)"""
+        check(lib.lsq_counts_export_device(self.h, vp(d_ptr)))
+
+    def import_counts_device(self, d_ptr):
+        """such a buffer (e.g. summed over the ranks of a read-sharded job) becomes the counts solve() works on"""
+        check(lib.lsq_counts_import_device(self.h, vp(d_ptr)))
+
     def launch_info(self):
         """(one-block reads a lane settles per table look, resident workgroups per compute unit) of the latest count()"""
         a, b = u32(), u32()

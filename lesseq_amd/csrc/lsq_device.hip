@@ -435,6 +435,38 @@ int lsq_results_set_counts(lsq_ctx *c, const uint64_t *class_count, const uint64
 	return LSQ_OK;
 }
 
+// The latest count's class counts and matched bases as they lie on the device -- [file][device class] counts, then the same
+// for the bases -- for an exchange that never leaves HBM (the read-sharded run sums them over the ranks: every rank has
+// the same events, hence the same order).
+uint64_t lsq_counts_device_words(const lsq_ctx *c) { return (c && c->E) ? 2ull * (uint64_t)c->E->n_methods * (uint64_t)c->E->n_cls_total : 0; }
+
+int lsq_counts_export_device(lsq_ctx *c, void *d_words) {
+	if (!c || !d_words) return fail(LSQ_E_ARG, "null argument");
+	if (!c->counted) return fail(LSQ_E_STATE, "lsq_count must come first");
+	HIP_TRY(hipSetDevice(c->device));
+	const size_t per = (size_t)c->E->n_methods * c->E->n_cls_total;
+	if (per) {         // on the result stream, behind the count's exception pass
+		HIP_TRY(hipMemcpyAsync(d_words, c->cnt.p, per * sizeof(unsigned long long), hipMemcpyDeviceToDevice, c->stream_em));
+		HIP_TRY(hipMemcpyAsync((unsigned long long *)d_words + per, c->bases.p, per * sizeof(unsigned long long), hipMemcpyDeviceToDevice, c->stream_em));
+	}
+	return LSQ_OK;
+}
+
+int lsq_counts_import_device(lsq_ctx *c, const void *d_words) {
+	if (!c || !d_words) return fail(LSQ_E_ARG, "null argument");
+	if (!c->E) return fail(LSQ_E_STATE, "lsq_events_upload must come first");
+	HIP_TRY(hipSetDevice(c->device));
+	const size_t per = (size_t)c->E->n_methods * c->E->n_cls_total;
+	{ int rc = sync_all(c); if (rc) return rc; }
+	if (per) {
+		HIP_TRY(hipMemcpyAsync(c->cnt.p, d_words, per * sizeof(unsigned long long), hipMemcpyDeviceToDevice, c->stream_em));
+		HIP_TRY(hipMemcpyAsync(c->bases.p, (const unsigned long long *)d_words + per, per * sizeof(unsigned long long), hipMemcpyDeviceToDevice, c->stream_em));
+	}
+	c->counted = true; c->solved = false;
+	c->counts_external = true;
+	return LSQ_OK;
+}
+
 int lsq_results_solve(lsq_ctx *c, double *theta, double *logll, uint32_t *em_iters, uint8_t *em_flags) {
 	if (!c || !theta || !logll) return fail(LSQ_E_ARG, "null argument");
 	if (!c->solved) return fail(LSQ_E_STATE, "lsq_solve must come first");
@@ -556,6 +588,13 @@ void lsq_device_free(lsq_ctx *c, void *p) {
 	if (!c || !p) return;
 	(void)hipSetDevice(c->device);
 	(void)hipFree(p);
+}
+int lsq_device_write(lsq_ctx *c, void *device_dst, const void *host_src, uint64_t bytes) {
+	if (!c || !device_dst || !host_src) return fail(LSQ_E_ARG, "null argument");
+	HIP_TRY(hipSetDevice(c->device));
+	{ int rc = sync_all(c); if (rc) return rc; }
+	HIP_TRY(hipMemcpy(device_dst, host_src, (size_t)bytes, hipMemcpyHostToDevice));
+	return LSQ_OK;
 }
 int lsq_device_read(lsq_ctx *c, void *host_dst, const void *device_src, uint64_t bytes) {
 	if (!c || !host_dst || !device_src) return fail(LSQ_E_ARG, "null argument");

@@ -231,10 +231,37 @@ def run_read_sharded(tool, argv, rank, world, device_index=0, group=None, comm_d
         for t in texts:
             api.lib.lsq_text_free(t)
     ctx.count()
-    cnt, bases = ctx.counts()
     if world > 1:
-        cnt, bases = combine([cnt, bases], group, comm_device)
-        ctx.set_counts(cnt, bases)
+        # the sum over the ranks on the device: the class counts and matched bases as they lie in HBM (every rank has the same
+        # events, hence the same order), one all-reduce, and the sums become the counts the EM and the getters work on
+        # (gloo, i.e. the tests on one GPU: the same words through a host tensor and the library's own copies -- no torch.cuda
+        # there: a process that loaded this library before torch holds the system's HIP runtime, and torch's own then finds no GPU)
+        n_words = max(ctx.counts_device_words(), 1)
+        if dist.get_backend(group) == "gloo" or (comm_device is not None and torch.device(comm_device).type == "cpu"):
+            import ctypes as C
+            d_buf = C.c_void_p()
+            api.check(api.lib.lsq_device_alloc(ctx.h, 8 * n_words, C.byref(d_buf)))
+            try:
+                ctx.export_counts_device(d_buf.value)
+                host = np.zeros(n_words, dtype=np.int64)
+                api.check(api.lib.lsq_device_read(ctx.h, host.ctypes.data_as(C.c_void_p), d_buf, 8 * n_words))
+                h = torch.from_numpy(host)
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+                api.check(api.lib.lsq_device_write(ctx.h, d_buf, host.ctypes.data_as(C.c_void_p), 8 * n_words))
+                ctx.import_counts_device(d_buf.value)
+                ctx.synchronize()
+            finally:
+                api.lib.lsq_device_free(ctx.h, d_buf)
+        else:
+            dev = torch.device("cuda", device_index)
+            t = torch.empty(n_words, dtype=torch.int64, device=dev)
+            ctx.export_counts_device(t.data_ptr())
+            ctx.synchronize()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            torch.cuda.synchronize(dev)
+            ctx.import_counts_device(t.data_ptr())
+            ctx.synchronize()
+    cnt, bases = ctx.counts()
     if tool == "count":
         text = api.format_count(ev, cnt)
     else:

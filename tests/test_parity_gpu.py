@@ -655,6 +655,42 @@ def test_pools_are_laid_out_by_cell_and_by_junction(compact, tmp_path):
     ctx.close()
 
 
+def test_counts_leave_and_enter_the_context_on_the_device(tmp_path):
+    """lsq_counts_export_device / lsq_counts_import_device: what a read-sharded job sums over its ranks without the host.
+    A buffer exported, doubled and imported gives twice the tables, and the EM of proportional counts the same theta
+    (read.h:592-618 is homogeneous in the counts)."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")          # the runtime the library itself is linked to
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    spec = L.SynthSpec(23, 400, 60000, 100, 2, L.EVENT_TYPES)
+    L.synth_write(spec, str(tmp_path), "d", write_mrf=False)
+    ann = L.Annotation(str(tmp_path / "d.interval"), str(tmp_path / "d.map"))
+    ev = L.Events(ann, ("SHORT_READ",), (100,))
+    ctx = L.Context(0)
+    ctx.upload_events(ev)
+    ctx.upload_reads(0, L.Reads.synthetic(spec, ev))
+    ctx.count(); ctx.solve()
+    cnt, bases = [x.copy() for x in ctx.counts()]
+    theta = ctx.solution()[0].copy()
+    n = ctx.counts_device_words()
+    assert n > 0
+    d_buf = C.c_void_p()
+    assert L.lib.lsq_device_alloc(ctx.h, 8 * n, C.byref(d_buf)) == 0
+    ctx.export_counts_device(d_buf.value)
+    host = np.zeros(n, dtype=np.uint64)
+    assert L.lib.lsq_device_read(ctx.h, host.ctypes.data_as(C.c_void_p), d_buf, 8 * n) == 0      # waits for the context's streams
+    assert int(host.sum()) == int(cnt.sum()) + int(bases.sum())
+    host *= 2
+    assert hip.hipMemcpy(d_buf, host.ctypes.data_as(C.c_void_p), 8 * n, 1) == 0                    # hipMemcpyHostToDevice
+    ctx.import_counts_device(d_buf.value)
+    cnt2, bases2 = ctx.counts()
+    assert np.array_equal(cnt2, 2 * cnt) and np.array_equal(bases2, 2 * bases)
+    ctx.solve()
+    assert np.allclose(ctx.solution()[0], theta, rtol=0, atol=1e-6)
+    L.lib.lsq_device_free(ctx.h, d_buf)
+    ctx.close()
+
+
 def test_steps_submitted_back_to_back_with_changing_reads(tmp_path):
     """The step pipeline (two streams, two counter sets): steps are only submitted, with another
     read set uploaded in between and the hand-off going to a buffer per step; every step's tables must be the ones
