@@ -6,7 +6,9 @@
  * This header is the seam a maintainer would cut: each entry point replaces a contiguous
  * stretch of those main() bodies, cited per function.  INTEGRATION.md shows the call sites.
  *
- * Conventions: plain C, caller-owned buffers, no exceptions across the boundary.  Every
+ * Conventions: plain C, caller-owned buffers, no exceptions across the boundary (every entry
+ * point that can allocate catches what is thrown below it and returns LSQ_E_INTERNAL; helper
+ * threads are joined on every way out).  Every
  * function returns LSQ_OK (0) or a negative lsq_status; lsq_last_error() gives the text for
  * the calling thread.  Coordinates are 0-based half-open, as the reference holds them after
  * `start - 1` (count/count.cpp:319,323).  One lsq_ctx per GPU, used from one host thread.
@@ -41,7 +43,9 @@ typedef enum {
 	LSQ_E_RANGE = -5,        /* coordinate or size outside what the device tables hold */
 	LSQ_E_UNSUPPORTED = -6,  /* event shape outside the device kernels' limits */
 	LSQ_E_DEVICE = -7,       /* HIP error, or no gfx950 device */
-	LSQ_E_STATE = -8         /* call order violated (e.g. count before uploads) */
+	LSQ_E_STATE = -8,        /* call order violated (e.g. count before uploads) */
+	LSQ_E_INTERNAL = -9,     /* out of memory, or a C++ exception caught at the boundary (never thrown across it) */
+	LSQ_E_TIMEOUT = -10      /* lsq_ctx_synchronize_for: the context's streams had not drained when the time was up */
 } lsq_status;
 
 /* kernel limits (what the count and EM kernels hold in registers / LDS per event) */
@@ -160,6 +164,10 @@ void lsq_ctx_destroy(lsq_ctx *c);
  * lsq_ctx_synchronize waits for both streams; the host-side result getters do so themselves. */
 void *lsq_ctx_stream(lsq_ctx *c);
 int lsq_ctx_synchronize(lsq_ctx *c);
+/* The same with a time limit (seconds): LSQ_E_TIMEOUT when work is still queued after it -- e.g. a collective of a
+ * multi-GPU job (lesseq_rccl.h) whose peer never arrived; the caller then aborts the communicator (lsq_comm_abort)
+ * instead of waiting for ever.  Polls the streams; nothing is cancelled by the call itself. */
+int lsq_ctx_synchronize_for(lsq_ctx *c, double seconds);
 
 /* Uploads the compiled tables: per-bucket LDS images (bin directory, event records,
  * segments, isoform masks), tie-break records and G = 1/ARS. */

@@ -32,6 +32,15 @@ int lsq_debug_set_em_order(lsq_ctx *c, const uint32_t *order, unsigned n_small_p
  * eight grid / unroll combinations): the practical ceiling bench.py reports beside the nominal HBM peak. */
 int lsq_debug_stream_read_rate(lsq_ctx *c, unsigned long long bytes, double *gb_per_s);
 
+/* Throws a C++ exception below the boundary -- kind 0: std::bad_alloc, 1: std::length_error, 2: an int -- so that a test
+ * can see what a caller gets: LSQ_E_INTERNAL and a message, never std::terminate (lesseq_hip.h "no exceptions across
+ * the boundary").  kind 3 does the same from inside a helper thread of a ThreadGroup (lsq_internal.hpp). */
+int lsq_debug_throw(int kind);
+
+/* HIP_VERSION the library was compiled against and hipRuntimeGetVersion() of the runtime it found in the process (0
+ * when that call fails, e.g. without a driver): a binding that loads another runtime first (PyTorch's) can compare. */
+int lsq_debug_hip_versions(int *compiled, int *runtime);
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,6 +34,14 @@ int lsq_comm_init_all(int n, const int *devices, lsq_comm **comms /* n */);
 int lsq_comm_unique_id(void *id /* LSQ_COMM_ID_BYTES */);
 int lsq_comm_init_rank(int world, int rank, const void *id, int device, lsq_comm **out);
 void lsq_comm_destroy(lsq_comm *comm);
+/* The same two with a time limit (seconds; <= 0: none): the blocking RCCL call runs on a helper thread; when the time
+ * is up the call returns LSQ_E_TIMEOUT and that thread is given up (it cannot be cancelled: a process that saw the
+ * timeout should fall back to another exchange or leave) -- a rank whose peers never arrive does not hang the job. */
+int lsq_comm_init_rank_for(int world, int rank, const void *id, int device, double seconds, lsq_comm **out);
+int lsq_comm_init_all_for(int n, const int *devices, double seconds, lsq_comm **comms /* n */);
+/* Ends whatever the communicator has in flight (ncclCommAbort) and frees it: the way out when a collective does not
+ * complete (lsq_ctx_synchronize_for returned LSQ_E_TIMEOUT).  The other ranks' collectives fail or are aborted likewise. */
+void lsq_comm_abort(lsq_comm *comm);
 int lsq_comm_rank(const lsq_comm *comm);
 int lsq_comm_size(const lsq_comm *comm);
 

@@ -25,7 +25,7 @@ if not os.path.exists(LIB_PATH):
 if os.environ.get("LSQ_NO_TORCH") != "1":
     try:
         import torch  # noqa: F401
-    except ImportError:
+    except Exception:      # not installed, or an install that fails to load: the library then binds the system's runtime
         pass
 
 lib = C.CDLL(LIB_PATH)
@@ -86,6 +86,9 @@ _sig("lsq_ctx_create", C.c_int, C.c_int, P(vp))
 _sig("lsq_ctx_destroy", None, vp)
 _sig("lsq_ctx_stream", vp, vp)
 _sig("lsq_ctx_synchronize", C.c_int, vp)
+_sig("lsq_ctx_synchronize_for", C.c_int, vp, C.c_double)
+_sig("lsq_debug_throw", C.c_int, C.c_int)
+_sig("lsq_debug_hip_versions", C.c_int, P(C.c_int), P(C.c_int))
 _sig("lsq_events_upload", C.c_int, vp, vp)
 _sig("lsq_reads_upload", C.c_int, vp, C.c_int, vp)
 _sig("lsq_reads_arrays", C.c_int, vp, P(vp), P(vp), P(vp), P(vp), P(vp), P(vp))
@@ -142,6 +145,26 @@ _sig("lsq_format_solve", C.c_int, vp, C.c_int, P(u64), P(u64), P(C.c_double), P(
 _sig("lsq_cli_run", C.c_int, cs, C.c_int, P(cs), P(vp))
 _sig("lsq_synth_write", C.c_int, P(SynthSpecStruct), cs, cs, C.c_int)
 _sig("lsq_synth_reads", C.c_int, P(SynthSpecStruct), vp, C.c_int, P(vp))
+
+
+def _warn_on_runtime_mismatch():
+    """The library was compiled against one HIP (hipcc's) and runs on whichever libamdhip64 the process holds (torch's,
+    when torch came first -- on this image 7.0 under a library built with 7.2, which works): another MAJOR version would
+    show up far from its cause (LSQ_E_DEVICE, missing code objects), so that is said at import."""
+    comp, run = hip_versions()
+    if run and comp // 10000000 != run // 10000000:
+        import warnings
+        warnings.warn("liblesseq_hip.so was compiled against HIP %d and runs on HIP runtime %d" % (comp, run))
+
+
+def hip_versions():
+    """(HIP_VERSION the library was compiled against, hipRuntimeGetVersion() of the runtime in this process; 0 = unknown)"""
+    comp, run = C.c_int(0), C.c_int(0)
+    lib.lsq_debug_hip_versions(C.byref(comp), C.byref(run))
+    return comp.value, run.value
+
+
+_warn_on_runtime_mismatch()
 
 
 def check(status):

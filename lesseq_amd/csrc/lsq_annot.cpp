@@ -8,6 +8,7 @@
 #include <cstring>
 #include <fstream>
 #include <sstream>
+#include <stdexcept>
 #include <thread>
 
 #include "lsq_internal.hpp"
@@ -22,8 +23,16 @@ int fail(int status, const char *fmt, ...) {
 	va_start(ap, fmt);
 	vsnprintf(buf, sizeof buf, fmt, ap);
 	va_end(ap);
-	g_err = buf;
+	try { g_err = buf; } catch (...) { g_err.clear(); }      // (the text is lost before the status is)
 	return status;
+}
+
+// the catch-all of an extern "C" entry (LSQ_API_CATCH): called from inside a catch block, rethrows to read the exception
+int fail_exception(const char *where) noexcept {
+	try { throw; }
+	catch (const std::bad_alloc &) { return fail(LSQ_E_INTERNAL, "%s: out of memory", where); }
+	catch (const std::exception &e) { return fail(LSQ_E_INTERNAL, "%s: %s", where, e.what()); }
+	catch (...) { return fail(LSQ_E_INTERNAL, "%s: unknown exception", where); }
 }
 
 int host_threads(int requested) {
@@ -195,13 +204,27 @@ using namespace lsq;
 extern "C" {
 
 const char *lsq_last_error(void) { return lsq::g_err.c_str(); }
+
+// developer aid (include/lesseq_hip_dev.h): an exception below the boundary, as a loader or formatter out of memory would throw it
+int lsq_debug_throw(int kind) LSQ_API_TRY {
+	if (kind == 0) throw std::bad_alloc();
+	if (kind == 1) throw std::length_error("vector::_M_default_append");
+	if (kind == 2) throw 42;
+	if (kind == 3) {
+		lsq::ThreadGroup th;
+		for (int t = 0; t < 3; ++t) th.spawn([t] { if (t == 1) throw std::runtime_error("thrown inside a helper thread"); });
+		th.join();
+		if (th.failed()) return lsq::fail(LSQ_E_INTERNAL, "a helper thread failed: %s", th.error().c_str());
+	}
+	return LSQ_OK;
+} LSQ_API_CATCH
 int lsq_abi_version(void) { return LSQ_ABI_VERSION; }
 void lsq_free(void *p) { free(p); }
 
 // count/count.cpp:135-216; the formats beyond LH_GENE_TXT / UCSC_GENE2ISOFORM are solve's (solve/solve.cpp:152-329)
 int lsq_annotation_load(const char *isoform_format, const char *isoforms_path,
                         const char *g2i_format, const char *g2i_path,
-                        uint64_t gene_begin_idx, uint64_t gene_end_idx, lsq_annotation **out) {
+                        uint64_t gene_begin_idx, uint64_t gene_end_idx, lsq_annotation **out) LSQ_API_TRY {
 	if (!isoform_format || !isoforms_path || !g2i_format || !g2i_path || !out) return fail(LSQ_E_ARG, "null argument");
 	std::vector<std::string> lines;
 	if (!read_lines(isoforms_path, lines)) return fail(LSQ_E_IO, "cannot open isoforms file %s", isoforms_path);
@@ -342,7 +365,7 @@ int lsq_annotation_load(const char *isoform_format, const char *isoforms_path,
 	}
 	*out = a.release();
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 void lsq_annotation_free(lsq_annotation *a) { delete a; }
 int64_t lsq_annotation_num_genes(const lsq_annotation *a) { return a ? (int64_t)a->selected.size() : 0; }
 int64_t lsq_annotation_num_isoforms_loaded(const lsq_annotation *a) { return a ? (int64_t)a->recs.size() : 0; }
@@ -880,9 +903,9 @@ int compile_events(const lsq_annotation *a, int n_methods, const char *const *re
 extern "C" {
 
 int lsq_events_compile(const lsq_annotation *a, int n_methods, const char *const *read_types,
-                       const uint64_t *expected_read_lengths, lsq_events **out) {
+                       const uint64_t *expected_read_lengths, lsq_events **out) LSQ_API_TRY {
 	return lsq::compile_events(a, n_methods, read_types, expected_read_lengths, true, out);
-}
+} LSQ_API_CATCH
 void lsq_events_free(lsq_events *e) { delete e; }
 
 int64_t lsq_events_count(const lsq_events *e) { return e ? (int64_t)e->ev.size() : 0; }
@@ -898,12 +921,12 @@ const char *lsq_events_isoform_name(const lsq_events *e, int64_t ev, int iso) {
 	if (iso < 0 || iso >= e->ev[ev].K) return nullptr;
 	return e->ev[ev].iso_names[iso].c_str();
 }
-int lsq_events_segment(const lsq_events *e, int64_t ev, int n, int64_t *start, int64_t *end) {
+int lsq_events_segment(const lsq_events *e, int64_t ev, int n, int64_t *start, int64_t *end) LSQ_API_TRY {
 	EV_OR(LSQ_E_ARG);
 	if (n < 0 || n >= e->ev[ev].N) return LSQ_E_ARG;
 	*start = e->ev[ev].seg_s[n]; *end = e->ev[ev].seg_e[n];
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 uint64_t lsq_events_isoform_mask(const lsq_events *e, int64_t ev, int iso) { EV_OR(0); return (iso < 0 || iso >= e->ev[ev].K) ? 0 : e->ev[ev].iso_mask[iso]; }
 uint64_t lsq_events_isoform_length(const lsq_events *e, int64_t ev, int iso) { EV_OR(0); return (iso < 0 || iso >= e->ev[ev].K) ? 0 : e->ev[ev].iso_len[iso]; }
 uint64_t lsq_events_ars(const lsq_events *e, int method, int64_t ev, int iso) {
@@ -915,17 +938,17 @@ int lsq_events_span(const lsq_events *e, int64_t ev, int64_t *gs, int64_t *ge) {
 int64_t lsq_events_num_buckets(const lsq_events *e) { return e ? (int64_t)e->buckets.size() : 0; }
 int64_t lsq_events_lds_table_bytes(const lsq_events *e) { return e ? (int64_t)e->max_lds_bytes : 0; }
 
-int lsq_events_set_shard(lsq_events *e, uint64_t first_event, uint64_t n_events) {
+int lsq_events_set_shard(lsq_events *e, uint64_t first_event, uint64_t n_events) LSQ_API_TRY {
 	if (!e) return fail(LSQ_E_ARG, "null argument");
 	if (first_event > e->ev.size()) return fail(LSQ_E_ARG, "shard starts past the last event");
 	e->shard_first = first_event;
 	e->shard_count = n_events;
 	return plan_device(*e);
-}
+} LSQ_API_CATCH
 
 // Contiguous slices of the output-ordered events for `world` processes, balanced by weight (reads per event from a
 // pre-pass; NULL = by event count): slice r ends where the running weight first reaches r/world of the total.
-int lsq_shard_bounds(const lsq_events *e, int world, const double *weights, uint64_t *first, uint64_t *count) {
+int lsq_shard_bounds(const lsq_events *e, int world, const double *weights, uint64_t *first, uint64_t *count) LSQ_API_TRY {
 	if (!e || world < 1 || !first || !count) return fail(LSQ_E_ARG, "bad argument");
 	const size_t n = e->ev.size();
 	std::vector<double> cum(n + 1, 0.0);
@@ -945,7 +968,7 @@ int lsq_shard_bounds(const lsq_events *e, int world, const double *weights, uint
 	cuts[(size_t)world] = n;
 	for (int r = 0; r < world; ++r) { first[r] = cuts[(size_t)r]; count[r] = cuts[(size_t)r + 1] - cuts[(size_t)r]; }
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 
 // words (8 bytes) of the packed per-event records of events [first, first + count): class counts and matched bases
 // per read file, theta, log-likelihood -- lsq_results_pack_device's block
@@ -960,7 +983,7 @@ uint64_t lsq_record_words(const lsq_events *e, uint64_t first, uint64_t count) {
 // [first[r], first[r] + count[r]) in output order) put together as the whole job's tables, in the layout
 // lsq_results_counts / lsq_results_solve use.
 int lsq_gathered_unpack(const lsq_events *e, int world, const uint64_t *first, const uint64_t *count, const uint64_t *blocks, uint64_t stride_words,
-                        uint64_t *class_count, uint64_t *class_bases, double *theta, double *logll) {
+                        uint64_t *class_count, uint64_t *class_bases, double *theta, double *logll) LSQ_API_TRY {
 	if (!e || world < 1 || !first || !count || !blocks || !class_count) return fail(LSQ_E_ARG, "null argument");
 	const size_t n = e->ev.size(), M = (size_t)e->n_methods, n_out = (size_t)e->class_off[n];
 	memset(class_count, 0, M * n_out * sizeof(uint64_t));
@@ -981,23 +1004,23 @@ int lsq_gathered_unpack(const lsq_events *e, int world, const uint64_t *first, c
 		if (logll) memcpy(logll + a, blk + 2 * M * C + I, (b - a) * sizeof(double));
 	}
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 
-int lsq_events_chrom_id(lsq_events *e, const char *chrom) {
+int lsq_events_chrom_id(lsq_events *e, const char *chrom) LSQ_API_TRY {
 	if (!e || !chrom) return LSQ_E_ARG;
 	int id = e->chroms.intern(chrom);
 	if (id > 65000) return fail(LSQ_E_RANGE, "too many chromosome names");
 	return id;
-}
+} LSQ_API_CATCH
 const char *lsq_events_strand_name(const lsq_events *e, int id) {
 	if (!e || id < 0 || (size_t)id >= e->strands.names.size()) return nullptr;
 	return e->strands.names[id].c_str();
 }
-int lsq_events_strand_id(lsq_events *e, const char *strand) {
+int lsq_events_strand_id(lsq_events *e, const char *strand) LSQ_API_TRY {
 	if (!e || !strand) return LSQ_E_ARG;
 	int id = e->strands.intern(strand);
 	if (id > 255) return fail(LSQ_E_RANGE, "more than 256 distinct strand strings");
 	return id;
-}
+} LSQ_API_CATCH
 
 } // extern "C"

@@ -12,6 +12,9 @@
 #include <thread>
 #include <cstring>
 #include <ctime>
+#include <stdexcept>
+#include <condition_variable>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -158,6 +161,7 @@ int run_classify(int argc, const char *const *argv) {
 }
 
 bool g_exit_after_output = false;       // set by lsq_cli_main
+bool g_is_executable = false;           // set by lsq_cli_main: the process is ours alone
 
 // developer aid: LSQ_CLI_TIMING=1 prints the seconds each phase took on stderr
 struct PhaseTimer {
@@ -205,22 +209,25 @@ struct ShardedJob {
 
 struct RcclApi {
 	void *handle = nullptr;
-	int (*init_all)(int, const int *, void **) = nullptr;
+	int (*init_all)(int, const int *, double, void **) = nullptr;     // lsq_comm_init_all_for
 	void (*destroy)(void *) = nullptr;
+	void (*abort_comm)(void *) = nullptr;
 	int (*gather)(lsq_ctx *, void *, const void *, void *, uint64_t) = nullptr;
 	const char *(*last_error)(void) = nullptr;
+	std::string why;                       // dlerror() of the failing dlopen (read once: the call clears it)
 	bool load() {
 		Dl_info info;
 		std::string dir;
 		if (dladdr((const void *)&lsq_abi_version, &info) && info.dli_fname) { dir = info.dli_fname; const size_t s = dir.rfind('/'); dir = s == std::string::npos ? "" : dir.substr(0, s + 1); }
 		handle = dlopen((dir + "liblesseq_rccl.so").c_str(), RTLD_NOW | RTLD_LOCAL);
-		if (!handle) handle = dlopen("liblesseq_rccl.so", RTLD_NOW | RTLD_LOCAL);
-		if (!handle) return false;
-		init_all = (int (*)(int, const int *, void **))dlsym(handle, "lsq_comm_init_all");
+		if (!handle) { if (const char *e = dlerror()) why = e; handle = dlopen("liblesseq_rccl.so", RTLD_NOW | RTLD_LOCAL); }
+		if (!handle) { if (const char *e = dlerror()) { if (!why.empty()) why += "; "; why += e; } return false; }
+		init_all = (int (*)(int, const int *, double, void **))dlsym(handle, "lsq_comm_init_all_for");
 		destroy = (void (*)(void *))dlsym(handle, "lsq_comm_destroy");
+		abort_comm = (void (*)(void *))dlsym(handle, "lsq_comm_abort");
 		gather = (int (*)(lsq_ctx *, void *, const void *, void *, uint64_t))dlsym(handle, "lsq_gather");
 		last_error = (const char *(*)(void))dlsym(handle, "lsq_rccl_last_error");
-		return init_all && destroy && gather && last_error;
+		return init_all && destroy && abort_comm && gather && last_error;
 	}
 };
 
@@ -248,9 +255,13 @@ int run_sharded_job(const ShardedJob &J, lsq_ctx *ctx0, lsq_events *ev0, std::ve
 	const bool via_host = gmode && strcmp(gmode, "host") == 0;
 	RcclApi rccl;
 	std::vector<void *> comms((size_t)G, nullptr);
+	// nothing on this path waits without a limit (LSQ_COLLECTIVE_TIMEOUT seconds, default 120): the communicator set-up, and
+	// the gather itself -- whose kernel spins until every peer has joined it
+	double time_limit = 120.0;
+	if (const char *e = getenv("LSQ_COLLECTIVE_TIMEOUT")) { const double v = atof(e); if (v > 0) time_limit = v; }
 	if (!via_host) {
-		if (!rccl.load()) { logf(0, "LSQ_GPUS=%d needs liblesseq_rccl.so beside the library (%s)", G, dlerror() ? dlerror() : "symbols missing"); return 3; }
-		st = rccl.init_all(G, J.devices.data(), comms.data());
+		if (!rccl.load()) { logf(0, "LSQ_GPUS=%d needs liblesseq_rccl.so beside the library (%s)", G, rccl.why.empty() ? "symbols missing" : rccl.why.c_str()); return 3; }
+		st = rccl.init_all(G, J.devices.data(), time_limit, comms.data());
 		if (st) { logf(0, "%s", rccl.last_error()); return 3; }
 	}
 	std::vector<uint64_t> host_blocks((size_t)G * stride, 0);
@@ -258,9 +269,26 @@ int run_sharded_job(const ShardedJob &J, lsq_ctx *ctx0, lsq_events *ev0, std::ve
 	std::vector<std::string> errors((size_t)G);
 	std::vector<lsq_ctx *> ctxs((size_t)G, nullptr);
 	std::vector<lsq_events *> evs((size_t)G, nullptr);
+	std::vector<void *> d_blocks((size_t)G, nullptr), d_alls((size_t)G, nullptr);
+	std::vector<uint32_t> replayed((size_t)G, 0);
 	ctxs[0] = ctx0; evs[0] = ev0;
-	auto work = [&](int r) {
-		auto bad = [&](int s, const char *msg) { status[(size_t)r] = s ? s : LSQ_E_STATE; errors[(size_t)r] = msg; };
+	// Every GPU's thread does its slice up to the packed block, then all of them AGREE before any enters the collective: a
+	// thread that failed on the way (no context, a file it cannot parse, out of memory) would otherwise leave the others
+	// spinning in ncclAllGather for a peer that never comes.  One failure: nobody gathers, the job exits 3 with the message.
+	struct Agreement {
+		std::mutex mu; std::condition_variable cv; int arrived = 0, failed = 0; const int G;
+		explicit Agreement(int g) : G(g) {}
+		bool arrive(bool ok) {
+			std::unique_lock<std::mutex> lk(mu);
+			++arrived; if (!ok) ++failed;
+			cv.notify_all();
+			cv.wait(lk, [&] { return arrived == G; });
+			return failed == 0;
+		}
+		void absent() { std::lock_guard<std::mutex> g(mu); ++arrived; ++failed; cv.notify_all(); }      // a slice that never started
+	} agreement(G);
+	auto prepare = [&](int r) -> int {
+		auto bad = [&](int s2, const char *msg) { status[(size_t)r] = s2 ? s2 : LSQ_E_STATE; errors[(size_t)r] = msg; return status[(size_t)r]; };
 		int s;
 		if (r > 0) {
 			if ((s = lsq_ctx_create(J.devices[(size_t)r], &ctxs[(size_t)r])) || (s = apply_env_options(ctxs[(size_t)r]))) return bad(s, lsq_last_error());
@@ -280,32 +308,54 @@ int run_sharded_job(const ShardedJob &J, lsq_ctx *ctx0, lsq_events *ev0, std::ve
 			}
 			if (s) return bad(s, lsq_last_error());
 		}
-		uint32_t replayed = 0;
-		if ((s = lsq_count(c)) || (s = lsq_solve(c)) || (s = lsq_solve_finalize(c, &replayed))) return bad(s, lsq_last_error());
-		void *d_block = nullptr, *d_all = nullptr;
-		if ((s = lsq_device_alloc(c, stride * 8, &d_block))) return bad(s, lsq_last_error());
-		if ((s = lsq_results_pack_device(c, d_block))) { lsq_device_free(c, d_block); return bad(s, lsq_last_error()); }
-		if (via_host) {
-			s = lsq_device_read(c, host_blocks.data() + (size_t)r * stride, d_block, stride * 8);
-			if (s) bad(s, lsq_last_error());
-		} else {
-			if ((s = lsq_device_alloc(c, (uint64_t)G * stride * 8, &d_all))) { lsq_device_free(c, d_block); return bad(s, lsq_last_error()); }
-			s = rccl.gather(c, comms[(size_t)r], d_block, d_all, stride);
-			if (s) bad(s, rccl.last_error());
-			else if (r == 0) { s = lsq_device_read(c, host_blocks.data(), d_all, (uint64_t)G * stride * 8); if (s) bad(s, lsq_last_error()); }
-			else { s = lsq_ctx_synchronize(c); if (s) bad(s, lsq_last_error()); }
-			lsq_device_free(c, d_all);
-		}
-		lsq_device_free(c, d_block);
-		unsigned long long pooled = 0;
-		for (int m = 0; m < M; ++m) pooled += lsq_reads_pooled(c, m);
-		logf(2, "GPU %d: events %llu..%llu of the sorted list, %llu reads pooled for them%s", J.devices[(size_t)r], (unsigned long long)first[(size_t)r],
-		     (unsigned long long)(first[(size_t)r] + count[(size_t)r]), pooled, replayed ? " (guard-band events solved again in per-read order)" : "");
+		if ((s = lsq_count(c)) || (s = lsq_solve(c)) || (s = lsq_solve_finalize(c, &replayed[(size_t)r]))) return bad(s, lsq_last_error());
+		if ((s = lsq_device_alloc(c, stride * 8, &d_blocks[(size_t)r]))) return bad(s, lsq_last_error());
+		if (!via_host && (s = lsq_device_alloc(c, (uint64_t)G * stride * 8, &d_alls[(size_t)r]))) return bad(s, lsq_last_error());
+		if ((s = lsq_results_pack_device(c, d_blocks[(size_t)r]))) return bad(s, lsq_last_error());
+		// (the developer's way to see the agreement at work: LSQ_FAIL_RANK=r makes slice r fail here)
+		if (const char *fr = getenv("LSQ_FAIL_RANK")) if (atoi(fr) == r) return bad(LSQ_E_STATE, "failure of this slice requested (LSQ_FAIL_RANK)");
+		return LSQ_OK;
 	};
-	std::vector<std::thread> th;
-	for (int r = 1; r < G; ++r) th.emplace_back(work, r);
-	work(0);
-	for (auto &t : th) t.join();
+	auto work = [&](int r) {
+		int s = LSQ_E_INTERNAL;
+		try { s = prepare(r); }
+		catch (const std::exception &ex) { status[(size_t)r] = LSQ_E_INTERNAL; errors[(size_t)r] = ex.what(); }
+		catch (...) { status[(size_t)r] = LSQ_E_INTERNAL; errors[(size_t)r] = "unknown exception"; }
+		const bool everyone = agreement.arrive(s == LSQ_OK);
+		lsq_ctx *c = ctxs[(size_t)r];
+		if (everyone) {
+			auto bad = [&](int s2, const char *msg) { status[(size_t)r] = s2 ? s2 : LSQ_E_STATE; errors[(size_t)r] = msg; };
+			if (via_host) {
+				s = lsq_device_read(c, host_blocks.data() + (size_t)r * stride, d_blocks[(size_t)r], stride * 8);
+				if (s) bad(s, lsq_last_error());
+			} else {
+				s = rccl.gather(c, comms[(size_t)r], d_blocks[(size_t)r], d_alls[(size_t)r], stride);
+				if (s) bad(s, rccl.last_error());
+				else if ((s = lsq_ctx_synchronize_for(c, time_limit))) {
+					bad(s, lsq_last_error());
+					if (s == LSQ_E_TIMEOUT) { rccl.abort_comm(comms[(size_t)r]); comms[(size_t)r] = nullptr; }       // ends the spinning kernel
+				}
+				else if (r == 0) { s = lsq_device_read(c, host_blocks.data(), d_alls[0], (uint64_t)G * stride * 8); if (s) bad(s, lsq_last_error()); }
+			}
+		}
+		if (c) { lsq_device_free(c, d_alls[(size_t)r]); lsq_device_free(c, d_blocks[(size_t)r]); }
+		if (everyone && !status[(size_t)r]) {
+			unsigned long long pooled = 0;
+			for (int m = 0; m < M; ++m) pooled += lsq_reads_pooled(c, m);
+			logf(2, "GPU %d: events %llu..%llu of the sorted list, %llu reads pooled for them%s", J.devices[(size_t)r], (unsigned long long)first[(size_t)r],
+			     (unsigned long long)(first[(size_t)r] + count[(size_t)r]), pooled, replayed[(size_t)r] ? " (guard-band events solved again in per-read order)" : "");
+		}
+	};
+	{
+		ThreadGroup th;          // joined on every way out
+		// (a thread that cannot even be started counts as a slice that failed: the others must not wait for it)
+		for (int r = 1; r < G; ++r) {
+			try { th.spawn([&work, r] { work(r); }); }
+			catch (...) { status[(size_t)r] = LSQ_E_INTERNAL; errors[(size_t)r] = "the slice's host thread could not be started"; agreement.absent(); }
+		}
+		work(0);
+		th.join();
+	}
 	for (int r = 1; r < G; ++r) { if (ctxs[(size_t)r]) lsq_ctx_destroy(ctxs[(size_t)r]); lsq_events_free(evs[(size_t)r]); }
 	if (!via_host) for (void *cm : comms) if (cm) rccl.destroy(cm);
 	for (int r = 0; r < G; ++r) if (status[(size_t)r]) { logf(0, "GPU %d: %s", J.devices[(size_t)r], errors[(size_t)r].c_str()); return 3; }
@@ -377,18 +427,31 @@ int run_count_solve(bool solve, int argc, const char *const *argv, std::string &
 	// ... and the same thread goes on to copy the MRF text of every read file to HBM (that needs no event
 	// table); a file that does not open or is not MRF_SINGLE is left to the main thread, which reports it
 	std::vector<lsq_text *> texts((size_t)M, nullptr);
-	std::thread ctx_thread([&] {
+	auto make_context = [&] {
 		ctx_status = lsq_ctx_create(devices[0], &ctx_bg);
 		if (ctx_status) { ctx_error = lsq_last_error(); return; }          // the message lives in that thread
 		ctx_status = apply_env_options(ctx_bg);
 		if (ctx_status) { ctx_error = lsq_last_error(); return; }
 		for (int m = 0; m < M; ++m)
 			if (strcmp(fmts[m], "MRF_SINGLE") == 0 && lsq_text_stage(ctx_bg, paths[m], &texts[(size_t)m]) != LSQ_OK) texts[(size_t)m] = nullptr;
-	});
-	struct Joiner {
-		std::thread &t; lsq_ctx *&c; lsq_ctx *&owner; std::vector<lsq_text *> &tx;
-		~Joiner() { if (t.joinable()) t.join(); for (auto *x : tx) lsq_text_free(x); if (c && !owner) lsq_ctx_destroy(c); }
-	} joiner{ctx_thread, ctx_bg, F.c, texts};
+	};
+	// What the second thread made is released by this guard, which is declared BEFORE the thread group: on every way out
+	// of this function the group is destroyed first (it joins the thread, so nothing is being written any more), then the
+	// guard frees the staged texts and -- unless F owns it by then -- the context.
+	struct BackgroundProducts {
+		lsq_ctx *&c; lsq_ctx *&owner; std::vector<lsq_text *> &tx;
+		~BackgroundProducts() { for (auto *x : tx) lsq_text_free(x); if (c && c != owner) lsq_ctx_destroy(c); }
+	} products{ctx_bg, F.c, texts};
+	ThreadGroup ctx_thread;
+	// Only an executable overlaps the two (lsq_cli_main: a process of its own, 0.1-0.3 s of HIP start-up to hide).  Inside a
+	// host process (lsq_cli_run) the context is made on the calling thread, in order: the host may hold other contexts and
+	// other runtimes' threads, and a call that returns must leave no thread of its own behind.
+	if (g_is_executable) ctx_thread.spawn(make_context);
+	auto join_context = [&] {
+		if (g_is_executable) ctx_thread.join();
+		else if (!ctx_bg && ctx_status == LSQ_OK) make_context();
+		if (ctx_thread.failed() && ctx_status == LSQ_OK) { ctx_status = LSQ_E_INTERNAL; ctx_error = ctx_thread.error(); }
+	};
 	logf(2, "Loading isoforms...");
 	int st = solve ? LSQ_OK : count_formats_only(argv[4], argv[5], argv[6], argv[7]);
 	if (!st) st = lsq_annotation_load(argv[4], argv[5], argv[6], argv[7], gb, ge, &F.a);
@@ -419,7 +482,7 @@ int run_count_solve(bool solve, int argc, const char *const *argv, std::string &
 		st = precheck_reads_file(fmts[m], paths[m], solve);
 		if (st) { logf(0, "%s", lsq_last_error()); return status_to_exit(st); }
 		if (!F.c) {
-			if (ctx_thread.joinable()) ctx_thread.join();
+			join_context();
 			T.mark("wait for the device context");
 			if (ctx_status) { logf(0, "%s", ctx_error.c_str()); return 3; }
 			F.c = ctx_bg;
@@ -502,9 +565,11 @@ int run_count_solve(bool solve, int argc, const char *const *argv, std::string &
 	if (g_exit_after_output) {
 		// an executable (lsq_cli_main): the table is complete -- write it and leave.  Freeing gigabytes of HBM pools buffer by
 		// buffer, joining the helper threads and unloading the runtime is work the end of the process does for nothing.
-		fwrite(out.data(), 1, out.size(), stdout);
-		fflush(stdout); fflush(stderr);
-		_exit(0);
+		// (profilers and coverage tools that write their output at exit want LSQ_CLI_TEARDOWN=1)
+		const bool written = fwrite(out.data(), 1, out.size(), stdout) == out.size() && fflush(stdout) == 0;
+		if (!written) logf(0, "cannot write the table to stdout: %s", strerror(errno));
+		fflush(stderr);
+		_exit(written ? 0 : 2);
 	}
 	return 0;
 }
@@ -517,10 +582,13 @@ std::string format_events_parallel(size_t n, F &&one) {
 	const size_t T = n < 8192 ? 1 : std::min<size_t>({8, hw, n / 4096});
 	std::vector<std::string> parts(T);
 	auto run = [&](size_t k) { for (size_t i = n * k / T; i < n * (k + 1) / T; ++i) one(parts[k], i); };
-	std::vector<std::thread> th;
-	for (size_t k = 1; k < T; ++k) th.emplace_back(run, k);
-	run(0);
-	for (auto &x : th) x.join();
+	{
+		ThreadGroup th;          // joined on every way out; a body's exception (out of memory) is rethrown here, on the caller's thread
+		for (size_t k = 1; k < T; ++k) th.spawn([&run, k] { run(k); });
+		th.run_here([&run] { run(0); });
+		th.join();
+		if (th.failed()) throw std::runtime_error("formatting the rows: " + th.error());
+	}
 	if (T == 1) return std::move(parts[0]);
 	size_t total = 0;
 	for (const auto &s : parts) total += s.size();
@@ -534,7 +602,7 @@ std::string format_events_parallel(size_t n, F &&one) {
 
 extern "C" {
 
-int lsq_format_count(const lsq_events *E, int M, const uint64_t *cnt, char **out_text) {
+int lsq_format_count(const lsq_events *E, int M, const uint64_t *cnt, char **out_text) LSQ_API_TRY {
 	if (!E || !cnt || !out_text || M != E->n_methods) return fail(LSQ_E_ARG, "bad argument");
 	const size_t n_cls = E->class_off.back();
 	const std::string o = format_events_parallel(E->ev.size(), [&](std::string &o, size_t i) {
@@ -555,10 +623,10 @@ int lsq_format_count(const lsq_events *E, int M, const uint64_t *cnt, char **out
 	});
 	*out_text = dup_text(o);
 	return *out_text ? LSQ_OK : fail(LSQ_E_ARG, "out of memory");
-}
+} LSQ_API_CATCH
 
 int lsq_format_solve(const lsq_events *E, int M, const uint64_t *cnt, const uint64_t *bases,
-                     const double *theta, const double *logll, const double *total_read_bases, char **out_text) {
+                     const double *theta, const double *logll, const double *total_read_bases, char **out_text) LSQ_API_TRY {
 	if (!E || !cnt || !bases || !theta || !logll || !total_read_bases || !out_text || M != E->n_methods) return fail(LSQ_E_ARG, "bad argument");
 	const size_t n_cls = E->class_off.back();
 	const std::string o = format_events_parallel(E->ev.size(), [&](std::string &o, size_t i) {
@@ -594,17 +662,22 @@ int lsq_format_solve(const lsq_events *E, int M, const uint64_t *cnt, const uint
 	});
 	*out_text = dup_text(o);
 	return *out_text ? LSQ_OK : fail(LSQ_E_ARG, "out of memory");
-}
+} LSQ_API_CATCH
 
-int lsq_cli_main(const char *tool, int argc, const char *const *argv) {
+int lsq_cli_main(const char *tool, int argc, const char *const *argv) LSQ_API_TRY {
+	g_is_executable = true;
 	g_exit_after_output = getenv("LSQ_CLI_TEARDOWN") == nullptr;
 	char *text = nullptr;
-	const int rc = lsq_cli_run(tool, argc, argv, &text);
-	if (text) { fputs(text, stdout); fflush(stdout); free(text); }
+	int rc = lsq_cli_run(tool, argc, argv, &text);
+	if (text) {
+		const size_t n = strlen(text);
+		if ((fwrite(text, 1, n, stdout) != n || fflush(stdout) != 0) && rc == 0) { logf(0, "cannot write the table to stdout: %s", strerror(errno)); rc = 2; }
+		free(text);
+	}
 	return rc;
-}
+} LSQ_API_CATCH
 
-int lsq_cli_run(const char *tool, int argc, const char *const *argv, char **out_text) {
+int lsq_cli_run(const char *tool, int argc, const char *const *argv, char **out_text) LSQ_API_TRY {
 	std::string out;
 	int rc;
 	if (tool && strcmp(tool, "count") == 0) rc = run_count_solve(false, argc, argv, out);
@@ -613,6 +686,11 @@ int lsq_cli_run(const char *tool, int argc, const char *const *argv, char **out_
 	else { fail(LSQ_E_ARG, "unknown tool"); return 2; }
 	if (out_text) *out_text = dup_text(out);
 	return rc;
+} catch (...) {
+	// exit status 2: "a condition the reference has no defined behaviour for" (it would have died of the exception)
+	lsq::fail_exception(__func__);
+	logf(0, "%s", lsq_last_error());
+	return 2;
 }
 
 } // extern "C"

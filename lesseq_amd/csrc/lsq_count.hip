@@ -1430,7 +1430,7 @@ int run_count(lsq_ctx *c) {
 extern "C" {
 
 // per read file of the latest lsq_count: pairs handed to the exception pass, and whether the recount ran
-int lsq_count_status(lsq_ctx *c, uint32_t *exceptions, uint32_t *recounted) {
+int lsq_count_status(lsq_ctx *c, uint32_t *exceptions, uint32_t *recounted) LSQ_API_TRY {
 	if (!c) return fail(LSQ_E_ARG, "null context");
 	if (!c->counted) return fail(LSQ_E_STATE, "lsq_count must come first");
 	HIP_TRY(hipSetDevice(c->device));
@@ -1442,19 +1442,19 @@ int lsq_count_status(lsq_ctx *c, uint32_t *exceptions, uint32_t *recounted) {
 		if (recounted) recounted[m] = h[2 * (size_t)m + 1];
 	}
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 
 // how the latest lsq_count launched its streaming kernel
-int lsq_count_launch_info(lsq_ctx *c, uint32_t *reads_per_look, uint32_t *workgroups_per_cu) {
+int lsq_count_launch_info(lsq_ctx *c, uint32_t *reads_per_look, uint32_t *workgroups_per_cu) LSQ_API_TRY {
 	if (!c) return fail(LSQ_E_ARG, "null context");
 	if (!c->counted) return fail(LSQ_E_STATE, "lsq_count must come first");
 	if (reads_per_look) *reads_per_look = c->last_reads_per_look;
 	if (workgroups_per_cu) *workgroups_per_cu = c->last_wg_per_cu;
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 
 // developer aid (include/lesseq_hip_dev.h): counters filled when LSQ_ABLATE & 256
-int lsq_debug_counters(lsq_ctx *c, unsigned long long *out8) {
+int lsq_debug_counters(lsq_ctx *c, unsigned long long *out8) LSQ_API_TRY {
 	HIP_TRY(hipSetDevice(c->device));
 	{ int rc = sync_all(c); if (rc) return rc; }
 	HIP_TRY(hipMemcpy(out8, c->dbg.p, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -1462,16 +1462,16 @@ int lsq_debug_counters(lsq_ctx *c, unsigned long long *out8) {
 	HIP_TRY(hipMemcpy(h.data(), c->exc_count.p, h.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
 	out8[4] = h[0];
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 
 // developer aid (include/lesseq_hip_dev.h): per-bucket slot offsets of a method (n_buckets + 1 values)
-int lsq_debug_slot_offsets(lsq_ctx *c, int method, unsigned long long *out, unsigned long long n) {
+int lsq_debug_slot_offsets(lsq_ctx *c, int method, unsigned long long *out, unsigned long long n) LSQ_API_TRY {
 	HIP_TRY(hipSetDevice(c->device));
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	const MethodReads &mr = c->reads[method];
 	if (n > mr.slot_off.n) n = mr.slot_off.n;
 	HIP_TRY(hipMemcpy(out, mr.slot_off.p, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 
 } // extern "C"

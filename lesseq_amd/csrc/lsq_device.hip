@@ -2,6 +2,7 @@
 // The kernels live in lsq_count.hip, lsq_em.hip and lsq_ingest.hip.
 #include "lsq_device.hpp"
 #include <chrono>
+#include <thread>
 
 namespace lsq {
 
@@ -58,7 +59,7 @@ void select_counter_set(lsq_ctx *c, int set) {
 
 extern "C" {
 
-int lsq_ctx_create(int device_id, lsq_ctx **out) {
+int lsq_ctx_create(int device_id, lsq_ctx **out) LSQ_API_TRY {
 	if (!out) return fail(LSQ_E_ARG, "null argument");
 	int n = 0;
 	hipError_t e = hipGetDeviceCount(&n);
@@ -86,7 +87,7 @@ int lsq_ctx_create(int device_id, lsq_ctx **out) {
 	for (int m = 0; m < LSQ_MAX_METHODS; ++m) { HIP_TRY(hipEventCreate(&c->evf0[m])); HIP_TRY(hipEventCreate(&c->evf1[m])); }
 	*out = c.release();
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 
 void lsq_ctx_destroy(lsq_ctx *c) {
 	if (!c) return;
@@ -111,13 +112,31 @@ void lsq_ctx_destroy(lsq_ctx *c) {
 }
 
 void *lsq_ctx_stream(lsq_ctx *c) { return c ? (void *)c->stream : nullptr; }
-int lsq_ctx_synchronize(lsq_ctx *c) {
+int lsq_ctx_synchronize(lsq_ctx *c) LSQ_API_TRY {
 	if (!c) return fail(LSQ_E_ARG, "null context");
 	HIP_TRY(hipSetDevice(c->device));
 	return sync_all(c);
-}
+} LSQ_API_CATCH
 
-int lsq_events_upload(lsq_ctx *c, lsq_events *E) {
+int lsq_ctx_synchronize_for(lsq_ctx *c, double seconds) LSQ_API_TRY {
+	if (!c) return fail(LSQ_E_ARG, "null context");
+	HIP_TRY(hipSetDevice(c->device));
+	const auto t0 = std::chrono::steady_clock::now();
+	const hipStream_t all[5] = {c->stream_count2[0], c->stream_count2[1], c->stream_em2[0], c->stream_em2[1], c->stream};
+	for (const hipStream_t s : all) {
+		for (unsigned spins = 0;; ++spins) {
+			const hipError_t e = hipStreamQuery(s);
+			if (e == hipSuccess) break;
+			if (e != hipErrorNotReady) return fail(LSQ_E_DEVICE, "hipStreamQuery: %s", hipGetErrorString(e));
+			if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds)
+				return fail(LSQ_E_TIMEOUT, "the context's streams had not drained after %.1f s", seconds);
+			if (spins > 4096) std::this_thread::sleep_for(std::chrono::microseconds(200));       // a long wait need not burn a core
+		}
+	}
+	return LSQ_OK;
+} LSQ_API_CATCH
+
+int lsq_events_upload(lsq_ctx *c, lsq_events *E) LSQ_API_TRY {
 	if (!c || !E) return fail(LSQ_E_ARG, "null argument");
 	HIP_TRY(hipSetDevice(c->device));
 	{ int rc = sync_all(c); if (rc) return rc; }        // the buffers below may still be read by a solve in flight
@@ -253,9 +272,9 @@ int lsq_events_upload(lsq_ctx *c, lsq_events *E) {
 	if ((rc = upload_strand_ranks(c))) return rc;
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 
-int lsq_count(lsq_ctx *c) {
+int lsq_count(lsq_ctx *c) LSQ_API_TRY {
 	if (!c) return fail(LSQ_E_ARG, "null context");
 	if (!c->E) return fail(LSQ_E_STATE, "lsq_events_upload must come first");
 	HIP_TRY(hipSetDevice(c->device));
@@ -271,9 +290,9 @@ int lsq_count(lsq_ctx *c) {
 	c->solved = false;
 	c->counts_external = false;
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 
-int lsq_solve(lsq_ctx *c) {
+int lsq_solve(lsq_ctx *c) LSQ_API_TRY {
 	if (!c) return fail(LSQ_E_ARG, "null context");
 	if (!c->counted) return fail(LSQ_E_STATE, "lsq_count must come first");
 	HIP_TRY(hipSetDevice(c->device));
@@ -284,10 +303,10 @@ int lsq_solve(lsq_ctx *c) {
 	c->solved = true;
 	c->fim_done = false;
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 
 // fim.h / linalg.h (parity unpinned, see lsq_em.hip): needs lsq_solve's theta
-int lsq_fim(lsq_ctx *c) {
+int lsq_fim(lsq_ctx *c) LSQ_API_TRY {
 	if (!c) return fail(LSQ_E_ARG, "null context");
 	if (!c->solved) return fail(LSQ_E_STATE, "lsq_solve must come first");
 	HIP_TRY(hipSetDevice(c->device));
@@ -321,7 +340,7 @@ int lsq_fim(lsq_ctx *c) {
 	if (rc) return rc;
 	c->fim_done = true;
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 
 int64_t lsq_results_fim_size(const lsq_ctx *c) {
 	if (!c || !c->E) return 0;
@@ -330,15 +349,15 @@ int64_t lsq_results_fim_size(const lsq_ctx *c) {
 	return n;
 }
 
-int lsq_results_fim_offsets(const lsq_ctx *c, uint64_t *fim_off) {
+int lsq_results_fim_offsets(const lsq_ctx *c, uint64_t *fim_off) LSQ_API_TRY {
 	if (!c || !c->E || !fim_off) return fail(LSQ_E_ARG, "null argument");
 	uint64_t n = 0;
 	for (size_t o = 0; o < c->E->ev.size(); ++o) { fim_off[o] = n; n += (uint64_t)(c->E->ev[o].K - 1) * (uint64_t)(c->E->ev[o].K - 1); }
 	fim_off[c->E->ev.size()] = n;
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 
-int lsq_results_fim(lsq_ctx *c, double *fim, double *var_by_diag, double *var_by_inverse) {
+int lsq_results_fim(lsq_ctx *c, double *fim, double *var_by_diag, double *var_by_inverse) LSQ_API_TRY {
 	if (!c || !fim || !var_by_diag || !var_by_inverse) return fail(LSQ_E_ARG, "null argument");
 	if (!c->fim_done || !c->solved) return fail(LSQ_E_STATE, "lsq_fim must come first");
 	HIP_TRY(hipSetDevice(c->device));
@@ -367,17 +386,17 @@ int lsq_results_fim(lsq_ctx *c, double *fim, double *var_by_diag, double *var_by
 		}
 	}
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 
 int64_t lsq_results_num_classes(const lsq_ctx *c) { return (c && c->E) ? (int64_t)c->E->class_off.back() : 0; }
 
-int lsq_results_class_offsets(const lsq_ctx *c, uint64_t *class_off) {
+int lsq_results_class_offsets(const lsq_ctx *c, uint64_t *class_off) LSQ_API_TRY {
 	if (!c || !c->E || !class_off) return fail(LSQ_E_ARG, "null argument");
 	memcpy(class_off, c->E->class_off.data(), c->E->class_off.size() * sizeof(uint64_t));
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 
-int lsq_results_counts(lsq_ctx *c, uint64_t *class_count, uint64_t *class_bases) {
+int lsq_results_counts(lsq_ctx *c, uint64_t *class_count, uint64_t *class_bases) LSQ_API_TRY {
 	if (!c || !class_count) return fail(LSQ_E_ARG, "null argument");
 	if (!c->counted) return fail(LSQ_E_STATE, "lsq_count must come first");
 	HIP_TRY(hipSetDevice(c->device));
@@ -403,12 +422,12 @@ int lsq_results_counts(lsq_ctx *c, uint64_t *class_count, uint64_t *class_bases)
 			}
 	}
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 
 // The inverse of lsq_results_counts: class counts and matched bases (output order, as that call returns
 // them) become the context's counts -- e.g. the sums over several processes that each counted a slice
 // of the reads (lesseq_amd/dist.py::run_read_sharded); lsq_solve then runs on them.
-int lsq_results_set_counts(lsq_ctx *c, const uint64_t *class_count, const uint64_t *class_bases) {
+int lsq_results_set_counts(lsq_ctx *c, const uint64_t *class_count, const uint64_t *class_bases) LSQ_API_TRY {
 	if (!c || !class_count || !class_bases) return fail(LSQ_E_ARG, "null argument");
 	if (!c->E) return fail(LSQ_E_STATE, "lsq_events_upload must come first");
 	HIP_TRY(hipSetDevice(c->device));
@@ -433,14 +452,14 @@ int lsq_results_set_counts(lsq_ctx *c, const uint64_t *class_count, const uint64
 	c->counted = true; c->solved = false;
 	c->counts_external = true;
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 
 // The latest count's class counts and matched bases as they lie on the device -- [file][device class] counts, then the same
 // for the bases -- for an exchange that never leaves HBM (the read-sharded run sums them over the ranks: every rank has
 // the same events, hence the same order).
 uint64_t lsq_counts_device_words(const lsq_ctx *c) { return (c && c->E) ? 2ull * (uint64_t)c->E->n_methods * (uint64_t)c->E->n_cls_total : 0; }
 
-int lsq_counts_export_device(lsq_ctx *c, void *d_words) {
+int lsq_counts_export_device(lsq_ctx *c, void *d_words) LSQ_API_TRY {
 	if (!c || !d_words) return fail(LSQ_E_ARG, "null argument");
 	if (!c->counted) return fail(LSQ_E_STATE, "lsq_count must come first");
 	HIP_TRY(hipSetDevice(c->device));
@@ -450,9 +469,9 @@ int lsq_counts_export_device(lsq_ctx *c, void *d_words) {
 		HIP_TRY(hipMemcpyAsync((unsigned long long *)d_words + per, c->bases.p, per * sizeof(unsigned long long), hipMemcpyDeviceToDevice, c->stream_em));
 	}
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 
-int lsq_counts_import_device(lsq_ctx *c, const void *d_words) {
+int lsq_counts_import_device(lsq_ctx *c, const void *d_words) LSQ_API_TRY {
 	if (!c || !d_words) return fail(LSQ_E_ARG, "null argument");
 	if (!c->E) return fail(LSQ_E_STATE, "lsq_events_upload must come first");
 	HIP_TRY(hipSetDevice(c->device));
@@ -465,9 +484,9 @@ int lsq_counts_import_device(lsq_ctx *c, const void *d_words) {
 	c->counted = true; c->solved = false;
 	c->counts_external = true;
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 
-int lsq_results_solve(lsq_ctx *c, double *theta, double *logll, uint32_t *em_iters, uint8_t *em_flags) {
+int lsq_results_solve(lsq_ctx *c, double *theta, double *logll, uint32_t *em_iters, uint8_t *em_flags) LSQ_API_TRY {
 	if (!c || !theta || !logll) return fail(LSQ_E_ARG, "null argument");
 	if (!c->solved) return fail(LSQ_E_STATE, "lsq_solve must come first");
 	HIP_TRY(hipSetDevice(c->device));
@@ -498,7 +517,7 @@ int lsq_results_solve(lsq_ctx *c, double *theta, double *logll, uint32_t *em_ite
 		if (em_flags) em_flags[o] = hf[d];
 	}
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 
 } // extern "C"
 
@@ -517,7 +536,7 @@ __global__ void __launch_bounds__(256) lsq_copy_results_kernel(unsigned long lon
 
 extern "C" {
 
-int lsq_results_copy_device(lsq_ctx *c, void *d_class_count, void *d_theta, void *d_logll) {
+int lsq_results_copy_device(lsq_ctx *c, void *d_class_count, void *d_theta, void *d_logll) LSQ_API_TRY {
 	if (!c) return fail(LSQ_E_ARG, "null context");
 	if (!c->counted) return fail(LSQ_E_STATE, "lsq_count must come first");
 	if ((d_theta || d_logll) && !c->solved) return fail(LSQ_E_STATE, "lsq_solve must come first");
@@ -532,7 +551,7 @@ int lsq_results_copy_device(lsq_ctx *c, void *d_class_count, void *d_theta, void
 		HIP_TRY(hipGetLastError());
 	}
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 
 extern "C++" {
 namespace {
@@ -554,7 +573,7 @@ __global__ void __launch_bounds__(256) lsq_pack_results_kernel(unsigned long lon
 } // namespace
 } // extern "C++"
 
-int lsq_results_pack_device(lsq_ctx *c, void *d_block) {
+int lsq_results_pack_device(lsq_ctx *c, void *d_block) LSQ_API_TRY {
 	if (!c || !d_block) return fail(LSQ_E_ARG, "null argument");
 	if (!c->solved) return fail(LSQ_E_STATE, "lsq_solve must come first");
 	HIP_TRY(hipSetDevice(c->device));
@@ -569,12 +588,12 @@ int lsq_results_pack_device(lsq_ctx *c, void *d_block) {
 		HIP_TRY(hipGetLastError());
 	}
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 
 void *lsq_ctx_result_stream(lsq_ctx *c) { return c ? (void *)c->stream_em : nullptr; }
 
 // device buffers for a C host that has no HIP of its own (the executables hold the packed / gathered records in them)
-int lsq_device_alloc(lsq_ctx *c, uint64_t bytes, void **out) {
+int lsq_device_alloc(lsq_ctx *c, uint64_t bytes, void **out) LSQ_API_TRY {
 	if (!c || !out) return fail(LSQ_E_ARG, "null argument");
 	HIP_TRY(hipSetDevice(c->device));
 	HIP_TRY(hipMalloc(out, (size_t)std::max<uint64_t>(bytes, 8)));
@@ -583,32 +602,32 @@ int lsq_device_alloc(lsq_ctx *c, uint64_t bytes, void **out) {
 	HIP_TRY(hipMemsetAsync(*out, 0, (size_t)std::max<uint64_t>(bytes, 8), c->stream_em));
 	HIP_TRY(hipStreamSynchronize(c->stream_em));
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 void lsq_device_free(lsq_ctx *c, void *p) {
 	if (!c || !p) return;
 	(void)hipSetDevice(c->device);
 	(void)hipFree(p);
 }
-int lsq_device_write(lsq_ctx *c, void *device_dst, const void *host_src, uint64_t bytes) {
+int lsq_device_write(lsq_ctx *c, void *device_dst, const void *host_src, uint64_t bytes) LSQ_API_TRY {
 	if (!c || !device_dst || !host_src) return fail(LSQ_E_ARG, "null argument");
 	HIP_TRY(hipSetDevice(c->device));
 	{ int rc = sync_all(c); if (rc) return rc; }
 	HIP_TRY(hipMemcpy(device_dst, host_src, (size_t)bytes, hipMemcpyHostToDevice));
 	return LSQ_OK;
-}
-int lsq_device_read(lsq_ctx *c, void *host_dst, const void *device_src, uint64_t bytes) {
+} LSQ_API_CATCH
+int lsq_device_read(lsq_ctx *c, void *host_dst, const void *device_src, uint64_t bytes) LSQ_API_TRY {
 	if (!c || !host_dst || !device_src) return fail(LSQ_E_ARG, "null argument");
 	HIP_TRY(hipSetDevice(c->device));
 	{ int rc = sync_all(c); if (rc) return rc; }
 	HIP_TRY(hipMemcpy(host_dst, device_src, (size_t)bytes, hipMemcpyDeviceToHost));
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 
-int lsq_results_device_order(const lsq_ctx *c, int32_t *dev2out) {
+int lsq_results_device_order(const lsq_ctx *c, int32_t *dev2out) LSQ_API_TRY {
 	if (!c || !c->E || !dev2out) return fail(LSQ_E_ARG, "null argument");
 	memcpy(dev2out, c->E->dev2out.data(), c->E->dev2out.size() * sizeof(int32_t));
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 
 extern "C++" {
 namespace {
@@ -633,7 +652,7 @@ __global__ void __launch_bounds__(256) lsq_read_rate_kernel(const uint4 *src, si
 
 // developer aid (include/lesseq_hip_dev.h): what a plain read of `bytes` of HBM reaches on this device (GB/s, best launch over
 // eight grid / unroll combinations) -- the practical ceiling bench.py prints beside the 8 TB/s peak
-int lsq_debug_stream_read_rate(lsq_ctx *c, unsigned long long bytes, double *gb_per_s) {
+int lsq_debug_stream_read_rate(lsq_ctx *c, unsigned long long bytes, double *gb_per_s) LSQ_API_TRY {
 	if (!c || !gb_per_s || bytes < (1ull << 20)) return fail(LSQ_E_ARG, "bad argument");
 	HIP_TRY(hipSetDevice(c->device));
 	{ int rc = sync_all(c); if (rc) return rc; }
@@ -662,10 +681,16 @@ int lsq_debug_stream_read_rate(lsq_ctx *c, unsigned long long bytes, double *gb_
 	(void)hipEventDestroy(a); (void)hipEventDestroy(b);
 	*gb_per_s = (double)(n_words * 16) / ((double)best * 1e-3) / 1e9;
 	return LSQ_OK;
+} LSQ_API_CATCH
+
+int lsq_debug_hip_versions(int *compiled, int *runtime) {
+	if (compiled) *compiled = HIP_VERSION;
+	if (runtime) { int v = 0; if (hipRuntimeGetVersion(&v) != hipSuccess) v = 0; *runtime = v; }
+	return LSQ_OK;
 }
 
 // developer aid (include/lesseq_hip_dev.h): another placement of the events in the EM grid (experiments on wave make-up)
-int lsq_debug_set_em_order(lsq_ctx *c, const uint32_t *order, unsigned n_small_places, unsigned n_places) {
+int lsq_debug_set_em_order(lsq_ctx *c, const uint32_t *order, unsigned n_small_places, unsigned n_places) LSQ_API_TRY {
 	HIP_TRY(hipSetDevice(c->device));
 	{ int rc = sync_all(c); if (rc) return rc; }
 	int rc = c->em_order.upload(order, n_places, c->stream);
@@ -675,10 +700,10 @@ int lsq_debug_set_em_order(lsq_ctx *c, const uint32_t *order, unsigned n_small_p
 	c->em_order_lane_valid[0] = c->em_order_lane_valid[1] = false;
 	c->opt_em_regroup = false;            // a placement given by hand stays
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 
 // Tuning knobs of a context (none is needed for correct results).
-int lsq_ctx_set_option(lsq_ctx *c, const char *name, double value) {
+int lsq_ctx_set_option(lsq_ctx *c, const char *name, double value) LSQ_API_TRY {
 	if (!c || !name) return fail(LSQ_E_ARG, "null argument");
 	const std::string n(name);
 	if (n == "grid_multiplier") {
@@ -716,15 +741,15 @@ int lsq_ctx_set_option(lsq_ctx *c, const char *name, double value) {
 	} else
 		return fail(LSQ_E_ARG, "unknown option '%s'", name);
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 
-int lsq_set_timing(lsq_ctx *c, int on) {
+int lsq_set_timing(lsq_ctx *c, int on) LSQ_API_TRY {
 	if (!c) return fail(LSQ_E_ARG, "null context");
 	c->time_events = on != 0;
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 
-int lsq_last_fast_kernel_ms(lsq_ctx *c, float *ms) {
+int lsq_last_fast_kernel_ms(lsq_ctx *c, float *ms) LSQ_API_TRY {
 	if (!c || !ms) return fail(LSQ_E_ARG, "null argument");
 	if (!c->counted || !c->count_timed) return fail(LSQ_E_STATE, "the last lsq_count ran without timing (lsq_set_timing)");
 	HIP_TRY(hipSetDevice(c->device));
@@ -732,9 +757,9 @@ int lsq_last_fast_kernel_ms(lsq_ctx *c, float *ms) {
 	*ms = 0;
 	for (int m = 0; m < LSQ_MAX_METHODS; ++m) if (c->fast_launched >> m & 1) { float t = 0; HIP_TRY(hipEventElapsedTime(&t, c->evf0[m], c->evf1[m])); *ms += t; }
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 
-int lsq_last_timing(lsq_ctx *c, float *count_ms, float *solve_ms) {
+int lsq_last_timing(lsq_ctx *c, float *count_ms, float *solve_ms) LSQ_API_TRY {
 	if (!c) return fail(LSQ_E_ARG, "null context");
 	HIP_TRY(hipSetDevice(c->device));
 	{ int rc = sync_all(c); if (rc) return rc; }
@@ -743,6 +768,6 @@ int lsq_last_timing(lsq_ctx *c, float *count_ms, float *solve_ms) {
 	if (count_ms) { *count_ms = 0; if (c->counted) HIP_TRY(hipEventElapsedTime(count_ms, c->ev0, c->ev1)); }
 	if (solve_ms) { *solve_ms = 0; if (c->solved) HIP_TRY(hipEventElapsedTime(solve_ms, c->ev2, c->ev3)); }
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 
 } // extern "C"

@@ -477,7 +477,7 @@ static int ingest_device(lsq_ctx *c, int method, const IngestRaw &Rw, uint64_t n
 
 extern "C" {
 
-int lsq_reads_upload(lsq_ctx *c, int method, const lsq_reads *R) {
+int lsq_reads_upload(lsq_ctx *c, int method, const lsq_reads *R) LSQ_API_TRY {
 	if (!c || !R) return fail(LSQ_E_ARG, "null argument");
 	if (!c->E) return fail(LSQ_E_STATE, "lsq_events_upload must come first");
 	if (method < 0 || method >= c->E->n_methods) return fail(LSQ_E_ARG, "method %d out of range", method);
@@ -510,9 +510,9 @@ int lsq_reads_upload(lsq_ctx *c, int method, const lsq_reads *R) {
 		HIP_TRY(hipStreamSynchronize(st));
 	}
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 
-int lsq_reads_upload_mrf(lsq_ctx *c, int method, const char *read_format, const char *path) {
+int lsq_reads_upload_mrf(lsq_ctx *c, int method, const char *read_format, const char *path) LSQ_API_TRY {
 	if (!c) return fail(LSQ_E_ARG, "null argument");
 	if (!c->E) return fail(LSQ_E_STATE, "lsq_events_upload must come first");
 	if (method < 0 || method >= c->E->n_methods) return fail(LSQ_E_ARG, "method %d out of range", method);
@@ -527,9 +527,9 @@ int lsq_reads_upload_mrf(lsq_ctx *c, int method, const char *read_format, const 
 	Rw.blk_chrom = P.bc.p; Rw.blk_strand = P.bst.p;
 	c->reads[method].named = false;
 	return ingest_device(c, method, Rw, P.n_blocks);
-}
+} LSQ_API_CATCH
 
-int lsq_text_stage_range(lsq_ctx *c, const char *path, uint64_t byte_begin, uint64_t byte_end, lsq_text **out) {
+int lsq_text_stage_range(lsq_ctx *c, const char *path, uint64_t byte_begin, uint64_t byte_end, lsq_text **out) LSQ_API_TRY {
 	if (!c || !path || !out) return fail(LSQ_E_ARG, "null argument");
 	HIP_TRY(hipSetDevice(c->device));
 	std::unique_ptr<lsq_text> T(new lsq_text);
@@ -537,24 +537,24 @@ int lsq_text_stage_range(lsq_ctx *c, const char *path, uint64_t byte_begin, uint
 	if (rc) return rc;
 	*out = T.release();
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 int lsq_text_stage(lsq_ctx *c, const char *path, lsq_text **out) { return lsq_text_stage_range(c, path, 0, ~0ull, out); }
 
-int lsq_text_lines(lsq_ctx *c, lsq_text *t, uint64_t *n_newlines) {
+int lsq_text_lines(lsq_ctx *c, lsq_text *t, uint64_t *n_newlines) LSQ_API_TRY {
 	if (!c || !t || !n_newlines) return fail(LSQ_E_ARG, "null argument");
 	HIP_TRY(hipSetDevice(c->device));
 	int rc = scan_newlines(c, *t);
 	if (rc) return rc;
 	*n_newlines = t->n_nl;
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 void lsq_text_free(lsq_text *t) { delete t; }
 
-int lsq_reads_upload_text(lsq_ctx *c, int method, const char *read_format, lsq_text *t) {
+int lsq_reads_upload_text(lsq_ctx *c, int method, const char *read_format, lsq_text *t) LSQ_API_TRY {
 	return lsq_reads_upload_text_at(c, method, read_format, t, 1, 1);
-}
+} LSQ_API_CATCH
 
-int lsq_reads_upload_text_at(lsq_ctx *c, int method, const char *read_format, lsq_text *t, int has_header, uint64_t first_line) {
+int lsq_reads_upload_text_at(lsq_ctx *c, int method, const char *read_format, lsq_text *t, int has_header, uint64_t first_line) LSQ_API_TRY {
 	if (!c || !t) return fail(LSQ_E_ARG, "null argument");
 	if (!c->E) return fail(LSQ_E_STATE, "lsq_events_upload must come first");
 	if (method < 0 || method >= c->E->n_methods) return fail(LSQ_E_ARG, "method %d out of range", method);
@@ -567,9 +567,9 @@ int lsq_reads_upload_text_at(lsq_ctx *c, int method, const char *read_format, ls
 	Rw.blk_chrom = P.bc.p; Rw.blk_strand = P.bst.p;
 	c->reads[method].named = false;
 	return ingest_device(c, method, Rw, P.n_blocks);
-}
+} LSQ_API_CATCH
 
-int lsq_mrf_parse_device(lsq_ctx *c, const char *read_format, const char *path, lsq_reads **out) {
+int lsq_mrf_parse_device(lsq_ctx *c, const char *read_format, const char *path, lsq_reads **out) LSQ_API_TRY {
 	if (!c || !out) return fail(LSQ_E_ARG, "null argument");
 	HIP_TRY(hipSetDevice(c->device));
 	DevParsed P;
@@ -589,14 +589,14 @@ int lsq_mrf_parse_device(lsq_ctx *c, const char *read_format, const char *path, 
 	R->adopt();
 	*out = R.release();
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 
-int lsq_last_mrf_timing(lsq_ctx *c, float *h2d_ms, float *parse_ms) {
+int lsq_last_mrf_timing(lsq_ctx *c, float *h2d_ms, float *parse_ms) LSQ_API_TRY {
 	if (!c) return fail(LSQ_E_ARG, "null context");
 	if (h2d_ms) *h2d_ms = c->mrf_h2d_ms;
 	if (parse_ms) *parse_ms = c->mrf_parse_ms;
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 
 uint64_t lsq_reads_retained(const lsq_ctx *c, int method) { return (c && method >= 0 && method < LSQ_MAX_METHODS) ? c->reads[method].n_retained : 0; }
 uint64_t lsq_reads_pooled(const lsq_ctx *c, int method) {
@@ -611,7 +611,7 @@ uint64_t lsq_reads_pooled_blocks(const lsq_ctx *c, int method) {
 }
 uint64_t lsq_reads_retained_blocks(const lsq_ctx *c, int method) { return (c && method >= 0 && method < LSQ_MAX_METHODS) ? c->reads[method].n_retained_blocks : 0; }
 
-int lsq_reads_pool_format(const lsq_ctx *c, int method, int *compact, uint64_t *pool_bytes, uint64_t *pool_reads) {
+int lsq_reads_pool_format(const lsq_ctx *c, int method, int *compact, uint64_t *pool_bytes, uint64_t *pool_reads) LSQ_API_TRY {
 	if (!c || method < 0 || method >= LSQ_MAX_METHODS) return fail(LSQ_E_ARG, "bad context or method");
 	const MethodReads &mr = c->reads[method];
 	if (!mr.present) return fail(LSQ_E_STATE, "no reads uploaded for method %d", method);
@@ -619,6 +619,6 @@ int lsq_reads_pool_format(const lsq_ctx *c, int method, int *compact, uint64_t *
 	if (pool_bytes) *pool_bytes = 4ull * (mr.p1.n + mr.p2.n + mr.pn_se.n);
 	if (pool_reads) { pool_reads[0] = mr.n1_reads; pool_reads[1] = mr.n2_reads; pool_reads[2] = mr.pn_line.n; }
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 
 } // extern "C"

@@ -7,7 +7,10 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <exception>
+#include <new>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -17,6 +20,48 @@ namespace lsq {
 
 // ---- error text for the calling thread -------------------------------------------------
 int fail(int status, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+// ---- no exception crosses the C ABI (include/lesseq_hip.h; the reference's contract for a failure is a logged message
+// and `return 1`, count/count.cpp:20-38) -----------------------------------------------------------------------------
+// Every extern "C" entry that can allocate is a function-try-block: `int lsq_x(...) LSQ_API_TRY { ... } LSQ_API_CATCH`.
+// std::bad_alloc / std::length_error / anything else thrown below it comes back as LSQ_E_INTERNAL with the text in
+// lsq_last_error() instead of std::terminate in the host process.
+int fail_exception(const char *where) noexcept;
+#define LSQ_API_TRY try
+#define LSQ_API_CATCH catch (...) { return lsq::fail_exception(__func__); }
+
+// Helper threads of one call.  A std::thread that is destroyed while joinable, and an exception that leaves a thread's
+// function, both end the process (std::terminate): the group joins whatever it started on every way out of its scope, and
+// a body's exception is kept as text for the caller (failed() / error()).
+class ThreadGroup {
+	std::vector<std::thread> th_;
+	std::mutex mu_;
+	std::string error_;
+	bool failed_ = false;
+	void note(const char *what) noexcept {
+		try { std::lock_guard<std::mutex> g(mu_); if (!failed_) { failed_ = true; error_ = what; } } catch (...) { failed_ = true; }
+	}
+public:
+	ThreadGroup() = default;
+	ThreadGroup(const ThreadGroup &) = delete;
+	ThreadGroup &operator=(const ThreadGroup &) = delete;
+	template <class F>
+	void spawn(F f) {
+		th_.emplace_back([this, f]() mutable noexcept {
+			try { f(); } catch (const std::exception &e) { note(e.what()); } catch (...) { note("unknown exception"); }
+		});
+	}
+	// the body on the calling thread, under the same guard
+	template <class F>
+	void run_here(F &&f) noexcept {
+		try { f(); } catch (const std::exception &e) { note(e.what()); } catch (...) { note("unknown exception"); }
+	}
+	void join() noexcept { for (auto &t : th_) if (t.joinable()) t.join(); }
+	bool failed() const { return failed_; }
+	const std::string &error() const { return error_; }
+	size_t size() const { return th_.size(); }
+	~ThreadGroup() { join(); }
+};
 
 // ---- interval_list<long> semantics (jsc/util/interval_list.hpp:396-422,462-503) -----------
 struct IntervalList {

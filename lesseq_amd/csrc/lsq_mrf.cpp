@@ -103,7 +103,7 @@ void parse_chunk(Chunk &ck, lsq_events *E) {
 
 extern "C" {
 
-int lsq_mrf_parse(const char *read_format, const char *path, lsq_events *E, int n_threads, lsq_reads **out) {
+int lsq_mrf_parse(const char *read_format, const char *path, lsq_events *E, int n_threads, lsq_reads **out) LSQ_API_TRY {
 	if (!read_format || !path || !E || !out) return fail(LSQ_E_ARG, "null argument");
 	int fd = open(path, O_RDONLY);
 	if (fd < 0) return fail(LSQ_E_IO, "cannot open reads file %s", path);
@@ -114,9 +114,10 @@ int lsq_mrf_parse(const char *read_format, const char *path, lsq_events *E, int 
 	std::unique_ptr<lsq_reads> R(new lsq_reads);
 	R->o_blk_off.push_back(0);
 	const char *data = nullptr;
+	struct Unmapper { const char *&d; size_t n; ~Unmapper() { if (d) munmap((void *)d, n); } } unmapper{data, len};     // on every way out
 	if (len > 0) {
 		data = (const char *)mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0);
-		if (data == MAP_FAILED) { close(fd); return fail(LSQ_E_IO, "cannot map %s", path); }
+		if (data == MAP_FAILED) { data = nullptr; close(fd); return fail(LSQ_E_IO, "cannot map %s", path); }
 		madvise((void *)data, len, MADV_SEQUENTIAL);
 	}
 	close(fd);
@@ -148,8 +149,8 @@ int lsq_mrf_parse(const char *read_format, const char *path, lsq_events *E, int 
 		// line numbers: count newlines per chunk, prefix
 		std::vector<uint64_t> nlines(T, 0);
 		{
-			std::vector<std::thread> th;
-			for (int t = 0; t < T; ++t) th.emplace_back([&, t] {
+			ThreadGroup th;
+			for (int t = 0; t < T; ++t) th.spawn([&, t] {
 				uint64_t c = 0;
 				const char *q = chunks[t].begin;
 				while (q < chunks[t].end) {
@@ -159,19 +160,20 @@ int lsq_mrf_parse(const char *read_format, const char *path, lsq_events *E, int 
 				}
 				nlines[t] = c;
 			});
-			for (auto &x : th) x.join();
+			th.join();
+			if (th.failed()) return fail(LSQ_E_INTERNAL, "a helper thread failed: %s", th.error().c_str());
 		}
 		uint64_t ln = 1;
 		for (int t = 0; t < T; ++t) { chunks[t].first_line = ln; ln += nlines[t]; }
 		{
-			std::vector<std::thread> th;
-			for (int t = 0; t < T; ++t) th.emplace_back([&, t] { parse_chunk(chunks[t], E); });
-			for (auto &x : th) x.join();
+			ThreadGroup th;
+			for (int t = 0; t < T; ++t) th.spawn([&, t] { parse_chunk(chunks[t], E); });
+			th.join();
+			if (th.failed()) return fail(LSQ_E_INTERNAL, "a helper thread failed: %s", th.error().c_str());
 		}
 		for (int t = 0; t < T; ++t) if (chunks[t].status != LSQ_OK) {
 			int st2 = chunks[t].status;
 			std::string msg = chunks[t].err;
-			munmap((void *)data, len);
 			return fail(st2, "%s", msg.c_str());
 		}
 		size_t nr = 0, nbk = 0;
@@ -190,11 +192,10 @@ int lsq_mrf_parse(const char *read_format, const char *path, lsq_events *E, int 
 			std::vector<int32_t>().swap(c.bs); std::vector<int32_t>().swap(c.be);
 		}
 	}
-	if (data) munmap((void *)data, len);
 	R->adopt();
 	*out = R.release();
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 
 // solve's name-keyed read formats (solve/solve.cpp:413-428 UCSC_GFF, :487-551 UCSC_BED, :552-634
 // WORMBASE_GFF3).  Every accepted line adds its blocks to the read of its name, in file order; the
@@ -202,7 +203,7 @@ int lsq_mrf_parse(const char *read_format, const char *path, lsq_events *E, int 
 // block, which is the last accepted line.  UCSC_BED and WORMBASE_GFF3 accept or drop a line by its
 // whole span, so that test runs here against the covered regions; UCSC_GFF tests the block itself, as
 // the ingest kernel does anyway.
-int lsq_reads_parse(const char *read_format, const char *path, lsq_events *E, int n_threads, lsq_reads **out) {
+int lsq_reads_parse(const char *read_format, const char *path, lsq_events *E, int n_threads, lsq_reads **out) LSQ_API_TRY {
 	if (!read_format || !path || !E || !out) return fail(LSQ_E_ARG, "null argument");
 	const std::string fmt = read_format;
 	if (fmt == "MRF_SINGLE") return lsq_mrf_parse(read_format, path, E, n_threads, out);
@@ -369,11 +370,11 @@ int lsq_reads_parse(const char *read_format, const char *path, lsq_events *E, in
 	R->adopt();
 	*out = R.release();
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 
 int lsq_reads_wrap(uint64_t n_reads, const uint64_t *blk_off, const uint32_t *line_no,
                    const int32_t *blk_start, const int32_t *blk_end,
-                   const uint16_t *blk_chrom_id, const uint8_t *blk_strand_id, lsq_reads **out) {
+                   const uint16_t *blk_chrom_id, const uint8_t *blk_strand_id, lsq_reads **out) LSQ_API_TRY {
 	if (!out || (n_reads && (!blk_off || !line_no || !blk_start || !blk_end || !blk_chrom_id || !blk_strand_id)))
 		return fail(LSQ_E_ARG, "null array");
 	std::unique_ptr<lsq_reads> R(new lsq_reads);
@@ -384,9 +385,9 @@ int lsq_reads_wrap(uint64_t n_reads, const uint64_t *blk_off, const uint32_t *li
 	R->blk_chrom = blk_chrom_id; R->blk_strand = blk_strand_id;
 	*out = R.release();
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 int lsq_reads_arrays(const lsq_reads *r, const uint64_t **blk_off, const uint32_t **line_no, const int32_t **blk_start,
-                     const int32_t **blk_end, const uint16_t **blk_chrom_id, const uint8_t **blk_strand_id) {
+                     const int32_t **blk_end, const uint16_t **blk_chrom_id, const uint8_t **blk_strand_id) LSQ_API_TRY {
 	if (!r) return fail(LSQ_E_ARG, "null read set");
 	if (blk_off) *blk_off = r->blk_off;
 	if (line_no) *line_no = r->line_no;
@@ -395,7 +396,7 @@ int lsq_reads_arrays(const lsq_reads *r, const uint64_t **blk_off, const uint32_
 	if (blk_chrom_id) *blk_chrom_id = r->blk_chrom;
 	if (blk_strand_id) *blk_strand_id = r->blk_strand;
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 void lsq_reads_free(lsq_reads *r) { delete r; }
 uint64_t lsq_reads_count(const lsq_reads *r) { return r ? r->n_reads : 0; }
 uint64_t lsq_reads_num_blocks(const lsq_reads *r) { return r ? r->n_blocks : 0; }

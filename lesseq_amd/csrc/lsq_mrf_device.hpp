@@ -247,10 +247,12 @@ static int stage_text_file(lsq_ctx *c, const char *path, unsigned long long byte
 			const long n_slices = (long)((len + SLICE - 1) / SLICE);
 			std::atomic<long> go{-1}, filled{0};
 			std::atomic<int> io_error{0};
-			std::vector<std::thread> workers;
-			for (int t = 0; t < T; ++t) workers.emplace_back([&, t] {
+			std::atomic<bool> give_up{false};         // set on every way out of this block: a worker that still waits for its slice leaves
+			ThreadGroup workers;                      // (joined on every way out, after give_up is set: declared first, destroyed last)
+			struct GiveUp { std::atomic<bool> &f; ~GiveUp() { f.store(true, std::memory_order_release); } } give_up_on_exit{give_up};
+			for (int t = 0; t < T; ++t) workers.spawn([&, t] {
 				for (long sl = 0; sl < n_slices; ++sl) {
-					while (go.load(std::memory_order_acquire) < sl) std::this_thread::yield();
+					while (go.load(std::memory_order_acquire) < sl) { if (give_up.load(std::memory_order_acquire)) return; std::this_thread::yield(); }
 					const size_t off = (size_t)sl * SLICE, nby = std::min<size_t>(SLICE, len - off);
 					size_t a = nby * (size_t)t / (size_t)T;
 					const size_t b = nby * (size_t)(t + 1) / (size_t)T;
@@ -271,7 +273,7 @@ static int stage_text_file(lsq_ctx *c, const char *path, unsigned long long byte
 				if (rc_copy == LSQ_OK && (hipMemcpyAsync(d_text.p + off, pin[k], nby, hipMemcpyHostToDevice, st) != hipSuccess || hipEventRecord(drained[k], st) != hipSuccess))
 					rc_copy = fail(LSQ_E_DEVICE, "hipMemcpyAsync failed in the text copy");
 			}
-			for (auto &w : workers) w.join();
+			workers.join();
 			if (hipStreamSynchronize(st) != hipSuccess && rc_copy == LSQ_OK) rc_copy = fail(LSQ_E_DEVICE, "text copy failed");
 			if (io_error.load() && rc_copy == LSQ_OK) rc_copy = fail(LSQ_E_IO, "cannot read %s", path);
 		} else {

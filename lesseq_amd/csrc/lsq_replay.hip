@@ -403,14 +403,14 @@ int host_solve(lsq_ctx *c) {
 
 extern "C" {
 
-int lsq_set_em_guard_band(lsq_ctx *c, double band) {
+int lsq_set_em_guard_band(lsq_ctx *c, double band) LSQ_API_TRY {
 	if (!c) return fail(LSQ_E_ARG, "null context");
 	if (!(band >= 0.0)) return fail(LSQ_E_ARG, "the guard band must be a non-negative number");
 	c->em_band = band;
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 
-int lsq_solve_finalize(lsq_ctx *c, uint32_t *n_replayed) {
+int lsq_solve_finalize(lsq_ctx *c, uint32_t *n_replayed) LSQ_API_TRY {
 	if (!c) return fail(LSQ_E_ARG, "null context");
 	if (!c->solved) return fail(LSQ_E_STATE, "lsq_solve must come first");
 	HIP_TRY(hipSetDevice(c->device));
@@ -418,14 +418,14 @@ int lsq_solve_finalize(lsq_ctx *c, uint32_t *n_replayed) {
 	int rc = lsq::replay_flagged(c, &n);
 	if (n_replayed) *n_replayed = n;
 	return rc;
-}
+} LSQ_API_CATCH
 
 // Developer check of the pools' layout (tests): every aligned group of eight one-block records starts in one cell (or all
 // in none), every aligned quadruple of two-block records of a junction group crosses one junction, and the records that are
 // not padding number what the ingest counted.  out: [0] one-block records, [1] of them padding, [2] groups of eight over more
 // than one cell, [3] two-block records, [4] of them padding, [5] quadruples whose first read crosses a junction of the
 // annotation and another of whose reads crosses another or none.
-int lsq_debug_check_pool_layout(lsq_ctx *c, int method, unsigned long long *out) {
+int lsq_debug_check_pool_layout(lsq_ctx *c, int method, unsigned long long *out) LSQ_API_TRY {
 	if (!c || !c->E || !out || method < 0 || method >= c->E->n_methods) return fail(LSQ_E_ARG, "bad argument");
 	HIP_TRY(hipSetDevice(c->device));
 	{ int rc = lsq::sync_all(c); if (rc) return rc; }
@@ -485,6 +485,6 @@ int lsq_debug_check_pool_layout(lsq_ctx *c, int method, unsigned long long *out)
 		return fail(LSQ_E_STATE, "the pools hold %llu + %llu reads, the ingest counted %llu + %llu", out[0] - out[1], out[3] - out[4],
 		            (unsigned long long)mr.n1_reads, (unsigned long long)mr.n2_reads);
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 
 } // extern "C"

@@ -208,7 +208,7 @@ std::string chrom_name(int c) { return "chr" + std::to_string(c + 1); }
 
 extern "C" {
 
-int lsq_synth_write(const lsq_synth_spec *S, const char *dir, const char *stem, int write_mrf) {
+int lsq_synth_write(const lsq_synth_spec *S, const char *dir, const char *stem, int write_mrf) LSQ_API_TRY {
 	if (!S || !dir || !stem) return fail(LSQ_E_ARG, "null argument");
 	SynModel Mo;
 	int rc = build_model(*S, Mo);
@@ -247,9 +247,9 @@ int lsq_synth_write(const lsq_synth_spec *S, const char *dir, const char *stem, 
 		};
 		bool io_ok = true;
 		for (uint64_t round0 = 0; round0 < S->n_reads && io_ok; round0 += CHUNK * (uint64_t)T) {
-			std::vector<std::thread> th;
+			ThreadGroup th;
 			for (int t = 0; t < T; ++t) {
-				th.emplace_back([&, t] {
+				th.spawn([&, t] {
 					std::string &o = bufs[(size_t)t];
 					o.clear();
 					const uint64_t i0 = round0 + CHUNK * (uint64_t)t, i1 = std::min<uint64_t>(i0 + CHUNK, S->n_reads);
@@ -270,15 +270,16 @@ int lsq_synth_write(const lsq_synth_spec *S, const char *dir, const char *stem, 
 					}
 				});
 			}
-			for (auto &x : th) x.join();
+			th.join();
+			if (th.failed()) { fclose(fr); return fail(LSQ_E_INTERNAL, "a helper thread failed: %s", th.error().c_str()); }
 			for (int t = 0; t < T; ++t) if (!bufs[(size_t)t].empty() && fwrite(bufs[(size_t)t].data(), 1, bufs[(size_t)t].size(), fr) != bufs[(size_t)t].size()) io_ok = false;
 		}
 		if (fclose(fr) != 0 || !io_ok) return fail(LSQ_E_IO, "cannot write %s.mrf", base.c_str());
 	}
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 
-int lsq_synth_reads(const lsq_synth_spec *S, lsq_events *E, int n_threads, lsq_reads **out) {
+int lsq_synth_reads(const lsq_synth_spec *S, lsq_events *E, int n_threads, lsq_reads **out) LSQ_API_TRY {
 	if (!S || !E || !out) return fail(LSQ_E_ARG, "null argument");
 	SynModel Mo;
 	int rc = build_model(*S, Mo);
@@ -300,20 +301,21 @@ int lsq_synth_reads(const lsq_synth_spec *S, lsq_events *E, int n_threads, lsq_r
 	Rd->o_line_no.resize(n);
 	auto range = [&](int t, uint64_t &a, uint64_t &b) { a = n * (uint64_t)t / (uint64_t)T; b = n * (uint64_t)(t + 1) / (uint64_t)T; };
 	{
-		std::vector<std::thread> th;
-		for (int t = 0; t < T; ++t) th.emplace_back([&, t] {
+		ThreadGroup th;
+		for (int t = 0; t < T; ++t) th.spawn([&, t] {
 			uint64_t a, b; range(t, a, b);
 			OneRead r;
 			for (uint64_t i = a; i < b; ++i) { gen_read(*S, Mo, S->first_read + i, r); Rd->o_blk_off[i + 1] = (uint64_t)r.nb; Rd->o_line_no[i] = (uint32_t)(i + 1); }
 		});
-		for (auto &x : th) x.join();
+		th.join();
+		if (th.failed()) return fail(LSQ_E_INTERNAL, "a helper thread failed: %s", th.error().c_str());
 	}
 	for (uint64_t i = 0; i < n; ++i) Rd->o_blk_off[i + 1] += Rd->o_blk_off[i];
 	const uint64_t nb = Rd->o_blk_off[n];
 	Rd->o_start.resize(nb); Rd->o_end.resize(nb); Rd->o_chrom.resize(nb); Rd->o_strand.resize(nb);
 	{
-		std::vector<std::thread> th;
-		for (int t = 0; t < T; ++t) th.emplace_back([&, t] {
+		ThreadGroup th;
+		for (int t = 0; t < T; ++t) th.spawn([&, t] {
 			uint64_t a, b; range(t, a, b);
 			OneRead r;
 			for (uint64_t i = a; i < b; ++i) {
@@ -326,11 +328,12 @@ int lsq_synth_reads(const lsq_synth_spec *S, lsq_events *E, int n_threads, lsq_r
 				}
 			}
 		});
-		for (auto &x : th) x.join();
+		th.join();
+		if (th.failed()) return fail(LSQ_E_INTERNAL, "a helper thread failed: %s", th.error().c_str());
 	}
 	Rd->adopt();
 	*out = Rd.release();
 	return LSQ_OK;
-}
+} LSQ_API_CATCH
 
 } // extern "C"

@@ -234,8 +234,8 @@ def run_read_sharded(tool, argv, rank, world, device_index=0, group=None, comm_d
     if world > 1:
         # the sum over the ranks on the device: the class counts and matched bases as they lie in HBM (every rank has the same
         # events, hence the same order), one all-reduce, and the sums become the counts the EM and the getters work on
-        # (gloo, i.e. the tests on one GPU: the same words through a host tensor and the library's own copies -- no torch.cuda
-        # there: a process that loaded this library before torch holds the system's HIP runtime, and torch's own then finds no GPU)
+        # (gloo, i.e. the tests on one GPU: the same words through a host tensor and the library's own copies; the tensors of
+        # a gloo group are host tensors, so torch.cuda is not needed there)
         n_words = max(ctx.counts_device_words(), 1)
         if dist.get_backend(group) == "gloo" or (comm_device is not None and torch.device(comm_device).type == "cpu"):
             import ctypes as C

@@ -34,3 +34,40 @@ def gpu_ctx():
     c = L.Context(0)      # fails loudly when there is no gfx950 device
     yield c
     c.close()
+
+
+# A native abort (glibc's heap checks, std::terminate, an assertion inside the HIP runtime) prints its reason on file
+# descriptor 2 and kills the process: under pytest's fd capture that text lands in a temporary file that dies with it
+# (round 2 lost the one piece of evidence of such an abort that way).  GPU tests therefore run with fd 2 appended to a
+# log that survives: gpurun_out/native_stderr.log when that directory can be made (gpurun carries it back), else the
+# system's temporary directory; every test writes a header line first.  faulthandler (pytest's own plugin) adds the
+# Python stack to the same descriptor.
+@pytest.fixture(autouse=True)
+def _native_stderr_survives(request):
+    if request.node.get_closest_marker("gpu") is None or os.environ.get("LSQ_KEEP_STDERR") == "0":
+        yield
+        return
+    import tempfile
+    path = None
+    for d in (os.path.join(ROOT, "gpurun_out"), tempfile.gettempdir()):
+        try:
+            os.makedirs(d, exist_ok=True)
+            path = os.path.join(d, "native_stderr.log")
+            fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_APPEND, 0o644)
+            break
+        except OSError:
+            path = None
+    if path is None:
+        yield
+        return
+    sys.stderr.flush()
+    saved = os.dup(2)
+    os.write(fd, ("=== %s\n" % request.node.nodeid).encode())
+    os.dup2(fd, 2)
+    os.close(fd)
+    try:
+        yield
+    finally:
+        sys.stderr.flush()
+        os.dup2(saved, 2)
+        os.close(saved)

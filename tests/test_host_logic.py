@@ -366,3 +366,59 @@ def test_oracle_fisher_information_against_a_direct_derivation(tmp_path, monkeyp
         assert abs(info - g["fim"][0][0][0]) <= 1e-9 * abs(info), (g["gname"], info, g["fim"])
         assert abs(g["fim_var"][0][0] - 1.0 / info) <= 1e-9 / info
         assert abs(g["fim_var"][0][1] - 2.0 / info) <= 1e-9 / info       # fim.h:74-93: all entries of the inverse plus its trace
+
+
+def test_no_exception_crosses_the_boundary(tmp_path):
+    """include/lesseq_hip.h: "no exceptions across the boundary" (the reference's contract for a failure is a logged
+    message and a status, count/count.cpp:20-38).  A C++ exception below an entry point -- out of memory in a loader, a
+    length_error, something thrown inside a helper thread -- comes back as LSQ_E_INTERNAL (-9) with its text; before
+    round 3 it was std::terminate, i.e. SIGABRT in the host process.  A child process makes the calls, so that a
+    regression shows up as that child's death and not as the death of the test run."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys
+        sys.path.insert(0, %r)
+        import ctypes as C
+        import lesseq_amd as L
+        lib = L.lib
+        for kind, want in ((0, b"out of memory"), (1, b"vector"), (2, b"unknown exception"), (3, b"thrown inside a helper thread")):
+            st = lib.lsq_debug_throw(kind)
+            assert st == -9, (kind, st)
+            assert want in lib.lsq_last_error(), (kind, lib.lsq_last_error())
+        assert lib.lsq_debug_throw(9) == 0
+        # a real path: with the address space capped, the arrays of 2^31 reads cannot be allocated (std::bad_alloc inside lsq_synth_reads)
+        d = %r
+        spec = L.SynthSpec(seed=1, n_events=4, n_reads=100, read_length=50, n_chrom=1)
+        L.synth_write(spec, d, "s", write_mrf=False)
+        a = L.Annotation(d + "/s.interval", d + "/s.map")
+        ev = L.Events(a, ("SHORT_READ",), (50,))
+        big = L.SynthSpec(seed=1, n_events=4, n_reads=2 ** 31, read_length=50, n_chrom=1)
+        import resource
+        used = int(open("/proc/self/statm").read().split()[0]) * resource.getpagesize()
+        resource.setrlimit(resource.RLIMIT_AS, (used + (1 << 30), used + (1 << 30)))
+        h = C.c_void_p()
+        st = lib.lsq_synth_reads(C.byref(big.c), ev.h, 1, C.byref(h))
+        assert st == -9 and lib.lsq_last_error().startswith(b"lsq_synth_reads"), (st, lib.lsq_last_error())
+        print("contained")
+    """) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, LSQ_NO_TORCH="1"))
+    assert p.returncode == 0 and "contained" in p.stdout, (p.returncode, p.stdout, p.stderr)
+
+
+def test_in_process_cli_leaves_no_thread_behind(tmp_path, monkeypatch):
+    """lsq_cli_run inside a host process makes its device context on the calling thread (an executable overlaps it with
+    the annotation load on a second thread, lsq_cli_main); whatever the outcome -- here: no GPU, or a GPU -- the call
+    returns with every helper thread joined"""
+    import threading
+    c, d = load_case("toy", tmp_path)
+    monkeypatch.chdir(d)
+
+    def native_threads():
+        return len(os.listdir("/proc/self/task"))
+    L.cli_run("count", c["count"][0]["argv"])          # first call: the runtime may start service threads of its own
+    before = native_threads()
+    for _ in range(3):
+        rc, _ = L.cli_run("count", c["count"][0]["argv"])
+        assert rc in (0, 3)
+    assert native_threads() <= before
+    assert threading.active_count() >= 1

@@ -80,10 +80,12 @@ def test_oracle_matches_reference_on_whole_config0(tmp_path):
     assert rc == 0 and text == sexp
 
 
-def test_oracle_matches_reference_on_whole_config1_count(tmp_path):
+def test_oracle_matches_reference_on_whole_config1(tmp_path):
     """BASELINE.json configs[1] at full size (10 M reads, 5 k SE/RI events): the 10 000 rows the reference's count printed
-    in its 158 s run, byte for byte (the solve table is compared on the GPU side; the oracle reproduced it too when the
-    vectors were made)"""
+    in its 158 s run and the 10 000 rows its solve printed in 166 s (solve/solve.cpp:829-847: theta, RPKM, mean
+    log-likelihood at six significant digits), both byte for byte"""
     argv, cexp, sexp = full_case("c2", tmp_path)
     rc, text, _ = ob.run("count", argv[:-1])
     assert rc == 0 and text == cexp
+    rc, text, _ = ob.run("solve", argv)
+    assert rc == 0 and text == sexp

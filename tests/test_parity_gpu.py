@@ -1103,6 +1103,23 @@ def test_executables_run_one_job_over_several_gpu_slices(name, env, tmp_path):
     assert n
 
 
+@pytest.mark.parametrize("env", [
+    {"LSQ_GPUS": "3", "LSQ_DEVICES": "0,0,0", "LSQ_GATHER": "host", "LSQ_FAIL_RANK": "1"},      # a slice fails before the hand-over
+    {"LSQ_GPUS": "2", "LSQ_DEVICES": "0,99", "LSQ_GATHER": "host"},                               # a slice whose device does not exist
+    {"LSQ_GPUS": "1", "LSQ_GATHER": "rccl", "LSQ_FAIL_RANK": "0"},                                # ... with the RCCL communicator made
+])
+def test_a_failing_slice_ends_the_job_with_its_message(env, tmp_path):
+    """The slices' host threads agree before anyone enters the collective: one slice that failed on the way (no context,
+    an unreadable file, out of memory) makes the job exit 3 with that slice's message -- the others neither gather nor
+    wait for it (they used to enqueue ncclAllGather and block for the missing peer)."""
+    import subprocess
+    c, d = load_case("toy", tmp_path)
+    r = c["count"][0]
+    p = subprocess.run([os.path.join(BIN, "count")] + r["argv"], cwd=d, capture_output=True, text=True, env=dict(os.environ, **env), timeout=120)
+    assert p.returncode == 3 and p.stdout == "", (p.returncode, p.stdout, p.stderr)
+    assert "ERROR" in p.stderr and ("LSQ_FAIL_RANK" in p.stderr or "out of range" in p.stderr), p.stderr
+
+
 @pytest.mark.parametrize("name", ["c1", "c2"])
 def test_whole_reference_runs_of_config0_and_config1(name, tmp_path):
     """tests/golden_full: stdout of the reference's own binaries on BASELINE.json configs[0] and configs[1] at full size
