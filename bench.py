@@ -17,6 +17,13 @@ cut into N contiguous slices of equal read weight (reads per event from a first 
 lsq_shard_bounds; the reference's own scale-out unit is such a slice, count/count.cpp:204-215), every rank
 ingests the reads of its slice, and `value` = the job's retained reads x steps / time: strong scaling.  After the
 loop rank 0 checks that the gathered tables equal the unsharded run's.
+With the default workload the line of an N > 1 run is the c3 job (BASELINE configs[3]) and carries, under
+`config.c5_*`, the same measurement of BASELINE configs[4] (1 B reads, 200 k events, Zipf depth: a millisecond of
+count work per step on one GPU, where the fixed terms of a step weigh less), and under `config.e2e_cli_gpus_*` the
+wall-clock of `LSQ_GPUS=N lesseq_amd/bin/solve` from the MRF text as a child process, its table compared with the
+one-GPU table.  Nothing on that path waits without a limit: the RCCL communicator of liblesseq_rccl is made with a time
+limit, the first in-loop gather is waited for with one, and on expiry the gather falls back to torch.distributed's
+all_gather_into_tensor; `config.gather_through` / `config.lsq_comm_size` say which ran.
 N > 1, --mode weak: every rank runs its own job of the workload's size (seed + 1000 x rank), no collective in the
 loop (the path has no exchange step); one all-gather after it.
 
@@ -28,6 +35,7 @@ executable), and `cpu_baseline`: the oracle (a port; never part of the product p
 same read stream over the same events.
 """
 import argparse
+import datetime
 import hashlib
 import json
 import os
@@ -35,6 +43,7 @@ import shutil
 import subprocess
 import sys
 import tempfile
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -72,7 +81,8 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="strong", choices=("strong", "weak"), help="N > 1: one job sharded by events (strong), or one job per rank (weak)")
     ap.add_argument("--cpu-sample", type=int, default=15_000_000, help="reads in the cpu_baseline sample (0 = skip)")
-    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end legs (N = 1 only)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end legs")
+    ap.add_argument("--no-c5", action="store_true", help="N > 1: skip the configs[4] leg (config.c5_*)")
     a = ap.parse_args()
 
     # stdout carries the one JSON line and nothing else: libraries that greet on stdout (RCCL's version banner, gloo's
@@ -107,14 +117,139 @@ def main():
         if rehearse:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            # (a collective that cannot complete raises after this long instead of waiting for ever)
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=float(os.environ.get("LSQ_BENCH_PG_TIMEOUT", "600"))))
     on_host = rehearse and world > 1          # gloo moves host tensors
 
-    W = WORKLOADS[a.workload]
+    env = dict(rank=rank, world=world, local_rank=local_rank, strong=strong, rehearse=rehearse, on_host=on_host, dev=dev)
+    out = run_workload(env, a, a.workload, True)
+    # N > 1, default job: the same measurement on BASELINE configs[4] (1 B reads: a millisecond of count work per step on one
+    # GPU) rides along under config.c5_* -- strong scaling of the 0.13 ms c3 job is bounded by the fixed terms of a step
+    if strong and a.workload == "c3" and not a.no_c5:
+        # The parsed line is c3's and must come out whatever the c5 leg does: a watchdog per rank ends the process after
+        # LSQ_BENCH_C5_LIMIT seconds (default 300) -- rank 0 prints the c3 line with c5_error first -- and an exception on one
+        # rank (which leaves the others inside a collective) is reported the same way.
+        printed = threading.Lock()
+
+        def give_up(why):
+            if not printed.acquire(blocking=False):
+                return
+            if rank == 0:
+                out["config"]["c5_error"] = why
+                os.write(json_fd, (json.dumps(out) + "\n").encode())
+            os._exit(0)
+        limit = float(os.environ.get("LSQ_BENCH_C5_LIMIT", "300"))
+        dog = threading.Timer(limit, give_up, args=("the configs[4] leg did not finish within %.0f s" % limit,))
+        dog.daemon = True
+        dog.start()
+        try:
+            c5 = run_workload(env, a, "c5", False)
+        except BaseException as e:
+            give_up("%s: %s" % (type(e).__name__, e))
+        dog.cancel()
+        if rank == 0:
+            out["config"].update({
+                "c5_workload": c5["config"]["workload"], "c5_value_reads_per_s": c5["value"], "c5_ms_per_step": c5["ms_per_step"],
+                "c5_steps": c5["steps"], "c5_retained_reads": c5["config"]["retained_reads"], "c5_events": c5["config"]["events"],
+                "c5_roofline_frac_rank0": c5["roofline"]["frac"], "c5_roofline_frac_alone_rank0": c5["roofline"]["frac_alone"],
+                "c5_count_launch_rank0": c5["config"]["count_launch_rank0"],
+                "c5_per_rank": c5["config"]["per_rank"], "c5_gather_ms_alone": c5["config"]["gather_ms_alone"],
+                "c5_gather_through": c5["config"]["gather_through"], "c5_lsq_comm_size": c5["config"]["lsq_comm_size"],
+                "c5_tables_equal_unsharded_run": c5["config"]["tables_equal_unsharded_run"],
+                "c5_generate_s": c5["config"]["generate_s"], "c5_ingest_from_text_s": c5["config"]["ingest_from_text_s"],
+                "c5_em_replayed_events": c5["config"]["em_replayed_events"],
+                "c5_note": "BASELINE configs[4] measured by the same code in the same run (strong scaling: one job, events sharded by index, gather in the loop); "
+                           "c5_value_reads_per_s = the job's retained reads x steps / max-over-ranks time",
+            })
+        if not printed.acquire(blocking=False):
+            return                  # (the watchdog fired while the results were being folded in)
+    if rank == 0:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if env.get("comm") is not None:
+        env["rccl"].lsq_comm_destroy(env["comm"])
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def setup_lsq_comm(env):
+    """liblesseq_rccl's communicator for this run (env["rccl"], env["comm"]; None when it did not come up on EVERY rank):
+    rank 0's RCCL id travels through torch.distributed, every rank joins with a time limit (lsq_comm_init_rank_for), and the
+    ranks agree on the outcome -- one that failed or timed out sends everybody to the torch.distributed gather."""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    import lesseq_amd as L
+    rank, world, local_rank, dev = env["rank"], env["world"], env["local_rank"], env["dev"]
+    limit = float(os.environ.get("LSQ_COLLECTIVE_TIMEOUT", "120"))
+    env["rccl"], env["comm"], env["lsq_comm_error"] = None, None, None
+    rccl, comm, ok, why = None, C.c_void_p(), 1, None
+    try:
+        rccl = C.CDLL(os.path.join(os.path.dirname(L._lib.LIB_PATH), "liblesseq_rccl.so"))
+        rccl.lsq_comm_unique_id.argtypes = [C.c_void_p]
+        rccl.lsq_comm_init_rank_for.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_double, C.POINTER(C.c_void_p)]
+        rccl.lsq_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+        rccl.lsq_step_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+        rccl.lsq_comm_destroy.argtypes = [C.c_void_p]
+        rccl.lsq_comm_abort.argtypes = [C.c_void_p]
+        rccl.lsq_comm_size.argtypes = [C.c_void_p]
+        rccl.lsq_rccl_last_error.restype = C.c_char_p
+    except Exception as e:
+        ok, rccl, why = 0, None, "liblesseq_rccl.so: %s" % e
+    # every rank takes part in the exchanges below whatever happened above (a rank that skipped one would leave the
+    # others waiting); the communicator is only set up when every rank has the library AND rank 0 has an id
+    uid = torch.zeros(129, dtype=torch.uint8)
+    if rank == 0 and ok:
+        buf = (C.c_ubyte * 128)()
+        ok = 1 if rccl.lsq_comm_unique_id(buf) == 0 else 0
+        uid = torch.tensor(list(buf) + [ok], dtype=torch.uint8)
+    have = torch.tensor([ok], dtype=torch.int32, device=dev)
+    if world > 1:
+        uid_d = uid.to(dev)
+        dist.broadcast(uid_d, 0)
+        uid = uid_d.cpu()
+        dist.all_reduce(have, op=dist.ReduceOp.MIN)
+    ok = 1 if (int(have.item()) == 1 and int(uid[128]) == 1) or (world == 1 and ok) else 0
+    if ok:
+        idb = (C.c_ubyte * 128)(*uid[:128].tolist())
+        st = rccl.lsq_comm_init_rank_for(world, rank, idb, local_rank, limit, C.byref(comm))
+        if st != 0:
+            ok, why = 0, rccl.lsq_rccl_last_error().decode("utf-8", "replace")
+    elif why is None:
+        why = "no RCCL id, or a rank without the library"
+    flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+    if world > 1:
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        if comm.value:
+            rccl.lsq_comm_abort(comm)        # (abort, not destroy: some peer never joined)
+        env["lsq_comm_error"] = why or "another rank failed to join"
+        return
+    env["rccl"], env["comm"] = rccl, comm
+
+
+def run_workload(env, a, wl_name, primary):
+    """One workload, measured as the module docstring says; returns the JSON line as a dict on rank 0 (None elsewhere).
+    primary: the run's own workload (end-to-end legs, cpu_baseline); otherwise only the timed loop and what describes it."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import lesseq_amd as L
+    from lesseq_amd import dist as ld
+    rank, world, local_rank, strong = env["rank"], env["world"], env["local_rank"], env["strong"]
+    rehearse, on_host, dev = env["rehearse"], env["on_host"], env["dev"]
+    W = dict(WORKLOADS[wl_name])
+    scale = float(os.environ.get("LSQ_BENCH_SCALE_%s" % wl_name.upper(), "1"))      # rehearsals on one GPU (developer aid): a smaller job of the same shape
+    if scale != 1:
+        W["n_reads"], W["n_events"] = max(1000, int(W["n_reads"] * scale)), max(10, int(W["n_events"] * scale))
+        W["desc"] += " -- SCALED by %g for a rehearsal" % scale
+    no_e2e = a.no_e2e or not primary
+    cpu_sample = a.cpu_sample if primary else 0
     types = W["types"] or L.EVENT_TYPES
     job_rank = 0 if (strong or world == 1) else rank            # weak mode: a job of its own per rank
     spec = L.SynthSpec(W["seed"] + 1000 * job_rank, W["n_events"], W["n_reads"], W["R"], W["n_chrom"], types, W.get("zipf", False))
-    tmp = shared_dir("%s_%s_j%d" % (os.environ.get("MASTER_PORT", "solo"), a.workload, job_rank))
+    tmp = shared_dir("%s_%s_j%d" % (os.environ.get("MASTER_PORT", "solo"), wl_name, job_rank))
     writer = rank == 0 or not strong
 
     # ---- the job's files (untimed): annotation + MRF text, written once per job
@@ -132,21 +267,74 @@ def main():
 
     # ---- (iii) the `solve` executable on the text, as a child process, before this process holds a context
     e2e = {}
-    if world == 1 and not a.no_e2e:
-        exe = os.path.join(ROOT, "lesseq_amd", "bin", "solve")
+
+    def run_cli(tool, av, extra_env=None, timeout=600):
+        """wall-clock, stdout and the phase breakdown (LSQ_CLI_TIMING lines on stderr) of one executable run"""
+        t0 = time.perf_counter()
+        p = subprocess.run([os.path.join(ROOT, "lesseq_amd", "bin", tool)] + av, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           env=dict(os.environ, LSQ_CLI_TIMING="1", **(extra_env or {})), timeout=timeout)
+        dt = time.perf_counter() - t0
+        phases = {}
+        for ln in p.stderr.decode("utf-8", "replace").splitlines():
+            if ln.startswith("[timing]"):
+                name, _, sec = ln[len("[timing]"):].strip().rpartition(" s")[0].rpartition(" ")
+                try:
+                    phases[name.strip()] = phases.get(name.strip(), 0.0) + float(sec)
+                except ValueError:
+                    pass
+        return p.returncode, dt, p.stdout, phases, p.stderr[-2000:].decode("utf-8", "replace")
+    if world == 1 and not no_e2e:
         for tool, av in (("count", argv_solve[:-1]), ("solve", argv_solve)):
-            t0 = time.perf_counter()
-            p = subprocess.run([os.path.join(ROOT, "lesseq_amd", "bin", tool)] + av, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
-            dt = time.perf_counter() - t0
-            assert p.returncode == 0, "lesseq_amd/bin/%s failed" % tool
+            rc, dt, stdout, phases, err = run_cli(tool, av)
+            assert rc == 0, "lesseq_amd/bin/%s failed: %s" % (tool, err)
             e2e["e2e_cli_%s_s" % tool] = dt
-            e2e["e2e_cli_%s_rows" % tool] = p.stdout.count(b"\n")
+            e2e["e2e_cli_%s_rows" % tool] = stdout.count(b"\n")
             if tool == "solve":
-                e2e["e2e_cli_solve_table_sha256"] = hashlib.sha256(p.stdout).hexdigest()
+                e2e["e2e_cli_solve_table_sha256"] = hashlib.sha256(stdout).hexdigest()
+                e2e["e2e_cli_phases"] = phases
         e2e["e2e_cli_solve_mrf_reads_per_s"] = W["n_reads"] / e2e["e2e_cli_solve_s"]
         e2e["e2e_cli_note"] = ("wall-clock of lesseq_amd/bin/{count,solve} as child processes on the %d-byte MRF text (page cache): process start, HIP "
-                               "initialisation, annotation load, text copy, device parse, ingest, count, EM, formatting, every output row" % os.path.getsize(mrf))
-        del exe
+                               "initialisation, annotation load, text copy, device parse, ingest, count, EM, formatting, every output row; e2e_cli_phases: the "
+                               "executable's own phase clock (LSQ_CLI_TIMING), seconds, the solve run" % os.path.getsize(mrf))
+    if strong and not no_e2e:
+        # N > 1: the same from the text over N GPUs -- `LSQ_GPUS=N solve`, one process, a host thread per GPU, the RCCL gather of
+        # liblesseq_rccl (ncclCommInitAll) -- beside the one-GPU run of the same executable, tables compared.  Rank 0 runs the two
+        # children while the other ranks wait for a file (their GPUs idle: no collective is pending anywhere).
+        done = os.path.join(tmp, "cli_done.json")
+        if rank == 0:
+            res = {}
+            try:
+                rc1, dt1, out1, ph1, err1 = run_cli("solve", argv_solve, timeout=300)
+                res["e2e_cli_gpus_1_solve_s"] = dt1 if rc1 == 0 else None
+                menv = {"LSQ_GPUS": str(world)}
+                if rehearse:
+                    menv.update(LSQ_DEVICES=",".join(["0"] * world), LSQ_GATHER="host")
+                rcn, dtn, outn, phn, errn = run_cli("solve", argv_solve, menv, timeout=300)
+                res["e2e_cli_gpus_n"] = world
+                res["e2e_cli_gpus_n_solve_s"] = dtn if rcn == 0 else None
+                res["e2e_cli_gpus_n_exit"] = rcn
+                if rcn != 0:
+                    res["e2e_cli_gpus_n_error"] = errn[-600:]
+                res["e2e_cli_gpus_n_table_equals_one_gpu_table"] = bool(rc1 == 0 and rcn == 0 and out1 == outn)
+                res["e2e_cli_gpus_n_table_sha256"] = hashlib.sha256(outn).hexdigest() if rcn == 0 else None
+                res["e2e_cli_gpus_n_phases"] = phn
+                res["e2e_cli_gpus_1_phases"] = ph1
+                if rcn == 0:
+                    res["e2e_cli_gpus_n_mrf_reads_per_s"] = W["n_reads"] / dtn
+                res["e2e_cli_gpus_n_note"] = ("LSQ_GPUS=%d lesseq_amd/bin/solve as a child process on the MRF text: pre-pass count on GPU 0, slices of equal read weight, every "
+                                              "GPU's thread parses the text and ingests its slice, count + EM + pack, %s, one table printed" %
+                                              (world, "blocks through host memory (rehearsal on one GPU)" if rehearse else "ncclAllGather"))
+            except Exception as e:
+                res["e2e_cli_gpus_n_error"] = "%s: %s" % (type(e).__name__, e)
+            with open(done + ".tmp", "w") as f:
+                json.dump(res, f)
+            os.rename(done + ".tmp", done)
+            e2e.update(res)
+        else:
+            t_wait = time.time()
+            while not os.path.exists(done) and time.time() - t_wait < 700:
+                time.sleep(0.05)
+        dist.barrier()
 
     # ---- ingest (untimed): annotation -> compiled events -> MRF text -> HBM -> parsed, filtered, pooled
     ann = L.Annotation(argv_solve[4], argv_solve[6])
@@ -164,7 +352,7 @@ def main():
     theta_full, ll_full, iters_full, flags_full = [x.copy() for x in ctx.solution()]
     t_first = time.perf_counter() - t0
     job_retained, job_blocks = ctx.retained(0), ctx.retained_blocks(0)
-    if world == 1 and not a.no_e2e:
+    if world == 1 and not no_e2e:
         # (iii, in-process) text in the page cache -> the formatted solve table, given the compiled events
         table = L.format_solve(ev, cnt_full, bases_full, theta_full, ll_full, [float(W["n_reads"] * W["R"])])
         e2e["e2e_from_text_s"] = time.perf_counter() - t0
@@ -183,7 +371,7 @@ def main():
     my_weight = float(ld.event_weights(ev, cnt_full)[bounds[rank][0]:bounds[rank][0] + bounds[rank][1]].sum()) if strong else float(cnt_full.sum())
 
     # ---- (ii) device-resident end to end, from parsed arrays in host memory (N = 1)
-    if world == 1 and not a.no_e2e:
+    if world == 1 and not no_e2e:
         reads = L.Reads.synthetic(spec, ev)
         ctx.synchronize()
         t0 = time.perf_counter()
@@ -212,44 +400,31 @@ def main():
     # travels through torch.distributed); otherwise torch.distributed's all_gather_into_tensor on torch's stream, ordered
     # against the lane by events.  LSQ_BENCH_GATHER=torch forces the latter.
     import ctypes as C
-    rccl, comm = None, C.c_void_p()
     want_lsq = ((strong and not rehearse) or os.environ.get("LSQ_BENCH_SELFTEST") == "2") and os.environ.get("LSQ_BENCH_GATHER", "lsq") != "torch"
-    if want_lsq:
+    if want_lsq and "rccl" not in env:
+        setup_lsq_comm(env)
+    rccl, comm = (env.get("rccl"), env.get("comm")) if want_lsq else (None, None)
+    if comm is None:
+        rccl, comm = None, C.c_void_p()
+    if rccl is not None and comm.value:
+        # the first gather of this job's blocks, waited for with a time limit: the collective's kernel spins until every peer has
+        # joined it, so a peer that never does must not hang the run.  On expiry (or any error) on ANY rank every rank aborts its
+        # communicator and the loop gathers through torch.distributed instead.
+        limit = float(os.environ.get("LSQ_COLLECTIVE_TIMEOUT", "120"))
         ok = 1
-        try:
-            rccl = C.CDLL(os.path.join(os.path.dirname(L._lib.LIB_PATH), "liblesseq_rccl.so"))
-            rccl.lsq_comm_unique_id.argtypes = [C.c_void_p]
-            rccl.lsq_comm_init_rank.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
-            rccl.lsq_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
-            rccl.lsq_step_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
-            rccl.lsq_comm_destroy.argtypes = [C.c_void_p]
-        except Exception:
-            ok, rccl = 0, None
-        # every rank takes part in the two exchanges below whatever happened above (a rank that skipped one would leave the
-        # others waiting); the communicator is only set up when every rank has the library AND rank 0 has an id
-        uid = torch.zeros(129, dtype=torch.uint8)
-        if rank == 0 and ok:
-            buf = (C.c_ubyte * 128)()
-            ok = 1 if rccl.lsq_comm_unique_id(buf) == 0 else 0
-            uid = torch.tensor(list(buf) + [ok], dtype=torch.uint8)
-        have = torch.tensor([ok], dtype=torch.int32, device=dev)
-        if world > 1:
-            uid_d = uid.to(dev)
-            dist.broadcast(uid_d, 0)
-            uid = uid_d.cpu()
-            dist.all_reduce(have, op=dist.ReduceOp.MIN)
-        ok = 1 if (int(have.item()) == 1 and int(uid[128]) == 1) or (world == 1 and ok) else 0
-        if ok:
-            idb = (C.c_ubyte * 128)(*uid[:128].tolist())
-            if rccl.lsq_comm_init_rank(world, rank, idb, local_rank, C.byref(comm)) != 0:
-                ok = 0
+        if rccl.lsq_step_gather(ctx.h, comm, blocks[0].data_ptr(), gathered[0].data_ptr(), stride) != 0:
+            ok = 0
+        elif L.lib.lsq_ctx_synchronize_for(ctx.h, limit) != 0:
+            ok = 0
         flag = torch.tensor([ok], dtype=torch.int32, device=dev)
         if world > 1:
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
-            if comm.value:
-                rccl.lsq_comm_destroy(comm)
+            env["lsq_comm_error"] = "the first lsq_step_gather did not complete on every rank within %.0f s: %s" % (limit, L.lib.lsq_last_error().decode("utf-8", "replace") if not ok else "another rank")
+            rccl.lsq_comm_abort(comm)
+            env["rccl"], env["comm"] = None, None
             rccl, comm = None, C.c_void_p()
+            ctx.synchronize()
     use_lsq_gather = rccl is not None and bool(comm.value)
     ext_streams = {}                          # the library's result streams (two lanes, taken in turn), for event ordering
     cur = torch.cuda.current_stream(dev)
@@ -410,6 +585,7 @@ def main():
     assert np.isfinite(theta_full).all() and abs(float(theta_full.sum()) - n_ev) < 1e-6 * n_ev
     exc, recounted = ctx.count_status()
 
+    out = None
     if rank == 0:
         fk = float(np.mean(fast_ms))
         ev_bytes = 0
@@ -423,10 +599,10 @@ def main():
         # HBM bytes per launch of the same kernel from the committed rocprofv3 PMC passes (tools/bench_prof.sh): not measured by this run
         committed = None
         for rr in ("r02", "r01"):
-            tpath = os.path.join(ROOT, "profiles", "%s_traffic_%s.json" % (rr, a.workload))
+            tpath = os.path.join(ROOT, "profiles", "%s_traffic_%s.json" % (rr, wl_name))
             if world == 1 and os.path.exists(tpath):
                 committed = {"hbm_bytes_per_launch": json.load(open(tpath)).get("count_fast_kernel_hbm_bytes_per_launch"),
-                             "source": "profiles/%s_traffic_%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; 2 x FETCH_SIZE + WRITE_SIZE)" % (rr, a.workload)}
+                             "source": "profiles/%s_traffic_%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; 2 x FETCH_SIZE + WRITE_SIZE)" % (rr, wl_name)}
                 break
         # what a plain streaming read of the same number of bytes reaches on this device (state both ceilings)
         import ctypes as C
@@ -455,7 +631,7 @@ def main():
             "dtype": "int32 coordinates / u64 counters (count), f64 (EM)",
             "data": "synthetic",
             "config": {
-                "workload": W["desc"] + ("; BASELINE configs[3]: the same job sharded by event index over %d GPUs with an RCCL gather" % world if strong and a.workload == "c3" else ""),
+                "workload": W["desc"] + ("; BASELINE configs[3]: the same job sharded by event index over %d GPUs with an RCCL gather" % world if strong and wl_name == "c3" else ""),
                 "events": n_ev * (1 if strong or world == 1 else world), "mrf_reads": total_mrf, "retained_reads": total_retained,
                 "retained_blocks": total_blocks, "buckets_rank0": ev.num_buckets,
                 "count_launch_rank0": {"one_block_reads_per_lane_and_look": launch_info[0], "workgroups_per_cu": launch_info[1]},
@@ -478,7 +654,9 @@ def main():
                 "generate_s": t_gen, "ingest_from_text_s": t_ingest, "first_count_solve_fetch_s": t_first - t_ingest,
                 "gather_ms_alone": gather_ms,
                 "gather_through": ("liblesseq_rccl lsq_gather (ncclAllGather on the step's result lane)" if use_lsq_gather else
-                                   ("torch.distributed all_gather_into_tensor" if world > 1 else None)),
+                                   ("torch.distributed all_gather_into_tensor (%s)" % ("gloo, host tensors: rehearsal" if on_host else "RCCL through torch") if world > 1 else None)),
+                "lsq_comm_size": (int(rccl.lsq_comm_size(comm)) if use_lsq_gather else 0),
+                "lsq_comm_error": env.get("lsq_comm_error"),
                 "tables_equal_unsharded_run": tables_equal, "max_abs_theta_diff_vs_unsharded": max_theta_diff,
                 "count_table_sha256": hashlib.sha256(cnt_full.tobytes()).hexdigest(),
                 "per_rank": [{"rank": r, "events": int(x[4]), "valid_read_assignments": x[3], "count_fast_kernel_ms": x[0],
@@ -506,10 +684,10 @@ def main():
         }
         out["config"].update(e2e)
         # ---- cpu_baseline: the oracle on a bounded prefix of the same stream (rank 0, N = 1 only)
-        if world == 1 and a.cpu_sample > 0:
+        if world == 1 and cpu_sample > 0:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_binding as ob
-            ns = min(a.cpu_sample, W["n_reads"])
+            ns = min(cpu_sample, W["n_reads"])
             sspec = L.SynthSpec(W["seed"], W["n_events"], ns, W["R"], W["n_chrom"], types, W.get("zipf", False))
             sdir = os.path.join(tmp, "sample")
             os.makedirs(sdir, exist_ok=True)
@@ -545,18 +723,13 @@ def main():
                     "how": "%d oracle processes over disjoint gene_begin_idx..gene_end_idx slices of the same sample (each parses the whole "
                            "file, as the reference's own scale-out does), wall-clock %.1f s" % (P, dt_all),
                 }
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
-    if comm.value:
-        ctx.synchronize()
-        rccl.lsq_comm_destroy(comm)
+    ctx.synchronize()
     ctx.close()
     if world > 1:
         dist.barrier()
     if writer:
         shutil.rmtree(tmp, ignore_errors=True)
-    if world > 1:
-        dist.destroy_process_group()
+    return out if rank == 0 else None
 
 
 if __name__ == "__main__":

@@ -505,7 +505,7 @@ int run_count_solve(bool solve, int argc, const char *const *argv, std::string &
 		if (st) { logf(0, "%s", lsq_last_error()); return st == LSQ_E_DEVICE ? 3 : (st == LSQ_E_IO || st == LSQ_E_FORMAT ? status_to_exit(st) : 2); }
 		logf(2, "Sampling method #%d: loaded %llu reads associated with the selected gene regions", m, (unsigned long long)lsq_reads_retained(F.c, m));
 		T.mark("reads: copy, parse, ingest");
-		if (T.on) { float h2d = 0, parse = 0; lsq_last_mrf_timing(F.c, &h2d, &parse); fprintf(stderr, "[timing]   of which text copy %.3f s, parse kernels %.3f s\n", h2d * 1e-3, parse * 1e-3); }
+		if (T.on) { float h2d = 0, parse = 0; lsq_last_mrf_timing(F.c, &h2d, &parse); fprintf(stderr, "[timing] %-28s %.3f s\n[timing] %-28s %.3f s\n", "  of which text copy", h2d * 1e-3, "  of which parse kernels", parse * 1e-3); }
 	}
 	if (bad_type && n_ev > 0) { logf(0, "Unknown read type error: %s", bad_type_name.c_str()); return 1; }
 	logf(2, "Processing reads info for genes");

@@ -38,31 +38,31 @@ def gpu_ctx():
 
 # A native abort (glibc's heap checks, std::terminate, an assertion inside the HIP runtime) prints its reason on file
 # descriptor 2 and kills the process: under pytest's fd capture that text lands in a temporary file that dies with it
-# (round 2 lost the one piece of evidence of such an abort that way).  GPU tests therefore run with fd 2 appended to a
-# log that survives: gpurun_out/native_stderr.log when that directory can be made (gpurun carries it back), else the
-# system's temporary directory; every test writes a header line first.  faulthandler (pytest's own plugin) adds the
-# Python stack to the same descriptor.
-@pytest.fixture(autouse=True)
-def _native_stderr_survives(request):
-    if request.node.get_closest_marker("gpu") is None or os.environ.get("LSQ_KEEP_STDERR") == "0":
+# (round 2 lost the one piece of evidence of such an abort that way).  The call phase of every GPU test therefore runs
+# with fd 2 appended to a log that survives: gpurun_out/native_stderr.log when that directory can be made (gpurun carries
+# it back), else the system's temporary directory; every test writes a header line first.  faulthandler (pytest's own
+# plugin) adds the Python stack to the same descriptor.  (A hook wrapper, innermost: pytest's capture re-points fd 2 at
+# the start of every phase, so a fixture's redirection would be undone before the test body runs.)
+@pytest.hookimpl(hookwrapper=True, trylast=True)
+def pytest_runtest_call(item):
+    if item.get_closest_marker("gpu") is None or os.environ.get("LSQ_KEEP_STDERR") == "0":
         yield
         return
     import tempfile
-    path = None
+    fd = None
     for d in (os.path.join(ROOT, "gpurun_out"), tempfile.gettempdir()):
         try:
             os.makedirs(d, exist_ok=True)
-            path = os.path.join(d, "native_stderr.log")
-            fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_APPEND, 0o644)
+            fd = os.open(os.path.join(d, "native_stderr.log"), os.O_WRONLY | os.O_CREAT | os.O_APPEND, 0o644)
             break
         except OSError:
-            path = None
-    if path is None:
+            fd = None
+    if fd is None:
         yield
         return
     sys.stderr.flush()
     saved = os.dup(2)
-    os.write(fd, ("=== %s\n" % request.node.nodeid).encode())
+    os.write(fd, ("=== %s\n" % item.nodeid).encode())
     os.dup2(fd, 2)
     os.close(fd)
     try:
