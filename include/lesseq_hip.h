@@ -156,12 +156,17 @@ typedef struct lsq_ctx lsq_ctx;
 
 int lsq_ctx_create(int device_id, lsq_ctx **out);
 void lsq_ctx_destroy(lsq_ctx *c);
-/* The context works on two HIP streams of its own: uploads, ingest and the count kernels on one
- * (returned here as hipStream_t in a void*, for callers timing with events), the EM and the
- * hand-off of results (lsq_results_copy_device) on a second one, ordered after the count they
- * belong to.  lsq_count / lsq_solve / lsq_results_copy_device only submit work; a following
- * lsq_count runs beside the tail of the previous lsq_solve (the counters exist twice).
- * lsq_ctx_synchronize waits for both streams; the host-side result getters do so themselves. */
+/* The context works on HIP streams of its own.  Uploads and ingest run on one (returned here as hipStream_t in a
+ * void*).  A step -- lsq_count, lsq_solve, the hand-off of its results -- runs on one of two LANES that consecutive
+ * lsq_count calls take in turn: a lane has a count stream (the streaming kernels), a result stream (exception pass, EM,
+ * lsq_results_copy_device / lsq_results_pack_device, behind an event recorded after the count), a counter set and the
+ * EM's output arrays.  These calls only submit work; step k+1's count runs beside step k's EM.  Hence two rules for a
+ * host that submits steps without waiting in between:
+ *   - lsq_ctx_result_stream names the LATEST count's lane: ask again after every lsq_count, never cache it;
+ *   - the device buffers handed to consecutive unsynchronised steps (d_block / d_gathered of lsq_step_gather, the
+ *     arguments of lsq_results_copy_device) must be DISTINCT -- two of each, alternated, as the lanes are: step k+1's
+ *     pack runs on the other lane and is not ordered behind a collective that still reads step k's block.
+ * lsq_ctx_synchronize waits for all of the context's streams; the host-side result getters do so themselves. */
 void *lsq_ctx_stream(lsq_ctx *c);
 int lsq_ctx_synchronize(lsq_ctx *c);
 /* The same with a time limit (seconds): LSQ_E_TIMEOUT when work is still queued after it -- e.g. a collective of a
@@ -318,7 +323,7 @@ int lsq_results_fim(lsq_ctx *c, double *fim, double *var_by_diag, double *var_by
 
 /* Copies the raw device-order results into caller-provided DEVICE buffers (e.g. tensors of a
  * framework that will run a collective on them), asynchronously on the context's RESULT stream (the
- * one the EM runs on, not lsq_ctx_stream's: lsq_ctx_synchronize waits for both), behind the count's
+ * one the EM runs on, not lsq_ctx_stream's: lsq_ctx_synchronize waits for all of them), behind the count's
  * exception pass -- and its recount, should the exception list have overflowed -- and the EM, so the
  * tables are complete.  theta / logll are the kernel's numbers; an event inside the EM guard band
  * (rare; em_flags bit 0) gets the reference's exact-order numbers from lsq_solve_finalize.
@@ -327,7 +332,8 @@ int lsq_results_fim(lsq_ctx *c, double *fim, double *var_by_diag, double *var_by
  * index, so a gathered buffer can be put in output order on the receiving side. */
 int lsq_results_copy_device(lsq_ctx *c, void *d_class_count, void *d_theta, void *d_logll);
 /* The stream those hand-offs run on (hipStream_t in a void*): a caller that launches its own work on the
- * handed-over buffers -- a collective, say -- orders it behind an event recorded here. */
+ * handed-over buffers -- a collective, say -- orders it behind an event recorded here.  It is the result stream of the
+ * latest lsq_count's lane, so it changes with every lsq_count (see lsq_ctx_stream above): query it per step. */
 void *lsq_ctx_result_stream(lsq_ctx *c);
 
 /* ---- one job over several GPUs: events sharded by index, per-event records gathered -------------------
@@ -345,7 +351,7 @@ int lsq_shard_bounds(const lsq_events *e, int world, const double *weights /* pe
                      uint64_t *first /* world */, uint64_t *count /* world */);
 uint64_t lsq_record_words(const lsq_events *e, uint64_t first, uint64_t count);
 int lsq_results_pack_device(lsq_ctx *c, void *d_block);
-/* Device buffers for a host without HIP of its own (zeroed; lsq_device_read waits for both streams of the context). */
+/* Device buffers for a host without HIP of its own (zeroed; lsq_device_read waits for all streams of the context). */
 int lsq_device_alloc(lsq_ctx *c, uint64_t bytes, void **out);
 void lsq_device_free(lsq_ctx *c, void *p);
 int lsq_device_read(lsq_ctx *c, void *host_dst, const void *device_src, uint64_t bytes);

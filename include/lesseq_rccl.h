@@ -47,11 +47,13 @@ int lsq_comm_size(const lsq_comm *comm);
 
 /* The gather: every rank's packed record block (lsq_results_pack_device wrote it; stride_words words of 8 bytes,
  * the longest block of the job, shorter ones padded) into d_gathered (world * stride_words words) on every rank:
- * ncclAllGather on the context's result stream, behind the pack -- asynchronous, like the rest of a step.
+ * ncclAllGather on the result stream of the latest count's lane, behind the pack -- asynchronous, like the rest of a step.
  * lsq_ctx_synchronize, then lsq_gathered_unpack on a host copy, gives the whole job's tables. */
 int lsq_gather(lsq_ctx *c, lsq_comm *comm, const void *d_block, void *d_gathered, uint64_t stride_words);
 /* lsq_count + lsq_solve + lsq_results_pack_device(d_block) + lsq_gather in one call: a step of a loop over batches
- * (reads uploaded beforehand).  Asynchronous like its parts; the status of the first part that fails. */
+ * (reads uploaded beforehand).  Asynchronous like its parts; the status of the first part that fails.  A loop that does
+ * not synchronise between steps alternates between TWO d_block / d_gathered pairs (steps take the context's two lanes in
+ * turn, lesseq_hip.h: step k+1's pack is not ordered behind step k's gather, which may still be reading its block). */
 int lsq_step_gather(lsq_ctx *c, lsq_comm *comm, void *d_block, void *d_gathered, uint64_t stride_words);
 
 #ifdef __cplusplus
