@@ -879,6 +879,277 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 	if (R.live() && !ABL(A, 32u)) walk_parked<NB, PACKED2>(C, R, true, base);
 }
 
+// ---- compact pools: the streaming loops proper ---------------------------------------------------------------------
+// The two loops below are what lsq_count_fast_kernel<true, *> runs (the generic stream_pool_fast above keeps the wide
+// records).  They lean on the pools' layout, which the ingest establishes with the kernel's own look at the tables and
+// lsq_debug_check_pool_layout verifies in the tests:
+//   one-block pool: the records of an aligned group of eight (P1_GROUP_PAD) start in ONE cell -- the cell of the group's
+//     first record -- or all in none; padding records are empty (length 0) and sit at the tail of a cell's records;
+//   two-block pool: an aligned quadruple lies in ONE junction group -- block 1 starts in the same one-owner cell and ends
+//     on the end of that owner's segment, block 2 starts on the same first base of a later segment of that event -- or in
+//     the bucket's last group (everything else); padding (length 0) never comes first in a quadruple.
+// So a lane looks at the tables once, for its first record, and every further record only has to show where it ENDS.
+
+// One-block reads, NR = 4 or 8 per lane and step (one or two 16-byte loads).  Records stay in their own terms (offset
+// from `base`, length); the cell's bounds are brought into those terms once per lane.  Per record: its end against the
+// two thresholds of the cell (e1: inside the owner's segment; e2: inside the segment that abuts it / the farther owner's),
+// count and bases summed per lane in one word each (count << 24 | bases), one LDS atomic per class at the end.  Whether
+// anything is left for the general walk falls out of the sums (records counted against records settled): no per-record
+// flag, no scalar mask logic in the loop.
+template <int NR>
+__device__ inline void stream_pool1_compact(FastCtx &C, const uint4 *bins, const uint4 *cells, const uint4 *cellx, const unsigned n_cells, const BucketDesc &d,
+                                            const CountArgs &A, uint4 *queue, const void *pool, const unsigned long long g0, const unsigned long long g1) {
+	static_assert(NR == 4 || NR == 8, "one or two 16-byte words of four compact records");
+	static_assert((unsigned)NR <= P1_GROUP_PAD, "a lane's records of a step lie in one cell group");
+	constexpr int CW = NR / 4;                     // 16-byte loads a lane issues per step
+	constexpr unsigned TILE = 64u * NR;            // records per wave step
+	C.pool = 0u;
+	C.slot0 = g0;
+	global_words src = (global_words)pool;
+	const unsigned lane = threadIdx.x & 63u, wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	// records [R0, R0 + n) of the pool, R0 = g0 rounded down to a lane's NR (ranges start on whole groups anyway); the
+	// range proper is [first_rel, n) of them
+	const unsigned long long R0 = g0 & ~(unsigned long long)(NR - 1);
+	const unsigned n = (unsigned)(g1 - R0), first_rel = (unsigned)(g0 - R0), n_rel = (unsigned)(g1 - g0);      // a workgroup's range stays below 2^21 reads
+	const unsigned last_word = (n - 1u) >> 2;
+	const int base = d.lo - lsq::COMPACT_BIAS;
+	uint4 nxt[CW];
+	auto fetch = [&](const unsigned t) {
+#pragma unroll
+		for (int cq = 0; cq < CW; ++cq) {
+			// past the end of the range the last word is read again (no predication: the range test discards it)
+			const unsigned w = min((t >> 2) + lane * (unsigned)CW + (unsigned)cq, last_word);
+			const u32x4 v = src[(R0 >> 2) + w];
+			nxt[cq] = make_uint4(v.x, v.y, v.z, v.w);
+		}
+	};
+	Ring<1> R;
+	R.q = queue;
+	const unsigned t_begin = min(wave * TILE, n);
+	if (t_begin < n) fetch(t_begin);
+	for (unsigned t = t_begin; t < n; t += WAVES * TILE) {
+		unsigned rec[NR];
+#pragma unroll
+		for (int cq = 0; cq < CW; ++cq) { rec[4 * cq] = nxt[cq].x; rec[4 * cq + 1] = nxt[cq].y; rec[4 * cq + 2] = nxt[cq].z; rec[4 * cq + 3] = nxt[cq].w; }
+		if (t + WAVES * TILE < n) fetch(t + WAVES * TILE);
+		if (ABL(A, 512u)) {      // developer switch: stream only
+#pragma unroll
+			for (int j = 0; j < NR; ++j) asm volatile("" ::"v"(rec[j]));
+			continue;
+		}
+		// ---- one look at the tables: the cell of the lane's first record
+		const int p0 = (int)(rec[0] & lsq::COMPACT_OFF_MASK) + base;
+		const int rel0 = p0 - d.lo;
+		const unsigned bin = rel0 <= 0 ? 0u : ((unsigned)rel0 >> d.shift);
+		const uint4 br = bins[min(bin, d.n_bins - 1u)];     // first cell | first event << 16, ends of that cell and the next two
+		unsigned ci = (br.x & 0xFFFFu) + (unsigned)(p0 >= (int)br.y) + (unsigned)(p0 >= (int)br.z) + (unsigned)(p0 >= (int)br.w);
+		if (__any(p0 >= (int)br.w) && !ABL(A, 65536u)) {
+			while (ci + 1u < n_cells && p0 >= (int)cells[ci + 1u].x) ++ci;
+		}
+		const unsigned cc = min(ci, n_cells - 1u);
+		const uint4 cw = cells[cc];           // lo, hi, e1, e2
+		const uint4 cx = cellx[cc];           // slots, info, flags, owner event
+		// the lane's records start in this cell (layout) -- if it is one: the bucket's last group holds the reads of no cell
+		const bool has = ci < n_cells && (int)cw.x <= p0 && p0 < (int)cw.y && !ABL(A, 8u);
+		const bool both = (cx.z & CELLX_BOTH) != 0;          // two owners: e1 / e2 the ends of their segments, slot 1 / slot 2 theirs
+		// thresholds in the records' terms; without a cell nothing is settled here
+		const int e1 = has ? (int)cw.z - base : -1, e2 = has ? (int)cw.w - base : -1;
+		// every step but the first and last of a workgroup's range lies wholly inside it: no per-record range test there
+		const bool interior = t + TILE <= n && t >= first_rel;
+		unsigned accN = 0, accA = 0, accL = 0;          // all records / those that end by e1 / by e2: count << 24 | bases
+		auto decide = [&](auto whole_step) {
+#pragma unroll
+			for (int j = 0; j < NR; ++j) {
+				const unsigned len = rec[j] >> lsq::COMPACT_OFF_BITS;
+				const int e = (int)(rec[j] & lsq::COMPACT_OFF_MASK) + (int)len;
+				unsigned p = len | (min(len, 1u) << 24);           // (an empty record -- the padding of a cell's group -- counts for nothing)
+				if (!decltype(whole_step)::value) {
+					const unsigned idx = t + lane * (unsigned)NR + (unsigned)j;
+					p = (idx < n && idx - first_rel < n_rel) ? p : 0u;
+				}
+				accN += p;
+				accA += e <= e1 ? p : 0u;
+				accL += e <= e2 ? p : 0u;
+			}
+		};
+		if (interior) decide(std::true_type{}); else decide(std::false_type{});
+		const unsigned s1 = cx.x & 0xFFFFu, s2 = cx.x >> 16;
+		if (!ABL(A, (1u | 16384u))) {
+			const unsigned long long addA = ((unsigned long long)(accA >> 24) << 40) | (accA & 0xFFFFFFu);
+			const unsigned accX = accL - accA;
+			if (accA && s1 != CELL_NONE) atomicAdd(&C.hist[s1], addA);
+			if (accA && both && s2 != CELL_NONE) atomicAdd(&C.hist[s2], addA);
+			if (accX && s2 != CELL_NONE) atomicAdd(&C.hist[s2], ((unsigned long long)(accX >> 24) << 40) | (accX & 0xFFFFFFu));
+		} else asm volatile("" ::"v"(accA), "v"(accL));
+		// settled here: one owner -- every record that ends by e2; two owners -- by e1 (one that ends in (e1, e2] has been
+		// counted for the farther owner and still goes to the walk for the nearer one)
+		const bool lane_open = (accN >> 24) != ((both ? accA : accL) >> 24);
+		if (ABL(A, 256u)) {
+			const bool any_open = __any(lane_open);
+			if (lane == 0) { atomicAdd(&A.dbg[12], 1ull); atomicAdd(&A.dbg[11], any_open ? 1ull : 0ull); }
+		}
+		if (__any(lane_open) && !ABL(A, 17u | 524288u)) {
+			// Parked for the general walk, two records of every lane at a time: a read in a one-owner cell with that owner as the
+			// one event to look at, one in a two-owner cell and inside the farther segment with the nearer owner, the others from
+			// the first event of their bin.
+#pragma unroll
+			for (int h = 0; h < NR; h += 2) {
+				uint4 en[2];
+				unsigned open = 0;
+#pragma unroll
+				for (int j = h; j < h + 2; ++j) {
+					const unsigned len = rec[j] >> lsq::COMPACT_OFF_BITS;
+					const int so = (int)(rec[j] & lsq::COMPACT_OFF_MASK), e = so + (int)len;
+					const unsigned idx = t + lane * (unsigned)NR + (unsigned)j, rel = idx - first_rel;
+					const bool in = idx < n && rel < n_rel;
+					const bool op = in && len != 0u && !(e <= (both ? e1 : e2));
+					open |= op ? 1u << (j - h) : 0u;
+					en[j - h] = make_uint4((unsigned)(so + base), (unsigned)(so + base) + len, (has && (!both || e <= e2)) ? (cx.w | PARK_ONE_EVENT) : PARK_EVENT_UNKNOWN, rel);
+					if (ABL(A, 256u) && op) { atomicAdd(&A.dbg[5 + (has ? (both ? 2 : 1) : 0)], 1ull); atomicAdd(&A.dbg[0], 1ull); }
+				}
+				R.push2(open, lane, en[0], en[1]);
+				// the ring holds what one walk leaves behind (< 64) plus these 128 entries
+				if (R.live() >= 64u) {             // wave-uniform
+					if (!ABL(A, 32u)) walk_parked<1, false>(C, R, false, base);
+					else R.head = R.tail;
+				}
+			}
+		}
+	}
+	if (R.live() && !ABL(A, 32u)) walk_parked<1, false>(C, R, true, base);
+}
+
+// Two-block reads, NR = 2 or 4 per lane and step (8-byte records: block 1 as offset | length, block 2 as gap | length).
+// The lane's first record gets the full look -- cell of block 1, the owner's packed record, the segment block 2 starts --
+// and is settled as before: J (block 1 to the end of its segment, block 2 from the first base of a later segment and
+// ending inside it: the two-segment class, matched == total), S (block 2 cannot continue the match: block 1's segment
+// alone, if that is more than 98 % of the read) or parked.  When it crosses a junction, the other records of the quadruple
+// cross the same one (layout): each only shows that block 2 ends inside that segment -- gap + length against one
+// threshold -- and adds its bases; one that runs on, and every follower of a first record that crosses no junction, is
+// parked for the general walk.
+template <int NR>
+__device__ inline void stream_pool2_compact(FastCtx &C, const uint4 *bins, const uint4 *cells, const uint4 *cellx, const unsigned n_cells, const BucketDesc &d,
+                                            const CountArgs &A, uint4 *queue, const void *pool, const unsigned long long g0, const unsigned long long g1) {
+	static_assert(NR == 2 || NR == 4, "one or two 16-byte words of two compact records");
+	constexpr int CW = NR / 2;
+	constexpr unsigned TILE = 64u * NR;
+	C.pool = 1u;
+	C.slot0 = g0;
+	global_words src = (global_words)pool;
+	const unsigned lane = threadIdx.x & 63u, wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	const unsigned long long R0 = g0 & ~(unsigned long long)(NR - 1);
+	const unsigned n = (unsigned)(g1 - R0), first_rel = (unsigned)(g0 - R0), n_rel = (unsigned)(g1 - g0);
+	const unsigned last_word = (n - 1u) >> 1;
+	const int base = d.lo - lsq::COMPACT_BIAS;
+	uint4 nxt[CW];
+	auto fetch = [&](const unsigned t) {
+#pragma unroll
+		for (int cq = 0; cq < CW; ++cq) {
+			const unsigned w = min((t >> 1) + lane * (unsigned)CW + (unsigned)cq, last_word);
+			const u32x4 v = src[(R0 >> 1) + w];
+			nxt[cq] = make_uint4(v.x, v.y, v.z, v.w);
+		}
+	};
+	Ring<1> R;
+	R.q = queue;
+	const unsigned t_begin = min(wave * TILE, n);
+	if (t_begin < n) fetch(t_begin);
+	for (unsigned t = t_begin; t < n; t += WAVES * TILE) {
+		unsigned ra[NR], rb[NR];           // block 1: offset | length << 22; block 2: gap | length << 22
+#pragma unroll
+		for (int cq = 0; cq < CW; ++cq) { ra[2 * cq] = nxt[cq].x; rb[2 * cq] = nxt[cq].y; ra[2 * cq + 1] = nxt[cq].z; rb[2 * cq + 1] = nxt[cq].w; }
+		if (t + WAVES * TILE < n) fetch(t + WAVES * TILE);
+		if (ABL(A, 512u)) {
+#pragma unroll
+			for (int j = 0; j < NR; ++j) asm volatile("" ::"v"(ra[j]), "v"(rb[j]));
+			continue;
+		}
+		const bool interior = t + TILE <= n && t >= first_rel;
+		const unsigned idx0 = t + lane * (unsigned)NR, rel0 = idx0 - first_rel;
+		const bool in0 = interior || (idx0 < n && rel0 < n_rel);
+		// ---- the first record: the full look
+		const int4 rd = unpack_two_block(ra[0], rb[0], base);
+		const int rel_p = rd.x - d.lo;
+		const unsigned bin = rel_p <= 0 ? 0u : ((unsigned)rel_p >> d.shift);
+		const uint4 br = bins[min(bin, d.n_bins - 1u)];
+		unsigned c1 = (br.x & 0xFFFFu) + (unsigned)(rd.x >= (int)br.y) + (unsigned)(rd.x >= (int)br.z) + (unsigned)(rd.x >= (int)br.w);
+		const unsigned evf = br.x >> 16;
+		if (__any(rd.x >= (int)br.w) && !ABL(A, 65536u)) {
+			while (c1 + 1u < n_cells && rd.x >= (int)cells[c1 + 1u].x) ++c1;
+		}
+		const unsigned c1c = min(c1, n_cells - 1u);
+		const uint4 cw1 = cells[c1c];          // lo, hi, e1, e2
+		const uint4 cx1 = cellx[c1c];          // slots, info, link, owner event
+		const unsigned i1 = cx1.y;
+		const unsigned k1 = (i1 >> 2) & 0x3Fu;
+		const bool here = c1 < n_cells && (int)cw1.x <= rd.x && rd.x < (int)cw1.y && !ABL(A, 8u);
+		const bool v1 = here && i1 < CELL_INFO_EMPTY;                                       // block 1 starts in a one-owner cell
+		const bool start1 = k1 == CELL_K_START;
+		const bool inside1 = v1 && !start1 && rd.y <= (int)cw1.z && rd.z != rd.y;            // block 1 ends inside its segment (touching blocks: the exception pass decides)
+		const bool ends1 = inside1 && rd.y == (int)cw1.z;                                      // ... on its end
+		// the owner's record: where its segments start and end (unused ones hold INT32_MAX, which no block reaches)
+		const unsigned ri = 3u * (v1 ? cx1.w : 0u);
+		const uint4 w0r = C.recs[ri], w1r = C.recs[ri + 1u], w2r = C.recs[ri + 2u];
+		// block 2 continues the match only from the first base of a later segment of the same event
+		const unsigned k2 = rd.z == (int)w1r.z ? 1u : (rd.z == (int)w2r.x ? 2u : (rd.z == (int)w2r.z ? 3u : 0u));
+		const int end2 = k2 == 1u ? (int)w1r.w : (k2 == 2u ? (int)w2r.y : (int)w2r.w);
+		const bool junction = ends1 && k2 > k1;
+		const bool J = junction && rd.w <= end2;
+		const bool S = inside1 && !junction;
+		// counts for nobody: from a start cell and over before gene_end; or block 1 starts inside no segment at all
+		const bool drop = (v1 && start1 && rd.w <= (int)cw1.w) || (here && i1 == CELL_INFO_EMPTY);
+		const unsigned len1 = ra[0] >> lsq::COMPACT_OFF_BITS, total = len1 + (rb[0] >> lsq::COMPACT_OFF_BITS);
+		const unsigned long long tbl = ((unsigned long long)w0r.w << 32) | w0r.z;
+		const unsigned cls = (unsigned)(tbl >> (4u * ((1u << (k1 & 3u)) | (1u << k2)))) & 0xFu;
+		const unsigned sa = cx1.x & 0xFFFFu;
+		const unsigned jslot = cls != 0u ? (w0r.y & 0xFFFFu) + cls - 1u : CELL_NONE;      // the histogram slot of the junction's two-segment class
+		const bool add0 = in0 && ((J && cls != 0u) || (S && sa != CELL_NONE && 50u * len1 > 49u * total));
+		const unsigned slot0 = J ? jslot : sa;
+		bool park[NR];
+		park[0] = in0 && len1 != 0u && !(J || S || drop) && !ABL(A, 17u | 1048576u);
+		if (ABL(A, 256u) && park[0]) atomicAdd(&A.dbg[8 + (v1 ? 1 : 0)], 1ull);       // parked: block 1 in no one-owner cell / in one
+		unsigned n_add = add0 ? 1u : 0u, s_add = add0 ? (J ? total : len1) : 0u, n_add2 = 0, s_add2 = 0;
+		// ---- the other records: block 2 must end inside the junction's second segment, i.e. gap + length <= lim
+		const int lim = junction ? end2 - rd.y : -1;
+		bool any_park = park[0];
+#pragma unroll
+		for (int j = 1; j < NR; ++j) {
+			const unsigned l1 = ra[j] >> lsq::COMPACT_OFF_BITS, l2 = rb[j] >> lsq::COMPACT_OFF_BITS;
+			const int reach = (int)(rb[j] & lsq::COMPACT_OFF_MASK) + (int)l2;         // from the end of block 1 to the end of block 2
+			bool in = l1 != 0u;                                                          // (padding of a junction group: an empty record)
+			if (!interior) { const unsigned idx = idx0 + (unsigned)j; in = in && idx < n && idx - first_rel < n_rel; }
+			const bool same = in && reach <= lim;
+			const bool cnt = same && jslot != CELL_NONE;
+			n_add2 += cnt ? 1u : 0u;
+			s_add2 += cnt ? l1 + l2 : 0u;
+			park[j] = in && !same && !ABL(A, 17u | 1048576u | 2097152u);
+			any_park = any_park || park[j];
+		}
+		if (!ABL(A, 1u)) {
+			if (n_add && n_add2 && slot0 == jslot) { n_add += n_add2; s_add += s_add2; n_add2 = 0; }
+			if (n_add) atomicAdd(&C.hist[slot0], ((unsigned long long)n_add << 40) | s_add);
+			if (n_add2) atomicAdd(&C.hist[jslot], ((unsigned long long)n_add2 << 40) | s_add2);
+		} else asm volatile("" ::"v"(n_add), "v"(s_add), "v"(n_add2), "v"(s_add2));
+		if (__any(any_park)) {
+			// parked as their compact records: (block 1, block 2, event to look at, position in the range)
+			const unsigned hint0 = v1 ? (cx1.w | PARK_ONE_EVENT) : evf;
+#pragma unroll
+			for (int h = 0; h < NR; h += 2) {
+				const uint4 qa = make_uint4(ra[h], rb[h], h == 0 ? hint0 : PARK_EVENT_UNKNOWN, rel0 + (unsigned)h);
+				const uint4 qb = make_uint4(ra[h + 1], rb[h + 1], PARK_EVENT_UNKNOWN, rel0 + (unsigned)h + 1u);
+				if (ABL(A, 256u)) atomicAdd(&A.dbg[1], (park[h] ? 1ull : 0ull) + (park[h + 1] ? 1ull : 0ull));
+				R.push2((park[h] ? 1u : 0u) | (park[h + 1] ? 2u : 0u), lane, qa, qb);
+				// the ring holds what one walk leaves behind (< 64) plus these 128 one-word entries
+				if (R.live() >= 64u) {             // wave-uniform
+					if (!ABL(A, 32u)) walk_parked<2, true>(C, R, false, base);
+					else R.head = R.tail;
+				}
+			}
+		}
+	}
+	if (R.live() && !ABL(A, 32u)) walk_parked<2, true>(C, R, true, base);
+}
+
 // Global count/bases adds of a whole wave, merged by class before they reach L2: with skewed read
 // depth most lanes of a worker wave hit the classes of one hot event, and atomics on one address
 // run one after the other.  Up to four distinct classes are summed across the wave (ballot, DPP
@@ -1071,12 +1342,16 @@ __global__ void __launch_bounds__(COUNT_BLOCK, P1W == 4 ? 5 : LSQ_FAST_WAVES) ls
 		const unsigned long long l1 = (s_end < V.be ? s_end : V.be) - V.bs;
 		const unsigned long long n1 = V.p1n, n2 = V.p2n;
 		// ---- pool 1
-		if (l0 < n1 && !ABL(A, 1024u))
-			stream_pool_fast<2, COMPACT, P1W>(C, bins, cells, cellx, n_cells, d, A, wave_queue, reinterpret_cast<const uint4 *>(A.p1), V.p1o + l0, V.p1o + (l1 < n1 ? l1 : n1));
+		if (l0 < n1 && !ABL(A, 1024u)) {
+			if constexpr (COMPACT) stream_pool1_compact<2 * P1W>(C, bins, cells, cellx, n_cells, d, A, wave_queue, A.p1, V.p1o + l0, V.p1o + (l1 < n1 ? l1 : n1));
+			else stream_pool_fast<2, COMPACT, P1W>(C, bins, cells, cellx, n_cells, d, A, wave_queue, reinterpret_cast<const uint4 *>(A.p1), V.p1o + l0, V.p1o + (l1 < n1 ? l1 : n1));
+		}
 		// ---- pool 2
-		if (l1 > n1 && l0 < n1 + n2 && !ABL(A, 2048u))
-			stream_pool_fast<1, COMPACT, P1W>(C, bins, cells, cellx, n_cells, d, A, wave_queue, reinterpret_cast<const uint4 *>(A.p2), V.p2o + ((l0 > n1 ? l0 : n1) - n1),
-			                    V.p2o + ((l1 < n1 + n2 ? l1 : n1 + n2) - n1));
+		if (l1 > n1 && l0 < n1 + n2 && !ABL(A, 2048u)) {
+			const unsigned long long q0 = V.p2o + ((l0 > n1 ? l0 : n1) - n1), q1 = V.p2o + ((l1 < n1 + n2 ? l1 : n1 + n2) - n1);
+			if constexpr (COMPACT) stream_pool2_compact<(P1W == 4 ? LSQ_P2_COMPACT_WORDS_W5 : LSQ_P2_COMPACT_WORDS)>(C, bins, cells, cellx, n_cells, d, A, wave_queue, A.p2, q0, q1);
+			else stream_pool_fast<1, COMPACT, P1W>(C, bins, cells, cellx, n_cells, d, A, wave_queue, reinterpret_cast<const uint4 *>(A.p2), q0, q1);
+		}
 		// (reads with three or more blocks are the workers')
 		__syncthreads();
 		// ---- flush
