@@ -111,6 +111,7 @@ uint64_t lsq_events_ars(const lsq_events *e, int method, int64_t ev, int iso);
 int lsq_events_span(const lsq_events *e, int64_t ev, int64_t *gene_start, int64_t *gene_end);
 int64_t lsq_events_num_buckets(const lsq_events *e);
 int64_t lsq_events_lds_table_bytes(const lsq_events *e);   /* largest bucket image + histogram */
+int64_t lsq_events_host_genes(const lsq_events *e);        /* genes beyond the kernel limits below: evaluated on the host (lsq_host_evaluated) */
 /* Restricts the device plan to events [first_event, first_event + n_events) of the output order
  * (the reference's own scale-out unit, count/count.cpp:204-215) while the covered regions -- and so
  * the load-time read filter -- stay those of the whole selected range: every shard then gives
@@ -247,6 +248,11 @@ int lsq_count_status(lsq_ctx *c, uint32_t *exceptions, uint32_t *recounted);
  * lsq_count_fast_kernel<.., 2>, 8: lsq_count_fast_kernel<true, 4>) and resident workgroups per compute unit.  Either
  * pointer may be null. */
 int lsq_count_launch_info(lsq_ctx *c, uint32_t *reads_per_look, uint32_t *workgroups_per_cu);
+/* What the latest lsq_count evaluated on the HOST: genes beyond the kernel limits above (more than LSQ_MAX_ISOFORMS isoforms
+ * or LSQ_MAX_SEGMENTS segments, or a cluster of overlapping genes too large for the LDS) and the reads their clusters held.
+ * Results are the reference's either way; throughput is not (host threads: LSQ_THREADS), so a caller may want to say so --
+ * the executables do at log level 1.  Either pointer may be null. */
+int lsq_host_evaluated(const lsq_ctx *c, uint64_t *n_genes, uint64_t *n_reads);
 /* Tuning knobs; results never depend on them.  "grid_multiplier" (workgroups per resident slot of the
  * count kernel's grid, 0 = chosen from the read set's skew), "exception_capacity" (entries of a read
  * file's exception list, 0 = a quarter of its reads and at least 65 536; applies to read sets uploaded

@@ -56,6 +56,14 @@ int lsq_gather(lsq_ctx *c, lsq_comm *comm, const void *d_block, void *d_gathered
  * turn, lesseq_hip.h: step k+1's pack is not ordered behind step k's gather, which may still be reading its block). */
 int lsq_step_gather(lsq_ctx *c, lsq_comm *comm, void *d_block, void *d_gathered, uint64_t stride_words);
 
+/* The exchange of a READ-sharded job (every rank counts a slice of the reads against all events; lesseq_hip.h
+ * lsq_text_stage_range / lsq_reads_upload_text_at): the latest count's class counts and matched bases -- as they lie on the
+ * device, lsq_counts_device_words(c) words, the same order on every rank -- are copied into d_words and summed over the
+ * ranks there (ncclAllReduce, uint64 sum, on the result stream: integer sums, any order, count/count.cpp:378,467-482).
+ * Asynchronous; lsq_ctx_synchronize_for, then lsq_counts_import_device(c, d_words) makes the sums the counts that
+ * lsq_solve and the getters work on. */
+int lsq_allreduce_counts(lsq_ctx *c, lsq_comm *comm, void *d_words);
+
 #ifdef __cplusplus
 }
 #endif

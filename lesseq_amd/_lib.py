@@ -73,6 +73,7 @@ _sig("lsq_events_ars", u64, vp, C.c_int, i64, C.c_int)
 _sig("lsq_events_span", C.c_int, vp, i64, P(i64), P(i64))
 _sig("lsq_events_num_buckets", i64, vp)
 _sig("lsq_events_lds_table_bytes", i64, vp)
+_sig("lsq_events_host_genes", i64, vp)
 _sig("lsq_events_set_shard", C.c_int, vp, u64, u64)
 _sig("lsq_mrf_parse", C.c_int, cs, cs, vp, C.c_int, P(vp))
 _sig("lsq_reads_parse", C.c_int, cs, cs, vp, C.c_int, P(vp))
@@ -116,6 +117,7 @@ _sig("lsq_results_counts", C.c_int, vp, P(u64), P(u64))
 _sig("lsq_results_solve", C.c_int, vp, P(C.c_double), P(C.c_double), P(u32), P(u8))
 _sig("lsq_count_status", C.c_int, vp, P(u32), P(u32))
 _sig("lsq_count_launch_info", C.c_int, vp, P(u32), P(u32))
+_sig("lsq_host_evaluated", C.c_int, vp, P(u64), P(u64))
 _sig("lsq_counts_device_words", u64, vp)
 _sig("lsq_counts_export_device", C.c_int, vp, vp)
 _sig("lsq_counts_import_device", C.c_int, vp, vp)

@@ -937,6 +937,11 @@ uint64_t lsq_events_ars(const lsq_events *e, int method, int64_t ev, int iso) {
 int lsq_events_span(const lsq_events *e, int64_t ev, int64_t *gs, int64_t *ge) { EV_OR(LSQ_E_ARG); *gs = e->ev[ev].gene_start; *ge = e->ev[ev].gene_end; return LSQ_OK; }
 int64_t lsq_events_num_buckets(const lsq_events *e) { return e ? (int64_t)e->buckets.size() : 0; }
 int64_t lsq_events_lds_table_bytes(const lsq_events *e) { return e ? (int64_t)e->max_lds_bytes : 0; }
+int64_t lsq_events_host_genes(const lsq_events *e) {
+	int64_t n = 0;
+	if (e) for (const lsq::BucketDesc &b : e->buckets) if (b.kind == 2) n += b.n_events;
+	return n;
+}
 
 int lsq_events_set_shard(lsq_events *e, uint64_t first_event, uint64_t n_events) LSQ_API_TRY {
 	if (!e) return fail(LSQ_E_ARG, "null argument");

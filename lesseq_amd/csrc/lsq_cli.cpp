@@ -213,6 +213,7 @@ struct RcclApi {
 	void (*destroy)(void *) = nullptr;
 	void (*abort_comm)(void *) = nullptr;
 	int (*gather)(lsq_ctx *, void *, const void *, void *, uint64_t) = nullptr;
+	int (*allreduce_counts)(lsq_ctx *, void *, void *) = nullptr;
 	const char *(*last_error)(void) = nullptr;
 	std::string why;                       // dlerror() of the failing dlopen (read once: the call clears it)
 	bool load() {
@@ -226,10 +227,168 @@ struct RcclApi {
 		destroy = (void (*)(void *))dlsym(handle, "lsq_comm_destroy");
 		abort_comm = (void (*)(void *))dlsym(handle, "lsq_comm_abort");
 		gather = (int (*)(lsq_ctx *, void *, const void *, void *, uint64_t))dlsym(handle, "lsq_gather");
+		allreduce_counts = (int (*)(lsq_ctx *, void *, void *))dlsym(handle, "lsq_allreduce_counts");
 		last_error = (const char *(*)(void))dlsym(handle, "lsq_rccl_last_error");
-		return init_all && destroy && abort_comm && gather && last_error;
+		return init_all && destroy && abort_comm && gather && allreduce_counts && last_error;
 	}
 };
+
+// Where the host threads of a job's GPUs meet: everybody arrives, and learns whether everybody is well.  A thread that
+// failed on the way must keep the others out of the collective that follows (they would spin in it for a peer that never comes).
+struct Agreement {
+	std::mutex mu; std::condition_variable cv; int arrived = 0, failed = 0; const int G;
+	explicit Agreement(int g) : G(g) {}
+	bool arrive(bool ok) {
+		std::unique_lock<std::mutex> lk(mu);
+		++arrived; if (!ok) ++failed;
+		cv.notify_all();
+		cv.wait(lk, [&] { return arrived == G; });
+		return failed == 0;
+	}
+	void absent() { std::lock_guard<std::mutex> g(mu); ++arrived; ++failed; cv.notify_all(); }      // a slice that never started
+};
+
+// The other way to cut one job (LSQ_SHARD=reads; SURVEY 8(e)'s alternative): every GPU takes a slice of the READS -- a byte
+// range of each MRF file, cut at line starts, copied and parsed on that GPU only -- against ALL events; the slices' newline
+// counts give every slice the file-wide number of its first line (read names "read-<line>" decide span-start ties,
+// count/count.cpp:64-85,293-295); the class counts and matched bases are summed over the GPUs (integer sums: any order,
+// count.cpp:378,467-482) with one ncclAllReduce (liblesseq_rccl's lsq_allreduce_counts; LSQ_GATHER=host: through host
+// memory), and GPU 0 goes on with the sums as a single-GPU run does (EM, rows).  Here the loader scales with the GPUs (the
+// event-sharded job parses the whole text on every GPU, twice); MRF_SINGLE files and genes within the kernels' limits only
+// -- the caller falls back to the event-sharded job otherwise -- and an event inside the EM guard band cannot be replayed in
+// per-read order (no GPU holds all of its reads): it keeps the kernel's numbers and is named at log level 1.
+// On return ctx0 holds the whole job's counts (lsq_counts_import_device).
+int run_read_sharded_job(const ShardedJob &J, lsq_ctx *ctx0, lsq_events *ev0) {
+	const int G = J.G, M = J.M;
+	const char *gmode = getenv("LSQ_GATHER");
+	const bool via_host = gmode && strcmp(gmode, "host") == 0;
+	double time_limit = 120.0;
+	if (const char *e = getenv("LSQ_COLLECTIVE_TIMEOUT")) { const double v = atof(e); if (v > 0) time_limit = v; }
+	RcclApi rccl;
+	std::vector<void *> comms((size_t)G, nullptr);
+	if (!via_host) {
+		if (!rccl.load()) { logf(0, "LSQ_GPUS=%d needs liblesseq_rccl.so beside the library (%s)", G, rccl.why.empty() ? "symbols missing" : rccl.why.c_str()); return 3; }
+		const int st = rccl.init_all(G, J.devices.data(), time_limit, comms.data());
+		if (st) { logf(0, "%s", rccl.last_error()); return 3; }
+	}
+	// the slices: byte cuts moved to line starts (the first slice keeps the header line)
+	std::vector<std::vector<uint64_t>> cuts((size_t)M);
+	for (int m = 0; m < M; ++m) {
+		FILE *f = fopen(J.paths[(size_t)m], "rb");
+		if (!f) { logf(0, "cannot open reads file %s", J.paths[(size_t)m]); return EXIT_ABORT; }
+		fseeko(f, 0, SEEK_END);
+		const uint64_t size = (uint64_t)ftello(f);
+		cuts[(size_t)m].assign((size_t)G + 1, size);
+		cuts[(size_t)m][0] = 0;
+		for (int r = 1; r < G; ++r) {
+			uint64_t at = std::max(size / (uint64_t)G * (uint64_t)r, cuts[(size_t)m][(size_t)r - 1]);
+			fseeko(f, (off_t)at, SEEK_SET);
+			int ch;
+			while (at < size && (ch = fgetc(f)) != EOF) { ++at; if (ch == '\n') break; }      // to the first byte after the next newline
+			cuts[(size_t)m][(size_t)r] = std::min(at, size);
+		}
+		fclose(f);
+	}
+	const uint64_t words = lsq_counts_device_words(ctx0);
+	std::vector<std::vector<uint64_t>> lines((size_t)G, std::vector<uint64_t>((size_t)M, 0));     // newlines per slice and file
+	std::vector<std::vector<uint64_t>> host_words(via_host ? (size_t)G : 0, std::vector<uint64_t>(std::max<uint64_t>(words, 1), 0));
+	std::vector<int> status((size_t)G, LSQ_OK);
+	std::vector<std::string> errors((size_t)G);
+	std::vector<lsq_ctx *> ctxs((size_t)G, nullptr);
+	std::vector<lsq_events *> evs((size_t)G, nullptr);
+	std::vector<std::vector<lsq_text *>> texts((size_t)G, std::vector<lsq_text *>((size_t)M, nullptr));
+	std::vector<void *> d_words((size_t)G, nullptr);
+	ctxs[0] = ctx0; evs[0] = ev0;
+	Agreement staged(G), counted(G);
+	auto work = [&](int r) {
+		auto bad = [&](int s2, const char *msg) { status[(size_t)r] = s2 ? s2 : LSQ_E_STATE; errors[(size_t)r] = msg; return status[(size_t)r]; };
+		auto guarded = [&](auto &&body) -> int {
+			try { return body(); }
+			catch (const std::exception &ex) { return bad(LSQ_E_INTERNAL, ex.what()); }
+			catch (...) { return bad(LSQ_E_INTERNAL, "unknown exception"); }
+		};
+		// 1. context, event tables, this GPU's byte range of every file, its newline counts
+		int s = guarded([&]() -> int {
+			int q;
+			if (r > 0) {
+				if ((q = lsq_ctx_create(J.devices[(size_t)r], &ctxs[(size_t)r])) || (q = apply_env_options(ctxs[(size_t)r]))) return bad(q, lsq_last_error());
+				if ((q = lsq_events_compile(J.ann, M, J.types.data(), J.lens.data(), &evs[(size_t)r]))) return bad(q, lsq_last_error());
+				if ((q = lsq_events_upload(ctxs[(size_t)r], evs[(size_t)r]))) return bad(q, lsq_last_error());
+			}
+			for (int m = 0; m < M; ++m) {
+				if ((q = lsq_text_stage_range(ctxs[(size_t)r], J.paths[(size_t)m], cuts[(size_t)m][(size_t)r], cuts[(size_t)m][(size_t)r + 1], &texts[(size_t)r][(size_t)m]))) return bad(q, lsq_last_error());
+				if ((q = lsq_text_lines(ctxs[(size_t)r], texts[(size_t)r][(size_t)m], &lines[(size_t)r][(size_t)m]))) return bad(q, lsq_last_error());
+			}
+			return LSQ_OK;
+		});
+		bool everyone = staged.arrive(s == LSQ_OK);
+		lsq_ctx *c = ctxs[(size_t)r];
+		// 2. parse and ingest the slice under its file-wide line numbers, count, hand the counters over
+		s = LSQ_E_STATE;
+		if (everyone) s = guarded([&]() -> int {
+			int q;
+			for (int m = 0; m < M; ++m) {
+				uint64_t before = 0;
+				for (int p = 0; p < r; ++p) before += lines[(size_t)p][(size_t)m];
+				if ((q = lsq_reads_upload_text_at(c, m, J.fmts[(size_t)m], texts[(size_t)r][(size_t)m], r == 0 ? 1 : 0, r == 0 ? 1 : before))) return bad(q, lsq_last_error());
+				lsq_text_free(texts[(size_t)r][(size_t)m]); texts[(size_t)r][(size_t)m] = nullptr;
+			}
+			if ((q = lsq_count(c))) return bad(q, lsq_last_error());
+			if ((q = lsq_device_alloc(c, std::max<uint64_t>(words, 1) * 8, &d_words[(size_t)r]))) return bad(q, lsq_last_error());
+			if (via_host) {
+				if ((q = lsq_counts_export_device(c, d_words[(size_t)r])) || (q = lsq_device_read(c, host_words[(size_t)r].data(), d_words[(size_t)r], words * 8))) return bad(q, lsq_last_error());
+			}
+			if (const char *fr = getenv("LSQ_FAIL_RANK")) if (atoi(fr) == r) return bad(LSQ_E_STATE, "failure of this slice requested (LSQ_FAIL_RANK)");
+			return LSQ_OK;
+		});
+		everyone = everyone && counted.arrive(s == LSQ_OK);
+		// 3. the sum over the GPUs; GPU 0 takes it as its counts
+		if (everyone) (void)guarded([&]() -> int {
+			int q;
+			if (via_host) {
+				if (r == 0) {
+					for (int p = 1; p < G; ++p) for (uint64_t w = 0; w < words; ++w) host_words[0][(size_t)w] += host_words[(size_t)p][(size_t)w];
+					if ((q = lsq_device_write(c, d_words[0], host_words[0].data(), words * 8)) || (q = lsq_counts_import_device(c, d_words[0])) || (q = lsq_ctx_synchronize(c))) return bad(q, lsq_last_error());
+				}
+				return LSQ_OK;
+			}
+			if ((q = rccl.allreduce_counts(c, comms[(size_t)r], d_words[(size_t)r]))) return bad(q, rccl.last_error());
+			if ((q = lsq_ctx_synchronize_for(c, time_limit))) {
+				bad(q, lsq_last_error());
+				if (q == LSQ_E_TIMEOUT) { rccl.abort_comm(comms[(size_t)r]); comms[(size_t)r] = nullptr; }       // ends the spinning kernel
+				return q;
+			}
+			if (r == 0 && ((q = lsq_counts_import_device(c, d_words[0])) || (q = lsq_ctx_synchronize(c)))) return bad(q, lsq_last_error());
+			return LSQ_OK;
+		});
+		for (auto *&t : texts[(size_t)r]) { lsq_text_free(t); t = nullptr; }
+		if (c) lsq_device_free(c, d_words[(size_t)r]);
+		if (everyone && !status[(size_t)r])
+			logf(2, "GPU %d: bytes %llu..%llu of %s%s, %llu reads retained of them", J.devices[(size_t)r], (unsigned long long)cuts[0][(size_t)r], (unsigned long long)cuts[0][(size_t)r + 1],
+			     J.paths[0], M > 1 ? " (and the like of the other files)" : "", (unsigned long long)lsq_reads_retained(c, 0));
+	};
+	{
+		ThreadGroup th;
+		for (int r = 1; r < G; ++r) {
+			try { th.spawn([&work, r] { work(r); }); }
+			catch (...) { status[(size_t)r] = LSQ_E_INTERNAL; errors[(size_t)r] = "the slice's host thread could not be started"; staged.absent(); }
+		}
+		work(0);
+		th.join();
+	}
+	uint64_t retained_all = 0;
+	for (int r = 0; r < G; ++r) if (ctxs[(size_t)r]) retained_all += lsq_reads_retained(ctxs[(size_t)r], 0);
+	for (int r = 1; r < G; ++r) { if (ctxs[(size_t)r]) lsq_ctx_destroy(ctxs[(size_t)r]); lsq_events_free(evs[(size_t)r]); }
+	if (!via_host) for (void *cm : comms) if (cm) rccl.destroy(cm);
+	// the first failing slice in file order speaks (a field that fails the cast: the reference reports the first such line)
+	for (int r = 0; r < G; ++r) if (status[(size_t)r]) {
+		if (status[(size_t)r] == LSQ_E_PARSE) { logf(0, "%s", errors[(size_t)r].c_str()); logf(0, "Lexical_cast error when converting arguments to numeric values"); return 1; }
+		logf(0, "GPU %d: %s", J.devices[(size_t)r], errors[(size_t)r].c_str());
+		return 3;
+	}
+	logf(2, "Sampling method #0: loaded %llu reads associated with the selected gene regions (over %d GPUs)", (unsigned long long)retained_all, G);
+	return 0;
+}
 
 // F.c / F.e: GPU 0's context with the whole job counted on it (the pre-pass); texts0: its staged MRF texts (kept)
 int run_sharded_job(const ShardedJob &J, lsq_ctx *ctx0, lsq_events *ev0, std::vector<lsq_text *> &texts0, const std::vector<double> &trb, std::string &out) {
@@ -275,18 +434,7 @@ int run_sharded_job(const ShardedJob &J, lsq_ctx *ctx0, lsq_events *ev0, std::ve
 	// Every GPU's thread does its slice up to the packed block, then all of them AGREE before any enters the collective: a
 	// thread that failed on the way (no context, a file it cannot parse, out of memory) would otherwise leave the others
 	// spinning in ncclAllGather for a peer that never comes.  One failure: nobody gathers, the job exits 3 with the message.
-	struct Agreement {
-		std::mutex mu; std::condition_variable cv; int arrived = 0, failed = 0; const int G;
-		explicit Agreement(int g) : G(g) {}
-		bool arrive(bool ok) {
-			std::unique_lock<std::mutex> lk(mu);
-			++arrived; if (!ok) ++failed;
-			cv.notify_all();
-			cv.wait(lk, [&] { return arrived == G; });
-			return failed == 0;
-		}
-		void absent() { std::lock_guard<std::mutex> g(mu); ++arrived; ++failed; cv.notify_all(); }      // a slice that never started
-	} agreement(G);
+	Agreement agreement(G);
 	auto prepare = [&](int r) -> int {
 		auto bad = [&](int s2, const char *msg) { status[(size_t)r] = s2 ? s2 : LSQ_E_STATE; errors[(size_t)r] = msg; return status[(size_t)r]; };
 		int s;
@@ -417,6 +565,10 @@ int run_count_solve(bool solve, int argc, const char *const *argv, std::string &
 	if (G > 1 && devices.size() < (size_t)G) { devices.clear(); for (int r = 0; r < G; ++r) devices.push_back(r); }
 	if (G == 1) { int dev = 0; if (const char *e = getenv("LSQ_DEVICE")) dev = atoi(e); devices.assign(1, dev); }
 	devices.resize((size_t)G);
+	// LSQ_SHARD=reads: the job's GPUs share the READS instead of the events (run_read_sharded_job): MRF_SINGLE files only
+	bool shard_reads = false;
+	if (const char *e = getenv("LSQ_SHARD")) shard_reads = strcmp(e, "reads") == 0 && G > 1 && !want_fim;
+	for (const char *f : fmts) if (strcmp(f, "MRF_SINGLE") != 0) shard_reads = false;
 	Freer F;
 	// the device context (HIP start-up, a tenth of a second or more) is created on a second thread while
 	// this one reads the annotation; its status is looked at only where the reference would be past
@@ -432,6 +584,7 @@ int run_count_solve(bool solve, int argc, const char *const *argv, std::string &
 		if (ctx_status) { ctx_error = lsq_last_error(); return; }          // the message lives in that thread
 		ctx_status = apply_env_options(ctx_bg);
 		if (ctx_status) { ctx_error = lsq_last_error(); return; }
+		if (shard_reads) return;          // every GPU stages its own byte range later
 		for (int m = 0; m < M; ++m)
 			if (strcmp(fmts[m], "MRF_SINGLE") == 0 && lsq_text_stage(ctx_bg, paths[m], &texts[(size_t)m]) != LSQ_OK) texts[(size_t)m] = nullptr;
 	};
@@ -490,6 +643,11 @@ int run_count_solve(bool solve, int argc, const char *const *argv, std::string &
 			if (st) { logf(0, "%s", lsq_last_error()); return 3; }
 			T.mark("event tables upload");
 		}
+		if (shard_reads && lsq_events_host_genes(F.e) > 0) {
+			logf(1, "LSQ_SHARD=reads: %lld gene(s) beyond the device kernels' limits need all of their reads in one place; the job is sharded by events instead", (long long)lsq_events_host_genes(F.e));
+			shard_reads = false;
+		}
+		if (shard_reads) continue;          // (the files open and are MRF_SINGLE: the GPUs read their slices below)
 		// MRF text -> HBM -> parsed and ingested there; the name-keyed formats are grouped by name on the host first
 		if (texts[(size_t)m]) {
 			st = lsq_reads_upload_text(F.c, m, fmts[m], texts[(size_t)m]);
@@ -507,10 +665,27 @@ int run_count_solve(bool solve, int argc, const char *const *argv, std::string &
 		T.mark("reads: copy, parse, ingest");
 		if (T.on) { float h2d = 0, parse = 0; lsq_last_mrf_timing(F.c, &h2d, &parse); fprintf(stderr, "[timing] %-28s %.3f s\n[timing] %-28s %.3f s\n", "  of which text copy", h2d * 1e-3, "  of which parse kernels", parse * 1e-3); }
 	}
-	if (bad_type && n_ev > 0) { logf(0, "Unknown read type error: %s", bad_type_name.c_str()); return 1; }
+	// (read-sharded: the reads are loaded below, and a line that fails the cast there comes first, as in the reference)
+	if (bad_type && n_ev > 0 && !shard_reads) { logf(0, "Unknown read type error: %s", bad_type_name.c_str()); return 1; }
 	logf(2, "Processing reads info for genes");
-	st = lsq_count(F.c);
-	if (st) { logf(0, "%s", lsq_last_error()); return 3; }
+	if (shard_reads && n_ev > 0) {
+		ShardedJob J{solve, G, M, F.a, fmts, use_types, paths, lens, devices};
+		const int rc = run_read_sharded_job(J, F.c, F.e);
+		T.mark("read-sharded ingest + count + sum");
+		if (rc) return rc;
+		if (bad_type) { logf(0, "Unknown read type error: %s", bad_type_name.c_str()); return 1; }
+		G = 1;                  // the sums are GPU 0's counts now: the rest is a single-GPU run
+	} else {
+		shard_reads = false;
+		st = lsq_count(F.c);
+		if (st) { logf(0, "%s", lsq_last_error()); return 3; }
+	}
+	{
+		uint64_t hg = 0, hr = 0;
+		if (lsq_host_evaluated(F.c, &hg, &hr) == LSQ_OK && hg)
+			logf(1, "%llu gene(s) beyond the device kernels' limits (more than %d isoforms or %d segments, or a cluster too large for the LDS) are evaluated on the host: %llu reads",
+			     (unsigned long long)hg, LSQ_MAX_ISOFORMS, LSQ_MAX_SEGMENTS, (unsigned long long)hr);
+	}
 	// (LSQ_GPUS=1 with LSQ_GATHER=rccl spelled out takes the same path with one slice: a self-check of the gather on one GPU)
 	const char *gm = getenv("LSQ_GATHER");
 	if ((G > 1 || (getenv("LSQ_GPUS") && gm && strcmp(gm, "rccl") == 0 && !want_fim)) && n_ev > 0) {

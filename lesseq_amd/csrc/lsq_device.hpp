@@ -199,6 +199,7 @@ struct lsq_ctx {
 	bool counts_external = false;           // lsq_results_set_counts: the counts are sums the reads here do not explain
 	double em_band = 1E-11;                 // lsq_set_em_guard_band: events whose stop test comes this close to its threshold are replayed
 	bool has_fast = false, has_generic = false, has_host = false;
+	uint64_t host_genes = 0, host_reads = 0;     // host buckets of the latest count: their events, and the reads their clusters held
 	std::map<size_t, std::vector<unsigned short>> host_seq;     // host buckets: [device event * M + method] -> classes of its valid reads, index order
 	float count_ms = 0, solve_ms = 0;
 	float mrf_h2d_ms = 0, mrf_parse_ms = 0;

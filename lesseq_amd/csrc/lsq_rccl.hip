@@ -196,6 +196,18 @@ int lsq_gather(lsq_ctx *c, lsq_comm *comm, const void *d_block, void *d_gathered
 	return LSQ_OK;
 } LSQ_API_CATCH
 
+int lsq_allreduce_counts(lsq_ctx *c, lsq_comm *comm, void *d_words) LSQ_API_TRY {
+	if (!c || !comm || !d_words) return fail(LSQ_E_ARG, "bad argument");
+	if (hipSetDevice(comm->device) != hipSuccess) return fail(LSQ_E_DEVICE, "device %d cannot be selected", comm->device);
+	const uint64_t words = lsq_counts_device_words(c);
+	int rc = lsq_counts_export_device(c, d_words);           // on the result stream, behind the count's exception pass
+	if (rc) return fail(rc, "%s", lsq_last_error());
+	if (!words) return LSQ_OK;
+	hipStream_t st = (hipStream_t)lsq_ctx_result_stream(c);
+	NCCL_TRY(ncclAllReduce(d_words, d_words, (size_t)words, ncclUint64, ncclSum, comm->comm, st));
+	return LSQ_OK;
+} LSQ_API_CATCH
+
 // One step of an event-sharded job in one call: count, solve, pack, gather (what a loop over batches does per batch;
 // four calls through a binding's foreign-function layer cost more host time than the launches themselves).
 int lsq_step_gather(lsq_ctx *c, lsq_comm *comm, void *d_block, void *d_gathered, uint64_t stride_words) LSQ_API_TRY {

@@ -12,6 +12,7 @@
 // libm's log -- the operations of read.h:592-660 in the same order, so the result is the reference's.
 // Flagged events are rare (3 of 200 000 on the skewed 1 B-read workload), so this is not a throughput path.
 #include "lsq_device.hpp"
+#include <atomic>
 
 // The same unit evaluates HOST BUCKETS (BucketDesc::kind 2): clusters of events that hold a gene beyond the kernels'
 // limits (more than LSQ_MAX_ISOFORMS isoforms or LSQ_MAX_SEGMENTS segments: the whole-gene annotations solve's further
@@ -344,57 +345,112 @@ int replay_flagged(lsq_ctx *c, unsigned *n_done) {
 }
 
 // Host buckets, count: every read of the bucket against every event of it; the class counts and matched bases go
-// into the device tables, the class sequences stay in the context for host_solve.
+// into the device tables, the class sequences stay in the context for host_solve.  The reads come back on the calling
+// thread (HIP calls stay there); the evaluation -- events x reads of a bucket -- is dealt to LSQ_THREADS host threads,
+// an event at a time (a whole-gene annotation through solve's other formats puts thousands of genes here).
 int host_count(lsq_ctx *c) {
 	const lsq_events &E = *c->E;
 	const size_t M = (size_t)E.n_methods, n_cls = E.n_cls_total;
 	c->host_seq.clear();
+	c->host_genes = 0; c->host_reads = 0;
 	{ int rc = sync_all(c); if (rc) return rc; }
 	std::vector<NameTable> names;
 	{ int rc = fetch_names(c, names); if (rc) return rc; }
+	struct Item { size_t b, m, d; const BucketReads *R; std::vector<unsigned long long> cnt, bases; std::vector<unsigned short> *seq; int status = LSQ_OK; std::string error; };
+	std::vector<std::unique_ptr<BucketReads>> fetched;
+	std::vector<Item> items;
 	for (size_t b = 0; b < E.buckets.size(); ++b) {
 		const BucketDesc &bd = E.buckets[b];
 		if (bd.kind != 2) continue;
+		c->host_genes += bd.n_events;
 		for (size_t m = 0; m < M; ++m) {
 			const MethodReads &mr = c->reads[m];
-			BucketReads R;
+			fetched.emplace_back(new BucketReads);
+			BucketReads &R = *fetched.back();
 			{ int rc = fetch_bucket(mr, b, E.buckets[b].lo, R); if (rc) return rc; }
+			for (size_t i = 0; i < R.p1_line.size(); ++i) c->host_reads += R.p1[2 * i] != R.p1[2 * i + 1];       // (padding aside)
+			for (size_t i = 0; i < R.p2_line.size(); ++i) c->host_reads += R.p2[4 * i] != R.p2[4 * i + 1];
+			c->host_reads += R.pn_line.size();
 			for (size_t d = bd.ev_base; d < (size_t)bd.ev_base + bd.n_events; ++d) {
-				const Event &ev = E.ev[(size_t)E.dev2out[d]];
-				std::vector<HostRead> valid;
-				{ int rc = valid_reads(E, ev, R, names[m], valid); if (rc) return rc; }
-				const size_t nc = ((size_t)1 << ev.K) - 1;
-				std::vector<unsigned long long> cnt(nc, 0), bases(nc, 0);
-				std::vector<unsigned short> &seq = c->host_seq[d * M + m];
-				seq.reserve(valid.size());
-				for (const HostRead &r : valid) { ++cnt[r.cls - 1u]; bases[r.cls - 1u] += r.matched; seq.push_back(r.cls); }
-				HIP_TRY(hipMemcpy(c->cnt.p + m * n_cls + E.dev_cls_base[d], cnt.data(), nc * sizeof(unsigned long long), hipMemcpyHostToDevice));
-				HIP_TRY(hipMemcpy(c->bases.p + m * n_cls + E.dev_cls_base[d], bases.data(), nc * sizeof(unsigned long long), hipMemcpyHostToDevice));
+				Item it;
+				it.b = b; it.m = m; it.d = d; it.R = &R;
+				it.seq = &c->host_seq[d * M + m];          // the map grows here, on one thread; the workers fill the vectors
+				items.push_back(std::move(it));
 			}
 		}
+	}
+	if (items.empty()) return LSQ_OK;
+	std::atomic<size_t> next{0};
+	auto work = [&] {
+		for (;;) {
+			const size_t q = next.fetch_add(1, std::memory_order_relaxed);
+			if (q >= items.size()) return;
+			Item &it = items[q];
+			const Event &ev = E.ev[(size_t)E.dev2out[it.d]];
+			std::vector<HostRead> valid;
+			it.status = valid_reads(E, ev, *it.R, names[it.m], valid);
+			if (it.status) { it.error = lsq_last_error(); continue; }        // (the text lives in this thread)
+			const size_t nc = ((size_t)1 << ev.K) - 1;
+			it.cnt.assign(nc, 0); it.bases.assign(nc, 0);
+			it.seq->reserve(valid.size());
+			for (const HostRead &r : valid) { ++it.cnt[r.cls - 1u]; it.bases[r.cls - 1u] += r.matched; it.seq->push_back(r.cls); }
+		}
+	};
+	{
+		ThreadGroup th;
+		const size_t T = std::min<size_t>((size_t)std::max(1, host_threads(0)), items.size());
+		for (size_t t = 1; t < T; ++t) th.spawn(work);
+		th.run_here(work);
+		th.join();
+		if (th.failed()) return fail(LSQ_E_INTERNAL, "host evaluation of genes beyond the kernels' limits: %s", th.error().c_str());
+	}
+	for (const Item &it : items) {
+		if (it.status) return fail(it.status, "%s", it.error.c_str());
+		const size_t nc = it.cnt.size();
+		HIP_TRY(hipMemcpy(c->cnt.p + it.m * n_cls + E.dev_cls_base[it.d], it.cnt.data(), nc * sizeof(unsigned long long), hipMemcpyHostToDevice));
+		HIP_TRY(hipMemcpy(c->bases.p + it.m * n_cls + E.dev_cls_base[it.d], it.bases.data(), nc * sizeof(unsigned long long), hipMemcpyHostToDevice));
 	}
 	return LSQ_OK;
 }
 
-// Host buckets, solve: the reference's per-read EM over the sequences host_count kept (flag bit 2: exact order)
+// Host buckets, solve: the reference's per-read EM over the sequences host_count kept (flag bit 2: exact order), the
+// events dealt to the host threads like the count's
 int host_solve(lsq_ctx *c) {
 	const lsq_events &E = *c->E;
 	const size_t M = (size_t)E.n_methods;
 	{ int rc = sync_all(c); if (rc) return rc; }
+	struct Item { size_t d; std::vector<double> theta; double logll = 0; unsigned iters = 0; };
+	std::vector<Item> items;
 	for (size_t b = 0; b < E.buckets.size(); ++b) {
 		const BucketDesc &bd = E.buckets[b];
 		if (bd.kind != 2) continue;
-		for (size_t d = bd.ev_base; d < (size_t)bd.ev_base + bd.n_events; ++d) {
-			const Event &ev = E.ev[(size_t)E.dev2out[d]];
+		for (size_t d = bd.ev_base; d < (size_t)bd.ev_base + bd.n_events; ++d) { Item it; it.d = d; items.push_back(std::move(it)); }
+	}
+	if (items.empty()) return LSQ_OK;
+	std::atomic<size_t> next{0};
+	auto work = [&] {
+		for (;;) {
+			const size_t q = next.fetch_add(1, std::memory_order_relaxed);
+			if (q >= items.size()) return;
+			Item &it = items[q];
+			const Event &ev = E.ev[(size_t)E.dev2out[it.d]];
 			ExactEm em;
 			fill_G(ev, M, em);
-			for (size_t m = 0; m < M; ++m) { auto it = c->host_seq.find(d * M + m); if (it != c->host_seq.end()) em.seq[m] = it->second; }
-			std::vector<double> theta;
-			double logll = 0;
-			const unsigned iters = em.run(theta, logll);
-			int rc = write_solution(c, d, ev, theta, logll, iters, (uint8_t)4u);
-			if (rc) return rc;
+			for (size_t m = 0; m < M; ++m) { auto f = c->host_seq.find(it.d * M + m); if (f != c->host_seq.end()) em.seq[m] = f->second; }      // (the map is only read here)
+			it.iters = em.run(it.theta, it.logll);
 		}
+	};
+	{
+		ThreadGroup th;
+		const size_t T = std::min<size_t>((size_t)std::max(1, host_threads(0)), items.size());
+		for (size_t t = 1; t < T; ++t) th.spawn(work);
+		th.run_here(work);
+		th.join();
+		if (th.failed()) return fail(LSQ_E_INTERNAL, "host solve of genes beyond the kernels' limits: %s", th.error().c_str());
+	}
+	for (const Item &it : items) {
+		int rc = write_solution(c, it.d, E.ev[(size_t)E.dev2out[it.d]], it.theta, it.logll, it.iters, (uint8_t)4u);
+		if (rc) return rc;
 	}
 	return LSQ_OK;
 }
@@ -418,6 +474,16 @@ int lsq_solve_finalize(lsq_ctx *c, uint32_t *n_replayed) LSQ_API_TRY {
 	int rc = lsq::replay_flagged(c, &n);
 	if (n_replayed) *n_replayed = n;
 	return rc;
+} LSQ_API_CATCH
+
+// Genes beyond the kernels' limits (host buckets) as the latest lsq_count met them: how many, and how many reads their
+// clusters held -- what the host evaluated instead of the kernels (the executables say so at log level 1)
+int lsq_host_evaluated(const lsq_ctx *c, uint64_t *n_genes, uint64_t *n_reads) LSQ_API_TRY {
+	if (!c) return fail(LSQ_E_ARG, "null context");
+	if (!c->counted) return fail(LSQ_E_STATE, "lsq_count must come first");
+	if (n_genes) *n_genes = c->has_host ? c->host_genes : 0;
+	if (n_reads) *n_reads = c->has_host ? c->host_reads : 0;
+	return LSQ_OK;
 } LSQ_API_CATCH
 
 // Developer check of the pools' layout (tests): every aligned group of eight one-block records starts in one cell (or all

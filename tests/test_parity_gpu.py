@@ -324,7 +324,7 @@ def test_empty_and_degenerate_inputs(tmp_path, monkeypatch):
         assert all(x.startswith("#fim\t") for x in extra) and len(extra) * 2 == n_rows      # the toy events have two isoforms each
 
 
-def _random_gene_set(rng, n_genes, max_exons, max_iso, chroms=("c1", "c2"), spacing=4000):
+def _random_gene_set(rng, n_genes, max_exons, max_iso, chroms=("c1", "c2"), spacing=4000, min_iso=1):
     """genes with up to `max_iso` isoforms over up to `max_exons` shared exon slots (so events get
     many segments and isoforms: the generic kernel's territory)"""
     iv, mp, genes = [], [], []
@@ -339,7 +339,7 @@ def _random_gene_set(rng, n_genes, max_exons, max_iso, chroms=("c1", "c2"), spac
             slots.append((p, p + ln))
             p += ln + (0 if rng.random() < 0.15 else rng.randint(40, 400))
         pos[c] = p + rng.randint(200, spacing)
-        K = rng.randint(1, max_iso)
+        K = rng.randint(min_iso, max_iso)
         forms = []
         for k in range(K):
             pick = sorted(rng.sample(range(n_slots), rng.randint(1, n_slots)))
@@ -356,6 +356,51 @@ def _random_gene_set(rng, n_genes, max_exons, max_iso, chroms=("c1", "c2"), spac
             mp.append("G%d\t%s\n" % (g, name))
         genes.append((c, "+" if g % 2 else "-", forms))
     return "".join(iv), "".join(mp), genes
+
+
+def test_a_thousand_genes_beyond_the_kernel_limits_vs_oracle(tmp_path):
+    """1 500 genes of 7 to 10 isoforms each (LSQ_MAX_ISOFORMS = 6): every one of them is evaluated on the host inside lsq_count /
+    lsq_solve -- their reads pooled on the device, events dealt to LSQ_THREADS host threads, the reference's per-read EM --
+    and equals the oracle bit for bit; the executable says at log level 1 that, and how much, the host evaluated"""
+    import random
+    import ctypes as C
+    import golden_inputs as gi
+    rng = random.Random(4711)
+    R = 60
+    iv, mp, genes = _random_gene_set(rng, 1500, 9, 10, chroms=("c1", "c2", "c3"), spacing=1500, min_iso=7)
+    reads = []
+    for _ in range(60000):
+        c, strand, forms = genes[rng.randrange(len(genes))]
+        f = sorted(forms[rng.randrange(len(forms))])
+        tlen = sum(e - s for s, e in f)
+        ln = min(tlen, rng.choice([R, R, R // 2, R + 30]))
+        reads.append(gi.mrf_line(c, strand, gi.transcript_blocks(f, rng.randint(0, tlen - ln), ln)))
+    _write(tmp_path / "h.interval", iv)
+    _write(tmp_path / "h.map", mp)
+    _write(tmp_path / "h.mrf", "AlignmentBlocks\n" + "".join(reads))
+    argv = ["1", "h", "./", "LH_GENE_TXT", str(tmp_path / "h.interval"), "UCSC_GENE2ISOFORM", str(tmp_path / "h.map"),
+            "0", "100000", "MRF_SINGLE", "SHORT_READ", str(R), str(tmp_path / "h.mrf"), str(60000 * R)]
+    rc, otext, exact = ob.run("solve", argv)
+    assert rc == 0
+    got = gpu_exact(argv)
+    n_exact = compare_exact(got, exact, "1500 genes beyond the limits")
+    assert min(g["K"] for g in got) >= 7 and n_exact >= 1000
+    assert sum(sum(g["supports"]) for g in got) > 30000
+    # the context's own account of what the host did
+    a = L.Annotation(argv[4], argv[6])
+    ev = L.Events(a, ("SHORT_READ",), (R,))
+    ctx = L.Context(0)
+    ctx.upload_events(ev)
+    ctx.upload_reads(0, L.Reads.from_mrf(argv[12], ev))
+    ctx.count()
+    hg, hr = C.c_uint64(0), C.c_uint64(0)
+    assert L.lib.lsq_host_evaluated(ctx.h, C.byref(hg), C.byref(hr)) == 0
+    assert hg.value == 1500 and 30000 < hr.value <= 60000
+    ctx.close()
+    import subprocess
+    p = subprocess.run([os.path.join(BIN, "solve")] + argv, capture_output=True, text=True)
+    assert p.returncode == 0 and ob.solve_text_close(p.stdout, otext)
+    assert "WARNING" in p.stderr and "1500 gene(s) beyond the device kernels' limits" in p.stderr, p.stderr[-400:]
 
 
 def gi_line(name, chrom, strand, exons):
@@ -1103,8 +1148,37 @@ def test_executables_run_one_job_over_several_gpu_slices(name, env, tmp_path):
     assert n
 
 
+@pytest.mark.parametrize("name,env", [("events_s1", dict(LSQ_GPUS="3", LSQ_DEVICES="0,0,0", LSQ_GATHER="host", LSQ_SHARD="reads")),
+                                      ("multi_method", dict(LSQ_GPUS="2", LSQ_DEVICES="0,0", LSQ_GATHER="host", LSQ_SHARD="reads")),
+                                      ("edge", dict(LSQ_GPUS="2", LSQ_DEVICES="0,0", LSQ_GATHER="host", LSQ_SHARD="reads")),
+                                      ("wild_s12", dict(LSQ_GPUS="3", LSQ_DEVICES="0,0,0", LSQ_GATHER="host", LSQ_SHARD="reads")),
+                                      ("errors", dict(LSQ_GPUS="2", LSQ_DEVICES="0,0", LSQ_GATHER="host", LSQ_SHARD="reads")),
+                                      ("events_s3", dict(LSQ_GPUS="1", LSQ_GATHER="rccl", LSQ_SHARD="reads"))])
+def test_executables_run_one_job_over_several_gpus_by_reads(name, env, tmp_path):
+    """LSQ_GPUS=N LSQ_SHARD=reads: every GPU copies and parses a byte range of each MRF file (cut at line starts; the slices'
+    newline counts give every slice its file-wide first line number, which names the reads in span-start ties), counts it
+    against ALL events, the class counts are summed over the GPUs (lsq_allreduce_counts; here through host memory, every
+    "GPU" being device 0) and GPU 0 goes on as a single-GPU run: the reference's golden tables, exit statuses included
+    (`errors`: a field that fails the cast is reported from whichever slice holds it).  With LSQ_GPUS=1 nothing is
+    sharded (one slice needs no exchange): the plain run."""
+    import subprocess
+    c, d = load_case(name, tmp_path)
+    n = 0
+    for tool, r in runs(c):
+        p = subprocess.run([os.path.join(BIN, tool)] + r["argv"], cwd=d, capture_output=True, text=True, env=dict(os.environ, **env), timeout=120)
+        exp = open(os.path.join(d, r["stdout"])).read()
+        assert p.returncode in ((r["exit"],) if r["exit"] != 134 else (134, -6)), (name, tool, r["argv"], p.returncode, p.stderr[-500:])
+        if tool == "count":
+            assert p.stdout == exp, (name, r["argv"])
+        else:
+            assert ob.solve_text_close(p.stdout, exp), (name, r["argv"])
+        n += 1
+    assert n
+
+
 @pytest.mark.parametrize("env", [
     {"LSQ_GPUS": "3", "LSQ_DEVICES": "0,0,0", "LSQ_GATHER": "host", "LSQ_FAIL_RANK": "1"},      # a slice fails before the hand-over
+    {"LSQ_GPUS": "3", "LSQ_DEVICES": "0,0,0", "LSQ_GATHER": "host", "LSQ_FAIL_RANK": "2", "LSQ_SHARD": "reads"},      # ... of a read-sharded job
     {"LSQ_GPUS": "2", "LSQ_DEVICES": "0,99", "LSQ_GATHER": "host"},                               # a slice whose device does not exist
     {"LSQ_GPUS": "1", "LSQ_GATHER": "rccl", "LSQ_FAIL_RANK": "0"},                                # ... with the RCCL communicator made
 ])
