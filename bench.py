@@ -598,7 +598,7 @@ def run_workload(env, a, wl_name, primary):
         achieved = alg_bytes / (fk * 1e-3) / 1e9
         # HBM bytes per launch of the same kernel from the committed rocprofv3 PMC passes (tools/bench_prof.sh): not measured by this run
         committed = None
-        for rr in ("r02", "r01"):
+        for rr in ("r03", "r02", "r01"):
             tpath = os.path.join(ROOT, "profiles", "%s_traffic_%s.json" % (rr, wl_name))
             if world == 1 and os.path.exists(tpath):
                 committed = {"hbm_bytes_per_launch": json.load(open(tpath)).get("count_fast_kernel_hbm_bytes_per_launch"),
