@@ -55,7 +55,8 @@ struct CountArgs {
 	unsigned compact;
 	const unsigned *pn_blk_off; const unsigned *pn_nblk; const int2 *pn_se; const unsigned char *pn_strand; const unsigned *pn_line; const unsigned *pn_bucket;
 	const unsigned long long *p1_off, *p2_off, *pn_off, *slot_off;    // n_buckets + 1 each
-	const unsigned *wg_first;          // per workgroup of the fast kernel's grid: the bucket its slot range starts in
+	const lsq::VisitRec *visits;       // per bucket: what a visit needs, in one record (n_buckets + 1)
+	const unsigned *wg_first;          // per workgroup of the fast kernel's grid: the first packed bucket that holds slots of its share (n_buckets: none)
 	const unsigned long long *wg_cut;  // ... and the ranges' bounds in slots (grid + 1 values)
 	unsigned long long total_slots;
 	unsigned long long n_pn;           // reads with three or more blocks
@@ -1241,61 +1242,12 @@ __device__ inline void pool_n_worker(const CountArgs &A, const unsigned long lon
 #ifndef LSQ_FAST_WAVES
 #define LSQ_FAST_WAVES 6
 #endif
-// What a workgroup needs to know about one bucket visit; found with scalar loads, kept in LDS
-// beside the bucket's tables while the bucket before it is still being streamed.
-struct BucketVisit {
-	BucketDesc d;
-	unsigned long long bs, be;            // the bucket's slots
-	unsigned long long p1o, p1n, p2o, p2n;   // first read and count of its one- and two-block pools
-	unsigned b, valid;
-};
-constexpr unsigned VISIT_LDS_BYTES = 128;
-static_assert(sizeof(BucketVisit) <= VISIT_LDS_BYTES, "BucketVisit has a fixed LDS slot");
-
-// next packed bucket at or after b that holds slots of [s_begin, s_end); n_buckets when there is none
-__device__ inline unsigned find_bucket(const CountArgs &A, unsigned b, const unsigned long long s_begin, const unsigned long long s_end) {
-	for (b = (unsigned)__builtin_amdgcn_readfirstlane((int)b); b < A.n_buckets; ++b) {
-		const unsigned long long bs = A.slot_off[b], be = A.slot_off[b + 1];
-		const unsigned kind = A.buckets[b].kind;
-		if (bs >= s_end) return A.n_buckets;
-		if (be <= s_begin || be == bs || kind != 1) continue;
-		return b;
-	}
-	return A.n_buckets;
-}
-
-// tables of bucket b into an LDS buffer: the image, a cleared histogram, the visit record
-__device__ inline void stage_bucket(const CountArgs &A, const unsigned b, unsigned char *buf) {
-	const unsigned tid = threadIdx.x;
-	unsigned *rec = reinterpret_cast<unsigned *>(buf + A.tables_lds_bytes - VISIT_LDS_BYTES);
-	if (b >= A.n_buckets) {
-		if (tid == 0) rec[29] = 0u;
-		return;
-	}
-	const BucketDesc d = A.buckets[b];
-	const unsigned long long bs = A.slot_off[b], be = A.slot_off[b + 1];
-	const unsigned long long p1a = A.p1_off[b], p1b = A.p1_off[b + 1], p2a = A.p2_off[b], p2b = A.p2_off[b + 1];
-	global_words src = (global_words)(A.images + d.img_off);
-	uint4 *dst = reinterpret_cast<uint4 *>(buf);
-	for (unsigned i = tid; i < d.img_bytes / 16; i += COUNT_BLOCK) { const u32x4 t = src[i]; dst[i] = make_uint4(t.x, t.y, t.z, t.w); }
-	unsigned long long *h = reinterpret_cast<unsigned long long *>(buf + d.hist_off);
-	for (unsigned i = tid; i < HIST_REPLICAS * (d.n_cls | 1u); i += COUNT_BLOCK) h[i] = 0;
-	if (tid == 0) {
-		rec[0] = d.img_off; rec[1] = d.img_bytes; rec[2] = d.n_events; rec[3] = d.n_bins; rec[4] = (unsigned)d.lo; rec[5] = d.shift;
-		rec[6] = d.ev_off; rec[7] = d.seg_off; rec[8] = d.iso_off; rec[9] = d.hist_off; rec[10] = d.n_cls; rec[11] = d.cls_base;
-		rec[12] = d.ev_base; rec[13] = (unsigned)d.chrom_id; rec[14] = d.kind; rec[15] = (unsigned)d.hi;
-		unsigned long long *r64 = reinterpret_cast<unsigned long long *>(rec + 16);
-		r64[0] = bs; r64[1] = be; r64[2] = p1a; r64[3] = p1b - p1a; r64[4] = p2a; r64[5] = p2b - p2a;
-		rec[28] = b; rec[29] = 1u;
-	}
-}
-
 // <COMPACT, 2>: four one-block reads per lane and look, six waves a SIMD (80 registers); <true, 4>: eight, five waves (96
 // registers) -- for the launches that are held to five workgroups a compute unit anyway (run_count), where the longer
 // step of a lane costs no occupancy and the look is shared by twice the reads
 template <bool COMPACT, int P1W>
 __global__ void __launch_bounds__(COUNT_BLOCK, P1W == 4 ? 5 : LSQ_FAST_WAVES) lsq_count_fast_kernel(CountArgs A) {
-	// LDS: the bucket's tables (image, histograms, visit record), then the waves' rings
+	// LDS: the bucket's tables (image, histograms), then the waves' rings
 	extern __shared__ __align__(16) unsigned char lds[];
 	const unsigned tid = threadIdx.x;
 	if (blockIdx.x < A.n_workers) { pool_n_worker(A, A.n_pn, A.n_workers); return; }
@@ -1305,27 +1257,34 @@ __global__ void __launch_bounds__(COUNT_BLOCK, P1W == 4 ? 5 : LSQ_FAST_WAVES) ls
 	const unsigned long long s_begin = A.wg_cut[wg], s_end = A.wg_cut[wg + 1u];
 	if (s_begin >= s_end) return;
 	if (ABL(A, 4096u)) return;       // developer switch: dispatch cost only
-	{
-		const unsigned b0 = find_bucket(A, A.wg_first[wg], s_begin, s_end);   // wg_first: lsq_wg_plan_kernel
-		if (b0 >= A.n_buckets) return;
-		stage_bucket(A, b0, lds);
-	}
-	__syncthreads();
-	if (ABL(A, 8192u)) return;       // developer switch: dispatch + first staging
-	for (;;) {
+	// the share's buckets, one visit record each (scalar loads: the bucket number is wave-uniform); the host's plan names
+	// the first, every record the next packed bucket with slots
+	unsigned b = (unsigned)__builtin_amdgcn_readfirstlane((int)A.wg_first[wg]);
+	bool first_visit = true;
+	while (b < A.n_buckets) {
+		// (through the constant address space: the records are written before the launch and never during it, and a uniform
+		// address there is a scalar load -- as plain global memory the compiler, seeing the kernel's own atomics, took vector
+		// loads and two dozen readfirstlanes)
+		typedef const lsq::VisitRec __attribute__((address_space(4))) *const_visit;
+		const_visit vr = (const_visit)(A.visits + b);
+		const unsigned long long bs = vr->bs;
+		if (bs >= s_end) break;
+		const BucketDesc d = vr->d;
+		const unsigned long long be = vr->be, p1o = vr->p1o, n1 = vr->p1n, p2o = vr->p2o, n2 = vr->p2n;
+		const unsigned next = vr->next;
 		unsigned char *buf = lds;
-		// the visit record, wave-uniform: every dword through readfirstlane so that it lives in scalar registers
-		const unsigned *rec = reinterpret_cast<const unsigned *>(buf + A.tables_lds_bytes - VISIT_LDS_BYTES);
-		auto r32 = [&](unsigned q) { return (unsigned)__builtin_amdgcn_readfirstlane((int)rec[q]); };
-		auto r64 = [&](unsigned q) { return (unsigned long long)r32(q) | ((unsigned long long)r32(q + 1) << 32); };
-		BucketVisit V;
-		V.d.img_off = r32(0); V.d.img_bytes = r32(1); V.d.n_events = r32(2); V.d.n_bins = r32(3); V.d.lo = (int)r32(4); V.d.shift = r32(5);
-		V.d.ev_off = r32(6); V.d.seg_off = r32(7); V.d.iso_off = r32(8); V.d.hist_off = r32(9); V.d.n_cls = r32(10); V.d.cls_base = r32(11);
-		V.d.ev_base = r32(12); V.d.chrom_id = (int)r32(13); V.d.kind = r32(14); V.d.hi = (int)r32(15);
-		V.bs = r64(16); V.be = r64(18); V.p1o = r64(20); V.p1n = r64(22); V.p2o = r64(24); V.p2n = r64(26);
-		V.b = r32(28); V.valid = r32(29);
-		const BucketDesc &d = V.d;
-		const unsigned b = V.b;
+		// ---- stage: the image into LDS, the histograms cleared (the flush of the bucket before is behind a barrier)
+		if (!first_visit) __syncthreads();
+		first_visit = false;
+		{
+			global_words src = (global_words)(A.images + d.img_off);
+			uint4 *dst = reinterpret_cast<uint4 *>(buf);
+			for (unsigned i = tid; i < d.img_bytes / 16; i += COUNT_BLOCK) { const u32x4 t = src[i]; dst[i] = make_uint4(t.x, t.y, t.z, t.w); }
+			unsigned long long *h = reinterpret_cast<unsigned long long *>(buf + d.hist_off);
+			for (unsigned i = tid; i < HIST_REPLICAS * (d.n_cls | 1u); i += COUNT_BLOCK) h[i] = 0;
+		}
+		__syncthreads();
+		if (ABL(A, 8192u)) return;       // developer switch: dispatch + first staging
 		const uint4 *bins = reinterpret_cast<const uint4 *>(buf);
 		const uint4 *cells = reinterpret_cast<const uint4 *>(buf + d.seg_off);
 		// (iso_off of a packed bucket: cells proper | all owner records << 16; the CellX records follow the Cell ones)
@@ -1338,17 +1297,16 @@ __global__ void __launch_bounds__(COUNT_BLOCK, P1W == 4 ? 5 : LSQ_FAST_WAVES) ls
 		C.n_events = d.n_events; C.bucket = b;
 		C.slot0 = 0; C.pool = 0;
 		C.exc = A.exc; C.exc_count = A.exc_count; C.exc_cap = A.exc_cap; C.ablate = A.ablate; C.dbg = A.dbg;
-		const unsigned long long l0 = (s_begin > V.bs ? s_begin : V.bs) - V.bs;
-		const unsigned long long l1 = (s_end < V.be ? s_end : V.be) - V.bs;
-		const unsigned long long n1 = V.p1n, n2 = V.p2n;
+		const unsigned long long l0 = (s_begin > bs ? s_begin : bs) - bs;
+		const unsigned long long l1 = (s_end < be ? s_end : be) - bs;
 		// ---- pool 1
 		if (l0 < n1 && !ABL(A, 1024u)) {
-			if constexpr (COMPACT) stream_pool1_compact<2 * P1W>(C, bins, cells, cellx, n_cells, d, A, wave_queue, A.p1, V.p1o + l0, V.p1o + (l1 < n1 ? l1 : n1));
-			else stream_pool_fast<2, COMPACT, P1W>(C, bins, cells, cellx, n_cells, d, A, wave_queue, reinterpret_cast<const uint4 *>(A.p1), V.p1o + l0, V.p1o + (l1 < n1 ? l1 : n1));
+			if constexpr (COMPACT) stream_pool1_compact<2 * P1W>(C, bins, cells, cellx, n_cells, d, A, wave_queue, A.p1, p1o + l0, p1o + (l1 < n1 ? l1 : n1));
+			else stream_pool_fast<2, COMPACT, P1W>(C, bins, cells, cellx, n_cells, d, A, wave_queue, reinterpret_cast<const uint4 *>(A.p1), p1o + l0, p1o + (l1 < n1 ? l1 : n1));
 		}
 		// ---- pool 2
 		if (l1 > n1 && l0 < n1 + n2 && !ABL(A, 2048u)) {
-			const unsigned long long q0 = V.p2o + ((l0 > n1 ? l0 : n1) - n1), q1 = V.p2o + ((l1 < n1 + n2 ? l1 : n1 + n2) - n1);
+			const unsigned long long q0 = p2o + ((l0 > n1 ? l0 : n1) - n1), q1 = p2o + ((l1 < n1 + n2 ? l1 : n1 + n2) - n1);
 			if constexpr (COMPACT) stream_pool2_compact<(P1W == 4 ? LSQ_P2_COMPACT_WORDS_W5 : LSQ_P2_COMPACT_WORDS)>(C, bins, cells, cellx, n_cells, d, A, wave_queue, A.p2, q0, q1);
 			else stream_pool_fast<1, COMPACT, P1W>(C, bins, cells, cellx, n_cells, d, A, wave_queue, reinterpret_cast<const uint4 *>(A.p2), q0, q1);
 		}
@@ -1365,12 +1323,8 @@ __global__ void __launch_bounds__(COUNT_BLOCK, P1W == 4 ? 5 : LSQ_FAST_WAVES) ls
 				atomicAdd(&A.bases[d.cls_base + i], v & BASES_MASK);
 			}
 		}
-		// the next bucket of the share, staged between two barriers (a second table buffer, filled while
-		// this bucket streams, cost a resident workgroup per CU and measured slower)
-		__syncthreads();
-		stage_bucket(A, find_bucket(A, b + 1u, s_begin, s_end), lds);
-		__syncthreads();
-		if (!reinterpret_cast<const unsigned *>(lds + A.tables_lds_bytes - VISIT_LDS_BYTES)[29]) break;
+		if (be >= s_end) break;          // the share ends in this bucket
+		b = next;
 	}
 }
 
@@ -1535,7 +1489,7 @@ int run_count(lsq_ctx *c) {
 	bool counted_signalled = false;
 	if (c->time_events) HIP_TRY(hipEventRecord(c->ev0, st));      // ev0..ev1 brackets the count kernel launches only
 	const unsigned generic_tables_bytes = (std::max<unsigned>(E.max_lds_bytes, 16) + 15u) & ~15u;
-	const unsigned tables_bytes = generic_tables_bytes + VISIT_LDS_BYTES;            // fast kernel: + the visit record
+	const unsigned tables_bytes = generic_tables_bytes;
 	// Five workgroups a compute unit, not the six that registers and tables would allow: 5 x 80 registers a SIMD leave
 	// room for a wave of the EM kernel (104) beside them, so the EM of the step before runs without displacing count waves
 	// (measured with LDS padding at the same tables: 6 -> 0.1429, 5 -> 0.1366, 4 -> 0.1433 ms per step on C3).  The LDS
@@ -1617,10 +1571,13 @@ int run_count(lsq_ctx *c) {
 				cut[(size_t)g] = std::max(t, cut[(size_t)g - 1]);
 			}
 			cut[(size_t)grid] = mr.total_slots;
+			// the first packed bucket that holds slots of the share [cut[g], cut[g + 1]) (the kernel follows the visit
+			// records' links from there); B when there is none
 			bb = 0;
 			for (unsigned long long g = 0; g < grid; ++g) {
 				while (bb + 1 < B && so[bb + 1] <= cut[(size_t)g]) ++bb;
-				first[(size_t)g] = (unsigned)bb;
+				const unsigned f = mr.next_packed_host[bb];
+				first[(size_t)g] = (f < B && so[f] < cut[(size_t)g + 1]) ? f : (unsigned)B;
 			}
 			int rc = mr.wg_first.upload(first.data(), first.size(), st);
 			if (!rc) rc = mr.wg_cut.upload(cut.data(), cut.size(), st);
@@ -1630,7 +1587,7 @@ int run_count(lsq_ctx *c) {
 		}
 		CountArgs A{};
 		A.buckets = c->buckets.p; A.images = c->images.p; A.ties = c->ties.p; A.strand_rank = c->strand_rank.p;
-		A.wg_first = mr.wg_first.p; A.wg_cut = mr.wg_cut.p;
+		A.wg_first = mr.wg_first.p; A.wg_cut = mr.wg_cut.p; A.visits = mr.visits.p;
 		A.read_names = mr.named ? mr.names.p : nullptr; A.read_name_off = mr.named ? mr.name_off.p : nullptr;
 		A.gene_names = c->gene_names.p; A.gene_name_off = c->gene_name_off.p;
 		A.n_buckets = (unsigned)E.buckets.size();

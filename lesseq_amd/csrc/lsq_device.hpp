@@ -72,6 +72,19 @@ struct DevBuf {
 template <class T>
 struct DevView { T *p = nullptr; size_t n = 0; };     // a slice of somebody else's allocation
 
+// What a workgroup of the count kernel needs to know about one visit to a bucket, in one 128-byte record per (read file,
+// bucket), written once per read set (ingest): the bucket's description, where its slots and its one- and two-block
+// records lie, and the next packed bucket that holds any.  A wave reads it with scalar loads -- one memory round trip
+// where the kernel used to chase the description, three offset arrays and the bucket search one after the other.
+struct VisitRec {
+	BucketDesc d;
+	unsigned long long bs, be;               // the bucket's slots
+	unsigned long long p1o, p1n, p2o, p2n;   // first record and number of records of its one- and two-block pools
+	unsigned b, next;                        // this bucket; the next packed bucket with slots (n_buckets: none)
+	unsigned pad[2];
+};
+static_assert(sizeof(VisitRec) == 128, "VisitRec is read as 32 dwords");
+
 struct MethodReads {
 	DevBuf<ExcEntry> exc;                  // exception lists: two halves of exc_cap entries, one per counter set
 	size_t exc_cap = 0;
@@ -92,6 +105,8 @@ struct MethodReads {
 	DevBuf<unsigned> wg_first;             // per workgroup of the fast kernel's grid (`wg_grid` of them): the bucket its share starts in
 	DevBuf<unsigned long long> wg_cut;     // ... and the shares' bounds in slots (wg_grid + 1 values)
 	std::vector<unsigned long long> slot_off_host;   // the buckets' slot offsets (n_buckets + 1), for the share plan
+	DevBuf<VisitRec> visits;               // per bucket (n_buckets + 1: the last one ends every chain)
+	std::vector<unsigned> next_packed_host;          // per bucket b: the first packed bucket >= b that holds slots (n_buckets: none), for the share plan
 	unsigned long long wg_grid = 0;
 };
 

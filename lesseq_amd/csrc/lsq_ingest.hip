@@ -466,6 +466,27 @@ static int ingest_device(lsq_ctx *c, int method, const IngestRaw &Rw, uint64_t n
 		for (unsigned b = 0; b < B; ++b) mx = std::max(mx, so[b + 1] - so[b]);
 		mr.slot_off_host = so;
 		mr.skew = (B && mr.total_slots) ? (double)mx * (double)B / (double)mr.total_slots : 1.0;
+		// the count kernel's visit records (lsq_device.hpp VisitRec)
+		std::vector<unsigned long long> o1(B + 1, 0), o2(B + 1, 0);
+		HIP_TRY(hipMemcpyAsync(o1.data(), mr.p1_off.p, (B + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipMemcpyAsync(o2.data(), mr.p2_off.p, (B + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
+		std::vector<VisitRec> vis(B + 1);
+		mr.next_packed_host.assign(B + 1, B);
+		memset(vis.data(), 0, vis.size() * sizeof(VisitRec));
+		unsigned next = B;
+		for (unsigned b = B; b-- > 0;) {
+			VisitRec &v = vis[b];
+			v.d = E.buckets[b];
+			v.bs = so[b]; v.be = so[b + 1];
+			v.p1o = o1[b]; v.p1n = o1[b + 1] - o1[b]; v.p2o = o2[b]; v.p2n = o2[b + 1] - o2[b];
+			v.b = b; v.next = next;
+			if (E.buckets[b].kind == 1u && so[b + 1] > so[b]) next = b;
+			mr.next_packed_host[b] = next;
+		}
+		vis[B].b = B; vis[B].next = B; vis[B].bs = vis[B].be = mr.total_slots;
+		if ((rc = mr.visits.upload(vis.data(), vis.size(), st))) return rc;
+		HIP_TRY(hipStreamSynchronize(st));           // the host vector goes out of scope
 	}
 	mr.present = true;
 	c->counted = c->solved = false;
