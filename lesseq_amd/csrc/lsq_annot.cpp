@@ -779,7 +779,11 @@ int plan_device(lsq_events &E) {
 					const uint32_t k = (x.info >> 2) & 0x3Fu;
 					if (x.info >= CELL_INFO_EMPTY || k == CELL_K_START) continue;
 					const Event &e = E.ev[lst[b_begin + x.ev]];
-					for (int k2 = (int)k + 1; k2 < e.N; ++k2) E.jg_keys.push_back(((uint64_t)ci << 32) | (uint32_t)(int32_t)e.seg_s[k2]);
+					// block 1 ends on the end of the owner's segment k (variant 0) or, where k + 1 starts on that end, on the end of
+					// k + 1 (variant 1: the block runs through both); block 2 starts a later segment
+					for (int k2 = (int)k + 1; k2 < e.N; ++k2) E.jg_keys.push_back(jg_key(ci, 0u, (int32_t)e.seg_s[k2]));
+					if ((int)k + 1 < e.N && e.seg_s[k + 1] == e.seg_e[k])
+						for (int k2 = (int)k + 2; k2 < e.N; ++k2) E.jg_keys.push_back(jg_key(ci, 1u, (int32_t)e.seg_s[k2]));
 				}
 			E.buckets.push_back(d);
 		}

@@ -1088,30 +1088,39 @@ __device__ inline void stream_pool2_compact(FastCtx &C, const uint4 *bins, const
 		const bool start1 = k1 == CELL_K_START;
 		const bool inside1 = v1 && !start1 && rd.y <= (int)cw1.z && rd.z != rd.y;            // block 1 ends inside its segment (touching blocks: the exception pass decides)
 		const bool ends1 = inside1 && rd.y == (int)cw1.z;                                      // ... on its end
+		// ... or runs on through the segment that abuts the owner's (the cell's e2 > e1) and ends on that one's end
+		const bool ends1b = v1 && !start1 && (int)cw1.w > (int)cw1.z && rd.y == (int)cw1.w && rd.z != rd.y;
 		// the owner's record: where its segments start and end (unused ones hold INT32_MAX, which no block reaches)
 		const unsigned ri = 3u * (v1 ? cx1.w : 0u);
 		const uint4 w0r = C.recs[ri], w1r = C.recs[ri + 1u], w2r = C.recs[ri + 2u];
-		// block 2 continues the match only from the first base of a later segment of the same event
+		// block 2 continues the match only from the first base of a later segment of the same event ...
 		const unsigned k2 = rd.z == (int)w1r.z ? 1u : (rd.z == (int)w2r.x ? 2u : (rd.z == (int)w2r.z ? 3u : 0u));
 		const int end2 = k2 == 1u ? (int)w1r.w : (k2 == 2u ? (int)w2r.y : (int)w2r.w);
-		const bool junction = ends1 && k2 > k1;
-		const bool J = junction && rd.w <= end2;
+		// ... and may itself run on into the segment that abuts that one (abut bit k2: segment k2 + 1 starts where k2 ends)
+		const unsigned abut = (w0r.y >> FAST_ABUT_SHIFT) & 7u;
+		const bool abut2 = k2 != 0u && k2 < 3u && ((abut >> k2) & 1u) != 0u;
+		const int end2b = !abut2 ? end2 : (k2 == 1u ? (int)w2r.y : (int)w2r.w);
+		const unsigned k1e = ends1b ? k1 + 1u : k1;          // the last segment of block 1's run
+		const bool junction = (ends1 || ends1b) && k2 > k1e;
+		const bool J = junction && rd.w <= end2, Jb = junction && rd.w > end2 && rd.w <= end2b;
 		const bool S = inside1 && !junction;
 		// counts for nobody: from a start cell and over before gene_end; or block 1 starts inside no segment at all
 		const bool drop = (v1 && start1 && rd.w <= (int)cw1.w) || (here && i1 == CELL_INFO_EMPTY);
 		const unsigned len1 = ra[0] >> lsq::COMPACT_OFF_BITS, total = len1 + (rb[0] >> lsq::COMPACT_OFF_BITS);
 		const unsigned long long tbl = ((unsigned long long)w0r.w << 32) | w0r.z;
-		const unsigned cls = (unsigned)(tbl >> (4u * ((1u << (k1 & 3u)) | (1u << k2)))) & 0xFu;
+		const unsigned mask1 = (1u << (k1 & 3u)) | (ends1b ? 2u << (k1 & 3u) : 0u), maskA = mask1 | (1u << k2), maskB = maskA | (2u << k2);
+		const unsigned clsA = (unsigned)(tbl >> (4u * (maskA & 15u))) & 0xFu, clsB = abut2 ? (unsigned)(tbl >> (4u * (maskB & 15u))) & 0xFu : 0u;
 		const unsigned sa = cx1.x & 0xFFFFu;
-		const unsigned jslot = cls != 0u ? (w0r.y & 0xFFFFu) + cls - 1u : CELL_NONE;      // the histogram slot of the junction's two-segment class
-		const bool add0 = in0 && ((J && cls != 0u) || (S && sa != CELL_NONE && 50u * len1 > 49u * total));
-		const unsigned slot0 = J ? jslot : sa;
+		// the histogram slots of the junction's classes: segments of block 1 + segment k2, and + segment k2 + 1 (CELL_NONE: no compatible isoform)
+		const unsigned slotA = clsA != 0u ? (w0r.y & 0xFFFFu) + clsA - 1u : CELL_NONE, slotB = clsB != 0u ? (w0r.y & 0xFFFFu) + clsB - 1u : CELL_NONE;
+		const bool addS = in0 && S && sa != CELL_NONE && 50u * len1 > 49u * total;
 		bool park[NR];
-		park[0] = in0 && len1 != 0u && !(J || S || drop) && !ABL(A, 17u | 1048576u);
+		park[0] = in0 && len1 != 0u && !(J || Jb || S || drop) && !ABL(A, 17u | 1048576u);
 		if (ABL(A, 256u) && park[0]) atomicAdd(&A.dbg[8 + (v1 ? 1 : 0)], 1ull);       // parked: block 1 in no one-owner cell / in one
-		unsigned n_add = add0 ? 1u : 0u, s_add = add0 ? (J ? total : len1) : 0u, n_add2 = 0, s_add2 = 0;
-		// ---- the other records: block 2 must end inside the junction's second segment, i.e. gap + length <= lim
-		const int lim = junction ? end2 - rd.y : -1;
+		unsigned nA = (in0 && J && slotA != CELL_NONE) ? 1u : 0u, sA = nA ? total : 0u, nB = (in0 && Jb && slotB != CELL_NONE) ? 1u : 0u, sB = nB ? total : 0u;
+		// ---- the other records: block 2 must end inside the junction's second segment (gap + length <= lim) or inside the one
+		// that abuts it (<= limb)
+		const int lim = junction ? end2 - rd.y : -1, limb = junction ? end2b - rd.y : -1;
 		bool any_park = park[0];
 #pragma unroll
 		for (int j = 1; j < NR; ++j) {
@@ -1119,18 +1128,19 @@ __device__ inline void stream_pool2_compact(FastCtx &C, const uint4 *bins, const
 			const int reach = (int)(rb[j] & lsq::COMPACT_OFF_MASK) + (int)l2;         // from the end of block 1 to the end of block 2
 			bool in = l1 != 0u;                                                          // (padding of a junction group: an empty record)
 			if (!interior) { const unsigned idx = idx0 + (unsigned)j; in = in && idx < n && idx - first_rel < n_rel; }
-			const bool same = in && reach <= lim;
-			const bool cnt = same && jslot != CELL_NONE;
-			n_add2 += cnt ? 1u : 0u;
-			s_add2 += cnt ? l1 + l2 : 0u;
-			park[j] = in && !same && !ABL(A, 17u | 1048576u | 2097152u);
+			const bool sameA = in && reach <= lim, sameB = in && reach > lim && reach <= limb;
+			const bool cA = sameA && slotA != CELL_NONE, cB = sameB && slotB != CELL_NONE;
+			nA += cA ? 1u : 0u; sA += cA ? l1 + l2 : 0u;
+			nB += cB ? 1u : 0u; sB += cB ? l1 + l2 : 0u;
+			park[j] = in && !(sameA || sameB) && !ABL(A, 17u | 1048576u | 2097152u);
+			if (ABL(A, 256u) && park[j]) atomicAdd(&A.dbg[junction ? 14 : 13], 1ull);       // parked followers: block 2 runs past the junction's segments / the first record crosses no junction
 			any_park = any_park || park[j];
 		}
 		if (!ABL(A, 1u)) {
-			if (n_add && n_add2 && slot0 == jslot) { n_add += n_add2; s_add += s_add2; n_add2 = 0; }
-			if (n_add) atomicAdd(&C.hist[slot0], ((unsigned long long)n_add << 40) | s_add);
-			if (n_add2) atomicAdd(&C.hist[jslot], ((unsigned long long)n_add2 << 40) | s_add2);
-		} else asm volatile("" ::"v"(n_add), "v"(s_add), "v"(n_add2), "v"(s_add2));
+			if (addS) atomicAdd(&C.hist[sa], (1ull << 40) | len1);
+			if (nA) atomicAdd(&C.hist[slotA], ((unsigned long long)nA << 40) | sA);
+			if (nB) atomicAdd(&C.hist[slotB], ((unsigned long long)nB << 40) | sB);
+		} else asm volatile("" ::"v"(nA), "v"(sA), "v"(nB), "v"(sB));
 		if (__any(any_park)) {
 			// parked as their compact records: (block 1, block 2, event to look at, position in the range)
 			const unsigned hint0 = v1 ? (cx1.w | PARK_ONE_EVENT) : evf;
@@ -1269,7 +1279,10 @@ __global__ void __launch_bounds__(COUNT_BLOCK, P1W == 4 ? 5 : LSQ_FAST_WAVES) ls
 		const_visit vr = (const_visit)(A.visits + b);
 		const unsigned long long bs = vr->bs;
 		if (bs >= s_end) break;
-		const BucketDesc d = vr->d;
+		BucketDesc d;         // (member by member: a struct copy out of that address space has no constructor to bind to)
+		d.img_off = vr->d.img_off; d.img_bytes = vr->d.img_bytes; d.n_events = vr->d.n_events; d.n_bins = vr->d.n_bins; d.lo = vr->d.lo; d.shift = vr->d.shift;
+		d.ev_off = vr->d.ev_off; d.seg_off = vr->d.seg_off; d.iso_off = vr->d.iso_off; d.hist_off = vr->d.hist_off; d.n_cls = vr->d.n_cls; d.cls_base = vr->d.cls_base;
+		d.ev_base = vr->d.ev_base; d.chrom_id = vr->d.chrom_id; d.kind = vr->d.kind; d.hi = vr->d.hi;
 		const unsigned long long be = vr->be, p1o = vr->p1o, n1 = vr->p1n, p2o = vr->p2o, n2 = vr->p2n;
 		const unsigned next = vr->next;
 		unsigned char *buf = lds;

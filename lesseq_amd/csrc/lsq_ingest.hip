@@ -188,8 +188,8 @@ __global__ void __launch_bounds__(256) lsq_ingest_classify_kernel(IngestTables T
 									// later segment of that event does (the keys hold exactly those starts); else the bucket's last group
 									const unsigned k0 = T.jg_base[b], k1 = T.jg_base[b + 1];
 									unsigned g = k1;
-									if (cell < n_cells && e[0] == cells[cell].e1) {
-										const unsigned long long want = ((unsigned long long)cell << 32) | (unsigned)s[1];
+									if (cell < n_cells && (e[0] == cells[cell].e1 || e[0] == cells[cell].e2)) {
+										const unsigned long long want = lsq::jg_key(cell, e[0] == cells[cell].e1 ? 0u : 1u, s[1]);
 										unsigned lo_k = k0, hi_k = k1;
 										while (lo_k < hi_k) { const unsigned mid = (lo_k + hi_k) >> 1; if (T.jg_keys[mid] < want) lo_k = mid + 1; else hi_k = mid; }
 										if (lo_k < k1 && T.jg_keys[lo_k] == want) g = lo_k;

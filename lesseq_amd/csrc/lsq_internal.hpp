@@ -191,6 +191,12 @@ constexpr uint32_t CELL_INFO_EMPTY = 0xFFFFFFFEu;          // a stretch inside n
 // to the general walk
 constexpr uint32_t CELL_K_START = 63u;
 
+// key of a junction group of the two-block pool (lsq_events::jg_keys): ascending in (cell, variant, start of block 2)
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline uint64_t jg_key(uint32_t cell, uint32_t variant, int32_t block2_start) { return ((uint64_t)cell << 33) | ((uint64_t)(variant & 1u) << 32) | (uint32_t)block2_start; }
+
 struct TieRec {            // global memory, device event order; read only on start ties
 	uint8_t strand_id;
 	uint8_t tie_mode;
@@ -231,6 +237,8 @@ struct lsq_events {
 	// count kernel settles as junction reads -- block 1 starts in a one-owner cell, ends on the end of that owner's segment,
 	// block 2 starts on the first base of a later segment of the same event.  The ingest lays the two-block reads out by
 	// these groups (and one group per bucket for all others), padded to two records: a lane's two reads cross one junction.
+	// (keys: jg_key(cell, variant, start of block 2); variant 1: block 1 runs on through the segment that abuts the owner's and
+	// ends on THAT one's end)
 	std::vector<uint64_t> jg_keys;
 	std::vector<uint32_t> jg_base;                 // per bucket: first of its keys (n_buckets + 1)
 	std::vector<int32_t> dev2out;                  // device event index -> output index

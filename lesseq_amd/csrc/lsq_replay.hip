@@ -526,8 +526,8 @@ int lsq_debug_check_pool_layout(lsq_ctx *c, int method, unsigned long long *out)
 		const uint64_t *k0 = E.jg_keys.data() + E.jg_base[b], *k1 = E.jg_keys.data() + E.jg_base[b + 1];
 		auto group_of = [&](const int32_t *r) -> long {          // index of the read's junction key, -1: the bucket's last group
 			const long cl = cell_of(r[0]);
-			if (cl < 0 || r[1] != cells[cl].e1) return -1;
-			const uint64_t want = ((uint64_t)cl << 32) | (uint32_t)r[2];
+			if (cl < 0 || (r[1] != cells[cl].e1 && r[1] != cells[cl].e2)) return -1;
+			const uint64_t want = lsq::jg_key((uint32_t)cl, r[1] == cells[cl].e1 ? 0u : 1u, r[2]);
 			const uint64_t *it = std::lower_bound(k0, k1, want);
 			return (it != k1 && *it == want) ? (long)(it - k0) : -1;
 		};

@@ -66,6 +66,7 @@ for bud in budgets:
             print("   dbg: one-block wave steps %d, of which with a parked read %d" % (buf[12], buf[11]))
             print("   dbg: parked1=%d parked2=%d walk_steps=%d walk_lanes=%d exceptions=%d  (retained %d)" % (buf[0], buf[1], buf[2], buf[3], buf[4], ctx.retained(0)))
             print("   dbg: parked one-block reads: not in the lane's cell %d, one-owner cell %d, two-owner cell %d" % (buf[5], buf[6], buf[7]))
+            print("   dbg: parked two-block followers: first record crosses no junction %d, block 2 runs past the junction's segment %d" % (buf[13], buf[14]))
         print("abl=%d " % abl, end="")
         print("lds=%d " % ev.lds_table_bytes, end="")
         print("%s budget=%6d buckets=%5d mult=%2d count_ms med=%.4f min=%.4f  %.0f GB/s (%.1f%% of 8TB/s)  em_ms=%.4f ingest_s=%.2f check=%s" % (
