@@ -268,7 +268,11 @@ int lsq_host_evaluated(const lsq_ctx *c, uint64_t *n_genes, uint64_t *n_reads);
  * workgroups a compute unit and the pools are compact, else four; 4; 8), "workgroups_per_cu" (resident workgroups of the count kernel per compute unit: 0 = as many as fit, default -1 = five
  * when the EM runs its one-lane-per-event kernel beside it and the read set is evenly deep, else as many as fit), "em_flat_min_events" (default 16 384: with at
  * least that many two-isoform events the ones that converged within 32 iterations last time are solved one lane per
- * event instead of four -- fewer instructions, longer passes).  LSQ_E_ARG for an unknown name.  The executables
+ * event instead of four -- fewer instructions, longer passes), "em_closed_form" (default 0; 1: two-isoform events with one read
+ * file run six ordinary EM iterations and finish in the closed form of their EM map -- the step of read.h:592-618 is then a
+ * Moebius map of theta_0, theta after m more iterations one exponential away, and the iteration at which read.h:659 stops
+ * is found by search: the same iteration counts, theta within 1e-13; pays where the slowest events take hundreds of
+ * iterations and little else runs beside the EM, e.g. a rank of an event-sharded job).  LSQ_E_ARG for an unknown name.  The executables
  * pass LSQ_OPTIONS="name=value,..." from the environment through this call. */
 int lsq_ctx_set_option(lsq_ctx *c, const char *name, double value);
 

@@ -61,8 +61,18 @@ extern "C" {
 
 int lsq_ctx_create(int device_id, lsq_ctx **out) LSQ_API_TRY {
 	if (!out) return fail(LSQ_E_ARG, "null argument");
+	// developer aid: LSQ_CLI_TIMING=1 prints where the start-up goes (stderr)
+	const bool timing = getenv("LSQ_CLI_TIMING") != nullptr;
+	auto t_last = std::chrono::steady_clock::now();
+	auto mark = [&](const char *what) {
+		if (!timing) return;
+		const auto t = std::chrono::steady_clock::now();
+		fprintf(stderr, "[timing]     %-32s %.3f s\n", what, std::chrono::duration<double>(t - t_last).count());
+		t_last = t;
+	};
 	int n = 0;
 	hipError_t e = hipGetDeviceCount(&n);
+	mark("context: runtime start-up");
 	if (e != hipSuccess || n <= 0) return fail(LSQ_E_DEVICE, "no HIP device available (%s)", e == hipSuccess ? "device count 0" : hipGetErrorString(e));
 	if (device_id < 0 || device_id >= n) return fail(LSQ_E_ARG, "device %d out of range (%d devices)", device_id, n);
 	HIP_TRY(hipSetDevice(device_id));
@@ -70,6 +80,7 @@ int lsq_ctx_create(int device_id, lsq_ctx **out) LSQ_API_TRY {
 	HIP_TRY(hipGetDeviceProperties(&prop, device_id));
 	if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
 		return fail(LSQ_E_DEVICE, "device %d is %s; this library carries gfx950 code only", device_id, prop.gcnArchName);
+	mark("context: device selected");
 	std::unique_ptr<lsq_ctx> c(new lsq_ctx);
 	c->device = device_id;
 	c->n_cu = prop.multiProcessorCount;
@@ -81,10 +92,12 @@ int lsq_ctx_create(int device_id, lsq_ctx **out) LSQ_API_TRY {
 		HIP_TRY(hipEventCreateWithFlags(&c->ev_mark2[l], hipEventDisableTiming));
 	}
 	c->stream_em = c->stream_em2[0];
+	mark("context: streams");
 	HIP_TRY(hipEventCreate(&c->ev0)); HIP_TRY(hipEventCreate(&c->ev1));
 	HIP_TRY(hipEventCreate(&c->ev2)); HIP_TRY(hipEventCreate(&c->ev3));
 	HIP_TRY(hipEventCreate(&c->evt0)); HIP_TRY(hipEventCreate(&c->evt1));
 	for (int m = 0; m < LSQ_MAX_METHODS; ++m) { HIP_TRY(hipEventCreate(&c->evf0[m])); HIP_TRY(hipEventCreate(&c->evf1[m])); }
+	mark("context: events");
 	*out = c.release();
 	return LSQ_OK;
 } LSQ_API_CATCH
@@ -173,6 +186,13 @@ int lsq_events_upload(lsq_ctx *c, lsq_events *E) LSQ_API_TRY {
 		}
 		c->em_places = (unsigned)order.size();
 		c->em_order_lane_valid[0] = c->em_order_lane_valid[1] = false;
+		{
+			const size_t np = std::max<size_t>(c->em_small_places, 1);
+			if ((rc = c->em_tail_count.alloc(4))) return rc;
+			HIP_TRY(hipMemsetAsync(c->em_tail_count.p, 0, 4 * sizeof(uint32_t), c->stream));
+			for (int l = 0; l < 2; ++l)
+				if ((rc = c->em_tail_u32[l].alloc(2 * np)) || (rc = c->em_tail_flag[l].alloc(np)) || (rc = c->em_tail_f64[l].alloc(3 * np))) return rc;
+		}
 		if (c->em_split.n != 3) { if ((rc = c->em_split.alloc(3))) return rc; }
 		HIP_TRY(hipMemsetAsync(c->em_split.p, 0xFF, 3 * sizeof(uint32_t), c->stream));
 		if ((rc = c->em_order.upload(order.data(), order.size(), c->stream))) return rc;
@@ -731,6 +751,9 @@ int lsq_ctx_set_option(lsq_ctx *c, const char *name, double value) LSQ_API_TRY {
 	} else if (n == "em_flat_min_events") {
 		if (!(value >= 0 && value <= 4e9)) return fail(LSQ_E_ARG, "em_flat_min_events must lie in 0..4e9");
 		c->opt_em_flat_min = (unsigned)value;
+	} else if (n == "em_closed_form") {
+		{ int rc = sync_all(c); if (rc) return rc; }
+		c->opt_em_closed = value != 0;
 	} else if (n == "em_regroup") {
 		c->opt_em_regroup = value != 0;
 		c->em_order_lane_valid[0] = c->em_order_lane_valid[1] = false;

@@ -165,6 +165,12 @@ struct lsq_ctx {
 	bool em_order_lane_valid[2] = {false, false};
 	unsigned em_regroup_age[2] = {0, 0};    // solves since the lane's order was last refreshed (every 16th solve refreshes it)
 	bool opt_em_regroup = true;
+	// "em_closed_form" (default off): two-isoform events with one read file run a few ordinary iterations and finish in the
+	// closed form of their EM map (lsq_em.hip: lsq_em_head_kernel / lsq_em_tail_kernel); the tail's list per step lane
+	bool opt_em_closed = false;
+	DevBuf<uint32_t> em_tail_count, em_tail_u32[2];
+	DevBuf<uint8_t> em_tail_flag[2];
+	DevBuf<double> em_tail_f64[2];
 	unsigned opt_em_flat_min = 16384;      // "em_flat_min_events": lean events from which on the fast ones run one lane per event
 	unsigned em_places = 0;
 	unsigned em_small_places = 0;           // the first of them: events of the lean EM kernel

@@ -435,6 +435,319 @@ __device__ inline void em_flat_body(const EmArgs &A, const unsigned block) {
 	em_lean<FS, 2, true, EmCacheFlat<FS>>(A, C, e, 0u, ev_ok, K, ib, inv_n, any_reads, run);
 }
 
+// ---- the lean group with one read file, without a placement: a head of sequential passes, then a closed form ---------------
+// A two-isoform event with one read file has three compatibility classes -- n1 reads on isoform 0 alone, n2 on isoform 1
+// alone, n3 on both -- and the EM step (read.h:592-618) is then a Moebius map of x = theta_0:
+//     x' = a + b x G0 / (x G0 + (1 - x) G1),   a = n1 / n, b = n3 / n,
+// i.e. x' = (alpha x + beta) / (gamma x + delta) with alpha = a (G0 - G1) + b G0, beta = a G1, gamma = G0 - G1, delta = G1.
+// With its fixed points p (attracting, in (0, 1)) and q, w = (x - p) / (x - q) obeys w' = kappa w, kappa = (gamma q +
+// delta) / (gamma p + delta): theta after m more iterations is ONE exponential away, x_m = (p - q w0 kappa^m) / (1 - w0 kappa^m).
+// The reference stops at the first iteration t with |1 - l(t-1) / l(t)| <= 1e-6 (read.h:659); along the monotone approach of
+// x to p that test, once true, stays true (checked on 9e5 random events over five decades of counts and ARS: no exception
+// when n1, n2 >= 1), so the stopping iteration is found by doubling steps and bisection -- ~8 evaluations of two
+// log-likelihoods instead of up to hundreds of dependent passes -- and the last EM step and the final log-likelihood are
+// then done by the ordinary pass, from theta(T - 1).  The numbers differ from the sequential iteration's by ~1e-13
+// (measured), the iteration count not at all -- except where the test value lies within the guard band of the threshold
+// at T or T - 1: flagged, and replayed in per-read order like any such event (lsq_replay.hip).
+// Every event first runs EM_HEAD_PASSES ordinary iterations (lsq_em_head_kernel: most events are done by then: median 5);
+// what still runs is appended to a list, and lsq_em_tail_kernel finishes the list: the closed form where it applies
+// (n1, n2 >= 1, G0, G1 > 0, 0 <= kappa < 1), the ordinary iteration otherwise.  No event waits for the slowest of its wave
+// through hundreds of passes, and nothing is learnt from an earlier solve.
+constexpr unsigned EM_HEAD_PASSES = 6;
+struct EmTail {
+	unsigned *count;               // [0] events appended by the head; [1] tail workgroups done (the last one clears both)
+	unsigned *ev, *iters;
+	unsigned char *flag;
+	double *t0, *t1, *ll;          // theta and log-likelihood after `iters` accepted iterations
+};
+
+template <int FS>
+__device__ inline void em_load_flat(const EmArgs &A, const unsigned e, const bool ev_ok, int &K, unsigned &ib, EmCacheFlat<FS> &C, double &n_total) {
+	K = ev_ok ? A.K[e] : 1;
+	const unsigned cb = ev_ok ? A.cls_base[e] : 0;
+	ib = ev_ok ? A.iso_base[e] : 0;
+	const int nc = (1 << K) - 1;
+	const int n_pairs = (int)A.n_methods * nc;        // <= FS for every event of this group
+#pragma unroll
+	for (int q = 0; q < FS; ++q) {
+		const bool has = ev_ok && q < n_pairs;
+		const int m = has ? q / nc : 0, c = has ? q - m * nc : 0;
+		C.kd[q] = has ? (double)A.cnt[(size_t)m * A.n_cls + cb + (unsigned)c] : 0.0;      // exact: counts are far below 2^53
+		C.cls[q] = has ? c + 1 : 0;
+#pragma unroll
+		for (int j = 0; j < 2; ++j) C.g[q][j] = (has && j < K) ? A.G[(size_t)m * A.n_iso + ib + j] : 0.0;
+	}
+	n_total = ((0.0 + C.kd[0]) + (0.0 + C.kd[1])) + ((0.0 + C.kd[2]) + (0.0 + (FS == 4 ? C.kd[FS - 1] : 0.0)));
+}
+
+// the stop test of read.h:659 as the kernels form it: floating abs; -inf, nan, zero keep the division's own answers
+__device__ inline double em_crit(const double ll, const double nll) {
+	const unsigned ex = (unsigned)((unsigned long long)__double_as_longlong(nll) >> 52) & 0x7FFu;
+	return (ex - 1u < 0x7FEu) ? fabs(1.0 - ll * fast_recip(nll)) : fabs(1.0 - ll / nll);
+}
+
+// ordinary iterations from (t3, ll, z3 = numerators at t3) until the stop test holds, `budget` iterations are done or the
+// cap is reached; the lanes of a wave run together
+template <int FS>
+__device__ inline void em_iterate(const EmArgs &A, const double (&kd)[FS], const double (&gm)[FS][2], const double inv_n, EmPairState<FS> &P,
+                                  double (&t3)[2], double &ll, double (&z3)[2], unsigned &iters, unsigned char &flag, bool &run, const unsigned budget) {
+	for (unsigned it = 0; it < budget && __any(run); ++it) {
+		double n3[2], nll, nz3[2];
+#pragma unroll
+		for (int j = 0; j < 2; ++j) n3[j] = z3[j] * inv_n;
+		em_pass_lean<FS, 2, true>(kd, gm, n3, run, P, nll, nz3);
+		const double crit = em_crit(ll, nll);
+		if (run) {
+#pragma unroll
+			for (int j = 0; j < 2; ++j) { t3[j] = n3[j]; z3[j] = nz3[j]; }
+			ll = nll;
+			++iters;
+			if (fabs(crit - 1E-6) < A.band) flag |= 1;
+			if (!(crit > 1E-6)) run = false;
+			else if (iters >= A.max_iters) { flag |= 2; run = false; }
+		}
+	}
+}
+
+template <int FS>
+__global__ void __launch_bounds__(64) lsq_em_head_kernel(EmArgs A, EmTail T) {
+#ifndef LSQ_EM_NO_PRIO
+	__builtin_amdgcn_s_setprio(3);
+#endif
+	const unsigned place = A.place0 + blockIdx.x * blockDim.x + threadIdx.x;
+	const unsigned e = place < A.n_places ? A.order[place] : 0xFFFFFFFFu;
+	const bool ev_ok = e != 0xFFFFFFFFu;
+	int K; unsigned ib; EmCacheFlat<FS> C; double n_total;
+	em_load_flat<FS>(A, e, ev_ok, K, ib, C, n_total);
+	const double inv_n = 1.0 / n_total;
+	// no reads: theta stays 1/K, log-likelihood 0; one isoform: theta = 1 (solve/solve.cpp:798-802)
+	bool run = ev_ok && n_total > 0 && K > 1;
+	const bool any_reads = ev_ok && n_total > 0;
+	double kd[FS], gm[FS][2], t3[2], z3[2], ll = 0;
+#pragma unroll
+	for (int t = 0; t < FS; ++t) {
+		kd[t] = C.kd[t];
+#pragma unroll
+		for (int j = 0; j < 2; ++j) gm[t][j] = (C.cls[t] >> j & 1) ? C.g[t][j] : 0.0;
+	}
+#pragma unroll
+	for (int j = 0; j < 2; ++j) t3[j] = (K == 1) ? 1.0 : 1.0 / (double)K;   // solve/solve.cpp:798-802, read.h:642
+	EmPairState<FS> P;
+#pragma unroll
+	for (int t = 0; t < FS; ++t) { P.s[t] = 1.0; P.r[t] = 1.0; P.lg[t] = 0.0; }
+	unsigned iters = 0;
+	unsigned char flag = 0;
+	em_pass_lean<FS, 2, true>(kd, gm, t3, any_reads, P, ll, z3);
+	em_iterate<FS>(A, kd, gm, inv_n, P, t3, ll, z3, iters, flag, run, EM_HEAD_PASSES);
+	if (!ev_ok) return;
+	if (run) {            // still running: the tail's
+		const unsigned at = atomicAdd(&T.count[0], 1u);
+		T.ev[at] = e; T.iters[at] = iters; T.flag[at] = flag; T.t0[at] = t3[0]; T.t1[at] = t3[1]; T.ll[at] = ll;
+		return;
+	}
+#pragma unroll
+	for (int j = 0; j < 2; ++j) if (j < K) A.theta[ib + j] = t3[j];
+	A.logll[e] = ll;
+	A.iters[e] = iters;
+	A.flags[e] = flag;
+}
+
+// theta after m more iterations of the map, from the state the closed form was set up at: x = theta_0 and y = theta_1 = 1 - x,
+// each formed without cancellation (an event whose reads all sit on one isoform has its fixed point ON the boundary, p = 1
+// or p = 0 exactly, and the other theta decays like kappa^m: it is y = (1 - p) - (p - q) u with 1 - p = 0, not 1 - x)
+struct EmMoebius {
+	double p, omp, pq, lk, w0, x0, y0;      // attracting fixed point, 1 - p, p - q (linear map: 1), log kappa, w at m = 0, theta at m = 0
+	bool linear;                            // G0 == G1: the map is x' = a + b x, w = x - p
+	__device__ __forceinline__ void at(const unsigned m, double &x, double &y) const {
+		if (m == 0u) { x = x0; y = y0; return; }
+		const double w = w0 * exp((double)m * lk);
+		const double u = linear ? w : w / (1.0 - w);
+		x = p + pq * u;
+		y = omp - pq * u;
+	}
+};
+
+template <int FS>
+__global__ void __launch_bounds__(64) lsq_em_tail_kernel(EmArgs A, EmTail T) {
+#ifndef LSQ_EM_NO_PRIO
+	__builtin_amdgcn_s_setprio(3);
+#endif
+	const unsigned n_list = __builtin_amdgcn_readfirstlane((int)*(volatile unsigned *)&T.count[0]);
+	const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (blockIdx.x * blockDim.x < n_list) {
+		const bool ev_ok = i < n_list;
+		const unsigned e = ev_ok ? T.ev[i] : 0xFFFFFFFFu;
+		int K; unsigned ib; EmCacheFlat<FS> C; double n_total;
+		em_load_flat<FS>(A, e, ev_ok, K, ib, C, n_total);
+		const double inv_n = 1.0 / n_total;
+		double kd[FS], gm[FS][2], t3[2], z3[2], ll = ev_ok ? T.ll[i] : 0.0;
+#pragma unroll
+		for (int t = 0; t < FS; ++t) {
+			kd[t] = C.kd[t];
+#pragma unroll
+			for (int j = 0; j < 2; ++j) gm[t][j] = (C.cls[t] >> j & 1) ? C.g[t][j] : 0.0;
+		}
+		t3[0] = ev_ok ? T.t0[i] : 0.5; t3[1] = ev_ok ? T.t1[i] : 0.5;
+		unsigned iters = ev_ok ? T.iters[i] : 0u;
+		unsigned char flag = ev_ok ? T.flag[i] : (unsigned char)0;
+		EmPairState<FS> P;
+#pragma unroll
+		for (int t = 0; t < FS; ++t) { P.s[t] = 1.0; P.r[t] = 1.0; P.lg[t] = 0.0; }
+		// ---- the closed form, where it applies: classes {0}, {1}, {0, 1} in the slots 0, 1, 2 (one read file).  Reads on both
+		// isoforms alone: always.  On one of them alone (the fixed point may then lie on the boundary): only with at least two
+		// accessible starts per isoform (G < 1) -- with G = 1 the log-likelihood itself runs to 0 there, and the test, a ratio
+		// of log-likelihoods, need not stay true once it is (seen in the random check): those events keep the ordinary iteration
+		const double n1 = kd[0], n2 = kd[1], n3 = kd[2], G0 = C.g[0][0], G1 = C.g[1][1];
+		bool closed = ev_ok && K == 2 && FS == 3 && G0 > 0.0 && G1 > 0.0 && iters + 2u < A.max_iters &&
+		              ((n1 >= 1.0 && n2 >= 1.0) || ((n1 >= 1.0 || n2 >= 1.0) && G0 < 1.0 && G1 < 1.0));
+		EmMoebius M;
+		M.x0 = t3[0]; M.y0 = t3[1]; M.p = 0.5; M.omp = 0.5; M.pq = 1.0; M.lk = -1.0; M.w0 = 0.0; M.linear = false;
+		if (closed) {
+			const double a = n1 * inv_n, b = n3 * inv_n, g = G0 - G1;
+			double p, q, kap;
+			if (g == 0.0) {
+				M.linear = true; p = a / (1.0 - b); q = p - 1.0; kap = b;
+			} else {
+				const double al = a * g + b * G0, be = a * G1, de = G1;
+				const double qb = de - al, D = qb * qb + 4.0 * g * be;                      // g x^2 + (de - al) x - be = 0
+				const double sq = sqrt(D), tq = -0.5 * (qb + copysign(sq, qb));
+				const double r1 = tq / g, r2 = -be / tq;                                     // the two roots, without cancellation
+				const double k1 = (g * r2 + de) / (g * r1 + de);                             // the map's slope at r1 (at r2: its inverse)
+				const bool first = k1 >= 0.0 && k1 < 1.0;
+				p = first ? r1 : r2; q = first ? r2 : r1; kap = first ? k1 : 1.0 / k1;
+				closed = D > 0.0 && tq != 0.0 && (first || k1 > 1.0);
+			}
+			// a fixed point on the boundary is exactly there
+			if (n2 == 0.0 && fabs(p - 1.0) < 1E-9) p = 1.0;
+			if (n1 == 0.0 && fabs(p) < 1E-9) p = 0.0;
+			M.p = p; M.omp = 1.0 - p; M.pq = M.linear ? 1.0 : p - q;
+			M.lk = log(kap);                                                                 // (kappa = 0: -inf, kappa^m = 0)
+			const double dx = p == 1.0 ? -M.y0 : M.x0 - p;                                  // x0 - p without cancellation at the boundary
+			M.w0 = M.linear ? dx : dx / (M.x0 - q);
+			closed = closed && p >= 0.0 && p <= 1.0 && kap >= 0.0 && kap < 1.0 - 1E-9 && fabs(M.w0) < 1.0 && (M.linear || M.x0 != q);
+		}
+		// Test value of iteration s + m (m >= 1), |1 - l(m - 1) / l(m)| = |l(m) - l(m - 1)| / |l(m)|, from the closed form: the
+		// step dx = x(m) - x(m - 1) = (p - q) w (kappa - 1) / ((1 - w)(1 - kappa w)) without cancellation (w = w0 kappa^(m-1)),
+		// the numerator as sum n_i log1p(d_i) over the three mixtures (d_i: relative change of x G0, of y G1, of their sum),
+		// the denominator as the log-likelihood at m.  Relative accuracy ~1e-13, where the guard band asks for 1e-5.
+		const double kap = closed ? exp(M.lk) : 0.5, gd = G0 - G1;
+		auto log1p_any = [&](const double d) __attribute__((always_inline)) { return fabs(d) < 0.03125 ? log1p_small(d) : fast_log(1.0 + d); };
+		auto crit_at = [&](const unsigned m) __attribute__((always_inline)) {
+			const double wa = m == 1u ? M.w0 : M.w0 * exp((double)(m - 1u) * M.lk), wb = wa * kap;      // (kappa = 0: 0 x -inf is no number)
+			const double ua = M.linear ? wa : wa / (1.0 - wa), ub = M.linear ? wb : wb / (1.0 - wb);
+			const double xa = m == 1u ? M.x0 : M.p + M.pq * ua, ya = m == 1u ? M.y0 : M.omp - M.pq * ua;
+			const double xb = M.p + M.pq * ub, yb = M.omp - M.pq * ub;
+			const double dx = M.linear ? wa * (kap - 1.0) : M.pq * wa * (kap - 1.0) / ((1.0 - wa) * (1.0 - wb));
+			double num = 0.0, den = 0.0;
+			if (n1 > 0.0) { num += n1 * log1p_any(dx / xa); den += n1 * fast_log(xb * G0); }
+			if (n2 > 0.0) { num += n2 * log1p_any(-dx / ya); den += n2 * fast_log(yb * G1); }
+			if (n3 > 0.0) { num += n3 * log1p_any(dx * gd / (xa * G0 + ya * G1)); den += n3 * fast_log(xb * G0 + yb * G1); }
+			return fabs(num / den);
+		};
+		// The search.  lo: an iteration past `iters` at which the test fails (0: none tried), hi: one at which it holds.  First
+		// m = 1; then the iteration the asymptotic decay c(m) ~ c(1) kappa^(2 (m - 1)) names; from there in doubling steps to
+		// the other side, and bisection between the two: ~4 evaluations when the decay is already geometric.
+		unsigned lo = 0u, hi = 1u;
+		double c_lo = 1.0, c_hi = 1.0;
+		const unsigned m_cap = A.max_iters - iters;
+		bool capped = false;
+		{
+			bool up = false, down = false;                 // galloping away from the guess: towards later / earlier iterations
+			unsigned g = 1u, d = 1u;
+			if (closed) {
+				const double c1 = crit_at(1u);
+				if (!(c1 > 1E-6)) { hi = 1u; c_hi = c1; }
+				else {
+					lo = 1u; c_lo = c1;
+					// where the asymptotic decay of the test value crosses the threshold: around an interior fixed point l'(p) = 0 and
+					// l(m) - l(m - 1) ~ 1/2 |l''(p)| (p - q)^2 (1 - kappa^2) w^2, w = w0 kappa^(m - 1); on the boundary l'(p) != 0 and
+					// the difference is ~ |l'(p)| (p - q) (1 - kappa) w
+					const double sp = M.p * G0 + M.omp * G1;
+					double lp = 0.0, d1 = 0.0, d2 = 0.0;
+					if (n1 > 0.0) { lp += n1 * fast_log(M.p * G0); d1 += n1 / M.p; d2 += n1 / (M.p * M.p); }
+					if (n2 > 0.0) { lp += n2 * fast_log(M.omp * G1); d1 -= n2 / M.omp; d2 += n2 / (M.omp * M.omp); }
+					if (n3 > 0.0) { lp += n3 * fast_log(sp); d1 += n3 * gd / sp; d2 += n3 * gd * gd / (sp * sp); }
+					const bool edge = M.p == 1.0 || M.p == 0.0;
+					const double amp = edge ? fabs(d1 * M.pq * (1.0 - kap) / lp) * fabs(M.w0) : fabs(0.5 * d2 * M.pq * M.pq * (1.0 - kap * kap) / lp) * M.w0 * M.w0;
+					double est = 1.999 + log(1E-6 / amp) / ((edge ? 1.0 : 2.0) * M.lk);             // (kappa = 0: x / -inf = -0)
+					if (!(est > 2.0)) est = 2.0;                                                     // (no number: 2)
+					g = est < (double)m_cap ? (unsigned)est : m_cap;
+					g = min(g, m_cap);
+					const double cg = crit_at(g);
+					if (!(cg > 1E-6)) { hi = g; c_hi = cg; down = hi - lo > 1u; }
+					else if (g >= m_cap) { hi = g; c_hi = cg; capped = true; }
+					else { lo = g; c_lo = cg; up = true; }
+				}
+			}
+			while (__any(up)) {
+				if (up) {
+					const unsigned m = min(lo + d, m_cap);
+					const double c = crit_at(m);
+					if (!(c > 1E-6)) { hi = m; c_hi = c; up = false; }
+					else if (m >= m_cap) { hi = m; c_hi = c; capped = true; up = false; }
+					else { lo = m; c_lo = c; d *= 2u; }
+				}
+			}
+			while (__any(down)) {
+				if (down) {
+					const unsigned m = hi - lo > d ? hi - d : lo + 1u;
+					const double c = crit_at(m);
+					if (!(c > 1E-6)) { hi = m; c_hi = c; d *= 2u; down = hi - lo > 1u; }
+					else { lo = m; c_lo = c; down = false; }
+				}
+			}
+			bool bis = closed && !capped && hi - lo > 1u;  // bisection: the test, once true, stays true
+			while (__any(bis)) {
+				if (bis) {
+					const unsigned mid = lo + (hi - lo) / 2u;
+					const double c = crit_at(mid);
+					if (!(c > 1E-6)) { hi = mid; c_hi = c; } else { lo = mid; c_lo = c; }
+					bis = hi - lo > 1u;
+				}
+			}
+		}
+		if (closed) {
+			// theta(T - 1) from the closed form, then the last step and the final log-likelihood by the ordinary pass
+			if (hi > 1u) M.at(hi - 1u, t3[0], t3[1]);
+			if (fabs(c_hi - 1E-6) < A.band || (lo > 0u && fabs(c_lo - 1E-6) < A.band)) flag |= 1;
+			if (capped) flag |= 2;
+			iters += hi - 1u;
+		}
+		// the numerators at t3; then: closed form -- exactly one more iteration; otherwise ordinary iterations to the end
+		bool run = ev_ok;
+		em_pass_lean<FS, 2, true>(kd, gm, t3, run, P, ll, z3);
+		if (closed) {
+			double n3v[2], nll, nz3[2];
+#pragma unroll
+			for (int j = 0; j < 2; ++j) n3v[j] = z3[j] * inv_n;
+			em_pass_lean<FS, 2, true>(kd, gm, n3v, run, P, nll, nz3);
+			const double crit = em_crit(ll, nll);
+			// the ordinary arithmetic must agree with the search about this iteration; where it does not, the value sits on the
+			// threshold within rounding: flagged (the replay decides)
+			if (!capped && (crit > 1E-6 || fabs(crit - 1E-6) < A.band)) flag |= 1;
+			t3[0] = n3v[0]; t3[1] = n3v[1]; ll = nll; ++iters;
+			run = false;
+		}
+		{
+			bool seq = run && !closed;
+			em_iterate<FS>(A, kd, gm, inv_n, P, t3, ll, z3, iters, flag, seq, 0xFFFFFFFFu);
+		}
+		if (ev_ok) {
+#pragma unroll
+			for (int j = 0; j < 2; ++j) if (j < K) A.theta[ib + j] = t3[j];
+			A.logll[e] = ll;
+			A.iters[e] = iters;
+			A.flags[e] = flag;
+		}
+	}
+	// the last workgroup to finish clears the list for the lane's next solve
+	if (threadIdx.x == 0) {
+		__threadfence();
+		const unsigned done = atomicAdd(&T.count[1], 1u);
+		if (done == gridDim.x - 1u) { T.count[0] = 0u; T.count[1] = 0u; __threadfence(); }
+	}
+}
+
 // The lean group in one launch (two on one stream would run one after the other): the first n_quad workgroups take the
 // places below *A.split four lanes an event, the others the places from there on one lane an event; workgroups of 64.
 template <int FS>
@@ -606,7 +919,21 @@ int run_solve(lsq_ctx *c) {
 		// one wave per workgroup: beside a streaming kernel that fills the device, a wave that is done gives its
 		// registers back without waiting for three others (measured 0.259 -> 0.254 ms per pipelined step)
 		const unsigned blk = 64;
-		if (c->em_small_places) {
+		if (c->em_small_places && c->opt_em_closed && E.n_methods == 1) {
+			// two isoforms, one read file: a head of ordinary iterations for everybody, the closed form for what is left
+			// (no placement by earlier iteration counts, no chain of hundreds of passes)
+			const int lane = c->flip;
+			A.place0 = 0; A.n_places = c->em_small_places;
+			EmTail T{};
+			T.count = c->em_tail_count.p + 2 * lane;
+			T.ev = c->em_tail_u32[lane].p; T.iters = T.ev + c->em_small_places;
+			T.flag = c->em_tail_flag[lane].p;
+			T.t0 = c->em_tail_f64[lane].p; T.t1 = T.t0 + c->em_small_places; T.ll = T.t1 + c->em_small_places;
+			const unsigned n_wg = (c->em_small_places + blk - 1) / blk;
+			hipLaunchKernelGGL(lsq_em_head_kernel<3>, dim3(n_wg), dim3(blk), 0, st, A, T);
+			hipLaunchKernelGGL(lsq_em_tail_kernel<3>, dim3(n_wg), dim3(blk), 0, st, A, T);
+			HIP_TRY(hipGetLastError());
+		} else if (c->em_small_places) {
 			const int lane = c->flip;
 			A.place0 = 0; A.n_places = c->em_small_places;
 			const bool regrouped = c->opt_em_regroup && c->em_order_lane_valid[lane];

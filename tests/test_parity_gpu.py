@@ -31,7 +31,7 @@ def test_cli_matches_reference_golden(name, tmp_path, monkeypatch):
             assert ob.solve_text_close(text, exp), (name, r["argv"], text, exp)
 
 
-def gpu_exact(argv, tool="solve", want_fim=False, band=None, repeat=1):
+def gpu_exact(argv, tool="solve", want_fim=False, band=None, repeat=1, options=None):
     """runs the library pipeline step by step; returns per-gene dicts like the oracle's exact output.
     band: lsq_set_em_guard_band (None = the library's 1e-11); repeat: count + solve that many times (from the third
     time on a lane's solve uses the placement, and the one-lane form, it learned from its first)"""
@@ -42,6 +42,8 @@ def gpu_exact(argv, tool="solve", want_fim=False, band=None, repeat=1):
     ctx = L.Context(0)
     if band is not None:
         ctx.set_em_guard_band(band)
+    for k, v in (options or {}).items():
+        ctx.set_option(k, v)
     ctx.upload_events(ev)
     for m, g in enumerate(groups):
         ctx.upload_reads(m, L.Reads.from_mrf(g[3], ev, read_format=g[0]))
@@ -1146,6 +1148,27 @@ def test_executables_run_one_job_over_several_gpu_slices(name, env, tmp_path):
             assert ob.solve_text_close(p.stdout, exp), (name, r["argv"])
         n += 1
     assert n
+
+
+@pytest.mark.parametrize("seed", [501, 502, 503, 504, 505, 506, 507, 508])
+def test_em_closed_form_stops_where_the_reference_stops(seed, tmp_path):
+    """option em_closed_form: a two-isoform event with one read file runs six ordinary EM iterations and finishes in the
+    closed form of its EM map (a Moebius map of theta_0; the stopping iteration by search, lsq_em.hip) -- iteration count equal
+    to the oracle's for EVERY event, theta and log-likelihood within 1e-6 (guard-band events replayed as ever).  Event-shaped
+    inputs with skewed depth (few reads per event: fixed points on the boundary, slow events) and the golden toy."""
+    import golden_inputs as gi
+    R = [40, 60, 90, 120][seed % 4]
+    info = gi.write_events_case(str(tmp_path), "ev", seed=seed, n_events=400, n_reads=30000 if seed % 2 else 3000, R=R, n_chrom=2, zipf=(seed % 2 == 0))
+    argv = ["0", "ev", "./", "LH_GENE_TXT", str(tmp_path / "ev.interval"), "UCSC_GENE2ISOFORM", str(tmp_path / "ev.map"), "0", "1000",
+            "MRF_SINGLE", "SHORT_READ" if seed % 3 else "MEDIUM_READ", str(R), str(tmp_path / "ev.mrf"), str(info["total_read_bases"])]
+    rc, otext, exact = ob.run("solve", argv)
+    assert rc == 0
+    got = gpu_exact(argv, options={"em_closed_form": 1})
+    compare_exact(got, exact, "closed form, seed %d" % seed)
+    assert max(g["iters"] for g in got) > 6          # some event went past the head
+    plain = gpu_exact(argv)
+    for a, b in zip(got, plain):
+        assert a["iters"] == b["iters"] or (a["flags"] & 4) or (b["flags"] & 4), a["gname"]
 
 
 @pytest.mark.parametrize("name,env", [("events_s1", dict(LSQ_GPUS="3", LSQ_DEVICES="0,0,0", LSQ_GATHER="host", LSQ_SHARD="reads")),
