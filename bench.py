@@ -321,6 +321,17 @@ def run_workload(env, a, wl_name, primary):
                 res["e2e_cli_gpus_1_phases"] = ph1
                 if rcn == 0:
                     res["e2e_cli_gpus_n_mrf_reads_per_s"] = W["n_reads"] / dtn
+                # ... and the same job sharded by READS (LSQ_SHARD=reads: every GPU copies and parses a byte range of the text, one
+                # all-reduce of the class counts, GPU 0 solves): the mode in which the loader scales with the GPUs
+                rcr, dtr, outr, phr, errr = run_cli("solve", argv_solve, dict(menv, LSQ_SHARD="reads"), timeout=300)
+                res["e2e_cli_gpus_n_by_reads_solve_s"] = dtr if rcr == 0 else None
+                res["e2e_cli_gpus_n_by_reads_exit"] = rcr
+                if rcr != 0:
+                    res["e2e_cli_gpus_n_by_reads_error"] = errr[-600:]
+                else:
+                    res["e2e_cli_gpus_n_by_reads_mrf_reads_per_s"] = W["n_reads"] / dtr
+                res["e2e_cli_gpus_n_by_reads_table_equals_one_gpu_table"] = bool(rc1 == 0 and rcr == 0 and out1 == outr)
+                res["e2e_cli_gpus_n_by_reads_phases"] = phr
                 res["e2e_cli_gpus_n_note"] = ("LSQ_GPUS=%d lesseq_amd/bin/solve as a child process on the MRF text: pre-pass count on GPU 0, slices of equal read weight, every "
                                               "GPU's thread parses the text and ingests its slice, count + EM + pack, %s, one table printed" %
                                               (world, "blocks through host memory (rehearsal on one GPU)" if rehearse else "ncclAllGather"))

@@ -886,9 +886,9 @@ __device__ inline void stream_pool_fast(FastCtx &C, const uint4 *bins, const uin
 // lsq_debug_check_pool_layout verifies in the tests:
 //   one-block pool: the records of an aligned group of eight (P1_GROUP_PAD) start in ONE cell -- the cell of the group's
 //     first record -- or all in none; padding records are empty (length 0) and sit at the tail of a cell's records;
-//   two-block pool: an aligned quadruple lies in ONE junction group -- block 1 starts in the same one-owner cell and ends
+//   two-block pool: an aligned quadruple (P2_GROUP_PAD) lies in ONE junction group -- block 1 starts in the same one-owner cell and ends
 //     on the end of that owner's segment, block 2 starts on the same first base of a later segment of that event -- or in
-//     the bucket's last group (everything else); padding (length 0) never comes first in a quadruple.
+//     the bucket's last group (everything else); padding (length 0) never comes first in such a group.
 // So a lane looks at the tables once, for its first record, and every further record only has to show where it ENDS.
 
 // One-block reads, NR = 4 or 8 per lane and step (one or two 16-byte loads).  Records stay in their own terms (offset
@@ -1031,7 +1031,7 @@ __device__ inline void stream_pool1_compact(FastCtx &C, const uint4 *bins, const
 template <int NR>
 __device__ inline void stream_pool2_compact(FastCtx &C, const uint4 *bins, const uint4 *cells, const uint4 *cellx, const unsigned n_cells, const BucketDesc &d,
                                             const CountArgs &A, uint4 *queue, const void *pool, const unsigned long long g0, const unsigned long long g1) {
-	static_assert(NR == 2 || NR == 4, "one or two 16-byte words of two compact records");
+	static_assert((NR == 2 || NR == 4 || NR == 8) && (unsigned)NR <= P2_GROUP_PAD, "whole 16-byte words of two compact records, inside one junction group");
 	constexpr int CW = NR / 2;
 	constexpr unsigned TILE = 64u * NR;
 	C.pool = 1u;

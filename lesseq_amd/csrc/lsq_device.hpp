@@ -28,6 +28,10 @@ using namespace lsq;
 #ifndef LSQ_P1_PAD
 #define LSQ_P1_PAD 8
 #endif
+#ifndef LSQ_P2_PAD
+#define LSQ_P2_PAD 4
+#endif
+constexpr unsigned P2_GROUP_PAD = LSQ_P2_PAD;      // ... and a junction group of the two-block pool (eight, with eight two-block reads per look, measured 2 % slower on C3: more padding, longer steps)
 constexpr unsigned P1_GROUP_PAD = LSQ_P1_PAD;      // records a cell's group of the one-block pool is padded to: what a lane of the count kernel takes per look
 constexpr int EM_LANES = 4;          // lanes that share one event in the EM kernel (and one place of its grid)
 

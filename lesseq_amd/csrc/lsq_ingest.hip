@@ -310,7 +310,7 @@ __global__ void __launch_bounds__(256) lsq_ingest_pad_kernel(const BucketDesc *b
 	for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < n_groups1 + n_groups2; t += gridDim.x * blockDim.x) {
 		const bool one = t < n_groups1;
 		const unsigned g = one ? t : t - n_groups1;
-		const unsigned n = one ? cnt1[g] : cnt2[g], gp = one ? P1_GROUP_PAD : 4u, pad = ((n + gp - 1u) & ~(gp - 1u)) - n;
+		const unsigned n = one ? cnt1[g] : cnt2[g], gp = one ? P1_GROUP_PAD : P2_GROUP_PAD, pad = ((n + gp - 1u) & ~(gp - 1u)) - n;
 		if (!pad) continue;
 		const unsigned *gbase = one ? cell_base : jgroup_base;
 		unsigned lo_b = 0, hi_b = n_buckets;                 // bucket of the group: last b with gbase[b] <= g
@@ -390,7 +390,7 @@ static int ingest_device(lsq_ctx *c, int method, const IngestRaw &Rw, uint64_t n
 			HIP_TRY(hipGetLastError());
 		}
 		hipLaunchKernelGGL(lsq_scan_u32_kernel<P1_GROUP_PAD>, dim3(1), dim3(1024), 0, st, W.cnt1, (unsigned long long)FC, d_off1.p);      // groups padded to eight records, and to four
-		hipLaunchKernelGGL(lsq_scan_u32_kernel<4>, dim3(1), dim3(1024), 0, st, W.cnt2, (unsigned long long)FJ, d_off2.p);
+		hipLaunchKernelGGL(lsq_scan_u32_kernel<P2_GROUP_PAD>, dim3(1), dim3(1024), 0, st, W.cnt2, (unsigned long long)FJ, d_off2.p);
 		hipLaunchKernelGGL(lsq_scan_u32_kernel<1>, dim3(1), dim3(1024), 0, st, W.cntn, (unsigned long long)B, mr.pn_off.p);
 		hipLaunchKernelGGL(lsq_scan_u32_kernel<1>, dim3(1), dim3(1024), 0, st, W.cntnb, (unsigned long long)B, mr.pnb_off.p);
 		hipLaunchKernelGGL(lsq_ingest_offsets_kernel, dim3(B / 256 + 1), dim3(256), 0, st, c->cell_base.p, c->jgroup_base.p, B, d_off1.p, d_off2.p, mr.pn_off.p,

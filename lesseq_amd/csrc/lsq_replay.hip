@@ -487,9 +487,9 @@ int lsq_host_evaluated(const lsq_ctx *c, uint64_t *n_genes, uint64_t *n_reads) L
 } LSQ_API_CATCH
 
 // Developer check of the pools' layout (tests): every aligned group of eight one-block records starts in one cell (or all
-// in none), every aligned quadruple of two-block records of a junction group crosses one junction, and the records that are
+// in none), every aligned quadruple of two-block records (P2_GROUP_PAD) of a junction group crosses one junction, and the records that are
 // not padding number what the ingest counted.  out: [0] one-block records, [1] of them padding, [2] groups of eight over more
-// than one cell, [3] two-block records, [4] of them padding, [5] quadruples whose first read crosses a junction of the
+// than one cell, [3] two-block records, [4] of them padding, [5] such groups whose first read crosses a junction of the
 // annotation and another of whose reads crosses another or none.
 int lsq_debug_check_pool_layout(lsq_ctx *c, int method, unsigned long long *out) LSQ_API_TRY {
 	if (!c || !c->E || !out || method < 0 || method >= c->E->n_methods) return fail(LSQ_E_ARG, "bad argument");
@@ -510,7 +510,7 @@ int lsq_debug_check_pool_layout(lsq_ctx *c, int method, unsigned long long *out)
 			return -1;
 		};
 		const size_t n1 = R.p1_line.size(), n2 = R.p2_line.size();
-		if ((n1 % P1_GROUP_PAD) || (n2 & 3u)) return fail(LSQ_E_STATE, "bucket %zu: pool slices of %zu and %zu records are not whole groups of %u / quadruples", b, n1, n2, P1_GROUP_PAD);
+		if ((n1 % P1_GROUP_PAD) || (n2 % P2_GROUP_PAD)) return fail(LSQ_E_STATE, "bucket %zu: pool slices of %zu and %zu records are not whole groups of %u / %u", b, n1, n2, P1_GROUP_PAD, P2_GROUP_PAD);
 		out[0] += n1; out[3] += n2;
 		for (size_t q = 0; q < n1; q += P1_GROUP_PAD) {          // what a lane of lsq_count_fast_kernel<true, 4> settles with one look
 			long first = -2;
@@ -531,13 +531,13 @@ int lsq_debug_check_pool_layout(lsq_ctx *c, int method, unsigned long long *out)
 			const uint64_t *it = std::lower_bound(k0, k1, want);
 			return (it != k1 && *it == want) ? (long)(it - k0) : -1;
 		};
-		for (size_t q = 0; q < n2; q += 4) {
+		for (size_t q = 0; q < n2; q += P2_GROUP_PAD) {          // what a lane settles with one look
 			const int32_t *ra = &R.p2[4 * q];
 			const bool ea = ra[0] == ra[1];
 			const long ga = ea ? -1 : group_of(ra);
 			bool bad = false;
 			out[4] += ea ? 1u : 0u;
-			for (size_t k = q + 1; k < q + 4; ++k) {
+			for (size_t k = q + 1; k < q + P2_GROUP_PAD; ++k) {
 				const int32_t *rb = &R.p2[4 * k];
 				const bool eb = rb[0] == rb[1];
 				out[4] += eb ? 1u : 0u;
