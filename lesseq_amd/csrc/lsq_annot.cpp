@@ -664,7 +664,13 @@ int plan_device(lsq_events &E) {
 						const SegRef *sh = own[0]->sy <= own[1]->sy ? own[0] : own[1], *lg = sh == own[0] ? own[1] : own[0];      // the segment that ends first, the other
 						c.e1 = (int32_t)sh->sy; c.e2 = (int32_t)lg->sy;
 						x.slots = slot_of(sh, 1u << sh->k) | (slot_of(lg, 1u << lg->k) << 16);
-						x.info = CELL_INFO_SHARED; x.flags = CELLX_BOTH; x.ev = sh->ev;
+						x.info = CELL_INFO_SHARED; x.flags = CELLX_BOTH | (lg->ev & 0xFFFFu); x.ev = sh->ev;
+						{
+							const Event &es = E.ev[lst[b_begin + sh->ev]], &el = E.ev[lst[b_begin + lg->ev]];
+							const int ks = (int)sh->k, kl = (int)lg->k;
+							if (!(ks + 1 < es.N && es.seg_s[ks + 1] == es.seg_e[ks])) x.flags |= CELLX_NEAR_NO_ABUT;
+							if (!(kl + 1 < el.N && el.seg_s[kl + 1] == el.seg_e[kl])) x.flags |= CELLX_FAR_NO_ABUT;
+						}
 					} else continue;
 					cells.push_back(c); cellx.push_back(x);
 				}

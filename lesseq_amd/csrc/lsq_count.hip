@@ -952,7 +952,7 @@ __device__ inline void stream_pool1_compact(FastCtx &C, const uint4 *bins, const
 		const uint4 cx = cellx[cc];           // slots, info, flags, owner event
 		// the lane's records start in this cell (layout) -- if it is one: the bucket's last group holds the reads of no cell
 		const bool has = ci < n_cells && (int)cw.x <= p0 && p0 < (int)cw.y && !ABL(A, 8u);
-		const bool both = (cx.z & CELLX_BOTH) != 0;          // two owners: e1 / e2 the ends of their segments, slot 1 / slot 2 theirs
+		const bool both = has && (cx.z & CELLX_BOTH) != 0;   // two owners: e1 / e2 the ends of their segments, slot 1 / slot 2 theirs
 		// thresholds in the records' terms; without a cell nothing is settled here
 		const int e1 = has ? (int)cw.z - base : -1, e2 = has ? (int)cw.w - base : -1;
 		// every step but the first and last of a workgroup's range lies wholly inside it: no per-record range test there
@@ -1003,9 +1003,17 @@ __device__ inline void stream_pool1_compact(FastCtx &C, const uint4 *bins, const
 					const int so = (int)(rec[j] & lsq::COMPACT_OFF_MASK), e = so + (int)len;
 					const unsigned idx = t + lane * (unsigned)NR + (unsigned)j, rel = idx - first_rel;
 					const bool in = idx < n && rel < n_rel;
-					const bool op = in && len != 0u && !(e <= (both ? e1 : e2));
+					// two owners: past the end of an owner's segment with no segment abutting it the read matches that owner up to the
+					// end only -- valid for it only if 50 x the overhang < the read (count/count.cpp:441); otherwise settled: nothing to add
+					const bool gone_near = both && (cx.z & CELLX_NEAR_NO_ABUT) != 0u && e > e1 && 50 * (e - e1) >= (int)len;
+					const bool gone_far = both && (cx.z & CELLX_FAR_NO_ABUT) != 0u && e > e2 && 50 * (e - e2) >= (int)len;
+					const bool done_near = e <= e1 || gone_near, done_far = e <= e2 || gone_far;          // (one owner: e1 plays no part below)
+					const bool op = in && len != 0u && !(both ? (done_near && done_far) : e <= e2);
 					open |= op ? 1u << (j - h) : 0u;
-					en[j - h] = make_uint4((unsigned)(so + base), (unsigned)(so + base) + len, (has && (!both || e <= e2)) ? (cx.w | PARK_ONE_EVENT) : PARK_EVENT_UNKNOWN, rel);
+					// the one event to look at: one owner -- that owner; two owners -- the one that is not done with the read; both open: all
+					const unsigned hint = !has ? PARK_EVENT_UNKNOWN : (!both ? (cx.w | PARK_ONE_EVENT) :
+					                      (done_far ? (cx.w | PARK_ONE_EVENT) : (done_near ? ((cx.z & 0xFFFFu) | PARK_ONE_EVENT) : PARK_EVENT_UNKNOWN)));
+					en[j - h] = make_uint4((unsigned)(so + base), (unsigned)(so + base) + len, hint, rel);
 					if (ABL(A, 256u) && op) { atomicAdd(&A.dbg[5 + (has ? (both ? 2 : 1) : 0)], 1ull); atomicAdd(&A.dbg[0], 1ull); }
 				}
 				R.push2(open, lane, en[0], en[1]);

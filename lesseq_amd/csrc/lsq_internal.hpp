@@ -171,13 +171,18 @@ static_assert(sizeof(Cell) == 16, "Cell layout");
 struct CellX {
 	uint32_t slots;        // low 16 bits: histogram slot 1; high 16 bits: slot 2; 0xFFFF = no compatible isoform / absent
 	uint32_t info;         // one owner: event << 8 | segment << 2 | lo is the segment's start; CELL_INFO_SHARED with two owners; CELL_INFO_EMPTY with none
-	uint32_t flags;        // CELLX_BOTH
+	uint32_t flags;        // CELLX_BOTH, CELLX_*_NO_ABUT; two owners: low 16 bits = event of the owner that ends last
 	uint32_t ev;           // one owner: its event (index in the bucket); two owners: the one whose segment ends first
 };
 static_assert(sizeof(CellX) == 16, "CellX layout");
 constexpr uint32_t CELL_NONE = 0xFFFFu;
 constexpr int32_t CELL_NO_END = 0x7F000000;     // beyond every coordinate (< 2^30), and still so after the kernel has taken a bucket's base (> -2^22) off it
 constexpr uint32_t CELLX_BOTH = 1u << 16;
+// two owners (round 3): the owner whose segment ends first / last has NO segment that starts where that one ends -- a read
+// that runs past that end matches the owner only up to it, and is valid for it only if that is more than 98 % of the read
+// (count/count.cpp:441): almost never, and the loop can say so itself instead of parking the read for the walk.  The low 16
+// bits of the flags word hold the event (index in the bucket) of the owner whose segment ends LAST (CellX.ev: the other).
+constexpr uint32_t CELLX_NEAR_NO_ABUT = 1u << 17, CELLX_FAR_NO_ABUT = 1u << 18;
 // The LDS histogram of a bucket is kept HIST_REPLICAS times (lane & (R-1) picks the copy; copies
 // are (n_cls | 1) entries apart so that they start in different banks): neighbouring reads of the
 // start-ordered pools land in the same class, and atomics on one LDS address run one after the other.

@@ -21,7 +21,7 @@ for k in range(60):
         argv = ["0", "s", "./", "LH_GENE_TXT", d + "/s.interval", "UCSC_GENE2ISOFORM", d + "/s.map", "0", "100000000", "MRF_SINGLE", "SHORT_READ", str(R), d + "/s.mrf", str(n_reads * R)]
         rc, otext, exact = ob.run("solve", argv)
         assert rc == 0
-        for opts in ("em_flat_min_events=0", "compact_pools=0", "recount_every_read=1", "reads_per_look=8,workgroups_per_cu=5"):
+        for opts in ("em_flat_min_events=0", "compact_pools=0", "recount_every_read=1", "reads_per_look=8,workgroups_per_cu=5", "reads_per_look=4,workgroups_per_cu=6,em_closed_form=1"):
             os.environ["LSQ_OPTIONS"] = opts
             compare_exact(gpu_exact(argv, repeat=4 if opts.startswith("em_flat") else 1), exact, "synth %d %s" % (seed, opts))
         os.environ["LSQ_OPTIONS"] = ""
