@@ -532,6 +532,30 @@ def run_workload(env, a, wl_name, primary):
     fence()
     ms_regroup_off = (time.perf_counter() - t_off) / n_off * 1e3
     ctx.set_option("em_regroup", 1)
+    # ... and what a job with changing read sets sees in practice: the placement learnt on ANOTHER batch of the same library
+    # (the next n_reads reads of the same stream: same events, same expression, different reads), then the timed steps on
+    # this batch before any lane refreshes its placement (every sixteenth solve)
+    ms_other_batch = None
+    if world == 1 and not no_e2e:
+        reads_b = L.Reads.synthetic(L.SynthSpec(W["seed"], W["n_events"], W["n_reads"], W["R"], W["n_chrom"], types, W.get("zipf", False), first_read=W["n_reads"]), ev)
+        ctx.synchronize()
+        ctx.upload_reads(0, reads_b)
+        del reads_b
+        for k in range(6):
+            step(k)               # each lane learns from its first solve of the other batch
+        fence()
+        reads_a = L.Reads.synthetic(spec, ev)
+        ctx.upload_reads(0, reads_a)
+        del reads_a
+        for k in range(2):
+            step(k)               # (the first count of a read set plans the workgroups' shares: once, untimed)
+        fence()
+        n_ob = 22                 # a lane's placement is 4 solves old: 11 more per lane before the refresh
+        t_ob = time.perf_counter()
+        for k in range(n_ob):
+            step(k)
+        fence()
+        ms_other_batch = (time.perf_counter() - t_ob) / n_ob * 1e3
     # what the gather costs on its own (N > 1): submitted alone, timed on the host
     gather_ms = None
     if world > 1:
@@ -659,6 +683,9 @@ def run_workload(env, a, wl_name, primary):
                 "em_placement": "each step lane sorts the EM grid by the iteration counts of its own earlier solve (refreshed every 16th solve; the sort kernel "
                                 "runs inside the timed loop); the loop repeats one read set, so the prediction is exact here",
                 "ms_per_step_em_regroup_off_rank0": ms_regroup_off,
+                "ms_per_step_em_placement_from_another_batch": ms_other_batch,
+                "em_placement_from_another_batch_note": "EM placement learnt on the next n_reads reads of the same synthetic library (same events and expression, other reads), "
+                                                        "then 22 timed steps on this batch before any refresh: what a loop over changing batches of one library sees",
                 "valid_read_assignments": int(cnt_full.sum()), "exception_pairs": int(sum(exc)), "recounted": int(sum(recounted)),
                 "em_guard_band_events": int((flags_full & 1).sum()), "em_replayed_events": int(((flags_full >> 2) & 1).sum()),
                 "em_max_iters": int(iters_full.max()) if n_ev else 0,

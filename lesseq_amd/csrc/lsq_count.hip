@@ -976,11 +976,12 @@ __device__ inline void stream_pool1_compact(FastCtx &C, const uint4 *bins, const
 		if (interior) decide(std::true_type{}); else decide(std::false_type{});
 		const unsigned s1 = cx.x & 0xFFFFu, s2 = cx.x >> 16;
 		if (!ABL(A, (1u | 16384u))) {
-			const unsigned long long addA = ((unsigned long long)(accA >> 24) << 40) | (accA & 0xFFFFFFu);
-			const unsigned accX = accL - accA;
-			if (accA && s1 != CELL_NONE) atomicAdd(&C.hist[s1], addA);
-			if (accA && both && s2 != CELL_NONE) atomicAdd(&C.hist[s2], addA);
-			if (accX && s2 != CELL_NONE) atomicAdd(&C.hist[s2], ((unsigned long long)(accX >> 24) << 40) | (accX & 0xFFFFFFu));
+			// slot 1: the records inside the (nearer) owner's segment; slot 2: one owner -- those that run on into the abutting
+			// segment (L - A); two owners -- everything inside the farther owner's segment (L: the sums add up in one word,
+			// sixteen records of < 1 024 bases at most)
+			const unsigned acc2 = both ? accL : accL - accA;
+			if (accA && s1 != CELL_NONE) atomicAdd(&C.hist[s1], ((unsigned long long)(accA >> 24) << 40) | (accA & 0xFFFFFFu));
+			if (acc2 && s2 != CELL_NONE) atomicAdd(&C.hist[s2], ((unsigned long long)(acc2 >> 24) << 40) | (acc2 & 0xFFFFFFu));
 		} else asm volatile("" ::"v"(accA), "v"(accL));
 		// settled here: one owner -- every record that ends by e2; two owners -- by e1 (one that ends in (e1, e2] has been
 		// counted for the farther owner and still goes to the walk for the nearer one)
@@ -1122,8 +1123,25 @@ __device__ inline void stream_pool2_compact(FastCtx &C, const uint4 *bins, const
 		// the histogram slots of the junction's classes: segments of block 1 + segment k2, and + segment k2 + 1 (CELL_NONE: no compatible isoform)
 		const unsigned slotA = clsA != 0u ? (w0r.y & 0xFFFFu) + clsA - 1u : CELL_NONE, slotB = clsB != 0u ? (w0r.y & 0xFFFFu) + clsB - 1u : CELL_NONE;
 		const bool addS = in0 && S && sa != CELL_NONE && 50u * len1 > 49u * total;
+		// No junction.  The quadruple then shares the cell of this record (layout: the reads that cross no junction of the
+		// annotation are grouped by the cell block 1 starts in), and block 2 of none of its reads continues a match: a key of
+		// the junction groups would name it.  What is left per read is whether block 1 alone could carry it: matched <= |block 1|
+		// whenever block 1 ends inside a segment of every owner or past one that nothing abuts, so a read with 50 |block 1| <= 49
+		// total is valid for nobody (count/count.cpp:441) and is settled here as nothing.  e1c / e2c: the owners' segment ends
+		// in the records' terms; `gone_ok`: where block 1 may end.
+		const bool two = here && (cx1.z & CELLX_BOTH) != 0u, empty = here && i1 == CELL_INFO_EMPTY;
+		const int e1c = (int)cw1.z - base, e2c = (int)cw1.w - base;
+		const bool near_free = (cx1.z & CELLX_NEAR_NO_ABUT) != 0u, far_free = (cx1.z & CELLX_FAR_NO_ABUT) != 0u;
+		auto nothing = [&](const unsigned a, const unsigned b2) __attribute__((always_inline)) {      // a record (block 1, block 2) of this cell that counts for nobody
+			const unsigned l1 = a >> lsq::COMPACT_OFF_BITS, l2 = b2 >> lsq::COMPACT_OFF_BITS, gap = b2 & lsq::COMPACT_OFF_MASK;
+			const int y = (int)(a & lsq::COMPACT_OFF_MASK) + (int)l1;
+			const bool weak = gap != 0u && 50u * l1 <= 49u * (l1 + l2);                 // (touching blocks: the exception pass decides)
+			const bool one_ok = y <= e2c;                                                  // one owner: inside its segment or the one abutting it
+			const bool two_ok = y != e1c && y != e2c && (y < e1c || near_free) && (y < e2c || far_free);
+			return empty || (weak && (two ? two_ok : (v1 && !start1 && one_ok)));
+		};
 		bool park[NR];
-		park[0] = in0 && len1 != 0u && !(J || Jb || S || drop) && !ABL(A, 17u | 1048576u);
+		park[0] = in0 && len1 != 0u && !(J || Jb || S || drop || (!junction && nothing(ra[0], rb[0]))) && !ABL(A, 17u | 1048576u);
 		if (ABL(A, 256u) && park[0]) atomicAdd(&A.dbg[8 + (v1 ? 1 : 0)], 1ull);       // parked: block 1 in no one-owner cell / in one
 		unsigned nA = (in0 && J && slotA != CELL_NONE) ? 1u : 0u, sA = nA ? total : 0u, nB = (in0 && Jb && slotB != CELL_NONE) ? 1u : 0u, sB = nB ? total : 0u;
 		// ---- the other records: block 2 must end inside the junction's second segment (gap + length <= lim) or inside the one
@@ -1140,7 +1158,8 @@ __device__ inline void stream_pool2_compact(FastCtx &C, const uint4 *bins, const
 			const bool cA = sameA && slotA != CELL_NONE, cB = sameB && slotB != CELL_NONE;
 			nA += cA ? 1u : 0u; sA += cA ? l1 + l2 : 0u;
 			nB += cB ? 1u : 0u; sB += cB ? l1 + l2 : 0u;
-			park[j] = in && !(sameA || sameB) && !ABL(A, 17u | 1048576u | 2097152u);
+			const bool none = !junction && nothing(ra[j], rb[j]);
+			park[j] = in && !(sameA || sameB || none) && !ABL(A, 17u | 1048576u | 2097152u);
 			if (ABL(A, 256u) && park[j]) atomicAdd(&A.dbg[junction ? 14 : 13], 1ull);       // parked followers: block 2 runs past the junction's segments / the first record crosses no junction
 			any_park = any_park || park[j];
 		}

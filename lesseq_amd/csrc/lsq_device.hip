@@ -282,7 +282,9 @@ int lsq_events_upload(lsq_ctx *c, lsq_events *E) LSQ_API_TRY {
 		c->n_cell_groups = cb.back();
 		if ((rc = c->cell_base.upload(cb.data(), cb.size(), c->stream))) return rc;
 		std::vector<unsigned> jb(E->buckets.size() + 1, 0);
-		for (size_t b = 0; b <= E->buckets.size(); ++b) jb[b] = E->jg_base[b] + (unsigned)b;       // the bucket's junction groups, then its "other" group
+		// the bucket's junction groups, then -- round 3 -- one group per cell (and one for "no cell") for the two-block reads
+		// that cross no junction of the annotation: a quadruple of those shares the cell of its first record too
+		for (size_t b = 0; b <= E->buckets.size(); ++b) jb[b] = E->jg_base[b] + cb[b];
 		c->n_junction_groups = jb.back();
 		const unsigned long long none = 0;
 		if ((rc = c->jg_keys.upload(E->jg_keys.empty() ? &none : (const unsigned long long *)E->jg_keys.data(), std::max<size_t>(E->jg_keys.size(), 1), c->stream))) return rc;

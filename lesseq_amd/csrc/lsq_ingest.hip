@@ -194,7 +194,8 @@ __global__ void __launch_bounds__(256) lsq_ingest_classify_kernel(IngestTables T
 										while (lo_k < hi_k) { const unsigned mid = (lo_k + hi_k) >> 1; if (T.jg_keys[mid] < want) lo_k = mid + 1; else hi_k = mid; }
 										if (lo_k < k1 && T.jg_keys[lo_k] == want) g = lo_k;
 									}
-									fine = T.jgroup_base[b] + (g - k0);
+									// (no junction: the group of the read's cell -- `n_cells`: of no cell -- behind the junction groups)
+									fine = T.jgroup_base[b] + (g < k1 ? g - k0 : (k1 - k0) + cell);
 								}
 							} else if (pool == 1u) fine = T.jgroup_base[b] + (T.jg_base[b + 1] - T.jg_base[b]);
 							if (pool == 0u) fine = T.cell_base[b] + cell;

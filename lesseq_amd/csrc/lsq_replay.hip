@@ -543,6 +543,7 @@ int lsq_debug_check_pool_layout(lsq_ctx *c, int method, unsigned long long *out)
 				out[4] += eb ? 1u : 0u;
 				if (ea) bad = bad || !eb;                       // padding never comes first
 				else if (ga >= 0 && !eb && group_of(rb) != ga) bad = true;
+				else if (ga < 0 && !eb && (group_of(rb) >= 0 || cell_of(rb[0]) != cell_of(ra[0]))) bad = true;       // no junction: the quadruple shares the cell of block 1
 			}
 			if (bad) ++out[5];
 		}
