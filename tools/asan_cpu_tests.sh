@@ -16,4 +16,4 @@ wait
 cp ../_build/liblesseq_rccl.so $O/
 cd $R
 ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 LD_PRELOAD=$(gcc -print-file-name=libasan.so) LSQ_LIB=$O/liblesseq_hip.so \
-	python -m pytest tests -x -q -m "not gpu" -k "not exports"
+	python -m pytest tests -x -q -m "not gpu" -k "not exports and not crosses_the_boundary"      # (the boundary test caps the address space, which the sanitizer's shadow memory does not survive)
