@@ -1150,6 +1150,66 @@ def test_executables_run_one_job_over_several_gpu_slices(name, env, tmp_path):
     assert n
 
 
+def test_reads_on_every_threshold_of_the_streaming_loops_vs_oracle(tmp_path):
+    """The streaming loops of the count kernel settle reads by where they END (lsq_count.hip, round 3): inside the owner's
+    segment, in the segment abutting it, past an end nothing abuts (two-owner cells: valid only if 50 x the overhang < the
+    read), two-block reads through junctions of abutting runs, and two-block reads that cross no junction (nothing when
+    50 |block 1| <= 49 total).  Hand-made events -- an A5SS-like one with abutting segments, an SE-like one, and a third that
+    overlaps both (two-owner cells with and without abutting neighbours) -- and reads enumerated on, one base before and one
+    base after every such boundary, in every block-2 variant, with lengths that put the 98 % rule on and beside equality.
+    Exact integers against the oracle; compact and wide records."""
+    import golden_inputs as gi
+    c = "chr1"
+    #   event A (long form splits its first exon in two abutting segments): segments [1000,1100) [1100,1160) [1400,1500)
+    #   event B (skipped exon):                                             segments [2000,2100) [2300,2360) [2600,2700)
+    #   event C overlaps A's last segment and B's first (its own segments abut once): [1450,1520) [1520,1600) [2050,2130)
+    iv = (gi.interval_line("A.l", c, "+", [(1000, 1160), (1400, 1500)]) + gi.interval_line("A.s", c, "+", [(1000, 1100), (1400, 1500)])
+          + gi.interval_line("B.i", c, "+", [(2000, 2100), (2300, 2360), (2600, 2700)]) + gi.interval_line("B.k", c, "+", [(2000, 2100), (2600, 2700)])
+          + gi.interval_line("C.l", c, "-", [(1450, 1600), (2050, 2130)]) + gi.interval_line("C.s", c, "-", [(1450, 1520), (2050, 2130)]))
+    mp = "A\tA.l\nA\tA.s\nB\tB.i\nB\tB.k\nC\tC.l\nC\tC.s\n"
+    ends = sorted({1100, 1160, 1500, 1520, 1600, 2100, 2130, 2360, 2700})
+    starts = sorted({1000, 1100, 1400, 1450, 1520, 2000, 2050, 2300, 2600})
+    reads = []
+    # one-block reads: every start region x every end -1 / 0 / +1 / +2 / +30, several lengths
+    for s0 in (1001, 1040, 1099, 1101, 1130, 1401, 1449, 1451, 1470, 1499, 1501, 1530, 2001, 2049, 2051, 2080, 2099, 2101, 2120, 2301, 2601):
+        for e in ends:
+            for d in (-1, 0, 1, 2, 30):
+                if e + d > s0 and e + d - s0 < 900:
+                    reads.append(gi.mrf_line(c, "+" if (s0 + e) % 3 else "-", [(s0, e + d)]))
+    # two-block reads: block 1 ends on / beside every segment end, block 2 starts on / beside every later segment start or
+    # touches block 1; block 2 lengths put 50 |block 1| against 49 total on and around equality
+    for s0 in (1005, 1030, 1060, 1099, 1105, 1140, 1405, 1455, 1470, 1490, 1525, 1560, 2005, 2030, 2055, 2070, 2090, 2105, 2305, 2340):
+        for e in ends:
+            for d1 in (-1, 0, 1):
+                y = e + d1
+                if not (0 < y - s0 < 300):
+                    continue
+                l1 = y - s0
+                for z0 in starts:
+                    for dz in (0, 1):
+                        z = z0 + dz
+                        if z < y:
+                            continue
+                        for l2 in sorted({1, 2, max(1, l1 // 49), l1 // 49 + 1, 20, 60, 100, 131}):
+                            reads.append(gi.mrf_line(c, "+" if (s0 + z + l2) % 5 else "-", [(s0, y), (z, z + l2)]))
+                reads.append(gi.mrf_line(c, "+", [(s0, y), (y, y + 7)]))          # touching blocks
+    _write(tmp_path / "t.interval", iv)
+    _write(tmp_path / "t.map", mp)
+    _write(tmp_path / "t.mrf", "AlignmentBlocks\n" + "".join(reads))
+    assert len(reads) > 6000
+    for R in (40, 100):
+        argv = ["0", "t", "./", "LH_GENE_TXT", str(tmp_path / "t.interval"), "UCSC_GENE2ISOFORM", str(tmp_path / "t.map"), "0", "100",
+                "MRF_SINGLE", "SHORT_READ", str(R), str(tmp_path / "t.mrf"), str(len(reads) * R)]
+        rc, otext, exact = ob.run("solve", argv)
+        assert rc == 0
+        for opts in ({}, {"compact_pools": 0}, {"reads_per_look": 4, "workgroups_per_cu": 6}, {"recount_every_read": 1}):
+            compare_exact(gpu_exact(argv, options=opts), exact, "thresholds R=%d %s" % (R, opts))
+        assert sum(sum(g["supports"]) for g in gpu_exact(argv)) > 3000
+        rc1, text = L.cli_run("count", argv[:-1])
+        rc2, ctext, _ = ob.run("count", argv[:-1])
+        assert rc1 == rc2 == 0 and text == ctext
+
+
 @pytest.mark.parametrize("seed", [501, 502, 503, 504, 505, 506, 507, 508])
 def test_em_closed_form_stops_where_the_reference_stops(seed, tmp_path):
     """option em_closed_form: a two-isoform event with one read file runs six ordinary EM iterations and finishes in the
