@@ -258,7 +258,11 @@ int lsq_host_evaluated(const lsq_ctx *c, uint64_t *n_genes, uint64_t *n_reads);
  * file's exception list, 0 = a quarter of its reads and at least 65 536; applies to read sets uploaded
  * afterwards), "recount_every_read" (1: every count is redone by the one-lane-per-read kernel, a
  * self-check), "em_guard_band" (lsq_set_em_guard_band), "snap_shares" (0: the count kernel's workgroup
- * shares are cut at even read counts instead of at bucket ends), "compact_pools" (0: wide pool records for read sets
+ * shares are cut at even cost instead of at bucket ends), "share_weighted" (default 1: the shares are equal in estimated cost
+ * -- "share_cost_two_block": a two-block record in one-block records, default 4.3; "share_cost_parked": one look of the general
+ * walk at a read the streaming loops leave to it, default 9, counted per bucket by the ingest; "share_cost_visit": a bucket's
+ * staging and flush, default 7 000 -- and fall off in size along the grid, "share_taper": the last share as a fraction of the
+ * first, 0 = automatic, 0.5 for evenly deep read sets and 0.25 for skewed ones; 0: shares equal in reads), "compact_pools" (0: wide pool records for read sets
  * uploaded afterwards, see lsq_reads_pool_format), "em_regroup" (0: lsq_solve keeps the
  * placement of events in its grid chosen at lsq_events_upload; default 1: each of the two step lanes
  * re-sorts the placement by the iteration counts of one of its own earlier solves, refreshed every

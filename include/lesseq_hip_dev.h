@@ -17,10 +17,18 @@ extern "C" {
  * [5..7] reasons for parking one-block reads, [8..10], [13], [14] reasons for parking two-block reads, [11] / [12]
  * one-block steps of a wave with a parked read / all of them.  out16 holds 16 values. */
 int lsq_debug_counters(lsq_ctx *c, unsigned long long *out16);
+/* (start, end, steps of the general walk, reads those looked at) of each workgroup of the last count launch, times in 100 MHz
+ * ticks (developer library with LSQ_ABLATE bit 4194304; otherwise *n = 0): out holds 4 * cap values; the first *n_workers
+ * workgroups are the pool-n workers */
+int lsq_debug_wg_trace(lsq_ctx *c, unsigned long long *out, unsigned long long cap, unsigned long long *n, unsigned long long *n_workers);
 
 /* The combined slot offsets of a method's buckets (n_buckets + 1 values): the work partition of
  * the count kernels. */
 int lsq_debug_slot_offsets(lsq_ctx *c, int method, unsigned long long *out, unsigned long long n);
+/* An offset table of a method -- which = 0: slots per bucket, 1 / 2: the one- / two-block pool per bucket (n_buckets + 1
+ * values each), 3: the share bounds of the count launch's streaming workgroups (their number + 1), 4 / 5: the ingest's
+ * estimate of the one- / two-block reads per bucket that the streaming loops leave to the general walk; *n = values written. */
+int lsq_debug_offsets(lsq_ctx *c, int method, int which, unsigned long long *out, unsigned long long cap, unsigned long long *n);
 
 /* Another placement of the events in the EM grid (sixteen per wave; 0xFFFFFFFF = empty place):
  * the first n_small_places entries go to the lean kernel and must be events with at most two

@@ -58,6 +58,7 @@ struct CountArgs {
 	const lsq::VisitRec *visits;       // per bucket: what a visit needs, in one record (n_buckets + 1)
 	const unsigned *wg_first;          // per workgroup of the fast kernel's grid: the first packed bucket that holds slots of its share (n_buckets: none)
 	const unsigned long long *wg_cut;  // ... and the ranges' bounds in slots (grid + 1 values)
+	unsigned long long *wg_trace;      // developer build: (start, end) of every workgroup, 100 MHz clock (null: none)
 	unsigned long long total_slots;
 	unsigned long long n_pn;           // reads with three or more blocks
 	unsigned n_workers;                // leading workgroups of the fast kernel's grid that take them
@@ -311,6 +312,7 @@ struct FastCtx {                       // wave-uniform state of the bucket being
 	unsigned exc_cap;
 	unsigned ablate;
 	unsigned long long *dbg;
+	unsigned long long *trace;    // developer build: this workgroup's four trace words (null: none)
 };
 
 __device__ inline void emit_exception(const FastCtx &C, unsigned r, unsigned i, unsigned scan) {
@@ -479,6 +481,7 @@ __device__ inline void walk_parked(const FastCtx &C, Ring<(NB == 1 || PACKED2) ?
 		const unsigned n = min(R.live(), 64u);
 		const bool on = lane < n;
 		if (ABL(C, 256u) && lane == 0) { atomicAdd(&C.dbg[2], 1ull); atomicAdd(&C.dbg[3], (unsigned long long)n); }
+		if (ABL(C, 4194304u) && lane == 0 && C.trace) { atomicAdd(&C.trace[2], 1ull); atomicAdd(&C.trace[3], (unsigned long long)n); }
 		const unsigned at = (R.head + (on ? lane : 0u)) % Ring<RW>::CAP;
 		uint4 e0, e1 = make_uint4(0, 0, 0, 0);
 		if (RW == 1) e0 = R.q[at];
@@ -1287,6 +1290,12 @@ __global__ void __launch_bounds__(COUNT_BLOCK, P1W == 4 ? 5 : LSQ_FAST_WAVES) ls
 	// LDS: the bucket's tables (image, histograms), then the waves' rings
 	extern __shared__ __align__(16) unsigned char lds[];
 	const unsigned tid = threadIdx.x;
+	// (developer build: when each workgroup started and ended -- the picture of the launch's tail)
+	struct Trace {
+		unsigned long long *p;
+		__device__ Trace(unsigned long long *q) : p(q) { if (p && threadIdx.x == 0) p[4u * blockIdx.x] = wall_clock64(); }
+		__device__ ~Trace() { if (p && threadIdx.x == 0) p[4u * blockIdx.x + 1u] = wall_clock64(); }
+	} trace(ABL(A, 4194304u) ? A.wg_trace : nullptr);
 	if (blockIdx.x < A.n_workers) { pool_n_worker(A, A.n_pn, A.n_workers); return; }
 	const unsigned wg = blockIdx.x - A.n_workers, n_wg = gridDim.x - A.n_workers;     // the streaming workgroups
 	uint4 *wave_queue = reinterpret_cast<uint4 *>(lds + A.tables_lds_bytes) + (tid >> 6) * WAVE_QUEUE_WORDS;
@@ -1337,6 +1346,7 @@ __global__ void __launch_bounds__(COUNT_BLOCK, P1W == 4 ? 5 : LSQ_FAST_WAVES) ls
 		C.n_events = d.n_events; C.bucket = b;
 		C.slot0 = 0; C.pool = 0;
 		C.exc = A.exc; C.exc_count = A.exc_count; C.exc_cap = A.exc_cap; C.ablate = A.ablate; C.dbg = A.dbg;
+		C.trace = (ABL(A, 4194304u) && A.wg_trace) ? A.wg_trace + 4u * blockIdx.x : nullptr;
 		const unsigned long long l0 = (s_begin > bs ? s_begin : bs) - bs;
 		const unsigned long long l1 = (s_end < be ? s_end : be) - bs;
 		// ---- pool 1
@@ -1591,26 +1601,79 @@ int run_count(lsq_ctx *c) {
 		if (const char *e = getenv("LSQ_GRID_WGS")) { const long v = atol(e); if (v >= 1) grid = (unsigned long long)v; }      // timing experiments
 #endif
 		if (mr.wg_grid != grid) {
-			// The workgroups' shares: equal in reads, with a cut moved onto a bucket boundary when one lies within 30 % of
-			// a share of it -- a workgroup that owns whole buckets stages, drains and flushes each once, where a cut through
-			// the middle makes two workgroups do it (the planner's buckets of an evenly deep read set are about a share long).
+			// The workgroups' shares: equal in COST, with a cut moved onto a bucket boundary when one lies within 30 % of a share
+			// of it -- a workgroup that owns whole buckets stages, drains and flushes each once, where a cut through the middle
+			// makes two workgroups do it (the planner's buckets of an evenly deep read set are about a share long).
+			// Cost (round 3; the workgroup trace of the developer build, tools/kbench.py, fitted over C3's 3 840 shares: with shares
+			// equal in reads a workgroup took 11 to 72 us, median 31, and the wave slots of the launch were 68 % used -- the last
+			// third of the launch was a thinning tail of late, long shares): a two-block record costs what 4.3 one-block records
+			// do, a look of the general walk at a read that the streaming loops leave to it what 9 do (the ingest counts those looks
+			// per bucket as it pools the reads: plan_park*), a bucket's staging and flush what 7 000 do.  And the shares get smaller towards the end
+			// of the grid ("share_taper": the last is that fraction of the first), so that what is still running when the slots
+			// start to empty is short.
 			const std::vector<unsigned long long> &so = mr.slot_off_host;
 			const size_t B = E.buckets.size();
 			std::vector<unsigned long long> cut((size_t)grid + 1, 0);
 			std::vector<unsigned> first((size_t)grid, 0);
-			const double share = (double)mr.total_slots / (double)grid;
+			const bool weighted = c->opt_share_weighted && mr.plan_n1.size() == B && mr.plan_park1.size() == B;
+			const double c2 = weighted ? c->opt_share_cost_p2 : 1.0, cw = weighted ? c->opt_share_cost_park : 0.0, cv = weighted ? c->opt_share_cost_visit : 0.0;
+			// (the pipelined step on one box, taper 1 / 0.5 / 0.25: C3 0.1189 / 0.1165 / 0.1193 ms -- the next count's first workgroups fill this
+			// launch's tail there, and smaller last shares cost more stagings than they still save; the skewed c5s 0.1364 / 0.1358 / 0.1300,
+			// from 0.1607 with shares equal in reads; C2 0.0404 / 0.0389 / 0.0389 from 0.0400)
+			const double taper = !weighted ? 1.0 : (c->opt_share_taper > 0 ? std::min(1.0, std::max(0.05, c->opt_share_taper)) : (mr.skew >= 4.0 ? 0.25 : 0.5));
+			// cost per record of a bucket's one- and two-block pool (the rest of its slots -- many-block reads, the workers' -- next to nothing)
+			std::vector<double> d1(B, 1.0), d2(B, c2), cum(B + 1, 0.0);
+			const double d_rest = 1e-3;
+			for (size_t q = 0; q < B; ++q) {
+				const unsigned long long ns = so[q + 1] - so[q];
+				unsigned long long n1 = ns, n2 = 0;
+				if (weighted) {
+					n1 = std::min(mr.plan_n1[q], ns); n2 = std::min(mr.plan_n2[q], ns - n1);
+					if (n1) d1[q] = 1.0 + cw * (double)mr.plan_park1[q] / (double)n1;
+					if (n2) d2[q] = c2 + cw * (double)mr.plan_park2[q] / (double)n2;
+				}
+				const bool visited = ns != 0 && E.buckets[q].kind == 1u;
+				cum[q + 1] = cum[q] + (visited ? cv : 0.0) + (double)n1 * d1[q] + (double)n2 * d2[q] + (double)(ns - n1 - n2) * d_rest;
+			}
+			const double total_cost = cum[B];
+			// share g's part of the whole: falling in a line from 1 to `taper`
+			const double wsum = (double)grid * (1.0 + taper) / 2.0;
+			auto part_before = [&](unsigned long long g) {          // sum of the weights of shares 0 .. g - 1, over wsum
+				const double k = (double)g, slope = grid > 1 ? (taper - 1.0) / (double)(grid - 1) : 0.0;
+				return (k + slope * k * (k - 1.0) / 2.0) / wsum;
+			};
 			size_t bb = 0;
-			for (unsigned long long g = 1; g < grid; ++g) {
-				unsigned long long t = mr.total_slots * g / grid;
-				while (bb + 1 < B && so[bb + 1] <= t) ++bb;
-				const unsigned long long lo = so[bb], hi = so[bb + 1];
-				if (c->opt_snap_shares) {
-					if (t - lo <= hi - t && (double)(t - lo) < 0.3 * share) t = lo;
-					else if ((double)(hi - t) < 0.3 * share) t = hi;
+			for (unsigned long long g = 1; g < grid && total_cost > 0; ++g) {
+				const double tc = total_cost * part_before(g), share = total_cost * (part_before(g + 1) - part_before(g));
+				while (bb + 1 < B && cum[bb + 1] <= tc) ++bb;
+				const unsigned long long lo = so[bb], hi = so[bb + 1], ns = hi - lo;
+				const double x = tc - cum[bb], y = cum[bb + 1] - tc;          // cost of the bucket before / behind the cut
+				unsigned long long t;
+				if (c->opt_snap_shares && x <= y && x < 0.3 * share) t = lo;
+				else if (c->opt_snap_shares && y < x && y < 0.3 * share) t = hi;
+				else {
+					// inside the bucket: past the staging, then through the pools at their cost per record
+					const unsigned long long n1 = weighted ? std::min(mr.plan_n1[bb], ns) : ns, n2 = weighted ? std::min(mr.plan_n2[bb], ns - n1) : 0;
+					double r = std::max(0.0, x - ((ns != 0 && E.buckets[bb].kind == 1u) ? cv : 0.0));
+					double at = 0;
+					if (r < (double)n1 * d1[bb]) at = r / d1[bb];
+					else {
+						r -= (double)n1 * d1[bb];
+						if (r < (double)n2 * d2[bb]) at = (double)n1 + r / d2[bb];
+						else at = (double)(n1 + n2) + (r - (double)n2 * d2[bb]) / d_rest;
+					}
+					t = lo + std::min<unsigned long long>((unsigned long long)at, ns);
 				}
 				cut[(size_t)g] = std::max(t, cut[(size_t)g - 1]);
 			}
+			if (!(total_cost > 0)) for (unsigned long long g = 1; g < grid; ++g) cut[(size_t)g] = mr.total_slots * g / grid;
 			cut[(size_t)grid] = mr.total_slots;
+			// one workgroup's share must keep the packed LDS counters exact (see `grid` above): if the weights made one too long, equal shares
+			for (unsigned long long g = 0; g < grid; ++g)
+				if (cut[(size_t)g + 1] - cut[(size_t)g] > (1ull << 21)) {
+					for (unsigned long long q = 1; q < grid; ++q) cut[(size_t)q] = mr.total_slots * q / grid;
+					break;
+				}
 			// the first packed bucket that holds slots of the share [cut[g], cut[g + 1]) (the kernel follows the visit
 			// records' links from there); B when there is none
 			bb = 0;
@@ -1643,6 +1706,7 @@ int run_count(lsq_ctx *c) {
 		A.cnt = c->cnt.p + (size_t)m * n_cls; A.bases = c->bases.p + (size_t)m * n_cls;
 		A.exc = mr.exc.p + (size_t)set * mr.exc_cap; A.exc_count = c->exc_count.p + 2 * m; A.exc_cap = (unsigned)mr.exc_cap;
 		A.dbg = c->dbg.p;
+		A.wg_trace = nullptr;
 		const unsigned long long n_pn = mr.pn_strand.n;
 		// pool-n workers: one workgroup per CU at most, one lane per read and pass
 		A.n_pn = n_pn;
@@ -1657,6 +1721,14 @@ int run_count(lsq_ctx *c) {
 			// event record is one more packet between this kernel and the next count's (measured ~5 us each)
 			const bool last_streaming = m == M - 1 && !c->has_generic && !c->time_events;
 			const dim3 fgrid((unsigned)grid + A.n_workers);
+#ifdef LSQ_DEV
+			if (c->dev_ablate & 4194304u) {
+				if (c->wg_trace.n < 4ull * fgrid.x) { int rc = c->wg_trace.alloc(4ull * fgrid.x); if (rc) return rc; }
+				HIP_TRY(hipMemsetAsync(c->wg_trace.p, 0, 4ull * fgrid.x * sizeof(unsigned long long), st));
+				c->wg_trace_n = fgrid.x; c->wg_trace_workers = A.n_workers;
+				A.wg_trace = c->wg_trace.p;
+			}
+#endif
 			void *kargs[] = {(void *)&A};
 			HIP_TRY(hipExtLaunchKernel(mr.compact ? fn_compact : fn_wide, fgrid, dim3(COUNT_BLOCK), kargs, lds_bytes, st, nullptr, last_streaming ? c->ev_counted2[set] : nullptr, 0));
 			if (last_streaming) counted_signalled = true;
@@ -1736,6 +1808,17 @@ int lsq_debug_counters(lsq_ctx *c, unsigned long long *out8) LSQ_API_TRY {
 	return LSQ_OK;
 } LSQ_API_CATCH
 
+// developer aid (include/lesseq_hip_dev.h): (start, end, walk steps, reads walked) of the last count launch's workgroups, 100 MHz
+// ticks; returns their number through *n (out holds 4 * cap values), the pool-n workers among them (the first ones) through *n_workers
+int lsq_debug_wg_trace(lsq_ctx *c, unsigned long long *out, unsigned long long cap, unsigned long long *n, unsigned long long *n_workers) LSQ_API_TRY {
+	HIP_TRY(hipSetDevice(c->device));
+	{ int rc = sync_all(c); if (rc) return rc; }
+	const unsigned long long k = std::min<unsigned long long>(cap, c->wg_trace_n);
+	if (k) HIP_TRY(hipMemcpy(out, c->wg_trace.p, 4 * k * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	*n = k; *n_workers = c->wg_trace_workers;
+	return LSQ_OK;
+} LSQ_API_CATCH
+
 // developer aid (include/lesseq_hip_dev.h): per-bucket slot offsets of a method (n_buckets + 1 values)
 int lsq_debug_slot_offsets(lsq_ctx *c, int method, unsigned long long *out, unsigned long long n) LSQ_API_TRY {
 	HIP_TRY(hipSetDevice(c->device));
@@ -1743,6 +1826,26 @@ int lsq_debug_slot_offsets(lsq_ctx *c, int method, unsigned long long *out, unsi
 	const MethodReads &mr = c->reads[method];
 	if (n > mr.slot_off.n) n = mr.slot_off.n;
 	HIP_TRY(hipMemcpy(out, mr.slot_off.p, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	return LSQ_OK;
+} LSQ_API_CATCH
+
+// developer aid (include/lesseq_hip_dev.h): an offset table of a method -- 0: slots per bucket, 1 / 2: one- / two-block pool
+// per bucket (n_buckets + 1 values each), 3: the count launch's share bounds (workgroups + 1); *n = values written
+int lsq_debug_offsets(lsq_ctx *c, int method, int which, unsigned long long *out, unsigned long long cap, unsigned long long *n) LSQ_API_TRY {
+	HIP_TRY(hipSetDevice(c->device));
+	{ int rc = sync_all(c); if (rc) return rc; }
+	const MethodReads &mr = c->reads[method];
+	if (which == 4 || which == 5) {          // the ingest's estimate of the reads bound for the general walk, per bucket (one- / two-block)
+		const std::vector<unsigned> &v = which == 4 ? mr.plan_park1 : mr.plan_park2;
+		const unsigned long long k = std::min<unsigned long long>(cap, v.size());
+		for (unsigned long long i = 0; i < k; ++i) out[i] = v[i];
+		*n = k;
+		return LSQ_OK;
+	}
+	const DevBuf<unsigned long long> &src = which == 0 ? mr.slot_off : (which == 1 ? mr.p1_off : (which == 2 ? mr.p2_off : mr.wg_cut));
+	const unsigned long long k = std::min<unsigned long long>(cap, src.n);
+	if (k) HIP_TRY(hipMemcpy(out, src.p, k * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	*n = k;
 	return LSQ_OK;
 } LSQ_API_CATCH
 

@@ -110,6 +110,8 @@ struct MethodReads {
 	DevBuf<unsigned long long> wg_cut;     // ... and the shares' bounds in slots (wg_grid + 1 values)
 	std::vector<unsigned long long> slot_off_host;   // the buckets' slot offsets (n_buckets + 1), for the share plan
 	DevBuf<VisitRec> visits;               // per bucket (n_buckets + 1: the last one ends every chain)
+	std::vector<unsigned long long> plan_n1, plan_n2;   // per bucket: records of the one- / two-block pool (padding included) ...
+	std::vector<unsigned> plan_park1, plan_park2;       // ... and the looks of the general walk at the reads of each that the streaming loops leave to it (the ingest's estimate)
 	std::vector<unsigned> next_packed_host;          // per bucket b: the first packed bucket >= b that holds slots (n_buckets: none), for the share plan
 	unsigned long long wg_grid = 0;
 };
@@ -192,6 +194,8 @@ struct lsq_ctx {
 	bool fim_uploaded = false, fim_done = false;
 	DevBuf<unsigned long long> counters;   // two sets of cnt | bases | exc_count | dbg (one memset per count); the views below are the latest count's
 	DevView<unsigned long long> cnt, bases, dbg;
+	DevBuf<unsigned long long> wg_trace;   // developer build (LSQ_ABLATE 4194304): lsq_debug_wg_trace
+	unsigned long long wg_trace_n = 0, wg_trace_workers = 0;
 	DevView<unsigned> exc_count;           // per method: [2m] appended, [2m+1] overflow flag
 	DevBuf<unsigned> cov_off, cut_off, clu_off;     // ingest tables: covered regions, bucket cuts and event clusters per chromosome id
 	DevBuf<int> clu_s, clu_e;
@@ -216,6 +220,11 @@ struct lsq_ctx {
 	bool opt_compact_pools = true;          // "compact_pools": 0 keeps wide pool records whatever the reads look like
 	bool opt_recount = false;
 	bool opt_snap_shares = true;            // workgroup shares cut on bucket boundaries where one is near
+	bool opt_share_weighted = true;         // "share_weighted": the shares equal in cost, not in reads (run_count's plan)
+	double opt_share_cost_p2 = 4.3;         // "share_cost_two_block": a two-block record, in one-block records
+	double opt_share_cost_park = 9.0;       // "share_cost_parked": one look of the general walk at a parked read
+	double opt_share_cost_visit = 7000.0;   // "share_cost_visit": staging + flush of a bucket
+	double opt_share_taper = 0;             // "share_taper": the last share of the grid as a fraction of the first (0 = automatic)
 	unsigned dev_ablate = 0;                // developer build only (LSQ_ABLATE)
 	DevBuf<unsigned char> recount_args;     // the recount kernels' argument records (lsq_count.hip), and the host's copy of what was last written
 	std::vector<unsigned char> recount_args_host;

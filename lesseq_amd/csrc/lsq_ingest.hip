@@ -80,6 +80,7 @@ struct IngestWork {
 	int *ms, *me;                  // merged blocks, at the read's original block offset
 	unsigned *cnt1, *cnt2;         // one-block reads per group [n_cell_groups]; two-block reads per group [n_junction_groups]
 	unsigned *cntn, *cntnb;        // [n_buckets]: n-block reads, and their blocks
+	unsigned *park1, *park2;       // [n_buckets]: looks of the general walk at the one- / two-block reads that the count kernel's streaming loops will leave to it (an estimate, for the share plan)
 	unsigned *cur1, *cur2, *curn, *curnb;   // scatter cursors, same shapes
 	unsigned long long *totals;    // [0] retained reads, [1] retained blocks, [2] error flag, [3] one- and two-block reads that do not fit compact records, [4] / [5] one- / two-block reads pooled
 	unsigned compact;              // compact pool records: one- and two-block reads that do not fit them go with the many-block reads
@@ -174,6 +175,7 @@ __global__ void __launch_bounds__(256) lsq_ingest_classify_kernel(IngestTables T
 							// the read's cell, found as the count kernel finds it (bin record: first cell | first event << 16, the
 							// ends of that cell and the next two; then on through the cell table)
 							unsigned n_cells = 0, cell = 0;
+							bool in_junction_group = false;
 							if (d.kind == 1u) {
 								const unsigned char *img = T.images + d.img_off;
 								const uint4 br = reinterpret_cast<const uint4 *>(img)[bin];
@@ -196,6 +198,36 @@ __global__ void __launch_bounds__(256) lsq_ingest_classify_kernel(IngestTables T
 									}
 									// (no junction: the group of the read's cell -- `n_cells`: of no cell -- behind the junction groups)
 									fine = T.jgroup_base[b] + (g < k1 ? g - k0 : (k1 - k0) + cell);
+									in_junction_group = g < k1;
+								}
+								// Will the streaming loop settle the read, or leave it to the general walk -- and how many events will the walk look
+								// at for it?  What the parked reads cost beside the streamed ones is what makes buckets differ: the share plan weighs
+								// it (run_count).  An estimate: the loops' rules in short; the walk's own stepping rule (fast_trip's return).
+								bool parks = cell == n_cells, one_event = false;
+								if (!parks && !in_junction_group) {
+									const lsq::CellX *cellx = reinterpret_cast<const lsq::CellX *>(img + d.seg_off + 16u * (d.iso_off >> 16));
+									const lsq::Cell cw = cells[cell];
+									const unsigned fl = cellx[cell].flags;
+									const int len = e[0] - s[0];
+									const bool both = (fl & lsq::CELLX_BOTH) != 0u;
+									const bool near_free = (fl & lsq::CELLX_NEAR_NO_ABUT) != 0u, far_free = (fl & lsq::CELLX_FAR_NO_ABUT) != 0u;
+									const bool near_done = e[0] <= cw.e1 || (near_free && 50 * (e[0] - cw.e1) >= len), far_done = e[0] <= cw.e2 || (far_free && 50 * (e[0] - cw.e2) >= len);
+									if (pool == 0u) { parks = both ? !(near_done && far_done) : e[0] > cw.e2; one_event = !both || near_done || far_done; }
+									else if (cellx[cell].info == lsq::CELL_INFO_EMPTY) parks = false;
+									else parks = both ? (e[0] == cw.e1 || e[0] == cw.e2 || (e[0] > cw.e1 && !near_free) || (e[0] > cw.e2 && !far_free)) : e[0] > cw.e2;
+								}
+								if (parks) {
+									unsigned looks = 1;
+									if (!one_event) {
+										const lsq::FastRec *recs = reinterpret_cast<const lsq::FastRec *>(img + d.ev_off);
+										looks = 0;
+										for (unsigned i = br.x >> 16; i < d.n_events && looks < 64u; ++i) {
+											++looks;
+											const lsq::FastRec &fr = recs[i];
+											if (!(fr.seg[0] <= p && (p > fr.ge || (fr.meta & lsq::FAST_FLAG_OVERLAPS_NEXT) != 0u))) break;
+										}
+									}
+									atomicAdd(pool == 0u ? &W.park1[b] : &W.park2[b], looks);
 								}
 							} else if (pool == 1u) fine = T.jgroup_base[b] + (T.jg_base[b + 1] - T.jg_base[b]);
 							if (pool == 0u) fine = T.cell_base[b] + cell;
@@ -361,12 +393,13 @@ static int ingest_device(lsq_ctx *c, int method, const IngestRaw &Rw, uint64_t n
 	DevBuf<unsigned char> d_nb, d_strand;
 	DevBuf<unsigned> d_key, d_fine;
 	DevBuf<unsigned> d_cnt;                      // cnt1 | cnt2 | cntn | cntnb, then the four cursor arrays
+	DevBuf<unsigned> d_park;                     // park1 | park2
 	DevBuf<unsigned long long> d_off1, d_off2, d_totals;
 	const size_t FC = c->n_cell_groups;          // one-block groups of all buckets
 	const size_t FJ = c->n_junction_groups;      // two-block groups of all buckets
 	const size_t n_cnt = FC + FJ + 2 * (size_t)B;
 	if ((rc = d_ms.alloc(nblk)) || (rc = d_me.alloc(nblk)) || (rc = d_nb.alloc(n)) || (rc = d_strand.alloc(n)) || (rc = d_key.alloc(n)) || (rc = d_fine.alloc(n))) return rc;
-	if ((rc = d_cnt.alloc(2 * n_cnt)) || (rc = d_off1.alloc(FC + 1)) || (rc = d_off2.alloc(FJ + 1)) || (rc = d_totals.alloc(8))) return rc;
+	if ((rc = d_cnt.alloc(2 * n_cnt)) || (rc = d_off1.alloc(FC + 1)) || (rc = d_off2.alloc(FJ + 1)) || (rc = d_totals.alloc(8)) || (rc = d_park.alloc(2 * (size_t)B))) return rc;
 	IngestTables T{};
 	T.cov_off = c->cov_off.p; T.cov_s = c->cov_s.p; T.cov_e = c->cov_e.p;
 	T.cut_off = c->cut_off.p; T.cut_lo = c->cut_lo.p; T.chrom_first_bucket = c->chrom_first_bucket.p;
@@ -379,6 +412,7 @@ static int ingest_device(lsq_ctx *c, int method, const IngestRaw &Rw, uint64_t n
 	W.cnt1 = d_cnt.p; W.cnt2 = W.cnt1 + FC; W.cntn = W.cnt2 + FJ; W.cntnb = W.cntn + B;
 	W.cur1 = d_cnt.p + n_cnt; W.cur2 = W.cur1 + FC; W.curn = W.cur2 + FJ; W.curnb = W.curn + B;
 	W.totals = d_totals.p;
+	W.park1 = d_park.p; W.park2 = d_park.p + B;
 	W.compact = c->opt_compact_pools ? 1u : 0u;
 	const unsigned igrid = (unsigned)std::min<unsigned long long>((n + 255) / 256 + 1, (unsigned long long)c->n_cu * 16);
 	if ((rc = mr.p1_off.alloc(B + 1)) || (rc = mr.p2_off.alloc(B + 1)) || (rc = mr.pn_off.alloc(B + 1)) || (rc = mr.pnb_off.alloc(B + 1)) || (rc = mr.slot_off.alloc(B + 1))) return rc;
@@ -386,6 +420,7 @@ static int ingest_device(lsq_ctx *c, int method, const IngestRaw &Rw, uint64_t n
 	for (;;) {
 		HIP_TRY(hipMemsetAsync(d_cnt.p, 0, std::max<size_t>(2 * n_cnt, 1) * 4, st));
 		HIP_TRY(hipMemsetAsync(d_totals.p, 0, 8 * 8, st));
+		HIP_TRY(hipMemsetAsync(d_park.p, 0, std::max<size_t>(2 * (size_t)B, 1) * 4, st));
 		if (n) {
 			hipLaunchKernelGGL(lsq_ingest_classify_kernel, dim3(igrid), dim3(256), 0, st, T, Rw, W);
 			HIP_TRY(hipGetLastError());
@@ -472,6 +507,15 @@ static int ingest_device(lsq_ctx *c, int method, const IngestRaw &Rw, uint64_t n
 		HIP_TRY(hipMemcpyAsync(o1.data(), mr.p1_off.p, (B + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
 		HIP_TRY(hipMemcpyAsync(o2.data(), mr.p2_off.p, (B + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
 		HIP_TRY(hipStreamSynchronize(st));
+		// ... and what the share plan weighs: reads per pool and bucket, and those of them bound for the general walk
+		std::vector<unsigned> park(2 * (size_t)B + 1, 0);
+		if (B) HIP_TRY(hipMemcpyAsync(park.data(), d_park.p, 2 * (size_t)B * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
+		mr.plan_n1.resize(B); mr.plan_n2.resize(B); mr.plan_park1.resize(B); mr.plan_park2.resize(B);
+		for (unsigned b = 0; b < B; ++b) {
+			mr.plan_n1[b] = o1[b + 1] - o1[b]; mr.plan_n2[b] = o2[b + 1] - o2[b];
+			mr.plan_park1[b] = park[b]; mr.plan_park2[b] = park[(size_t)B + b];
+		}
 		std::vector<VisitRec> vis(B + 1);
 		mr.next_packed_host.assign(B + 1, B);
 		memset(vis.data(), 0, vis.size() * sizeof(VisitRec));

@@ -196,6 +196,29 @@ def test_results_do_not_depend_on_launch_geometry(tmp_path, monkeypatch):
     assert len({r[0] for r in results}) > 1
     for r in results[1:]:
         assert np.array_equal(r[1], results[0][1]) and np.array_equal(r[2], results[0][2])
+    # ... nor does the share plan (round 3: shares equal in estimated cost, tapering towards the end of the grid): one context,
+    # replanned between counts -- equal reads, extreme weights, the steepest taper, every cut snapped or none
+    monkeypatch.setenv("LSQ_LDS_BUDGET", "8192")
+    a = L.Annotation(os.path.join(a_dir, "g.interval"), os.path.join(a_dir, "g.map"))
+    ev = L.Events(a, ("SHORT_READ",), (100,))
+    zipf = L.SynthSpec(12, 3000, 500000, 100, 3, L.EVENT_TYPES, True)
+    for sp in (spec, zipf):
+        ctx = L.Context(0)
+        ctx.upload_events(ev)
+        ctx.upload_reads(0, L.Reads.synthetic(sp, ev))
+        ref = None
+        for opts in ({"share_weighted": 0}, {}, {"share_weighted": 1, "share_taper": 0.05, "grid_multiplier": 9}, {"share_taper": 1, "share_cost_parked": 1e6, "grid_multiplier": 0.3},
+                     {"share_cost_visit": 1e6, "share_cost_two_block": 0}, {"share_cost_visit": 0, "share_cost_two_block": 1000, "snap_shares": 0, "share_taper": 0.2}):
+            for k, v in opts.items():
+                ctx.set_option(k, v)
+            ctx.count()
+            got = [x.copy() for x in ctx.counts()]
+            if ref is None:
+                ref = got
+            assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]), opts
+        with pytest.raises(L.LsqError):
+            ctx.set_option("share_taper", -1)
+        ctx.close()
 
 
 def _full_size_linearity_and_sample(tmp_path, seed, n_ev, n_reads, n_chrom, types, zipf, chunks, sample_reads, R=100):
