@@ -1115,9 +1115,6 @@ __device__ inline void stream_pool2_compact(FastCtx &C, const uint4 *bins, const
 		const unsigned k1e = ends1b ? k1 + 1u : k1;          // the last segment of block 1's run
 		const bool junction = (ends1 || ends1b) && k2 > k1e;
 		const bool J = junction && rd.w <= end2, Jb = junction && rd.w > end2 && rd.w <= end2b;
-		const bool S = inside1 && !junction;
-		// counts for nobody: from a start cell and over before gene_end; or block 1 starts inside no segment at all
-		const bool drop = (v1 && start1 && rd.w <= (int)cw1.w) || (here && i1 == CELL_INFO_EMPTY);
 		const unsigned len1 = ra[0] >> lsq::COMPACT_OFF_BITS, total = len1 + (rb[0] >> lsq::COMPACT_OFF_BITS);
 		const unsigned long long tbl = ((unsigned long long)w0r.w << 32) | w0r.z;
 		const unsigned mask1 = (1u << (k1 & 3u)) | (ends1b ? 2u << (k1 & 3u) : 0u), maskA = mask1 | (1u << k2), maskB = maskA | (2u << k2);
@@ -1125,16 +1122,26 @@ __device__ inline void stream_pool2_compact(FastCtx &C, const uint4 *bins, const
 		const unsigned sa = cx1.x & 0xFFFFu;
 		// the histogram slots of the junction's classes: segments of block 1 + segment k2, and + segment k2 + 1 (CELL_NONE: no compatible isoform)
 		const unsigned slotA = clsA != 0u ? (w0r.y & 0xFFFFu) + clsA - 1u : CELL_NONE, slotB = clsB != 0u ? (w0r.y & 0xFFFFu) + clsB - 1u : CELL_NONE;
-		const bool addS = in0 && S && sa != CELL_NONE && 50u * len1 > 49u * total;
 		// No junction.  The quadruple then shares the cell of this record (layout: the reads that cross no junction of the
 		// annotation are grouped by the cell block 1 starts in), and block 2 of none of its reads continues a match: a key of
 		// the junction groups would name it.  What is left per read is whether block 1 alone could carry it: matched <= |block 1|
 		// whenever block 1 ends inside a segment of every owner or past one that nothing abuts, so a read with 50 |block 1| <= 49
 		// total is valid for nobody (count/count.cpp:441) and is settled here as nothing.  e1c / e2c: the owners' segment ends
 		// in the records' terms; `gone_ok`: where block 1 may end.
-		const bool two = here && (cx1.z & CELLX_BOTH) != 0u, empty = here && i1 == CELL_INFO_EMPTY;
-		const int e1c = (int)cw1.z - base, e2c = (int)cw1.w - base;
-		const bool near_free = (cx1.z & CELLX_NEAR_NO_ABUT) != 0u, far_free = (cx1.z & CELLX_FAR_NO_ABUT) != 0u;
+		// (a wave whose every lane crosses a junction -- the usual one: the junction groups come first in a bucket's pool and hold
+		// most of it -- skips all of this)
+		const bool any_plain = __any(!junction);
+		bool two = false, empty = false, near_free = false, far_free = false, S = false, drop = false, addS = false;
+		int e1c = 0, e2c = 0;
+		if (any_plain) {
+			S = inside1 && !junction;          // block 1 inside its segment and no junction: that segment's class, if it is more than 98 % of the read
+			// counts for nobody: from a start cell and over before gene_end; or block 1 starts inside no segment at all
+			drop = (v1 && start1 && rd.w <= (int)cw1.w) || (here && i1 == CELL_INFO_EMPTY);
+			addS = in0 && S && sa != CELL_NONE && 50u * len1 > 49u * total;
+			two = here && (cx1.z & CELLX_BOTH) != 0u; empty = here && i1 == CELL_INFO_EMPTY;
+			e1c = (int)cw1.z - base; e2c = (int)cw1.w - base;
+			near_free = (cx1.z & CELLX_NEAR_NO_ABUT) != 0u; far_free = (cx1.z & CELLX_FAR_NO_ABUT) != 0u;
+		}
 		auto nothing = [&](const unsigned a, const unsigned b2) __attribute__((always_inline)) {      // a record (block 1, block 2) of this cell that counts for nobody
 			const unsigned l1 = a >> lsq::COMPACT_OFF_BITS, l2 = b2 >> lsq::COMPACT_OFF_BITS, gap = b2 & lsq::COMPACT_OFF_MASK;
 			const int y = (int)(a & lsq::COMPACT_OFF_MASK) + (int)l1;
@@ -1143,8 +1150,15 @@ __device__ inline void stream_pool2_compact(FastCtx &C, const uint4 *bins, const
 			const bool two_ok = y != e1c && y != e2c && (y < e1c || near_free) && (y < e2c || far_free);
 			return empty || (weak && (two ? two_ok : (v1 && !start1 && one_ok)));
 		};
+		bool none[NR];
+#pragma unroll
+		for (int j = 0; j < NR; ++j) none[j] = false;
+		if (any_plain) {
+#pragma unroll
+			for (int j = 0; j < NR; ++j) none[j] = !junction && nothing(ra[j], rb[j]);
+		}
 		bool park[NR];
-		park[0] = in0 && len1 != 0u && !(J || Jb || S || drop || (!junction && nothing(ra[0], rb[0]))) && !ABL(A, 17u | 1048576u);
+		park[0] = in0 && len1 != 0u && !(J || Jb || S || drop || none[0]) && !ABL(A, 17u | 1048576u);
 		if (ABL(A, 256u) && park[0]) atomicAdd(&A.dbg[8 + (v1 ? 1 : 0)], 1ull);       // parked: block 1 in no one-owner cell / in one
 		unsigned nA = (in0 && J && slotA != CELL_NONE) ? 1u : 0u, sA = nA ? total : 0u, nB = (in0 && Jb && slotB != CELL_NONE) ? 1u : 0u, sB = nB ? total : 0u;
 		// ---- the other records: block 2 must end inside the junction's second segment (gap + length <= lim) or inside the one
@@ -1161,8 +1175,7 @@ __device__ inline void stream_pool2_compact(FastCtx &C, const uint4 *bins, const
 			const bool cA = sameA && slotA != CELL_NONE, cB = sameB && slotB != CELL_NONE;
 			nA += cA ? 1u : 0u; sA += cA ? l1 + l2 : 0u;
 			nB += cB ? 1u : 0u; sB += cB ? l1 + l2 : 0u;
-			const bool none = !junction && nothing(ra[j], rb[j]);
-			park[j] = in && !(sameA || sameB || none) && !ABL(A, 17u | 1048576u | 2097152u);
+			park[j] = in && !(sameA || sameB || none[j]) && !ABL(A, 17u | 1048576u | 2097152u);
 			if (ABL(A, 256u) && park[j]) atomicAdd(&A.dbg[junction ? 14 : 13], 1ull);       // parked followers: block 2 runs past the junction's segments / the first record crosses no junction
 			any_park = any_park || park[j];
 		}
