@@ -961,7 +961,8 @@ __device__ inline void stream_pool1_compact(FastCtx &C, const uint4 *bins, const
 		// every step but the first and last of a workgroup's range lies wholly inside it: no per-record range test there
 		const bool interior = t + TILE <= n && t >= first_rel;
 		unsigned accN = 0, accA = 0, accL = 0;          // all records / those that end by e1 / by e2: count << 24 | bases
-		auto decide = [&](auto whole_step) {
+		// (one_threshold: no lane's cell has a second one -- nothing abuts the owner's segment, no second owner: most waves)
+		auto decide = [&](auto whole_step, auto one_threshold) {
 #pragma unroll
 			for (int j = 0; j < NR; ++j) {
 				const unsigned len = rec[j] >> lsq::COMPACT_OFF_BITS;
@@ -973,10 +974,12 @@ __device__ inline void stream_pool1_compact(FastCtx &C, const uint4 *bins, const
 				}
 				accN += p;
 				accA += e <= e1 ? p : 0u;
-				accL += e <= e2 ? p : 0u;
+				if (!decltype(one_threshold)::value) accL += e <= e2 ? p : 0u;
 			}
+			if (decltype(one_threshold)::value) accL = accA;
 		};
-		if (interior) decide(std::true_type{}); else decide(std::false_type{});
+		if (__all(e1 == e2) && !ABL(A, 8388608u)) { if (interior) decide(std::true_type{}, std::true_type{}); else decide(std::false_type{}, std::true_type{}); }
+		else { if (interior) decide(std::true_type{}, std::false_type{}); else decide(std::false_type{}, std::false_type{}); }
 		const unsigned s1 = cx.x & 0xFFFFu, s2 = cx.x >> 16;
 		if (!ABL(A, (1u | 16384u))) {
 			// slot 1: the records inside the (nearer) owner's segment; slot 2: one owner -- those that run on into the abutting
@@ -1165,16 +1168,22 @@ __device__ inline void stream_pool2_compact(FastCtx &C, const uint4 *bins, const
 		// that abuts it (<= limb)
 		const int lim = junction ? end2 - rd.y : -1, limb = junction ? end2b - rd.y : -1;
 		bool any_park = park[0];
+		const bool any_b = __any(limb > lim) || ABL(A, 8388608u);
 #pragma unroll
 		for (int j = 1; j < NR; ++j) {
 			const unsigned l1 = ra[j] >> lsq::COMPACT_OFF_BITS, l2 = rb[j] >> lsq::COMPACT_OFF_BITS;
 			const int reach = (int)(rb[j] & lsq::COMPACT_OFF_MASK) + (int)l2;         // from the end of block 1 to the end of block 2
 			bool in = l1 != 0u;                                                          // (padding of a junction group: an empty record)
 			if (!interior) { const unsigned idx = idx0 + (unsigned)j; in = in && idx < n && idx - first_rel < n_rel; }
-			const bool sameA = in && reach <= lim, sameB = in && reach > lim && reach <= limb;
-			const bool cA = sameA && slotA != CELL_NONE, cB = sameB && slotB != CELL_NONE;
+			const bool sameA = in && reach <= lim;
+			bool sameB = false;
+			const bool cA = sameA && slotA != CELL_NONE;
 			nA += cA ? 1u : 0u; sA += cA ? l1 + l2 : 0u;
-			nB += cB ? 1u : 0u; sB += cB ? l1 + l2 : 0u;
+			if (any_b) {          // (wave-uniform: some lane's junction leads into a segment that another abuts)
+				sameB = in && reach > lim && reach <= limb;
+				const bool cB = sameB && slotB != CELL_NONE;
+				nB += cB ? 1u : 0u; sB += cB ? l1 + l2 : 0u;
+			}
 			park[j] = in && !(sameA || sameB || none[j]) && !ABL(A, 17u | 1048576u | 2097152u);
 			if (ABL(A, 256u) && park[j]) atomicAdd(&A.dbg[junction ? 14 : 13], 1ull);       // parked followers: block 2 runs past the junction's segments / the first record crosses no junction
 			any_park = any_park || park[j];
