@@ -58,6 +58,7 @@ struct CountArgs {
 	const lsq::VisitRec *visits;       // per bucket: what a visit needs, in one record (n_buckets + 1)
 	const unsigned *wg_first;          // per workgroup of the fast kernel's grid: the first packed bucket that holds slots of its share (n_buckets: none)
 	const unsigned long long *wg_cut;  // ... and the ranges' bounds in slots (grid + 1 values)
+	const lsq::WgPlan *wg_plan;        // both, per workgroup, with the first bucket's visit record (what the kernel reads)
 	unsigned long long *wg_trace;      // developer build: (start, end) of every workgroup, 100 MHz clock (null: none)
 	unsigned long long total_slots;
 	unsigned long long n_pn;           // reads with three or more blocks
@@ -1322,19 +1323,21 @@ __global__ void __launch_bounds__(COUNT_BLOCK, P1W == 4 ? 5 : LSQ_FAST_WAVES) ls
 	const unsigned wg = blockIdx.x - A.n_workers, n_wg = gridDim.x - A.n_workers;     // the streaming workgroups
 	uint4 *wave_queue = reinterpret_cast<uint4 *>(lds + A.tables_lds_bytes) + (tid >> 6) * WAVE_QUEUE_WORDS;
 	(void)n_wg;
-	const unsigned long long s_begin = A.wg_cut[wg], s_end = A.wg_cut[wg + 1u];
+	// the share and its buckets, one visit record each (scalar loads: everything here is wave-uniform); the plan holds the
+	// record of the first, every record names the next packed bucket with slots
+	// (through the constant address space: the records are written before the launch and never during it, and a uniform
+	// address there is a scalar load -- as plain global memory the compiler, seeing the kernel's own atomics, took vector
+	// loads and two dozen readfirstlanes)
+	typedef const lsq::VisitRec __attribute__((address_space(4))) *const_visit;
+	typedef const lsq::WgPlan __attribute__((address_space(4))) *const_plan;
+	const_plan plan = (const_plan)(A.wg_plan + wg);
+	const unsigned long long s_begin = plan->s_begin, s_end = plan->s_end;
 	if (s_begin >= s_end) return;
 	if (ABL(A, 4096u)) return;       // developer switch: dispatch cost only
-	// the share's buckets, one visit record each (scalar loads: the bucket number is wave-uniform); the host's plan names
-	// the first, every record the next packed bucket with slots
-	unsigned b = (unsigned)__builtin_amdgcn_readfirstlane((int)A.wg_first[wg]);
+	const_visit vr = &plan->first;
+	unsigned b = vr->b;
 	bool first_visit = true;
 	while (b < A.n_buckets) {
-		// (through the constant address space: the records are written before the launch and never during it, and a uniform
-		// address there is a scalar load -- as plain global memory the compiler, seeing the kernel's own atomics, took vector
-		// loads and two dozen readfirstlanes)
-		typedef const lsq::VisitRec __attribute__((address_space(4))) *const_visit;
-		const_visit vr = (const_visit)(A.visits + b);
 		const unsigned long long bs = vr->bs;
 		if (bs >= s_end) break;
 		BucketDesc d;         // (member by member: a struct copy out of that address space has no constructor to bind to)
@@ -1397,6 +1400,7 @@ __global__ void __launch_bounds__(COUNT_BLOCK, P1W == 4 ? 5 : LSQ_FAST_WAVES) ls
 		}
 		if (be >= s_end) break;          // the share ends in this bucket
 		b = next;
+		vr = (const_visit)(A.visits + b);
 	}
 }
 
@@ -1707,12 +1711,22 @@ int run_count(lsq_ctx *c) {
 			int rc = mr.wg_first.upload(first.data(), first.size(), st);
 			if (!rc) rc = mr.wg_cut.upload(cut.data(), cut.size(), st);
 			if (rc) return rc;
+			{
+				std::vector<WgPlan> plan((size_t)grid);
+				for (unsigned long long g = 0; g < grid; ++g) {
+					WgPlan &w = plan[(size_t)g];
+					w.s_begin = cut[(size_t)g]; w.s_end = cut[(size_t)g + 1];
+					w.first = mr.visits_host[std::min<size_t>(first[(size_t)g], B)];
+				}
+				if ((rc = mr.wg_plan.upload(plan.data(), plan.size(), st))) return rc;
+				HIP_TRY(hipStreamSynchronize(st));          // the host vector goes out of scope
+			}
 			HIP_TRY(hipStreamSynchronize(st));          // the host vectors go out of scope
 			mr.wg_grid = grid;
 		}
 		CountArgs A{};
 		A.buckets = c->buckets.p; A.images = c->images.p; A.ties = c->ties.p; A.strand_rank = c->strand_rank.p;
-		A.wg_first = mr.wg_first.p; A.wg_cut = mr.wg_cut.p; A.visits = mr.visits.p;
+		A.wg_first = mr.wg_first.p; A.wg_cut = mr.wg_cut.p; A.wg_plan = mr.wg_plan.p; A.visits = mr.visits.p;
 		A.read_names = mr.named ? mr.names.p : nullptr; A.read_name_off = mr.named ? mr.name_off.p : nullptr;
 		A.gene_names = c->gene_names.p; A.gene_name_off = c->gene_name_off.p;
 		A.n_buckets = (unsigned)E.buckets.size();

@@ -88,6 +88,13 @@ struct VisitRec {
 	unsigned pad[2];
 };
 static_assert(sizeof(VisitRec) == 128, "VisitRec is read as 32 dwords");
+// A workgroup's share of a count launch with the visit record of its first bucket beside it: one scalar load at the start of the
+// workgroup where the share's bounds, its first bucket and that bucket's record were three, two of them one after the other.
+struct WgPlan {
+	unsigned long long s_begin, s_end;       // the share, in slots
+	VisitRec first;                          // (b == n_buckets: the share holds no packed bucket's slots)
+};
+static_assert(sizeof(WgPlan) == 144, "WgPlan layout");
 
 struct MethodReads {
 	DevBuf<ExcEntry> exc;                  // exception lists: two halves of exc_cap entries, one per counter set
@@ -108,6 +115,8 @@ struct MethodReads {
 	DevBuf<unsigned long long> name_off;
 	DevBuf<unsigned> wg_first;             // per workgroup of the fast kernel's grid (`wg_grid` of them): the bucket its share starts in
 	DevBuf<unsigned long long> wg_cut;     // ... and the shares' bounds in slots (wg_grid + 1 values)
+	DevBuf<WgPlan> wg_plan;                // the same per workgroup, with its first visit record: what the kernel reads
+	std::vector<VisitRec> visits_host;     // (for the plan)
 	std::vector<unsigned long long> slot_off_host;   // the buckets' slot offsets (n_buckets + 1), for the share plan
 	DevBuf<VisitRec> visits;               // per bucket (n_buckets + 1: the last one ends every chain)
 	std::vector<unsigned long long> plan_n1, plan_n2;   // per bucket: records of the one- / two-block pool (padding included) ...

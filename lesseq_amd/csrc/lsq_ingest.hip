@@ -531,6 +531,7 @@ static int ingest_device(lsq_ctx *c, int method, const IngestRaw &Rw, uint64_t n
 		}
 		vis[B].b = B; vis[B].next = B; vis[B].bs = vis[B].be = mr.total_slots;
 		if ((rc = mr.visits.upload(vis.data(), vis.size(), st))) return rc;
+		mr.visits_host = vis;
 		HIP_TRY(hipStreamSynchronize(st));           // the host vector goes out of scope
 	}
 	mr.present = true;
