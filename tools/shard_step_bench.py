@@ -19,6 +19,8 @@ L.synth_write(spec, tmp, "w", write_mrf=True)
 ann = L.Annotation(tmp + "/w.interval", tmp + "/w.map")
 ev = L.Events(ann, ("SHORT_READ",), (W["R"],))
 ctx = L.Context(0)
+for kv in filter(None, os.environ.get("SSB_OPTS", "").split(",")):          # SSB_OPTS="name=value,...": context options
+    ctx.set_option(kv.split("=")[0], float(kv.split("=")[1]))
 text = ctx.stage_text(tmp + "/w.mrf")
 ctx.upload_events(ev); ctx.upload_reads_text(0, text, free=False)
 ctx.count(); ctx.solve()
