@@ -25,6 +25,13 @@ int lsq_debug_wg_trace(lsq_ctx *c, unsigned long long *out, unsigned long long c
 /* The combined slot offsets of a method's buckets (n_buckets + 1 values): the work partition of
  * the count kernels. */
 int lsq_debug_slot_offsets(lsq_ctx *c, int method, unsigned long long *out, unsigned long long n);
+/* The share plan of a count launch as lsq_count makes it, on given numbers (host only, no device): slot_off = the buckets' slot
+ * offsets (n_buckets + 1), packed = 1 per bucket the streaming kernel visits, n1 / n2 / look1 / look2 = per bucket the records of
+ * the one- and two-block pool and the walk's looks at each (null: every slot weighs the same), costs4 = {two-block record, walk
+ * look, visit, taper}; writes grid + 1 bounds in slots. */
+int lsq_debug_plan_shares(const unsigned long long *slot_off, const unsigned char *packed, const unsigned long long *n1, const unsigned long long *n2,
+                          const unsigned *look1, const unsigned *look2, unsigned long long n_buckets, unsigned long long grid,
+                          const double *costs4, int weighted, int snap, unsigned long long *cuts);
 /* An offset table of a method -- which = 0: slots per bucket, 1 / 2: the one- / two-block pool per bucket (n_buckets + 1
  * values each), 3: the share bounds of the count launch's streaming workgroups (their number + 1), 4 / 5: the ingest's
  * estimate of the one- / two-block reads per bucket that the streaming loops leave to the general walk; *n = values written. */

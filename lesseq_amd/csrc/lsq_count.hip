@@ -1541,6 +1541,74 @@ __global__ void __launch_bounds__(256) lsq_count_recount_kernel(const CountArgs 
 
 namespace lsq {
 
+// The share plan of a count launch (run_count): `grid` + 1 bounds in slots over buckets whose slots start at so[0 .. B].  Shares
+// equal in estimated cost -- a one-block record 1, a two-block record `two_block`, a look of the general walk `walk_look` (n1 /
+// n2 / look1 / look2 per bucket: the ingest's counts; null: every slot 1), staging + flush of a visited bucket `visit` -- and
+// falling off in size in a line from the first share to the last (`taper` = last / first); a cut within 30 % of a share of a
+// bucket boundary moves onto it (`snap`).  No share longer than 2^21 slots (the packed LDS counters): else equal shares.
+struct SharePlanCosts { bool weighted = true, snap = true; double two_block = 4.3, walk_look = 9.0, visit = 7000.0, taper = 0.5; };
+void plan_share_cuts(const unsigned long long *so, const unsigned char *visited_kind, const unsigned long long *pn1, const unsigned long long *pn2,
+                     const unsigned *look1, const unsigned *look2, const size_t B, const unsigned long long grid, const SharePlanCosts &pc, unsigned long long *cut) {
+	const unsigned long long total_slots = B ? so[B] : 0;
+	const bool weighted = pc.weighted && pn1 && pn2 && look1 && look2;
+	const double c2 = weighted ? pc.two_block : 1.0, cw = weighted ? pc.walk_look : 0.0, cv = weighted ? pc.visit : 0.0;
+	const double taper = weighted ? std::min(1.0, std::max(0.05, pc.taper)) : 1.0;
+	cut[0] = 0;
+	// cost per record of a bucket's one- and two-block pool (the rest of its slots -- many-block reads, the workers' -- next to nothing)
+	std::vector<double> d1(B, 1.0), d2(B, c2), cum(B + 1, 0.0);
+	const double d_rest = 1e-3;
+	for (size_t q = 0; q < B; ++q) {
+		const unsigned long long ns = so[q + 1] - so[q];
+		unsigned long long n1 = ns, n2 = 0;
+		if (weighted) {
+			n1 = std::min(pn1[q], ns); n2 = std::min(pn2[q], ns - n1);
+			if (n1) d1[q] = 1.0 + cw * (double)look1[q] / (double)n1;
+			if (n2) d2[q] = c2 + cw * (double)look2[q] / (double)n2;
+		}
+		const bool visited = ns != 0 && visited_kind[q] != 0;
+		cum[q + 1] = cum[q] + (visited ? cv : 0.0) + (double)n1 * d1[q] + (double)n2 * d2[q] + (double)(ns - n1 - n2) * d_rest;
+	}
+	const double total_cost = cum[B];
+	// share g's part of the whole: falling in a line from 1 to `taper`
+	const double wsum = (double)grid * (1.0 + taper) / 2.0;
+	auto part_before = [&](unsigned long long g) {          // sum of the weights of shares 0 .. g - 1, over wsum
+		const double k = (double)g, slope = grid > 1 ? (taper - 1.0) / (double)(grid - 1) : 0.0;
+		return (k + slope * k * (k - 1.0) / 2.0) / wsum;
+	};
+	size_t bb = 0;
+	for (unsigned long long g = 1; g < grid && total_cost > 0; ++g) {
+		const double tc = total_cost * part_before(g), share = total_cost * (part_before(g + 1) - part_before(g));
+		while (bb + 1 < B && cum[bb + 1] <= tc) ++bb;
+		const unsigned long long lo = so[bb], hi = so[bb + 1], ns = hi - lo;
+		const double x = tc - cum[bb], y = cum[bb + 1] - tc;          // cost of the bucket before / behind the cut
+		unsigned long long t;
+		if (pc.snap && x <= y && x < 0.3 * share) t = lo;
+		else if (pc.snap && y < x && y < 0.3 * share) t = hi;
+		else {
+			// inside the bucket: past the staging, then through the pools at their cost per record
+			const unsigned long long n1 = weighted ? std::min(pn1[bb], ns) : ns, n2 = weighted ? std::min(pn2[bb], ns - n1) : 0;
+			double r = std::max(0.0, x - ((ns != 0 && visited_kind[bb] != 0) ? cv : 0.0));
+			double at = 0;
+			if (r < (double)n1 * d1[bb]) at = r / d1[bb];
+			else {
+				r -= (double)n1 * d1[bb];
+				if (r < (double)n2 * d2[bb]) at = (double)n1 + r / d2[bb];
+				else at = (double)(n1 + n2) + (r - (double)n2 * d2[bb]) / d_rest;
+			}
+			t = lo + std::min<unsigned long long>((unsigned long long)at, ns);
+		}
+		cut[(size_t)g] = std::max(t, cut[(size_t)g - 1]);
+	}
+	if (!(total_cost > 0)) for (unsigned long long g = 1; g < grid; ++g) cut[(size_t)g] = total_slots * g / grid;
+	cut[(size_t)grid] = total_slots;
+	// one workgroup's share must keep the packed LDS counters exact: if the weights made one too long, equal shares
+	for (unsigned long long g = 0; g < grid; ++g)
+		if (cut[(size_t)g + 1] - cut[(size_t)g] > (1ull << 21)) {
+			for (unsigned long long q = 1; q < grid; ++q) cut[(size_t)q] = total_slots * q / grid;
+			break;
+		}
+}
+
 int run_count(lsq_ctx *c) {
 	const lsq_events &E = *c->E;
 	const size_t n_cls = E.n_cls_total;
@@ -1642,67 +1710,20 @@ int run_count(lsq_ctx *c) {
 			std::vector<unsigned long long> cut((size_t)grid + 1, 0);
 			std::vector<unsigned> first((size_t)grid, 0);
 			const bool weighted = c->opt_share_weighted && mr.plan_n1.size() == B && mr.plan_park1.size() == B;
-			const double c2 = weighted ? c->opt_share_cost_p2 : 1.0, cw = weighted ? c->opt_share_cost_park : 0.0, cv = weighted ? c->opt_share_cost_visit : 0.0;
 			// (the pipelined step on one box, taper 1 / 0.5 / 0.25: C3 0.1189 / 0.1165 / 0.1193 ms -- the next count's first workgroups fill this
 			// launch's tail there, and smaller last shares cost more stagings than they still save; the skewed c5s 0.1364 / 0.1358 / 0.1300,
 			// from 0.1607 with shares equal in reads; C2 0.0404 / 0.0389 / 0.0389 from 0.0400)
-			const double taper = !weighted ? 1.0 : (c->opt_share_taper > 0 ? std::min(1.0, std::max(0.05, c->opt_share_taper)) : (mr.skew >= 4.0 ? 0.25 : 0.5));
-			// cost per record of a bucket's one- and two-block pool (the rest of its slots -- many-block reads, the workers' -- next to nothing)
-			std::vector<double> d1(B, 1.0), d2(B, c2), cum(B + 1, 0.0);
-			const double d_rest = 1e-3;
-			for (size_t q = 0; q < B; ++q) {
-				const unsigned long long ns = so[q + 1] - so[q];
-				unsigned long long n1 = ns, n2 = 0;
-				if (weighted) {
-					n1 = std::min(mr.plan_n1[q], ns); n2 = std::min(mr.plan_n2[q], ns - n1);
-					if (n1) d1[q] = 1.0 + cw * (double)mr.plan_park1[q] / (double)n1;
-					if (n2) d2[q] = c2 + cw * (double)mr.plan_park2[q] / (double)n2;
-				}
-				const bool visited = ns != 0 && E.buckets[q].kind == 1u;
-				cum[q + 1] = cum[q] + (visited ? cv : 0.0) + (double)n1 * d1[q] + (double)n2 * d2[q] + (double)(ns - n1 - n2) * d_rest;
-			}
-			const double total_cost = cum[B];
-			// share g's part of the whole: falling in a line from 1 to `taper`
-			const double wsum = (double)grid * (1.0 + taper) / 2.0;
-			auto part_before = [&](unsigned long long g) {          // sum of the weights of shares 0 .. g - 1, over wsum
-				const double k = (double)g, slope = grid > 1 ? (taper - 1.0) / (double)(grid - 1) : 0.0;
-				return (k + slope * k * (k - 1.0) / 2.0) / wsum;
-			};
-			size_t bb = 0;
-			for (unsigned long long g = 1; g < grid && total_cost > 0; ++g) {
-				const double tc = total_cost * part_before(g), share = total_cost * (part_before(g + 1) - part_before(g));
-				while (bb + 1 < B && cum[bb + 1] <= tc) ++bb;
-				const unsigned long long lo = so[bb], hi = so[bb + 1], ns = hi - lo;
-				const double x = tc - cum[bb], y = cum[bb + 1] - tc;          // cost of the bucket before / behind the cut
-				unsigned long long t;
-				if (c->opt_snap_shares && x <= y && x < 0.3 * share) t = lo;
-				else if (c->opt_snap_shares && y < x && y < 0.3 * share) t = hi;
-				else {
-					// inside the bucket: past the staging, then through the pools at their cost per record
-					const unsigned long long n1 = weighted ? std::min(mr.plan_n1[bb], ns) : ns, n2 = weighted ? std::min(mr.plan_n2[bb], ns - n1) : 0;
-					double r = std::max(0.0, x - ((ns != 0 && E.buckets[bb].kind == 1u) ? cv : 0.0));
-					double at = 0;
-					if (r < (double)n1 * d1[bb]) at = r / d1[bb];
-					else {
-						r -= (double)n1 * d1[bb];
-						if (r < (double)n2 * d2[bb]) at = (double)n1 + r / d2[bb];
-						else at = (double)(n1 + n2) + (r - (double)n2 * d2[bb]) / d_rest;
-					}
-					t = lo + std::min<unsigned long long>((unsigned long long)at, ns);
-				}
-				cut[(size_t)g] = std::max(t, cut[(size_t)g - 1]);
-			}
-			if (!(total_cost > 0)) for (unsigned long long g = 1; g < grid; ++g) cut[(size_t)g] = mr.total_slots * g / grid;
-			cut[(size_t)grid] = mr.total_slots;
-			// one workgroup's share must keep the packed LDS counters exact (see `grid` above): if the weights made one too long, equal shares
-			for (unsigned long long g = 0; g < grid; ++g)
-				if (cut[(size_t)g + 1] - cut[(size_t)g] > (1ull << 21)) {
-					for (unsigned long long q = 1; q < grid; ++q) cut[(size_t)q] = mr.total_slots * q / grid;
-					break;
-				}
+			SharePlanCosts pc;
+			pc.weighted = weighted; pc.snap = c->opt_snap_shares;
+			pc.two_block = c->opt_share_cost_p2; pc.walk_look = c->opt_share_cost_park; pc.visit = c->opt_share_cost_visit;
+			pc.taper = c->opt_share_taper > 0 ? c->opt_share_taper : (mr.skew >= 4.0 ? 0.25 : 0.5);
+			std::vector<unsigned char> visited(B, 0);
+			for (size_t q = 0; q < B; ++q) visited[q] = E.buckets[q].kind == 1u ? 1 : 0;
+			plan_share_cuts(so.data(), visited.data(), weighted ? mr.plan_n1.data() : nullptr, weighted ? mr.plan_n2.data() : nullptr,
+			                weighted ? mr.plan_park1.data() : nullptr, weighted ? mr.plan_park2.data() : nullptr, B, grid, pc, cut.data());
 			// the first packed bucket that holds slots of the share [cut[g], cut[g + 1]) (the kernel follows the visit
 			// records' links from there); B when there is none
-			bb = 0;
+			size_t bb = 0;
 			for (unsigned long long g = 0; g < grid; ++g) {
 				while (bb + 1 < B && so[bb + 1] <= cut[(size_t)g]) ++bb;
 				const unsigned f = mr.next_packed_host[bb];
@@ -1852,6 +1873,19 @@ int lsq_debug_wg_trace(lsq_ctx *c, unsigned long long *out, unsigned long long c
 	const unsigned long long k = std::min<unsigned long long>(cap, c->wg_trace_n);
 	if (k) HIP_TRY(hipMemcpy(out, c->wg_trace.p, 4 * k * sizeof(unsigned long long), hipMemcpyDeviceToHost));
 	*n = k; *n_workers = c->wg_trace_workers;
+	return LSQ_OK;
+} LSQ_API_CATCH
+
+// developer aid (include/lesseq_hip_dev.h): the share plan of a count launch as run_count makes it, on given per-bucket numbers (host
+// only; costs: two-block record, walk look, visit, taper; weighted / snap as 0 / 1)
+int lsq_debug_plan_shares(const unsigned long long *slot_off, const unsigned char *packed, const unsigned long long *n1, const unsigned long long *n2,
+                          const unsigned *look1, const unsigned *look2, unsigned long long n_buckets, unsigned long long grid,
+                          const double *costs4, int weighted, int snap, unsigned long long *cuts) LSQ_API_TRY {
+	if (!slot_off || !packed || !costs4 || !cuts || grid == 0) return fail(LSQ_E_ARG, "null argument");
+	lsq::SharePlanCosts pc;
+	pc.weighted = weighted != 0; pc.snap = snap != 0;
+	pc.two_block = costs4[0]; pc.walk_look = costs4[1]; pc.visit = costs4[2]; pc.taper = costs4[3];
+	lsq::plan_share_cuts(slot_off, packed, n1, n2, look1, look2, (size_t)n_buckets, grid, pc, cuts);
 	return LSQ_OK;
 } LSQ_API_CATCH
 

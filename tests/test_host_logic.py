@@ -422,3 +422,84 @@ def test_in_process_cli_leaves_no_thread_behind(tmp_path, monkeypatch):
         assert rc in (0, 3)
     assert native_threads() <= before
     assert threading.active_count() >= 1
+
+
+def test_share_plan_of_a_count_launch():
+    """run_count's share plan on made-up buckets (host only, lsq_debug_plan_shares): the bounds rise from 0 to the last slot,
+    no share is longer than 2^21 slots, weighted shares are equal in cost where no cut snaps (a two-block record, a walk
+    look and a visit weigh what the options say), a taper makes them fall off along the grid, cuts near a bucket boundary
+    land on it, and without weights the shares are equal in slots."""
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    B = 400
+    n1 = rng.integers(0, 40000, B).astype(np.uint64)
+    n2 = rng.integers(0, 12000, B).astype(np.uint64)
+    rest = rng.integers(0, 50, B).astype(np.uint64)
+    n1[7] = n2[7] = rest[7] = 0                       # an empty bucket
+    so = np.concatenate([[0], np.cumsum(n1 + n2 + rest)]).astype(np.uint64)
+    look1 = (n1 * rng.random(B) * 0.05).astype(np.uint32)
+    look2 = (n2 * rng.random(B) * 0.5).astype(np.uint32)
+    look1[11] = 30 * int(n1[11])                      # a bucket the walk is busy with
+    packed = np.ones(B, dtype=np.uint8)
+
+    def ptr(a, t):
+        return a.ctypes.data_as(C.POINTER(t))
+
+    def plan(grid, costs, weighted=1, snap=0, with_counts=True):
+        cuts = np.zeros(grid + 1, dtype=np.uint64)
+        c4 = (C.c_double * 4)(*costs)
+        f = L.lib.lsq_debug_plan_shares
+        f.restype = C.c_int
+        rc = f(ptr(so, C.c_ulonglong), ptr(packed, C.c_ubyte),
+               ptr(n1, C.c_ulonglong) if with_counts else None, ptr(n2, C.c_ulonglong) if with_counts else None,
+               ptr(look1, C.c_uint) if with_counts else None, ptr(look2, C.c_uint) if with_counts else None,
+               C.c_ulonglong(B), C.c_ulonglong(grid), c4, weighted, snap, ptr(cuts, C.c_ulonglong))
+        assert rc == 0
+        return cuts.astype(np.int64)
+
+    def cost_of(cuts, c2, cw, cv):
+        """cost of every share by the plan's own model, record by record"""
+        dens = np.zeros(int(so[-1]))
+        for b in range(B):
+            a = int(so[b])
+            if n1[b]:
+                dens[a:a + int(n1[b])] = 1.0 + cw * look1[b] / n1[b]
+            if n2[b]:
+                dens[a + int(n1[b]):a + int(n1[b] + n2[b])] = c2 + cw * look2[b] / n2[b]
+            dens[a + int(n1[b] + n2[b]):int(so[b + 1])] = 1e-3
+        cum = np.concatenate([[0.0], np.cumsum(dens)])
+        per = cum[cuts[1:]] - cum[cuts[:-1]]
+        starts = np.searchsorted(so.astype(np.int64), cuts[:-1], side="right") - 1
+        ends = np.searchsorted(so.astype(np.int64), np.maximum(cuts[1:] - 1, cuts[:-1]), side="right") - 1
+        return per, per + cv * (ends - starts + 1)
+
+    grid = 1500
+    for costs in ((4.3, 9.0, 7000.0, 1.0), (2.0, 0.0, 0.0, 1.0), (4.3, 9.0, 7000.0, 0.25)):
+        cuts = plan(grid, costs)
+        assert cuts[0] == 0 and cuts[-1] == int(so[-1]) and np.all(np.diff(cuts) >= 0) and np.diff(cuts).max() <= 1 << 21
+        per, with_visits = cost_of(cuts, costs[0], costs[1], costs[2])
+        if costs[3] == 1.0:
+            # equal in cost: a share may differ from the mean by the visits the model charges per bucket start, not per cut
+            assert abs(with_visits - with_visits.mean()).max() < 0.02 * with_visits.mean() + 2 * costs[2] + 50
+            assert with_visits.std() < 0.5 * (np.diff(cuts) * 1.0).std() or costs[1] == 0.0
+        else:
+            k = grid // 10
+            first, last = with_visits[:k].mean(), with_visits[-k:].mean()
+            assert 0.2 < last / first < 0.45              # the last tenth against the first, taper 0.25 in a line
+            assert np.all(np.diff(np.convolve(with_visits, np.ones(100) / 100, mode="valid")) < 0.02 * first)
+    # the hot bucket gets more shares than its slots alone would
+    cuts = plan(grid, (4.3, 9.0, 7000.0, 1.0))
+    inside = np.sum((cuts[1:-1] > int(so[11])) & (cuts[1:-1] < int(so[12])))
+    assert inside > 5 * (int(so[12]) - int(so[11])) * grid / int(so[-1])
+    # snapping: with about one share per bucket most cuts land on bucket boundaries
+    cuts = plan(B, (4.3, 9.0, 7000.0, 1.0), snap=1)
+    on_boundary = np.isin(cuts[1:-1], so.astype(np.int64)).mean()
+    # (without snapping a cut lands on a boundary only where its target falls into the staging a bucket begins with)
+    assert on_boundary > 0.5 and np.isin(plan(B, (4.3, 9.0, 7000.0, 1.0), snap=0)[1:-1], so.astype(np.int64)).mean() < 0.5 * on_boundary
+    # no weights: equal slots
+    for kw in (dict(weighted=0), dict(with_counts=False)):
+        cuts = plan(grid, (4.3, 9.0, 7000.0, 0.25), **kw)
+        assert np.abs(np.diff(cuts) - int(so[-1]) / grid).max() <= 1
+    # a share longer than 2^21 slots is never planned: the weights give way to equal shares
+    big = plan(3, (1000.0, 0.0, 0.0, 0.05))
+    assert np.diff(big).max() <= max(1 << 21, int(so[-1]) // 3 + 1)
