@@ -73,6 +73,44 @@ def shared_dir(tag):
     return os.path.join(base, "lsq_bench_%s_%s" % (os.environ.get("USER", "u"), tag))
 
 
+def measure_traffic_live(wl_name, timeout=300):
+    """HBM bytes per launch of the count kernel, measured now: two short child runs of this script under `rocprofv3 --pmc`
+    (FETCH_SIZE, then WRITE_SIZE: separate passes, counters only, no trace domain), corrected as MI355X_MICROARCH.md's HBM section
+    says (both in KiB; gfx950 counts a wide coalesced read at half its bytes: 2 x FETCH_SIZE + WRITE_SIZE).
+    Returns (bytes or None, note)."""
+    import csv, glob, shutil
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found"
+    base = tempfile.mkdtemp(prefix="lsq_traffic_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    means = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(base, ctr)
+            cmd = [prof, "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+                   "--workload", wl_name, "--steps", "5", "--warmup", "1", "--no-e2e", "--cpu-sample", "0", "--no-traffic"]
+            try:
+                p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout)
+            except subprocess.TimeoutExpired:
+                return None, "the %s pass did not finish in %d s" % (ctr, timeout)
+            if p.returncode != 0:
+                return None, "the %s pass ended with %d: %s" % (ctr, p.returncode, p.stderr.decode(errors="replace")[-300:])
+            tot, n = 0.0, 0
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "lsq_count_fast_kernel" in row.get("Kernel_Name", "") and row.get("Counter_Name") == ctr:
+                        tot += float(row["Counter_Value"]); n += 1
+            if n == 0:
+                return None, "no %s rows for the count kernel" % ctr
+            means[ctr] = (tot / n, n)
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+    b = (2.0 * means["FETCH_SIZE"][0] + means["WRITE_SIZE"][0]) * 1024.0
+    return b, ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, one pass each over a 6-step child run of this command on this device "
+               "(%d / %d launches); 2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes (gfx950 counts a wide coalesced read at half its bytes)" % (means["FETCH_SIZE"][1], means["WRITE_SIZE"][1]))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,6 +121,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=15_000_000, help="reads in the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end legs")
     ap.add_argument("--no-c5", action="store_true", help="N > 1: skip the configs[4] leg (config.c5_*)")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the live HBM-traffic measurement (two short child runs under rocprofv3 --pmc)")
     a = ap.parse_args()
 
     # stdout carries the one JSON line and nothing else: libraries that greet on stdout (RCCL's version banner, gloo's
@@ -639,6 +678,10 @@ def run_workload(env, a, wl_name, primary):
                 committed = {"hbm_bytes_per_launch": json.load(open(tpath)).get("count_fast_kernel_hbm_bytes_per_launch"),
                              "source": "profiles/%s_traffic_%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; 2 x FETCH_SIZE + WRITE_SIZE)" % (rr, wl_name)}
                 break
+        # ... and by this run, when it is the one-GPU default: two short child runs under the profiler's counters (after the timed loop)
+        traffic_live, traffic_note = (None, "not measured by this run")
+        if world == 1 and primary and not a.no_traffic:
+            traffic_live, traffic_note = measure_traffic_live(wl_name)
         # what a plain streaming read of the same number of bytes reaches on this device (state both ceilings)
         import ctypes as C
         L.lib.lsq_debug_stream_read_rate.argtypes = [C.c_void_p, C.c_ulonglong, C.POINTER(C.c_double)]
@@ -715,7 +758,8 @@ def run_workload(env, a, wl_name, primary):
                 "resident_bytes_per_launch": float(pool_fmt[1] + ev_bytes),
                 "achieved_on_resident_bytes": (pool_fmt[1] + ev_bytes) / (fk * 1e-3) / 1e9,
                 "frac_on_resident_bytes": (pool_fmt[1] + ev_bytes) / (fk * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic_live, "traffic_note": traffic_note,
+                "traffic_over_algorithmic": (traffic_live / alg_bytes if traffic_live else None),
                 "traffic_from_committed_profile": committed,
                 "algorithmic_bytes_per_launch": alg_bytes,
             },
