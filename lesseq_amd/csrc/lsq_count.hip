@@ -1555,17 +1555,20 @@ void plan_share_cuts(const unsigned long long *so, const unsigned char *visited_
 	const double taper = weighted ? std::min(1.0, std::max(0.05, pc.taper)) : 1.0;
 	cut[0] = 0;
 	// cost per record of a bucket's one- and two-block pool (the rest of its slots -- many-block reads, the workers' -- next to nothing)
+	// (a bucket the streaming kernel does not visit -- a generic or a host bucket -- weighs next to nothing as a whole)
 	std::vector<double> d1(B, 1.0), d2(B, c2), cum(B + 1, 0.0);
+	std::vector<unsigned long long> en1(B, 0), en2(B, 0);          // the records that weigh: of the one- / two-block pool
 	const double d_rest = 1e-3;
 	for (size_t q = 0; q < B; ++q) {
 		const unsigned long long ns = so[q + 1] - so[q];
+		const bool visited = ns != 0 && visited_kind[q] != 0;
 		unsigned long long n1 = ns, n2 = 0;
 		if (weighted) {
-			n1 = std::min(pn1[q], ns); n2 = std::min(pn2[q], ns - n1);
+			n1 = visited ? std::min(pn1[q], ns) : 0; n2 = visited ? std::min(pn2[q], ns - n1) : 0;
 			if (n1) d1[q] = 1.0 + cw * (double)look1[q] / (double)n1;
 			if (n2) d2[q] = c2 + cw * (double)look2[q] / (double)n2;
 		}
-		const bool visited = ns != 0 && visited_kind[q] != 0;
+		en1[q] = n1; en2[q] = n2;
 		cum[q + 1] = cum[q] + (visited ? cv : 0.0) + (double)n1 * d1[q] + (double)n2 * d2[q] + (double)(ns - n1 - n2) * d_rest;
 	}
 	const double total_cost = cum[B];
@@ -1586,7 +1589,7 @@ void plan_share_cuts(const unsigned long long *so, const unsigned char *visited_
 		else if (pc.snap && y < x && y < 0.3 * share) t = hi;
 		else {
 			// inside the bucket: past the staging, then through the pools at their cost per record
-			const unsigned long long n1 = weighted ? std::min(pn1[bb], ns) : ns, n2 = weighted ? std::min(pn2[bb], ns - n1) : 0;
+			const unsigned long long n1 = en1[bb], n2 = en2[bb];
 			double r = std::max(0.0, x - ((ns != 0 && visited_kind[bb] != 0) ? cv : 0.0));
 			double at = 0;
 			if (r < (double)n1 * d1[bb]) at = r / d1[bb];

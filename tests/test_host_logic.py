@@ -496,6 +496,11 @@ def test_share_plan_of_a_count_launch():
     on_boundary = np.isin(cuts[1:-1], so.astype(np.int64)).mean()
     # (without snapping a cut lands on a boundary only where its target falls into the staging a bucket begins with)
     assert on_boundary > 0.5 and np.isin(plan(B, (4.3, 9.0, 7000.0, 1.0), snap=0)[1:-1], so.astype(np.int64)).mean() < 0.5 * on_boundary
+    # a bucket the streaming kernel does not visit (a generic or host bucket) weighs nothing: no share is spent inside it
+    packed[20] = 0
+    cuts = plan(grid, (4.3, 9.0, 7000.0, 1.0))
+    assert np.sum((cuts[1:-1] > int(so[20])) & (cuts[1:-1] < int(so[21]))) <= 1
+    packed[20] = 1
     # no weights: equal slots
     for kw in (dict(weighted=0), dict(with_counts=False)):
         cuts = plan(grid, (4.3, 9.0, 7000.0, 0.25), **kw)
