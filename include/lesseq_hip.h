@@ -261,7 +261,8 @@ int lsq_host_evaluated(const lsq_ctx *c, uint64_t *n_genes, uint64_t *n_reads);
  * shares are cut at even cost instead of at bucket ends), "share_weighted" (default 1: the shares are equal in estimated cost
  * -- "share_cost_two_block": a two-block record in one-block records, default 4.3; "share_cost_parked": one look of the general
  * walk at a read the streaming loops leave to it, default 9, counted per bucket by the ingest; "share_cost_visit": a bucket's
- * staging and flush, default 7 000 -- and fall off in size along the grid, "share_taper": the last share as a fraction of the
+ * staging and flush, default 7 000; "share_cost_hot": extra cost of a record of a cell or junction group of 8 192 records or more,
+ * default 0.5 (a deep gene's reads all add to the same few LDS counters) -- and fall off in size along the grid, "share_taper": the last share as a fraction of the
  * first, 0 = automatic, 0.5 for evenly deep read sets and 0.25 for skewed ones; 0: shares equal in reads), "compact_pools" (0: wide pool records for read sets
  * uploaded afterwards, see lsq_reads_pool_format), "em_regroup" (0: lsq_solve keeps the
  * placement of events in its grid chosen at lsq_events_upload; default 1: each of the two step lanes

@@ -1542,63 +1542,72 @@ __global__ void __launch_bounds__(256) lsq_count_recount_kernel(const CountArgs 
 namespace lsq {
 
 // The share plan of a count launch (run_count): `grid` + 1 bounds in slots over buckets whose slots start at so[0 .. B].  Shares
-// equal in estimated cost -- a one-block record 1, a two-block record `two_block`, a look of the general walk `walk_look` (n1 /
-// n2 / look1 / look2 per bucket: the ingest's counts; null: every slot 1), staging + flush of a visited bucket `visit` -- and
-// falling off in size in a line from the first share to the last (`taper` = last / first); a cut within 30 % of a share of a
-// bucket boundary moves onto it (`snap`).  No share longer than 2^21 slots (the packed LDS counters): else equal shares.
-struct SharePlanCosts { bool weighted = true, snap = true; double two_block = 4.3, walk_look = 9.0, visit = 7000.0, taper = 0.5; };
-void plan_share_cuts(const unsigned long long *so, const unsigned char *visited_kind, const unsigned long long *pn1, const unsigned long long *pn2,
-                     const unsigned *look1, const unsigned *look2, const size_t B, const unsigned long long grid, const SharePlanCosts &pc, unsigned long long *cut) {
+// equal in estimated cost and falling off in size in a line from the first share to the last (`taper` = last / first); a cut
+// within 30 % of a share of a bucket boundary moves onto it (`snap`).  No share longer than 2^21 slots (the packed LDS
+// counters): else equal shares.  The cost is given as stretches of slots (x[0 .. S], ascending from 0 to the last slot; a
+// bucket's stretches from bseg[b]): a stretch of one-block records (kind 0) weighs 1 a record, of two-block records (kind 1)
+// `two_block`, plus `walk_look` for every look the general walk will take at the stretch's reads (the ingest's count, per cell
+// and junction group: where a hot bucket is cut into many shares it matters WHICH of its groups are the walk's); anything else
+// (kind 2: many-block reads, buckets the kernel does not visit) next to nothing; staging + flush of a visited bucket `visit`.
+// x == null: every slot weighs 1.
+struct SharePlanCosts { bool weighted = true, snap = true; double two_block = 4.3, walk_look = 9.0, visit = 7000.0, taper = 0.5, hot = 0.0; };
+void plan_share_cuts_seg(const unsigned long long *so, const unsigned char *visited_kind, const size_t B, const unsigned long long *x, const unsigned char *kind,
+                         const unsigned *looks, const unsigned *bseg, const size_t S, const unsigned long long grid, const SharePlanCosts &pc, unsigned long long *cut) {
 	const unsigned long long total_slots = B ? so[B] : 0;
-	const bool weighted = pc.weighted && pn1 && pn2 && look1 && look2;
-	const double c2 = weighted ? pc.two_block : 1.0, cw = weighted ? pc.walk_look : 0.0, cv = weighted ? pc.visit : 0.0;
-	const double taper = weighted ? std::min(1.0, std::max(0.05, pc.taper)) : 1.0;
+	const bool weighted = pc.weighted && x && kind && looks && bseg && S > 0;
 	cut[0] = 0;
-	// cost per record of a bucket's one- and two-block pool (the rest of its slots -- many-block reads, the workers' -- next to nothing)
-	// (a bucket the streaming kernel does not visit -- a generic or a host bucket -- weighs next to nothing as a whole)
-	std::vector<double> d1(B, 1.0), d2(B, c2), cum(B + 1, 0.0);
-	std::vector<unsigned long long> en1(B, 0), en2(B, 0);          // the records that weigh: of the one- / two-block pool
-	const double d_rest = 1e-3;
-	for (size_t q = 0; q < B; ++q) {
-		const unsigned long long ns = so[q + 1] - so[q];
-		const bool visited = ns != 0 && visited_kind[q] != 0;
-		unsigned long long n1 = ns, n2 = 0;
-		if (weighted) {
-			n1 = visited ? std::min(pn1[q], ns) : 0; n2 = visited ? std::min(pn2[q], ns - n1) : 0;
-			if (n1) d1[q] = 1.0 + cw * (double)look1[q] / (double)n1;
-			if (n2) d2[q] = c2 + cw * (double)look2[q] / (double)n2;
+	if (!weighted) {
+		for (unsigned long long g = 1; g <= grid; ++g) cut[(size_t)g] = total_slots / grid * g + total_slots % grid * g / grid;
+		// (a cut still snaps to a bucket boundary: as before the weights existed)
+		if (pc.snap && grid > 0) {
+			const double share = (double)total_slots / (double)grid;
+			size_t bb = 0;
+			for (unsigned long long g = 1; g < grid; ++g) {
+				const unsigned long long t = cut[(size_t)g];
+				while (bb + 1 < B && so[bb + 1] <= t) ++bb;
+				const unsigned long long lo = so[bb], hi = so[bb + 1];
+				unsigned long long u = t;
+				if (t - lo <= hi - t && (double)(t - lo) < 0.3 * share) u = lo;
+				else if ((double)(hi - t) < 0.3 * share) u = hi;
+				cut[(size_t)g] = std::max(u, cut[(size_t)g - 1]);
+			}
 		}
-		en1[q] = n1; en2[q] = n2;
-		cum[q + 1] = cum[q] + (visited ? cv : 0.0) + (double)n1 * d1[q] + (double)n2 * d2[q] + (double)(ns - n1 - n2) * d_rest;
+		cut[(size_t)grid] = total_slots;
+		return;
 	}
-	const double total_cost = cum[B];
+	const double c2 = pc.two_block, cw = pc.walk_look, cv = pc.visit, d_rest = 1e-3;
+	const double taper = std::min(1.0, std::max(0.05, pc.taper));
+	std::vector<double> dens(S), cum(S + 1, 0.0), jump(S, 0.0), cum_b(B + 1, 0.0);
+	for (size_t b = 0; b < B; ++b) if (visited_kind[b] && so[b + 1] > so[b] && bseg[b] < bseg[b + 1]) jump[bseg[b]] = cv;
+	for (size_t i = 0; i < S; ++i) {
+		const double len = (double)(x[i + 1] - x[i]);
+		// (`hot`: a group of 8 192 records or more -- a deep gene's cell -- costs that much more a record: every lane of every wave on it
+		// adds to the same few histogram slots, and LDS atomics on one address run one after the other)
+		dens[i] = kind[i] == 2 || len <= 0 ? d_rest : (kind[i] == 0 ? 1.0 : c2) + cw * (double)looks[i] / len + (len >= 8192.0 ? pc.hot : 0.0);
+		cum[i + 1] = cum[i] + jump[i] + len * dens[i];
+	}
+	for (size_t b = 0; b <= B; ++b) cum_b[b] = cum[std::min<size_t>(bseg[b], S)];
+	const double total_cost = cum[S];
 	// share g's part of the whole: falling in a line from 1 to `taper`
 	const double wsum = (double)grid * (1.0 + taper) / 2.0;
 	auto part_before = [&](unsigned long long g) {          // sum of the weights of shares 0 .. g - 1, over wsum
 		const double k = (double)g, slope = grid > 1 ? (taper - 1.0) / (double)(grid - 1) : 0.0;
 		return (k + slope * k * (k - 1.0) / 2.0) / wsum;
 	};
-	size_t bb = 0;
+	size_t bb = 0, si = 0;
 	for (unsigned long long g = 1; g < grid && total_cost > 0; ++g) {
 		const double tc = total_cost * part_before(g), share = total_cost * (part_before(g + 1) - part_before(g));
-		while (bb + 1 < B && cum[bb + 1] <= tc) ++bb;
-		const unsigned long long lo = so[bb], hi = so[bb + 1], ns = hi - lo;
-		const double x = tc - cum[bb], y = cum[bb + 1] - tc;          // cost of the bucket before / behind the cut
+		while (bb + 1 < B && cum_b[bb + 1] <= tc) ++bb;
+		while (si + 1 < S && cum[si + 1] <= tc) ++si;
+		const double xb = tc - cum_b[bb], yb = cum_b[bb + 1] - tc;          // cost of the bucket before / behind the cut
 		unsigned long long t;
-		if (pc.snap && x <= y && x < 0.3 * share) t = lo;
-		else if (pc.snap && y < x && y < 0.3 * share) t = hi;
+		if (pc.snap && xb <= yb && xb < 0.3 * share) t = so[bb];
+		else if (pc.snap && yb < xb && yb < 0.3 * share) t = so[bb + 1];
 		else {
-			// inside the bucket: past the staging, then through the pools at their cost per record
-			const unsigned long long n1 = en1[bb], n2 = en2[bb];
-			double r = std::max(0.0, x - ((ns != 0 && visited_kind[bb] != 0) ? cv : 0.0));
-			double at = 0;
-			if (r < (double)n1 * d1[bb]) at = r / d1[bb];
-			else {
-				r -= (double)n1 * d1[bb];
-				if (r < (double)n2 * d2[bb]) at = (double)n1 + r / d2[bb];
-				else at = (double)(n1 + n2) + (r - (double)n2 * d2[bb]) / d_rest;
-			}
-			t = lo + std::min<unsigned long long>((unsigned long long)at, ns);
+			// inside the stretch: past the staging a bucket begins with, then at the stretch's cost per slot
+			const double r = tc - cum[si] - jump[si];
+			const unsigned long long len = x[si + 1] - x[si];
+			t = x[si] + (r <= 0.0 ? 0ull : std::min<unsigned long long>((unsigned long long)(r / dens[si]), len));
 		}
 		cut[(size_t)g] = std::max(t, cut[(size_t)g - 1]);
 	}
@@ -1610,6 +1619,27 @@ void plan_share_cuts(const unsigned long long *so, const unsigned char *visited_
 			for (unsigned long long q = 1; q < grid; ++q) cut[(size_t)q] = total_slots * q / grid;
 			break;
 		}
+}
+
+// ... the same from per-bucket numbers (records of the one- and two-block pool and the walk's looks at each as a whole): three
+// stretches a bucket (lsq_debug_plan_shares; run_count has the groups' own numbers from the ingest)
+void plan_share_cuts(const unsigned long long *so, const unsigned char *visited_kind, const unsigned long long *pn1, const unsigned long long *pn2,
+                     const unsigned *look1, const unsigned *look2, const size_t B, const unsigned long long grid, const SharePlanCosts &pc, unsigned long long *cut) {
+	if (!(pc.weighted && pn1 && pn2 && look1 && look2)) { plan_share_cuts_seg(so, visited_kind, B, nullptr, nullptr, nullptr, nullptr, 0, grid, pc, cut); return; }
+	std::vector<unsigned long long> x; std::vector<unsigned char> kind; std::vector<unsigned> looks, bseg(B + 1, 0);
+	for (size_t b = 0; b < B; ++b) {
+		bseg[b] = (unsigned)kind.size();
+		const unsigned long long ns = so[b + 1] - so[b];
+		if (!ns) continue;
+		const bool visited = visited_kind[b] != 0;
+		const unsigned long long n1 = visited ? std::min(pn1[b], ns) : 0, n2 = visited ? std::min(pn2[b], ns - n1) : 0;
+		if (n1) { x.push_back(so[b]); kind.push_back(0); looks.push_back(look1[b]); }
+		if (n2) { x.push_back(so[b] + n1); kind.push_back(1); looks.push_back(look2[b]); }
+		if (ns - n1 - n2) { x.push_back(so[b] + n1 + n2); kind.push_back(2); looks.push_back(0); }
+	}
+	bseg[B] = (unsigned)kind.size();
+	x.push_back(B ? so[B] : 0);
+	plan_share_cuts_seg(so, visited_kind, B, x.data(), kind.data(), looks.data(), bseg.data(), kind.size(), grid, pc, cut);
 }
 
 int run_count(lsq_ctx *c) {
@@ -1720,10 +1750,15 @@ int run_count(lsq_ctx *c) {
 			pc.weighted = weighted; pc.snap = c->opt_snap_shares;
 			pc.two_block = c->opt_share_cost_p2; pc.walk_look = c->opt_share_cost_park; pc.visit = c->opt_share_cost_visit;
 			pc.taper = c->opt_share_taper > 0 ? c->opt_share_taper : (mr.skew >= 4.0 ? 0.25 : 0.5);
+			pc.hot = c->opt_share_cost_hot;
 			std::vector<unsigned char> visited(B, 0);
 			for (size_t q = 0; q < B; ++q) visited[q] = E.buckets[q].kind == 1u ? 1 : 0;
-			plan_share_cuts(so.data(), visited.data(), weighted ? mr.plan_n1.data() : nullptr, weighted ? mr.plan_n2.data() : nullptr,
-			                weighted ? mr.plan_park1.data() : nullptr, weighted ? mr.plan_park2.data() : nullptr, B, grid, pc, cut.data());
+			if (weighted && mr.plan_seg_x.size() >= 2 && mr.plan_seg_first.size() == B + 1)
+				plan_share_cuts_seg(so.data(), visited.data(), B, mr.plan_seg_x.data(), mr.plan_seg_kind.data(), mr.plan_seg_looks.data(), mr.plan_seg_first.data(),
+				                    mr.plan_seg_kind.size(), grid, pc, cut.data());
+			else
+				plan_share_cuts(so.data(), visited.data(), weighted ? mr.plan_n1.data() : nullptr, weighted ? mr.plan_n2.data() : nullptr,
+				                weighted ? mr.plan_park1.data() : nullptr, weighted ? mr.plan_park2.data() : nullptr, B, grid, pc, cut.data());
 			// the first packed bucket that holds slots of the share [cut[g], cut[g + 1]) (the kernel follows the visit
 			// records' links from there); B when there is none
 			size_t bb = 0;

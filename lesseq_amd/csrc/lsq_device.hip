@@ -738,12 +738,13 @@ int lsq_ctx_set_option(lsq_ctx *c, const char *name, double value) LSQ_API_TRY {
 	} else if (n == "snap_shares") {
 		c->opt_snap_shares = value != 0;
 		for (auto &r : c->reads) r.wg_grid = 0;
-	} else if (n == "share_weighted" || n == "share_cost_two_block" || n == "share_cost_parked" || n == "share_cost_visit" || n == "share_taper") {
+	} else if (n == "share_weighted" || n == "share_cost_two_block" || n == "share_cost_parked" || n == "share_cost_visit" || n == "share_taper" || n == "share_cost_hot") {
 		if (!(value >= 0 && value <= 1e6)) return fail(LSQ_E_ARG, "%s must lie in 0..1e6", name);
 		if (n == "share_weighted") c->opt_share_weighted = value != 0;
 		else if (n == "share_cost_two_block") c->opt_share_cost_p2 = value;
 		else if (n == "share_cost_parked") c->opt_share_cost_park = value;
 		else if (n == "share_cost_visit") c->opt_share_cost_visit = value;
+		else if (n == "share_cost_hot") c->opt_share_cost_hot = value;
 		else c->opt_share_taper = value;
 		for (auto &r : c->reads) r.wg_grid = 0;
 	} else if (n == "compact_pools") {

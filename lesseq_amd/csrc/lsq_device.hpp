@@ -120,6 +120,11 @@ struct MethodReads {
 	std::vector<unsigned long long> slot_off_host;   // the buckets' slot offsets (n_buckets + 1), for the share plan
 	DevBuf<VisitRec> visits;               // per bucket (n_buckets + 1: the last one ends every chain)
 	std::vector<unsigned long long> plan_n1, plan_n2;   // per bucket: records of the one- / two-block pool (padding included) ...
+	// ... the same by cell and junction group, as stretches of slots (plan_share_cuts_seg): x[0 .. S] bounds, kind (0 one-block records, 1 two-block, 2 the rest),
+	// the walk's looks at the stretch's reads, and per bucket its first stretch
+	std::vector<unsigned long long> plan_seg_x;
+	std::vector<unsigned char> plan_seg_kind;
+	std::vector<unsigned> plan_seg_looks, plan_seg_first;
 	std::vector<unsigned> plan_park1, plan_park2;       // ... and the looks of the general walk at the reads of each that the streaming loops leave to it (the ingest's estimate)
 	std::vector<unsigned> next_packed_host;          // per bucket b: the first packed bucket >= b that holds slots (n_buckets: none), for the share plan
 	unsigned long long wg_grid = 0;
@@ -233,6 +238,7 @@ struct lsq_ctx {
 	double opt_share_cost_p2 = 4.3;         // "share_cost_two_block": a two-block record, in one-block records
 	double opt_share_cost_park = 9.0;       // "share_cost_parked": one look of the general walk at a parked read
 	double opt_share_cost_visit = 7000.0;   // "share_cost_visit": staging + flush of a bucket
+	double opt_share_cost_hot = 0.5;        // "share_cost_hot": extra cost a record of a group of 8 192 records or more
 	double opt_share_taper = 0;             // "share_taper": the last share of the grid as a fraction of the first (0 = automatic)
 	unsigned dev_ablate = 0;                // developer build only (LSQ_ABLATE)
 	DevBuf<unsigned char> recount_args;     // the recount kernels' argument records (lsq_count.hip), and the host's copy of what was last written

@@ -80,7 +80,7 @@ struct IngestWork {
 	int *ms, *me;                  // merged blocks, at the read's original block offset
 	unsigned *cnt1, *cnt2;         // one-block reads per group [n_cell_groups]; two-block reads per group [n_junction_groups]
 	unsigned *cntn, *cntnb;        // [n_buckets]: n-block reads, and their blocks
-	unsigned *park1, *park2;       // [n_buckets]: looks of the general walk at the one- / two-block reads that the count kernel's streaming loops will leave to it (an estimate, for the share plan)
+	unsigned *park1, *park2;       // [n_cell_groups] / [n_junction_groups]: looks of the general walk at the group's reads that the count kernel's streaming loops will leave to it (an estimate, for the share plan)
 	unsigned *cur1, *cur2, *curn, *curnb;   // scatter cursors, same shapes
 	unsigned long long *totals;    // [0] retained reads, [1] retained blocks, [2] error flag, [3] one- and two-block reads that do not fit compact records, [4] / [5] one- / two-block reads pooled
 	unsigned compact;              // compact pool records: one- and two-block reads that do not fit them go with the many-block reads
@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(256) lsq_ingest_classify_kernel(IngestTables T
 						key = b * 4u + pool;
 						const int rel = s[0] - d.lo;
 						const unsigned bin = rel <= 0 ? 0u : min((unsigned)rel >> d.shift, d.n_bins - 1u);
-						unsigned fine = 0;
+						unsigned fine = 0, looks_est = 0;
 						if (pool < 2u) {
 							// the read's cell, found as the count kernel finds it (bin record: first cell | first event << 16, the
 							// ends of that cell and the next two; then on through the cell table)
@@ -227,12 +227,13 @@ __global__ void __launch_bounds__(256) lsq_ingest_classify_kernel(IngestTables T
 											if (!(fr.seg[0] <= p && (p > fr.ge || (fr.meta & lsq::FAST_FLAG_OVERLAPS_NEXT) != 0u))) break;
 										}
 									}
-									atomicAdd(pool == 0u ? &W.park1[b] : &W.park2[b], looks);
+									looks_est = looks;
 								}
 							} else if (pool == 1u) fine = T.jgroup_base[b] + (T.jg_base[b + 1] - T.jg_base[b]);
 							if (pool == 0u) fine = T.cell_base[b] + cell;
 						}
 						W.fine[i] = fine;
+						if (looks_est) atomicAdd(pool == 0u ? &W.park1[fine] : &W.park2[fine], looks_est);
 						if (pool == 0) { atomicAdd(&W.cnt1[fine], 1u); ++pooled1; }
 						else if (pool == 1) { atomicAdd(&W.cnt2[fine], 1u); ++pooled2; }
 						else { atomicAdd(&W.cntn[b], 1u); atomicAdd(&W.cntnb[b], (unsigned)n); }
@@ -399,7 +400,7 @@ static int ingest_device(lsq_ctx *c, int method, const IngestRaw &Rw, uint64_t n
 	const size_t FJ = c->n_junction_groups;      // two-block groups of all buckets
 	const size_t n_cnt = FC + FJ + 2 * (size_t)B;
 	if ((rc = d_ms.alloc(nblk)) || (rc = d_me.alloc(nblk)) || (rc = d_nb.alloc(n)) || (rc = d_strand.alloc(n)) || (rc = d_key.alloc(n)) || (rc = d_fine.alloc(n))) return rc;
-	if ((rc = d_cnt.alloc(2 * n_cnt)) || (rc = d_off1.alloc(FC + 1)) || (rc = d_off2.alloc(FJ + 1)) || (rc = d_totals.alloc(8)) || (rc = d_park.alloc(2 * (size_t)B))) return rc;
+	if ((rc = d_cnt.alloc(2 * n_cnt)) || (rc = d_off1.alloc(FC + 1)) || (rc = d_off2.alloc(FJ + 1)) || (rc = d_totals.alloc(8)) || (rc = d_park.alloc(FC + FJ))) return rc;
 	IngestTables T{};
 	T.cov_off = c->cov_off.p; T.cov_s = c->cov_s.p; T.cov_e = c->cov_e.p;
 	T.cut_off = c->cut_off.p; T.cut_lo = c->cut_lo.p; T.chrom_first_bucket = c->chrom_first_bucket.p;
@@ -412,7 +413,7 @@ static int ingest_device(lsq_ctx *c, int method, const IngestRaw &Rw, uint64_t n
 	W.cnt1 = d_cnt.p; W.cnt2 = W.cnt1 + FC; W.cntn = W.cnt2 + FJ; W.cntnb = W.cntn + B;
 	W.cur1 = d_cnt.p + n_cnt; W.cur2 = W.cur1 + FC; W.curn = W.cur2 + FJ; W.curnb = W.curn + B;
 	W.totals = d_totals.p;
-	W.park1 = d_park.p; W.park2 = d_park.p + B;
+	W.park1 = d_park.p; W.park2 = d_park.p + FC;
 	W.compact = c->opt_compact_pools ? 1u : 0u;
 	const unsigned igrid = (unsigned)std::min<unsigned long long>((n + 255) / 256 + 1, (unsigned long long)c->n_cu * 16);
 	if ((rc = mr.p1_off.alloc(B + 1)) || (rc = mr.p2_off.alloc(B + 1)) || (rc = mr.pn_off.alloc(B + 1)) || (rc = mr.pnb_off.alloc(B + 1)) || (rc = mr.slot_off.alloc(B + 1))) return rc;
@@ -420,7 +421,7 @@ static int ingest_device(lsq_ctx *c, int method, const IngestRaw &Rw, uint64_t n
 	for (;;) {
 		HIP_TRY(hipMemsetAsync(d_cnt.p, 0, std::max<size_t>(2 * n_cnt, 1) * 4, st));
 		HIP_TRY(hipMemsetAsync(d_totals.p, 0, 8 * 8, st));
-		HIP_TRY(hipMemsetAsync(d_park.p, 0, std::max<size_t>(2 * (size_t)B, 1) * 4, st));
+		HIP_TRY(hipMemsetAsync(d_park.p, 0, std::max<size_t>(FC + FJ, 1) * 4, st));
 		if (n) {
 			hipLaunchKernelGGL(lsq_ingest_classify_kernel, dim3(igrid), dim3(256), 0, st, T, Rw, W);
 			HIP_TRY(hipGetLastError());
@@ -507,14 +508,41 @@ static int ingest_device(lsq_ctx *c, int method, const IngestRaw &Rw, uint64_t n
 		HIP_TRY(hipMemcpyAsync(o1.data(), mr.p1_off.p, (B + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
 		HIP_TRY(hipMemcpyAsync(o2.data(), mr.p2_off.p, (B + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
 		HIP_TRY(hipStreamSynchronize(st));
-		// ... and what the share plan weighs: reads per pool and bucket, and those of them bound for the general walk
-		std::vector<unsigned> park(2 * (size_t)B + 1, 0);
-		if (B) HIP_TRY(hipMemcpyAsync(park.data(), d_park.p, 2 * (size_t)B * sizeof(unsigned), hipMemcpyDeviceToHost, st));
-		HIP_TRY(hipStreamSynchronize(st));
-		mr.plan_n1.resize(B); mr.plan_n2.resize(B); mr.plan_park1.resize(B); mr.plan_park2.resize(B);
-		for (unsigned b = 0; b < B; ++b) {
-			mr.plan_n1[b] = o1[b + 1] - o1[b]; mr.plan_n2[b] = o2[b + 1] - o2[b];
-			mr.plan_park1[b] = park[b]; mr.plan_park2[b] = park[(size_t)B + b];
+		// ... and what the share plan weighs: the records of every cell and junction group and the looks the general walk will take at
+		// them (run_count: plan_share_cuts_seg), as stretches of slots; per bucket the sums as well
+		{
+			std::vector<unsigned long long> f1(FC + 1, 0), f2(FJ + 1, 0);
+			std::vector<unsigned> park(FC + FJ + 1, 0);
+			HIP_TRY(hipMemcpyAsync(f1.data(), d_off1.p, (FC + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+			HIP_TRY(hipMemcpyAsync(f2.data(), d_off2.p, (FJ + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+			if (FC + FJ) HIP_TRY(hipMemcpyAsync(park.data(), d_park.p, (FC + FJ) * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+			HIP_TRY(hipStreamSynchronize(st));
+			mr.plan_n1.resize(B); mr.plan_n2.resize(B); mr.plan_park1.assign(B, 0); mr.plan_park2.assign(B, 0);
+			mr.plan_seg_x.clear(); mr.plan_seg_kind.clear(); mr.plan_seg_looks.clear(); mr.plan_seg_first.assign(B + 1, 0);
+			size_t g1 = 0, g2 = 0;          // the buckets' groups follow one another: one per cell and one for "no cell"; the junction groups, then one per cell + 1
+			for (unsigned b = 0; b < B; ++b) {
+				const unsigned n_cg = (E.buckets[b].kind == 1 ? (E.buckets[b].iso_off & 0xFFFFu) : 0u) + 1u, n_jg = (E.jg_base[b + 1] - E.jg_base[b]) + n_cg;
+				const unsigned long long n1 = o1[b + 1] - o1[b], n2 = o2[b + 1] - o2[b], ns = so[b + 1] - so[b];
+				mr.plan_n1[b] = n1; mr.plan_n2[b] = n2;
+				mr.plan_seg_first[b] = (unsigned)mr.plan_seg_kind.size();
+				const bool visited = E.buckets[b].kind == 1u && ns != 0;
+				if (visited) {
+					for (unsigned q = 0; q < n_cg && g1 + q < FC; ++q) {
+						const unsigned long long a = f1[g1 + q], e = f1[g1 + q + 1];
+						mr.plan_park1[b] += park[g1 + q];
+						if (e > a) { mr.plan_seg_x.push_back(so[b] + (a - o1[b])); mr.plan_seg_kind.push_back(0); mr.plan_seg_looks.push_back(park[g1 + q]); }
+					}
+					for (unsigned q = 0; q < n_jg && g2 + q < FJ; ++q) {
+						const unsigned long long a = f2[g2 + q], e = f2[g2 + q + 1];
+						mr.plan_park2[b] += park[FC + g2 + q];
+						if (e > a) { mr.plan_seg_x.push_back(so[b] + n1 + (a - o2[b])); mr.plan_seg_kind.push_back(1); mr.plan_seg_looks.push_back(park[FC + g2 + q]); }
+					}
+					if (ns > n1 + n2) { mr.plan_seg_x.push_back(so[b] + n1 + n2); mr.plan_seg_kind.push_back(2); mr.plan_seg_looks.push_back(0); }
+				} else if (ns) { mr.plan_seg_x.push_back(so[b]); mr.plan_seg_kind.push_back(2); mr.plan_seg_looks.push_back(0); }
+				g1 += n_cg; g2 += n_jg;
+			}
+			mr.plan_seg_first[B] = (unsigned)mr.plan_seg_kind.size();
+			mr.plan_seg_x.push_back(B ? so[B] : 0);
 		}
 		std::vector<VisitRec> vis(B + 1);
 		mr.next_packed_host.assign(B + 1, B);

@@ -208,7 +208,8 @@ def test_results_do_not_depend_on_launch_geometry(tmp_path, monkeypatch):
         ctx.upload_reads(0, L.Reads.synthetic(sp, ev))
         ref = None
         for opts in ({"share_weighted": 0}, {}, {"share_weighted": 1, "share_taper": 0.05, "grid_multiplier": 9}, {"share_taper": 1, "share_cost_parked": 1e6, "grid_multiplier": 0.3},
-                     {"share_cost_visit": 1e6, "share_cost_two_block": 0}, {"share_cost_visit": 0, "share_cost_two_block": 1000, "snap_shares": 0, "share_taper": 0.2}):
+                     {"share_cost_visit": 1e6, "share_cost_two_block": 0}, {"share_cost_visit": 0, "share_cost_two_block": 1000, "snap_shares": 0, "share_taper": 0.2},
+                     {"share_cost_hot": 50, "share_cost_parked": 0}):
             for k, v in opts.items():
                 ctx.set_option(k, v)
             ctx.count()
