@@ -72,6 +72,11 @@ for bud in budgets:
             print("   dbg: parked two-block followers: first record crosses no junction %d, block 2 runs past the junction's segment %d" % (buf[13], buf[14]))
         if abl & 4194304:
             import ctypes as C
+            if os.environ.get("KB_PIPE"):          # the trace of a launch inside the pipelined loop (steps submitted back to back), not of a launch alone
+                ctx.set_timing(False)
+                for it in range(8):
+                    ctx.count(); ctx.solve()
+                ctx.synchronize(); ctx.set_timing(True)
             cap = 1 << 16
             buf = (C.c_ulonglong * (4 * cap))(); n = C.c_ulonglong(0); nw = C.c_ulonglong(0)
             L.lib.lsq_debug_wg_trace(ctx.h, buf, cap, C.byref(n), C.byref(nw))
