@@ -70,7 +70,8 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300
 
 def shared_dir(tag):
     base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
-    return os.path.join(base, "lsq_bench_%s_%s" % (os.environ.get("USER", "u"), tag))
+    # (LSQ_BENCH_TAG: a child run of this script -- measure_traffic_live -- keeps its files apart from its parent's)
+    return os.path.join(base, "lsq_bench_%s_%s%s" % (os.environ.get("USER", "u"), tag, os.environ.get("LSQ_BENCH_TAG", "")))
 
 
 def measure_traffic_live(wl_name, timeout=300):
@@ -83,7 +84,7 @@ def measure_traffic_live(wl_name, timeout=300):
     if not os.path.exists(prof):
         return None, "rocprofv3 not found"
     base = tempfile.mkdtemp(prefix="lsq_traffic_", dir="/tmp")
-    env = dict(os.environ, TMPDIR="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", LSQ_BENCH_TAG="_traffic%d" % os.getpid())
     means = {}
     try:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
