@@ -27,7 +27,8 @@ for seed in range(first, first + n):
             rc1, _ = L.cli_run("solve", argv)
             assert rc1 != 0, (seed, rc1, rc)      # (in a host process the library reports the error; the executables abort like the reference)
             continue
-        for opts in ("em_flat_min_events=0", "compact_pools=0", "reads_per_look=8,workgroups_per_cu=5", "reads_per_look=4,workgroups_per_cu=6,em_closed_form=1"):
+        for opts in ("em_flat_min_events=0", "compact_pools=0", "reads_per_look=8,workgroups_per_cu=5", "reads_per_look=4,workgroups_per_cu=6,em_closed_form=1",
+                     "share_taper=0.05,grid_multiplier=7,share_cost_hot=3", "share_weighted=0,grid_multiplier=0.2"):
             os.environ["LSQ_OPTIONS"] = opts
             compare_exact(gpu_exact(argv, repeat=4 if opts.startswith("em_flat") else 1), exact, "seed %d %s" % (seed, opts))
             rc1, text = L.cli_run("count", argv[:-1])
