@@ -722,7 +722,7 @@ def run_workload(env, a, wl_name, primary):
                                  "off-target reads are dropped at ingest.  The rate from MRF text on disk is e2e_cli_solve_mrf_reads_per_s / e2e_from_text_reads_per_s",
                 "count_fast_kernel_ms": fk, "count_fast_kernel_ms_alone": float(np.mean(alone_fast_ms)),
                 "count_stream_ms_alone": float(np.mean(count_ms)), "em_kernel_ms_alone": float(np.mean(solve_ms)),
-                "pipeline": "lsq_count on one HIP stream; exception pass (+ recount kernels that return at once unless the exception list overflowed), EM, record "
+                "pipeline": "lsq_count on one HIP stream; exception pass (which turns into a recount of every read where the exception list overflowed), EM, record "
                             "packing and counter zeroing on a second one, beside the next step's count (two counter sets)",
                 "em_placement": "each step lane sorts the EM grid by the iteration counts of its own earlier solve (refreshed every 16th solve; the sort kernel "
                                 "runs inside the timed loop); the loop repeats one read set, so the prediction is exact here",

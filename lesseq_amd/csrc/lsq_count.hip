@@ -68,6 +68,7 @@ struct CountArgs {
 	unsigned *exc_count;               // [0] entries appended, [1] set to 1 by the cleanup kernel when [0] > exc_cap
 	unsigned exc_cap;
 	unsigned long long *dbg;            // developer counters (LSQ_ABLATE & 256): parked one-block, parked two-block, walk steps, walk lanes
+	unsigned long long *bar;            // this read file's barrier word in the counter set (zeroed with it): the exception pass's way into the recount
 };
 
 // compact records to coordinates; base = the bucket's first base minus COMPACT_BIAS
@@ -1467,14 +1468,16 @@ __device__ inline unsigned first_event_for(const GlobalBucket &G, int p) {
 	return G.bins[4u * bin] >> 16;
 }
 
-__global__ void __launch_bounds__(256) lsq_count_cleanup_kernel(const CountArgs *Ap, int force_recount) {
+__device__ void recount_all_reads(const CountArgs &A, unsigned long long n_pn);
+
+__global__ void __launch_bounds__(256) lsq_count_cleanup_kernel(const CountArgs *Ap, int force_recount, unsigned long long n_pn) {
 	__builtin_amdgcn_s_setprio(3);          // runs beside the next count's streaming kernel: short, and the EM waits for it
-	const CountArgs &A = *Ap;               // (through a pointer, like the recount kernel below: no private copy of the record)
+	const CountArgs &A = *Ap;               // (through a pointer: no private copy of the record, see recount_all_reads)
 	const unsigned long long gtid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
 	const unsigned long long gsz = (unsigned long long)gridDim.x * blockDim.x;
 	const unsigned n_raw = A.exc_count[0];
-	// overflow: the list does not hold every pair the fast kernel left open.  The recount kernel behind this one on
-	// the stream sees the flag and counts every read of the method's packed buckets again, from zero.
+	// overflow: the list does not hold every pair the fast kernel left open: every read of the method's packed buckets is
+	// counted again, from zero (below; lsq_count_status reports it)
 	if (n_raw > A.exc_cap || force_recount) {
 		if (gtid == 0) A.exc_count[1] = 1u;
 		// ... and this launch clears what the fast kernel and its workers added to the packed buckets' class counters
@@ -1484,6 +1487,18 @@ __global__ void __launch_bounds__(256) lsq_count_cleanup_kernel(const CountArgs 
 			if (d.kind != 1) continue;
 			for (unsigned i = lane; i < d.n_cls; i += 64u) { A.cnt[d.cls_base + i] = 0; A.bases[d.cls_base + i] = 0; }
 		}
+		// ... and, once every workgroup of this launch has done its part of that (a barrier over the launch's few workgroups: a
+		// word of the counter set, zeroed with it before every count), counts every read of those buckets again.  The rare way
+		// through this kernel; it used to be a launch of its own behind this one, which found nothing to do step after step.
+		__threadfence();
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			atomicAdd(A.bar, 1ull);
+			while (__hip_atomic_load(A.bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned long long)gridDim.x) __builtin_amdgcn_s_sleep(8);
+		}
+		__syncthreads();
+		__threadfence();
+		recount_all_reads(A, n_pn);
 		return;
 	}
 	for (unsigned long long k = gtid; k < n_raw; k += gsz) {
@@ -1498,17 +1513,14 @@ __global__ void __launch_bounds__(256) lsq_count_cleanup_kernel(const CountArgs 
 	}
 }
 
-// The recount, decided on the device: this kernel follows the exception pass on the result stream and returns at once
-// unless that pass raised the method's overflow flag (and cleared the packed buckets' counters).  It then counts every
-// read of those buckets again: one lane per read, tables from L2, the reference's candidate scan event by event
-// (count/count.cpp:429-464), global atomics.  Slow, complete, and it keeps every table that leaves the context
-// whole -- also those handed over by lsq_results_pack_device / lsq_results_copy_device in a loop that never looks.
-// (The arguments come through a pointer, not by value: the evaluation functions take them by reference, and a by-value
-// kernel argument whose address is taken is copied to every thread's private segment in the prologue -- 288 bytes
+// The recount, decided on the device (lsq_count_cleanup_kernel's rare way out: the exception list overflowed, or the self-check
+// option asks for it): every read of the packed buckets once more -- one lane per read, tables from L2, the reference's
+// candidate scan event by event (count/count.cpp:429-464), global atomics.  Slow, complete, and it keeps every table that
+// leaves the context whole -- also those handed over by lsq_results_pack_device / lsq_results_copy_device in a loop that
+// never looks.  (The arguments come through a pointer, not by value: the evaluation functions take them by reference, and a
+// by-value kernel argument whose address is taken is copied to every thread's private segment in the prologue -- 288 bytes
 // per thread, written before the flag is even looked at: measured 115 us per launch of a 1 024-workgroup grid.)
-__global__ void __launch_bounds__(256) lsq_count_recount_kernel(const CountArgs *Ap, unsigned long long n_pn) {
-	if (!Ap->exc_count[1]) return;
-	const CountArgs &A = *Ap;
+__device__ void recount_all_reads(const CountArgs &A, unsigned long long n_pn) {
 	const unsigned long long gtid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
 	const unsigned long long gsz = (unsigned long long)gridDim.x * blockDim.x;
 	const unsigned lane = threadIdx.x & 63u;
@@ -1800,7 +1812,7 @@ int run_count(lsq_ctx *c) {
 		A.total_slots = mr.total_slots;
 		A.cnt = c->cnt.p + (size_t)m * n_cls; A.bases = c->bases.p + (size_t)m * n_cls;
 		A.exc = mr.exc.p + (size_t)set * mr.exc_cap; A.exc_count = c->exc_count.p + 2 * m; A.exc_cap = (unsigned)mr.exc_cap;
-		A.dbg = c->dbg.p;
+		A.dbg = c->dbg.p; A.bar = c->dbg.p + 16 + m;
 		A.wg_trace = nullptr;
 		const unsigned long long n_pn = mr.pn_strand.n;
 		// pool-n workers: one workgroup per CU at most, one lane per read and pass
@@ -1839,7 +1851,7 @@ int run_count(lsq_ctx *c) {
 	if (c->time_events) HIP_TRY(hipEventRecord(c->ev1, st));
 	c->count_timed = c->time_events;
 	// the exception pass, and everything that reads the counts, on the result stream behind the streaming kernels;
-	// behind it the two recount kernels, which do nothing unless the exception list overflowed
+	// (it turns into the recount where the exception list overflowed)
 	if (!counted_signalled) HIP_TRY(hipEventRecord(c->ev_counted2[set], st));
 	HIP_TRY(hipStreamWaitEvent(st_em, c->ev_counted2[set], 0));
 	// few workgroups: these launches normally find the flag clear and return, beside the next count's kernel on a full device
@@ -1857,8 +1869,7 @@ int run_count(lsq_ctx *c) {
 			HIP_TRY(hipMemcpyAsync(c->recount_args.p + slot, c->recount_args_host.data() + slot, sizeof(CountArgs), hipMemcpyHostToDevice, st_em));
 		}
 		const CountArgs *dA = reinterpret_cast<const CountArgs *>(c->recount_args.p + slot);
-		hipLaunchKernelGGL(lsq_count_cleanup_kernel, dim3(16), dim3(256), 0, st_em, dA, c->opt_recount ? 1 : 0);
-		hipLaunchKernelGGL(lsq_count_recount_kernel, dim3(rgrid), dim3(256), 0, st_em, dA, u.n_pn);
+		hipLaunchKernelGGL(lsq_count_cleanup_kernel, dim3(c->opt_recount ? rgrid : 16u), dim3(256), 0, st_em, dA, c->opt_recount ? 1 : 0, u.n_pn);
 		HIP_TRY(hipGetLastError());
 	}
 	return LSQ_OK;

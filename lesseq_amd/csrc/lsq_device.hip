@@ -236,7 +236,7 @@ int lsq_events_upload(lsq_ctx *c, lsq_events *E) LSQ_API_TRY {
 	const size_t n_cls = E->n_cls_total, n_ev = E->dev2out.size();
 	{
 		const size_t per = std::max<size_t>(M, 1) * n_cls;
-		c->counters_per_set = 2 * per + LSQ_MAX_METHODS + 16;
+		c->counters_per_set = 2 * per + LSQ_MAX_METHODS + 16 + LSQ_MAX_METHODS;          // cnt | bases | exc_count (two words a read file) | dbg | one barrier word a read file (lsq_count_cleanup_kernel)
 		if ((rc = c->counters.alloc(2 * c->counters_per_set))) return rc;
 		c->cnt.n = per; c->bases.n = per; c->exc_count.n = 2 * LSQ_MAX_METHODS; c->dbg.n = 16;
 		c->mark_recorded2[0] = c->mark_recorded2[1] = false;
