@@ -1470,15 +1470,20 @@ __device__ inline unsigned first_event_for(const GlobalBucket &G, int p) {
 
 __device__ void recount_all_reads(const CountArgs &A, unsigned long long n_pn);
 
-__global__ void __launch_bounds__(256) lsq_count_cleanup_kernel(const CountArgs *Ap, int force_recount, unsigned long long n_pn) {
+__global__ void __launch_bounds__(256) lsq_count_cleanup_kernel(const CountArgs *Ap, int force_recount, unsigned long long n_pn,
+                                                                const ExcEntry *exc, const unsigned *exc_count, unsigned exc_cap) {
 	__builtin_amdgcn_s_setprio(3);          // runs beside the next count's streaming kernel: short, and the EM waits for it
 	const CountArgs &A = *Ap;               // (through a pointer: no private copy of the record, see recount_all_reads)
 	const unsigned long long gtid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
 	const unsigned long long gsz = (unsigned long long)gridDim.x * blockDim.x;
-	const unsigned n_raw = A.exc_count[0];
+	// The kernel is a chain of dependent trips to memory (the EM of the step waits at its end): the list and its length come as
+	// kernel arguments of their own, so that the first entry is on its way before the record *Ap has been read, and an entry is
+	// loaded before it is known to be one (the list has exc_cap >= 1 slots; what lies beyond the length is an older step's).
+	const ExcEntry e_first = exc[gtid < exc_cap ? gtid : 0];
+	const unsigned n_raw = exc_count[0];
 	// overflow: the list does not hold every pair the fast kernel left open: every read of the method's packed buckets is
 	// counted again, from zero (below; lsq_count_status reports it)
-	if (n_raw > A.exc_cap || force_recount) {
+	if (n_raw > exc_cap || force_recount) {
 		if (gtid == 0) A.exc_count[1] = 1u;
 		// ... and this launch clears what the fast kernel and its workers added to the packed buckets' class counters
 		const unsigned lane = threadIdx.x & 63u, wave_id = (unsigned)(gtid >> 6), n_waves = (unsigned)(gsz >> 6);
@@ -1502,7 +1507,7 @@ __global__ void __launch_bounds__(256) lsq_count_cleanup_kernel(const CountArgs 
 		return;
 	}
 	for (unsigned long long k = gtid; k < n_raw; k += gsz) {
-		const ExcEntry e = A.exc[k];
+		const ExcEntry e = k == gtid ? e_first : exc[k];
 		const GlobalBucket G = global_bucket(A, e.bucket);
 		const unsigned i = e.ev_pool_scan & 0x1FFFFFFFu, pool = (e.ev_pool_scan >> 29) & 3u;
 		const bool scan = (e.ev_pool_scan >> 31) != 0;
@@ -1869,7 +1874,8 @@ int run_count(lsq_ctx *c) {
 			HIP_TRY(hipMemcpyAsync(c->recount_args.p + slot, c->recount_args_host.data() + slot, sizeof(CountArgs), hipMemcpyHostToDevice, st_em));
 		}
 		const CountArgs *dA = reinterpret_cast<const CountArgs *>(c->recount_args.p + slot);
-		hipLaunchKernelGGL(lsq_count_cleanup_kernel, dim3(c->opt_recount ? rgrid : 16u), dim3(256), 0, st_em, dA, c->opt_recount ? 1 : 0, u.n_pn);
+		hipLaunchKernelGGL(lsq_count_cleanup_kernel, dim3(c->opt_recount ? rgrid : 16u), dim3(256), 0, st_em, dA, c->opt_recount ? 1 : 0, u.n_pn,
+		                   (const ExcEntry *)u.A.exc, (const unsigned *)u.A.exc_count, u.A.exc_cap);
 		HIP_TRY(hipGetLastError());
 	}
 	return LSQ_OK;
