@@ -215,6 +215,15 @@ int lsq_reads_upload_text_at(lsq_ctx *c, int method, const char *read_format, ls
 int lsq_mrf_parse_device(lsq_ctx *c, const char *read_format, const char *path, lsq_reads **out);
 /* milliseconds of the last device parse: host-to-device copy of the text, and the parse kernels */
 int lsq_last_mrf_timing(lsq_ctx *c, float *h2d_ms, float *parse_ms);
+/* The loader as a chain of device passes (what replaces count/count.cpp:279-364 on the device): newline count, route
+ * (parse + containment filter + block merge + bucket), partition count, partition scatter, group classify, group
+ * offsets, group place.  lsq_ingest_stage_count / _name list them; lsq_last_ingest_stages gives, for the latest
+ * lsq_reads_upload* of the context, the device milliseconds of every pass (HIP events on the library's stream around the
+ * pass's launches) and the bytes the pass has to move at least (its input read once, its output written once) -- the
+ * two halves of a per-pass HBM roofline.  `capacity` entries of `ms` / `bytes` are written at most (either may be null). */
+int lsq_ingest_stage_count(void);
+const char *lsq_ingest_stage_name(int stage);
+int lsq_last_ingest_stages(const lsq_ctx *c, float *ms, uint64_t *bytes, int capacity);
 uint64_t lsq_reads_retained(const lsq_ctx *c, int method);      /* "loaded N reads" log line */
 uint64_t lsq_reads_retained_blocks(const lsq_ctx *c, int method);
 /* Of the retained reads, those kept in the pools: reads whose first base lies in the span of an event planned on this

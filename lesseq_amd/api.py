@@ -266,6 +266,13 @@ class Context:
         check(lib.lsq_last_mrf_timing(self.h, C.byref(a), C.byref(b)))
         return {"h2d_ms": a.value, "parse_ms": b.value}
 
+    def ingest_stages(self):
+        """device milliseconds and minimum bytes of every pass of the latest ingest (lsq_last_ingest_stages), in order"""
+        n = lib.lsq_ingest_stage_count()
+        ms, by = (C.c_float * n)(), (C.c_uint64 * n)()
+        check(lib.lsq_last_ingest_stages(self.h, ms, by, n))
+        return [{"stage": lib.lsq_ingest_stage_name(i).decode(), "ms": float(ms[i]), "bytes": int(by[i])} for i in range(n)]
+
     def retained(self, method):
         return lib.lsq_reads_retained(self.h, method)
 

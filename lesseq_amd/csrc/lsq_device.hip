@@ -119,6 +119,7 @@ void lsq_ctx_destroy(lsq_ctx *c) {
 	if (c->evt0) (void)hipEventDestroy(c->evt0);
 	if (c->evt1) (void)hipEventDestroy(c->evt1);
 	for (int m = 0; m < LSQ_MAX_METHODS; ++m) { if (c->evf0[m]) (void)hipEventDestroy(c->evf0[m]); if (c->evf1[m]) (void)hipEventDestroy(c->evf1[m]); }
+	for (hipEvent_t e : c->ing_ev) if (e) (void)hipEventDestroy(e);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	for (int l = 0; l < 2; ++l) { if (c->stream_em2[l]) (void)hipStreamDestroy(c->stream_em2[l]); if (c->stream_count2[l]) (void)hipStreamDestroy(c->stream_count2[l]); }
 	delete c;
@@ -273,6 +274,48 @@ int lsq_events_upload(lsq_ctx *c, lsq_events *E) LSQ_API_TRY {
 		if ((rc = c->cov_e.upload(ce.data(), ce.size(), c->stream))) return rc;
 		if ((rc = c->cut_lo.upload(cl.data(), cl.size(), c->stream))) return rc;
 		if ((rc = c->chrom_first_bucket.upload(cfb.data(), cfb.size(), c->stream))) return rc;
+		{
+			// the locator of the three searches (lsq_device.hpp: lsq_ctx::loc): bins of 2^shift bases over each chromosome's
+			// range of table values, the shift raised until all chromosomes together take at most 2^20 entries
+			unsigned shift = 12;
+			std::vector<long long> lo(nc, 0), hi(nc, -1);
+			for (size_t ch = 0; ch < nc; ++ch) {
+				bool any = false;
+				auto see = [&](const int *p, size_t a, size_t b) { for (size_t q = a; q < b; ++q) { if (!any) { lo[ch] = hi[ch] = p[q]; any = true; } lo[ch] = std::min<long long>(lo[ch], p[q]); hi[ch] = std::max<long long>(hi[ch], p[q]); } };
+				see(cs.data(), cov_off[ch], cov_off[ch + 1]); see(cl.data(), cut_off[ch], cut_off[ch + 1]); see(us.data(), clu_off[ch], clu_off[ch + 1]);
+				if (!any) { lo[ch] = 0; hi[ch] = -1; }
+			}
+			for (;; ++shift) {
+				unsigned long long total = 0;
+				for (size_t ch = 0; ch < nc; ++ch) if (hi[ch] >= lo[ch]) total += (unsigned long long)(((hi[ch] >> shift) - (lo[ch] >> shift)) + 2);
+				if (total <= (1ull << 20) || shift >= 30) break;
+			}
+			std::vector<uint4> loc;
+			std::vector<unsigned> lf(nc + 1, 0);
+			std::vector<int> lb(std::max<size_t>(nc, 1), 0);
+			for (size_t ch = 0; ch < nc; ++ch) {
+				lf[ch] = (unsigned)loc.size();
+				if (hi[ch] < lo[ch]) continue;
+				const long long base = (lo[ch] >> shift) << shift;          // (arithmetic shift: rounds towards minus infinity)
+				const long long nb = ((hi[ch] - base) >> shift) + 1;
+				lb[ch] = (int)base;
+				unsigned a = cov_off[ch], b = cut_off[ch], u = clu_off[ch];
+				for (long long k = 0; k <= nb; ++k) {
+					const long long x = base + (k << shift);
+					while (a < cov_off[ch + 1] && cs[a] < x) ++a;
+					while (b < cut_off[ch + 1] && cl[b] < x) ++b;
+					while (u < clu_off[ch + 1] && us[u] < x) ++u;
+					loc.push_back(make_uint4(a, b, u, 0u));
+				}
+			}
+			lf[nc] = (unsigned)loc.size();
+			if (loc.empty()) loc.push_back(make_uint4(0, 0, 0, 0));
+			c->loc_shift = shift;
+			if ((rc = c->loc.upload(loc.data(), loc.size(), c->stream))) return rc;
+			if ((rc = c->loc_first.upload(lf.data(), lf.size(), c->stream))) return rc;
+			if ((rc = c->loc_base.upload(lb.data(), lb.size(), c->stream))) return rc;
+			HIP_TRY(hipStreamSynchronize(c->stream));          // the host vectors go out of scope
+		}
 		std::vector<unsigned> bb(E->buckets.size() + 1, 0);
 		for (size_t b = 0; b < E->buckets.size(); ++b) bb[b + 1] = bb[b] + E->buckets[b].n_bins;
 		c->n_fine = bb.back();

@@ -33,6 +33,7 @@ using namespace lsq;
 #endif
 constexpr unsigned P2_GROUP_PAD = LSQ_P2_PAD;      // ... and a junction group of the two-block pool (eight, with eight two-block reads per look, measured 2 % slower on C3: more padding, longer steps)
 constexpr unsigned P1_GROUP_PAD = LSQ_P1_PAD;      // records a cell's group of the one-block pool is padded to: what a lane of the count kernel takes per look
+constexpr int LSQ_INGEST_STAGES = 7;     // newline count, route, partition count, partition scatter, group classify, group offsets, group place
 constexpr int EM_LANES = 4;          // lanes that share one event in the EM kernel (and one place of its grid)
 
 namespace lsq {
@@ -212,6 +213,13 @@ struct lsq_ctx {
 	unsigned long long wg_trace_n = 0, wg_trace_workers = 0;
 	DevView<unsigned> exc_count;           // per method: [2m] appended, [2m+1] overflow flag
 	DevBuf<unsigned> cov_off, cut_off, clu_off;     // ingest tables: covered regions, bucket cuts and event clusters per chromosome id
+	// locator of the three (round 4): per chromosome a grid of 2^loc_shift-base bins; entry k holds, for the bin's first base x,
+	// the lower bounds of x among the chromosome's covered starts (.x), bucket cuts (.y) and cluster starts (.z) -- indices into
+	// the concatenated arrays -- so a search starts one probe away from its answer instead of at the chromosome's whole range
+	DevBuf<uint4> loc;
+	DevBuf<unsigned> loc_first;            // per chromosome id: its first entry (n_chrom + 1; a chromosome has bins + 1 entries, or none)
+	DevBuf<int> loc_base;                  // per chromosome id: first base of bin 0
+	unsigned loc_shift = 12;
 	DevBuf<int> clu_s, clu_e;
 	DevBuf<int> cov_s, cov_e, cut_lo, chrom_first_bucket;
 	DevBuf<unsigned> bin_base;             // per bucket: first of its bins among all bins (n_buckets + 1)
@@ -252,6 +260,11 @@ struct lsq_ctx {
 	std::map<size_t, std::vector<unsigned short>> host_seq;     // host buckets: [device event * M + method] -> classes of its valid reads, index order
 	float count_ms = 0, solve_ms = 0;
 	float mrf_h2d_ms = 0, mrf_parse_ms = 0;
+	// device time and bytes of the stages of the latest ingest (lsq_ingest.hip: lsq_last_ingest_stages)
+	hipEvent_t ing_ev[2 * LSQ_INGEST_STAGES] = {};
+	float ing_ms[LSQ_INGEST_STAGES] = {};
+	unsigned long long ing_bytes[LSQ_INGEST_STAGES] = {};
+	bool ing_seen[LSQ_INGEST_STAGES] = {};
 };
 
 // MRF text of one file in HBM (lsq_text_stage).  Staging needs no event tables: the executables start it
@@ -261,9 +274,9 @@ struct lsq_text {
 	unsigned long long offset = 0, len = 0;        // the bytes [offset, offset + len) of the file
 	lsq::DevBuf<unsigned char> d_text;
 	float h2d_ms = 0;
-	bool scanned = false;                           // newline positions found (lsq_text_lines or the parse)
+	bool scanned = false;                           // newlines counted (lsq_text_lines or the parse)
 	unsigned long long n_nl = 0;
-	lsq::DevBuf<unsigned long long> d_nl_pos;
+	lsq::DevBuf<unsigned long long> d_tile_base;    // per 8 KiB tile of the text: newlines ahead of it (n_tiles + 1)
 };
 
 namespace lsq {

@@ -1,32 +1,57 @@
 // MRF_SINGLE parsed on the device (included by lsq_ingest.hip; not a public header).
 //
-// The text goes to HBM as it is.  Newlines are found 16 bytes per lane, their ordinals by a
-// two-level prefix sum; one lane then owns one line and runs the shared splitter
-// (lsq_mrf_line.hpp -- the same code the host parser runs) twice: once to count the line's
-// blocks, once to write them at the offsets a second prefix sum gives.  Result: the parsed
-// blocks in file order, identical to lsq_mrf_parse's arrays (count/count.cpp:279-336 minus the
-// containment filter), already in HBM for the ingest kernels.
+// The text goes to HBM as it is and is read there twice: once to count the newlines of every 8 KiB tile (16 bytes per
+// lane, the exact zero-byte test on word ^ 0x0A0A0A0A), once to parse.  A workgroup of the parse owns the lines that END
+// in its tile: it stages the tile and the 512 bytes before it in LDS (coalesced 16-byte loads), finds the newlines
+// there, and one lane per line runs the shared splitter (lsq_mrf_line.hpp -- the code the host parser runs) over LDS
+// bytes.  A line that began more than 512 bytes before the tile is walked in global memory by the same splitter.  The
+// newline ordinal of a line (tile base from a prefix sum over the tile counts + its place in the tile) is its line
+// number: the header and "read-<n>" fall out as in the reference (count/count.cpp:283,286,293-295).
+//
+// Round 4: the parse feeds the load-time filter directly (lsq_mrf_route_kernel: per line, every block is tested against
+// the covered regions and merged as it is split off; nothing but the routed read leaves the kernel), so no parsed array
+// exists in HBM either.  lsq_mrf_parse_device (tests, tools) still wants those arrays: the same tile walk run twice,
+// counting (lsq_mrf_count_kernel) and writing (lsq_mrf_write_kernel) around two prefix sums.
 //   - the first line is the header (count.cpp:283); a last line without '\n' is never seen (:285)
 //   - '#' lines and the literal "AlignmentBlocks" consume a line number only (:288)
 //   - a field that fails the cast stops the run: the FIRST such line in file order is reported
-//   - chromosome names resolve against the events' chromosomes (hash table in global memory);
+//   - chromosome names resolve against the events' chromosomes (hash table, in LDS when it is small);
 //     strand strings against a 256-slot table seeded with the strands already known, grown with
 //     atomicCAS (strings of at most 7 bytes; longer ones give LSQ_E_UNSUPPORTED -- use lsq_mrf_parse)
 #pragma once
 
-constexpr unsigned MRF_TILE = 4096;                 // text bytes per workgroup pass: 256 lanes x 16
+constexpr unsigned MRF_TILE = 8192;                 // text bytes per workgroup: 256 lanes x 2 x 16
+constexpr unsigned MRF_LB = 512;                    // bytes ahead of the tile that are staged with it
+constexpr unsigned MRF_NLCAP = 1024;                // newline positions held at a time (a tile of shorter lines takes several rounds)
 constexpr unsigned long long MRF_NO_ERR = ~0ull;
 constexpr unsigned long long STRAND_EMPTY = ~0ull;
 constexpr unsigned long long STRAND_UNMATCHABLE = ~0ull - 1;
 constexpr unsigned MRF_NOCHROM = 0xFFFFu;
+constexpr unsigned MRF_DICT_LDS_SLOTS = 256;        // chromosome hash tables up to this size are staged in LDS (<= 64 chromosomes)
+constexpr unsigned MRF_DICT_LDS_NAMES = 1024;
+
+typedef const __attribute__((address_space(3))) char *mrf_lds_cptr;
+typedef lsq::MrfViewT<mrf_lds_cptr, unsigned> MrfLdsView;
 
 struct MrfDict {
-	const unsigned long long *chrom_hash;   // open addressing, 0 = empty
+	const unsigned *chrom_hash;             // open addressing, 0 = empty; 32-bit FNV-1a of the name
 	const unsigned *chrom_id;
 	const unsigned *name_off;               // per chromosome id, into names
 	const char *names;
-	unsigned mask;
+	unsigned mask, n_chrom, names_bytes;
 	unsigned long long *strand_tab;         // 256 slots
+};
+
+struct MrfTileLds {
+	__align__(16) unsigned char text[MRF_LB + MRF_TILE + 16];
+	unsigned short nlpos[MRF_NLCAP];
+	unsigned scan4[4];
+	unsigned carry;                         // last newline of the previous round
+	long long first_start;                  // first byte of the first line that ends in the tile
+	// the dictionaries, when they are small
+	unsigned long long strand[256];
+	unsigned d_hash[MRF_DICT_LDS_SLOTS], d_id[MRF_DICT_LDS_SLOTS], d_off[MRF_DICT_LDS_SLOTS / 4 + 1];
+	char d_names[MRF_DICT_LDS_NAMES];
 };
 
 __device__ inline unsigned mrf_wave_incl_scan(unsigned v) {
@@ -46,85 +71,153 @@ __device__ inline unsigned mrf_block_excl_scan(unsigned v, unsigned *lds4, unsig
 	return base + inc - v;
 }
 
-// bit j set iff byte j of the lane's 16 bytes is '\n'
-__device__ inline unsigned mrf_newline_bits(const unsigned char *text, unsigned long long len, unsigned long long at) {
-	if (at >= len) return 0;
+// bit j set iff byte j of the 16 bytes is '\n'; only the first `valid` bytes count
+__device__ inline unsigned mrf_newline_bits16(const uint4 v, unsigned valid) {
+	const unsigned w[4] = {v.x, v.y, v.z, v.w};
 	unsigned bits = 0;
-	if (at + 16 <= len) {
-		const uint4 v = *reinterpret_cast<const uint4 *>(text + at);
-		const unsigned w[4] = {v.x, v.y, v.z, v.w};
-		for (int q = 0; q < 4; ++q) {
-			const unsigned x = w[q] ^ 0x0A0A0A0Au;
-			const unsigned z = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;   // 0x80 in every zero byte
-			bits |= (((z >> 7) & 1u) | ((z >> 14) & 2u) | ((z >> 21) & 4u) | ((z >> 28) & 8u)) << (4 * q);
-		}
-	} else {
-		for (unsigned j = 0; at + j < len; ++j) bits |= (text[at + j] == '\n' ? 1u : 0u) << j;
+#pragma unroll
+	for (int q = 0; q < 4; ++q) {
+		const unsigned x = w[q] ^ 0x0A0A0A0Au;
+		const unsigned z = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;   // 0x80 in every zero byte
+		bits |= (((z >> 7) & 1u) | ((z >> 14) & 2u) | ((z >> 21) & 4u) | ((z >> 28) & 8u)) << (4 * q);
 	}
-	return bits;
+	return valid >= 16u ? bits : (bits & ((1u << valid) - 1u));
+}
+// the 16 bytes at `at` of a text of `len` bytes (the buffer holds 16 bytes of slack behind the text) and how many of them are text
+__device__ inline uint4 mrf_load16(const unsigned char *text, unsigned long long len, unsigned long long at, unsigned &valid) {
+	if (at >= len) { valid = 0; return make_uint4(0, 0, 0, 0); }
+	valid = (unsigned)min(16ull, len - at);
+	return *reinterpret_cast<const uint4 *>(text + at);
 }
 
+// newlines per tile
 __global__ void __launch_bounds__(256) lsq_mrf_newline_count_kernel(const unsigned char *text, unsigned long long len, unsigned *tile_cnt) {
 	__shared__ unsigned lds4[4];
-	const unsigned long long at = (unsigned long long)blockIdx.x * MRF_TILE + threadIdx.x * 16ull;
+	const unsigned long long t0 = (unsigned long long)blockIdx.x * MRF_TILE;
+	unsigned n = 0;
+#pragma unroll
+	for (unsigned q = 0; q < MRF_TILE / 4096; ++q) {
+		unsigned valid;
+		const uint4 v = mrf_load16(text, len, t0 + q * 4096ull + threadIdx.x * 16ull, valid);
+		n += (unsigned)__popc(mrf_newline_bits16(v, valid));
+	}
 	unsigned total;
-	(void)mrf_block_excl_scan((unsigned)__popc(mrf_newline_bits(text, len, at)), lds4, total);
+	(void)mrf_block_excl_scan(n, lds4, total);
 	if (threadIdx.x == 0) tile_cnt[blockIdx.x] = total;
 }
 
-__global__ void __launch_bounds__(256) lsq_mrf_newline_pos_kernel(const unsigned char *text, unsigned long long len,
-                                                                  const unsigned long long *tile_base, unsigned long long *nl_pos) {
-	__shared__ unsigned lds4[4];
-	const unsigned long long at = (unsigned long long)blockIdx.x * MRF_TILE + threadIdx.x * 16ull;
-	unsigned bits = mrf_newline_bits(text, len, at);
-	unsigned total;
-	unsigned long long w = tile_base[blockIdx.x] + mrf_block_excl_scan((unsigned)__popc(bits), lds4, total);
-	while (bits) { const unsigned j = (unsigned)__ffs((int)bits) - 1u; bits &= bits - 1u; nl_pos[w++] = at + j; }
-}
+// The lines that end in this workgroup's tile: fn(i, view) is called once per data line -- i its 0-based index among the
+// data lines (with a header: the lines after the first), view the line's bytes without the newline -- by the lane that
+// owns it.  view is an LDS view, or a plain one for a line that began more than MRF_LB bytes ahead of the tile.
+// A line that began more than MRF_LB bytes ahead of its tile: its data line index, first byte and length.  At most one per tile.
+struct MrfLongLine { unsigned long long i, start, n; };
 
-// data line i (0-based) of the text: with a header the bytes between newlines i and i+1, without one (a
-// slice of a file that starts on a line boundary) those between newlines i-1 and i
-__device__ inline lsq::MrfView mrf_data_line(const unsigned char *text, const unsigned long long *nl_pos, unsigned long long i, unsigned has_header) {
-	const unsigned long long e = i + has_header;
-	const unsigned long long a = e == 0 ? 0ull : nl_pos[e - 1] + 1, b = nl_pos[e];
-	return lsq::MrfView{reinterpret_cast<const char *>(text) + a, (size_t)(b - a)};
-}
-
-// pass 1: blocks per data line (0 for skipped lines), first failing line, per-workgroup sums
-__global__ void __launch_bounds__(256) lsq_mrf_count_kernel(const unsigned char *text, const unsigned long long *nl_pos, unsigned long long n_lines,
-                                                            unsigned has_header, unsigned long long first_line,
-                                                            unsigned *line_nb, unsigned *wg_reads, unsigned *wg_blocks, unsigned long long *err) {
-	__shared__ unsigned lds4[4];
-	const unsigned long long i = (unsigned long long)blockIdx.x * 256ull + threadIdx.x;
-	unsigned nb = 0;
-	if (i < n_lines) {
-		const unsigned long long L = first_line + i;          // the line's number in the whole file (read name "read-<L>")
-		const lsq::MrfView line = mrf_data_line(text, nl_pos, i, has_header);
-		if (!lsq::mrf_line_is_skipped(line)) {
-			const bool ok = lsq::mrf_split_line(line, [&](lsq::MrfView, lsq::MrfView, int64_t, int64_t) { ++nb; });
-			if (!ok) { atomicMin(&err[0], L); nb = 0; }
-		}
-		line_nb[i] = nb;
+template <bool DEFER, class Fn>
+__device__ inline void mrf_tile_lines(MrfTileLds &S, const unsigned char *text, const unsigned long long len, const unsigned long long *tile_base,
+                                      const unsigned has_header, MrfLongLine *long_lines, unsigned *n_long, Fn &&fn) {
+	const unsigned tid = threadIdx.x;
+	const unsigned long long t0 = (unsigned long long)blockIdx.x * MRF_TILE;
+	unsigned bits[MRF_TILE / 4096];
+#pragma unroll
+	for (unsigned q = 0; q < MRF_TILE / 4096; ++q) {
+		unsigned valid;
+		const uint4 v = mrf_load16(text, len, t0 + q * 4096ull + tid * 16ull, valid);
+		*reinterpret_cast<uint4 *>(&S.text[MRF_LB + q * 4096u + tid * 16u]) = v;
+		bits[q] = mrf_newline_bits16(v, valid);
 	}
-	unsigned tr, tb;
-	(void)mrf_block_excl_scan(nb ? 1u : 0u, lds4, tr);
-	(void)mrf_block_excl_scan(nb, lds4, tb);
-	if (threadIdx.x == 0) { wg_reads[blockIdx.x] = tr; wg_blocks[blockIdx.x] = tb; }
+	if (tid < MRF_LB / 16u && t0 >= MRF_LB)
+		*reinterpret_cast<uint4 *>(&S.text[tid * 16u]) = *reinterpret_cast<const uint4 *>(text + (t0 - MRF_LB) + tid * 16ull);
+	// ordinals of the newlines: the lanes' first words cover bytes 0..4095 of the tile, their second words the rest
+	unsigned ord[MRF_TILE / 4096], nt = 0;
+#pragma unroll
+	for (unsigned q = 0; q < MRF_TILE / 4096; ++q) {
+		unsigned total;
+		ord[q] = nt + mrf_block_excl_scan((unsigned)__popc(bits[q]), S.scan4, total);
+		nt += total;
+	}
+	if (nt == 0) return;                      // (uniform: every lane holds the same total)
+	// the first line that ends here began after the last newline ahead of the tile
+	if (tid < 64u) {
+		long long found = -1;
+		if (t0 > 0) {
+			for (unsigned long long k = 0;; ++k) {
+				const long long pos = (long long)t0 - 1 - (long long)(k * 64ull + tid);
+				const bool hit = pos >= 0 && text[pos] == '\n';
+				const unsigned long long m = __ballot(hit);
+				if (m) { found = (long long)t0 - 1 - (long long)(k * 64ull + (unsigned)(__ffsll((long long)m) - 1)); break; }
+				if ((long long)t0 - 1 - (long long)(k * 64ull + 63ull) <= 0) break;
+			}
+		}
+		if (tid == 0) S.first_start = found + 1;
+	}
+	const unsigned long long g0 = tile_base[blockIdx.x];
+	const mrf_lds_cptr lds_text = (mrf_lds_cptr)(const char *)S.text;
+	for (unsigned rb = 0; rb < nt; rb += MRF_NLCAP) {
+#pragma unroll
+		for (unsigned q = 0; q < MRF_TILE / 4096; ++q) {
+			unsigned b = bits[q], o = ord[q];
+			while (b) {
+				const unsigned j = (unsigned)__ffs((int)b) - 1u; b &= b - 1u;
+				if (o >= rb && o < rb + MRF_NLCAP) S.nlpos[o - rb] = (unsigned short)(q * 4096u + tid * 16u + j);
+				++o;
+			}
+		}
+		__syncthreads();
+		const unsigned r_end = min(nt, rb + MRF_NLCAP);
+		for (unsigned j = rb + tid; j < r_end; j += 256u) {
+			const unsigned long long g = g0 + j;                 // the newline's ordinal in the text = the 0-based number of the line it ends
+			if (has_header && g == 0) continue;
+			const int end_rel = (int)S.nlpos[j - rb];
+			long long start_rel;
+			if (j == 0) start_rel = S.first_start - (long long)t0;
+			else if (j > rb) start_rel = (long long)S.nlpos[j - 1 - rb] + 1;
+			else start_rel = (long long)S.carry + 1;
+			const unsigned long long i = g - has_header;
+			if (start_rel >= -(long long)MRF_LB) fn(i, MrfLdsView{lds_text + (MRF_LB + (int)start_rel), (unsigned)(end_rel - (int)start_rel)});
+			else if constexpr (DEFER) long_lines[atomicAdd(n_long, 1u)] = MrfLongLine{i, (unsigned long long)((long long)t0 + start_rel), (unsigned long long)((long long)end_rel - start_rel)};
+			else fn(i, lsq::MrfView{reinterpret_cast<const char *>(text) + (t0 + start_rel), (size_t)((long long)end_rel - start_rel)});
+		}
+		__syncthreads();
+		if (tid == 0) S.carry = S.nlpos[MRF_NLCAP - 1];
+		__syncthreads();
+	}
 }
 
-__device__ inline unsigned mrf_chrom_lookup(const MrfDict &D, lsq::MrfView s) {
-	unsigned long long h = 0xcbf29ce484222325ull;
-	for (size_t j = 0; j < s.n; ++j) { h ^= (unsigned char)s.p[j]; h *= 0x100000001b3ull; }
+// the dictionaries into LDS when they fit; returns the view the lookups use
+__device__ inline MrfDict mrf_stage_dict(MrfTileLds &S, const MrfDict &G) {
+	S.strand[threadIdx.x & 255u] = __hip_atomic_load(&G.strand_tab[threadIdx.x & 255u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	MrfDict D = G;
+	if (G.mask < MRF_DICT_LDS_SLOTS && G.names_bytes <= MRF_DICT_LDS_NAMES && G.n_chrom <= MRF_DICT_LDS_SLOTS / 4) {
+		for (unsigned i = threadIdx.x; i <= G.mask; i += 256u) { S.d_hash[i] = G.chrom_hash[i]; S.d_id[i] = G.chrom_id[i]; }
+		for (unsigned i = threadIdx.x; i <= G.n_chrom; i += 256u) S.d_off[i] = G.name_off[i];
+		for (unsigned i = threadIdx.x; i < G.names_bytes; i += 256u) S.d_names[i] = G.names[i];
+		D.chrom_hash = S.d_hash; D.chrom_id = S.d_id; D.name_off = S.d_off; D.names = S.d_names;
+	}
+	__syncthreads();
+	return D;
+}
+
+LSQ_HD inline unsigned mrf_fnv32(const char *p, size_t n) {
+	unsigned h = 2166136261u;
+	for (size_t j = 0; j < n; ++j) { h ^= (unsigned char)p[j]; h *= 16777619u; }
+	return h ? h : 1u;
+}
+
+template <class V>
+__device__ inline unsigned mrf_chrom_lookup(const MrfDict &D, V s) {
+	typedef typename V::index_type Idx;
+	unsigned h = 2166136261u;
+	for (Idx j = 0; j < s.n; ++j) { h ^= (unsigned char)s.p[j]; h *= 16777619u; }
 	if (h == 0) h = 1;
-	for (unsigned i = (unsigned)h & D.mask;; i = (i + 1u) & D.mask) {
-		const unsigned long long t = D.chrom_hash[i];
+	for (unsigned i = h & D.mask;; i = (i + 1u) & D.mask) {
+		const unsigned t = D.chrom_hash[i];
 		if (t == 0) return MRF_NOCHROM;
 		if (t != h) continue;
 		const unsigned id = D.chrom_id[i];
 		const unsigned a = D.name_off[id], b = D.name_off[id + 1];
-		if ((size_t)(b - a) != s.n) continue;
+		if ((Idx)(b - a) != s.n) continue;
 		bool same = true;
-		for (size_t j = 0; j < s.n; ++j) same = same && D.names[a + j] == s.p[j];
+		for (Idx j = 0; j < s.n; ++j) same = same && D.names[a + j] == s.p[j];
 		if (same) return id;
 	}
 }
@@ -136,9 +229,18 @@ LSQ_HD inline unsigned long long mrf_strand_key(const char *p, size_t n) {
 	return k;
 }
 
-__device__ inline unsigned mrf_strand_slot(unsigned long long *tab, lsq::MrfView s, unsigned long long *err) {
+// the slot of a strand string: the workgroup's LDS copy of the table first (the strands every file has are there from the
+// start), the table itself -- and a place in it for a new string -- otherwise
+template <class V>
+__device__ inline unsigned mrf_strand_slot(const unsigned long long *lds_tab, unsigned long long *tab, V s, unsigned long long *err) {
 	if (s.n > 7) { atomicMax(&err[1], 1ull); return 0; }
-	const unsigned long long key = mrf_strand_key(s.p, s.n);
+	unsigned long long key = (unsigned long long)s.n;
+	for (unsigned j = 0; j < (unsigned)s.n; ++j) key |= (unsigned long long)(unsigned char)s.p[j] << (56 - 8 * j);
+	if (lds_tab) for (unsigned i = 0; i < 256; ++i) {
+		const unsigned long long cur = lds_tab[i];
+		if (cur == key) return i;
+		if (cur == STRAND_EMPTY) break;
+	}
 	for (unsigned i = 0; i < 256; ++i) {
 		const unsigned long long cur = __hip_atomic_load(&tab[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		if (cur == key) return i;
@@ -151,6 +253,64 @@ __device__ inline unsigned mrf_strand_slot(unsigned long long *tab, lsq::MrfView
 	return 0;
 }
 
+struct MrfText {
+	const unsigned char *text;
+	unsigned long long len;
+	const unsigned long long *tile_base;
+	unsigned has_header;
+	unsigned long long first_line;            // the number of data line 0 in the whole file (read name "read-<L>")
+	unsigned long long n_lines;
+};
+
+// ---- the parse that feeds the load-time filter (the product path): per line, every block through the covered regions and
+// the merge as it is split off; the routed read to key[i] / rec[i], i the data line's index
+template <class V>
+__device__ inline void mrf_route_line(const MrfText &X, const MrfDict &D, const unsigned long long *lds_strand, const RouteTables &T, const RouteOut &O,
+                                      unsigned long long *err, const unsigned long long i, const V line) {
+	const long long LIM = 1ll << 30;
+	if (lsq::mrf_line_is_skipped(line)) { O.key[i] = ROUTE_KEY_DROPPED; return; }
+	ReadAcc A;
+	A.init();
+	const bool ok = lsq::mrf_split_line(line, [&](const V chr, const V strand, const int64_t start, const int64_t end) {
+		const unsigned cid = mrf_chrom_lookup(D, chr);
+		const long long s0 = start - 1, e0 = end;
+		if (cid >= T.n_chrom || s0 <= -LIM || e0 >= LIM || s0 >= LIM || e0 <= -LIM) return;
+		if (!route_covered(T, cid, (int)s0, (int)e0)) return;
+		A.add(cid, mrf_strand_slot(lds_strand, D.strand_tab, strand, err), (int)s0, (int)e0);
+	});
+	if (!ok) { atomicMin(&err[0], X.first_line + i); O.key[i] = ROUTE_KEY_DROPPED; return; }
+	A.finish(T, O, (unsigned)i);
+}
+
+__global__ void __launch_bounds__(256) lsq_mrf_route_kernel(MrfText X, MrfDict G, RouteTables T, RouteOut O, unsigned long long *err, MrfLongLine *long_lines, unsigned *n_long) {
+	__shared__ MrfTileLds S;
+	const MrfDict D = mrf_stage_dict(S, G);
+	mrf_tile_lines<true>(S, X.text, X.len, X.tile_base, X.has_header, long_lines, n_long, [&](const unsigned long long i, const MrfLdsView line) {
+		mrf_route_line(X, D, S.strand, T, O, err, i, line);
+	});
+}
+// the lines that began far ahead of their tiles (none in a file of reads), one lane each, straight from HBM
+__global__ void __launch_bounds__(256) lsq_mrf_route_long_kernel(MrfText X, MrfDict G, RouteTables T, RouteOut O, unsigned long long *err, const MrfLongLine *long_lines, const unsigned *n_long) {
+	const unsigned n = *n_long;
+	for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+		const MrfLongLine L = long_lines[t];
+		mrf_route_line(X, G, nullptr, T, O, err, L.i, lsq::MrfView{reinterpret_cast<const char *>(X.text) + L.start, (size_t)L.n});
+	}
+}
+
+// ---- the same walk for lsq_mrf_parse_device: pass 1, blocks per data line (0 for skipped lines), first failing line
+__global__ void __launch_bounds__(256) lsq_mrf_count_kernel(MrfText X, unsigned *line_nb, unsigned long long *err) {
+	__shared__ MrfTileLds S;
+	mrf_tile_lines<false>(S, X.text, X.len, X.tile_base, X.has_header, nullptr, nullptr, [&](const unsigned long long i, auto line) {
+		unsigned nb = 0;
+		if (!lsq::mrf_line_is_skipped(line)) {
+			const bool ok = lsq::mrf_split_line(line, [&](auto, auto, int64_t, int64_t) { ++nb; });
+			if (!ok) { atomicMin(&err[0], X.first_line + i); nb = 0; }
+		}
+		line_nb[i] = nb;
+	});
+}
+
 struct MrfOut {
 	unsigned long long *blk_off;
 	unsigned *line_no;
@@ -159,32 +319,29 @@ struct MrfOut {
 	unsigned char *blk_strand;
 };
 
-// pass 2: every read's blocks to their place
-__global__ void __launch_bounds__(256) lsq_mrf_write_kernel(const unsigned char *text, const unsigned long long *nl_pos, unsigned long long n_lines,
-                                                            unsigned has_header, unsigned long long first_line, const unsigned *line_nb, const unsigned long long *rd_base, const unsigned long long *bk_base,
-                                                            MrfDict D, MrfOut O, unsigned long long *err) {
-	__shared__ unsigned lds4[4];
-	const unsigned long long i = (unsigned long long)blockIdx.x * 256ull + threadIdx.x;
-	const unsigned nb = i < n_lines ? line_nb[i] : 0u;
-	unsigned tr, tb;
-	const unsigned long long r = rd_base[blockIdx.x] + mrf_block_excl_scan(nb ? 1u : 0u, lds4, tr);
-	const unsigned long long o = bk_base[blockIdx.x] + mrf_block_excl_scan(nb, lds4, tb);
-	if (i + 1 == n_lines) O.blk_off[r + (nb ? 1u : 0u)] = o + nb;
-	if (!nb) return;
-	const unsigned long long L = first_line + i;
-	const lsq::MrfView line = mrf_data_line(text, nl_pos, i, has_header);
-	O.blk_off[r] = o;
-	O.line_no[r] = (unsigned)L;
-	unsigned long long w = o;
+// pass 2: every read's blocks to their place (rd_idx / bk_off: exclusive prefix sums of "has blocks" / of the block counts over the data lines)
+__global__ void __launch_bounds__(256) lsq_mrf_write_kernel(MrfText X, const unsigned *line_nb, const unsigned long long *rd_idx, const unsigned long long *bk_off,
+                                                            MrfDict G, MrfOut O, unsigned long long *err) {
+	__shared__ MrfTileLds S;
+	const MrfDict D = mrf_stage_dict(S, G);
 	const long long LIM = 1ll << 30;
-	(void)lsq::mrf_split_line(line, [&](lsq::MrfView chr, lsq::MrfView strand, int64_t start, int64_t end) {
-		unsigned cid = mrf_chrom_lookup(D, chr);
-		const unsigned sid = mrf_strand_slot(D.strand_tab, strand, err);
-		long long s0 = start - 1, e0 = end;
-		if (s0 <= -LIM || e0 >= LIM || s0 >= LIM || e0 <= -LIM) { cid = MRF_NOCHROM; s0 = 0; e0 = 0; }
-		O.blk_start[w] = (int)s0; O.blk_end[w] = (int)e0;
-		O.blk_chrom[w] = (unsigned short)cid; O.blk_strand[w] = (unsigned char)sid;
-		++w;
+	mrf_tile_lines<false>(S, X.text, X.len, X.tile_base, X.has_header, nullptr, nullptr, [&](const unsigned long long i, auto line) {
+		const unsigned nb = line_nb[i];
+		const unsigned long long r = rd_idx[i], o = bk_off[i];
+		if (i + 1 == X.n_lines) O.blk_off[r + (nb ? 1u : 0u)] = o + nb;
+		if (!nb) return;
+		O.blk_off[r] = o;
+		O.line_no[r] = (unsigned)(X.first_line + i);
+		unsigned long long w = o;
+		(void)lsq::mrf_split_line(line, [&](auto chr, auto strand, int64_t start, int64_t end) {
+			unsigned cid = mrf_chrom_lookup(D, chr);
+			const unsigned sid = mrf_strand_slot(S.strand, D.strand_tab, strand, err);
+			long long s0 = start - 1, e0 = end;
+			if (s0 <= -LIM || e0 >= LIM || s0 >= LIM || e0 <= -LIM) { cid = MRF_NOCHROM; s0 = 0; e0 = 0; }
+			O.blk_start[w] = (int)s0; O.blk_end[w] = (int)e0;
+			O.blk_chrom[w] = (unsigned short)cid; O.blk_strand[w] = (unsigned char)sid;
+			++w;
+		});
 	});
 }
 
@@ -299,9 +456,8 @@ static int stage_text_file(lsq_ctx *c, const char *path, unsigned long long byte
 	return LSQ_OK;
 }
 
-// Parses staged text on the device.  The events' strand dictionary grows by the strand strings the
-// file introduces (as it does under lsq_mrf_parse).
-// newline positions of a staged text (kept with it): lsq_text_lines runs this ahead of the parse
+
+// newline counts of a staged text, per tile, and their prefix sums (kept with the text): lsq_text_lines runs this ahead of the parse
 static int scan_newlines(lsq_ctx *c, lsq_text &T) {
 	if (T.scanned) return LSQ_OK;
 	hipStream_t st = c->stream;
@@ -310,37 +466,122 @@ static int scan_newlines(lsq_ctx *c, lsq_text &T) {
 	T.n_nl = 0;
 	if (len) {
 		const unsigned long long n_tiles = (len + MRF_TILE - 1) / MRF_TILE;
-		if (n_tiles > 0x7FFFFFFFull) return fail(LSQ_E_RANGE, "reads file larger than 8 TiB");
+		if (n_tiles > 0x7FFFFFFFull) return fail(LSQ_E_RANGE, "reads file larger than 16 TiB");
 		DevBuf<unsigned> d_tile_cnt;
-		DevBuf<unsigned long long> d_tile_base;
-		if ((rc = d_tile_cnt.alloc(n_tiles)) || (rc = d_tile_base.alloc(n_tiles + 1))) return rc;
+		ScanScratch SS;
+		if ((rc = d_tile_cnt.alloc(n_tiles)) || (rc = T.d_tile_base.alloc(n_tiles + 1)) || (rc = SS.reserve(n_tiles))) return rc;
+		StageClock k(c, st, 0);
 		hipLaunchKernelGGL(lsq_mrf_newline_count_kernel, dim3((unsigned)n_tiles), dim3(256), 0, st, T.d_text.p, len, d_tile_cnt.p);
 		HIP_TRY(hipGetLastError());
-		hipLaunchKernelGGL(lsq_scan_u32_kernel<1>, dim3(1), dim3(1024), 0, st, d_tile_cnt.p, n_tiles, d_tile_base.p);
-		HIP_TRY(hipGetLastError());
-		HIP_TRY(hipMemcpyAsync(&T.n_nl, d_tile_base.p + n_tiles, 8, hipMemcpyDeviceToHost, st));
+		if ((rc = device_scan<1>(SS, d_tile_cnt.p, n_tiles, T.d_tile_base.p, st))) return rc;
+		k.end(len + 12ull * n_tiles);
+		HIP_TRY(hipMemcpyAsync(&T.n_nl, T.d_tile_base.p + n_tiles, 8, hipMemcpyDeviceToHost, st));
 		HIP_TRY(hipStreamSynchronize(st));
-		if ((rc = T.d_nl_pos.alloc(T.n_nl))) return rc;
-		if (T.n_nl) {
-			hipLaunchKernelGGL(lsq_mrf_newline_pos_kernel, dim3((unsigned)n_tiles), dim3(256), 0, st, T.d_text.p, len, d_tile_base.p, T.d_nl_pos.p);
-			HIP_TRY(hipGetLastError());
-			HIP_TRY(hipStreamSynchronize(st));
-		}
 	}
 	T.scanned = true;
 	return LSQ_OK;
 }
 
+// The dictionaries of a parse: the events' chromosome names behind a hash table, the strand table seeded with the strands
+// already known.  The events' strand dictionary grows by the strings the file introduces (as it does under lsq_mrf_parse).
+struct MrfDictDev {
+	DevBuf<unsigned> d_hash, d_id, d_off;
+	DevBuf<unsigned long long> d_strand, d_err;
+	DevBuf<char> d_names;
+	size_t n_seed = 0;
+	MrfDict D{};
+	int build(lsq_ctx *c, hipStream_t st) {
+		lsq_events &E = *c->E;
+		int rc;
+		const size_t nc = E.covered.size();
+		size_t tab = 2;
+		while (tab < 4 * nc) tab <<= 1;
+		std::vector<unsigned> h_hash(tab, 0), h_id(tab, 0), h_off(nc + 1, 0);
+		std::string h_names;
+		for (size_t id = 0; id < nc; ++id) {
+			const std::string &nm = E.chroms.names[id];
+			const unsigned h = mrf_fnv32(nm.data(), nm.size());
+			size_t i = (size_t)(h & (unsigned)(tab - 1));
+			while (h_hash[i] != 0) i = (i + 1) & (tab - 1);
+			h_hash[i] = h; h_id[i] = (unsigned)id;
+			h_names += nm;
+			h_off[id + 1] = (unsigned)h_names.size();
+		}
+		if (E.strands.names.size() > 256) return fail(LSQ_E_RANGE, "more than 256 distinct strand strings");
+		n_seed = E.strands.names.size();
+		std::vector<unsigned long long> h_strand(256, STRAND_EMPTY);
+		for (size_t i = 0; i < n_seed; ++i) {
+			const std::string &s = E.strands.names[i];
+			h_strand[i] = s.size() <= 7 ? mrf_strand_key(s.data(), s.size()) : STRAND_UNMATCHABLE;
+		}
+		const unsigned long long err[4] = {MRF_NO_ERR, 0, 0, 0};
+		if ((rc = d_hash.upload(h_hash.data(), tab, st)) || (rc = d_id.upload(h_id.data(), tab, st)) || (rc = d_off.upload(h_off.data(), nc + 1, st)) ||
+		    (rc = d_names.upload(h_names.data(), h_names.size(), st)) || (rc = d_strand.upload(h_strand.data(), 256, st)) || (rc = d_err.upload(err, 4, st))) return rc;
+		HIP_TRY(hipStreamSynchronize(st));            // the host vectors go out of scope
+		D.chrom_hash = d_hash.p; D.chrom_id = d_id.p; D.name_off = d_off.p; D.names = d_names.p; D.mask = (unsigned)(tab - 1);
+		D.n_chrom = (unsigned)nc; D.names_bytes = (unsigned)h_names.size(); D.strand_tab = d_strand.p;
+		return LSQ_OK;
+	}
+	int reset_errors(hipStream_t st) {
+		static const unsigned long long err0[4] = {MRF_NO_ERR, 0, 0, 0};
+		HIP_TRY(hipMemcpyAsync(d_err.p, err0, sizeof(err0), hipMemcpyHostToDevice, st));
+		return LSQ_OK;
+	}
+	// after the parse kernels have run and the stream has been waited for: the first failing line, strand strings out of range, new strands
+	int settle(lsq_ctx *c, const lsq_text &T, unsigned has_header, unsigned long long first_line, hipStream_t st) {
+		lsq_events &E = *c->E;
+		unsigned long long err[4];
+		std::vector<unsigned long long> h_strand(256);
+		HIP_TRY(hipMemcpyAsync(err, d_err.p, sizeof(err), hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipMemcpyAsync(h_strand.data(), d_strand.p, 256 * 8, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
+		if (err[0] != MRF_NO_ERR) {
+			// the text of the failing line, from the file: between the newline that ends the line before it and its own
+			const unsigned long long want = err[0] - first_line + has_header;      // ordinal of the newline that ends the failing line
+			std::string text;
+			const int fd = open(T.path.c_str(), O_RDONLY);
+			if (fd >= 0) {
+				// walk the file's range for the want-th newline (an error path: speed does not matter, bounded memory does)
+				std::vector<char> buf(1 << 20);
+				unsigned long long seen = 0, pos = 0;
+				bool in_line = want == 0, done = false;
+				while (!done && pos < T.len) {
+					const size_t ask = (size_t)std::min<unsigned long long>(buf.size(), T.len - pos);
+					const ssize_t got = pread(fd, buf.data(), ask, (off_t)(T.offset + pos));
+					if (got <= 0) break;
+					for (ssize_t q = 0; q < got && !done; ++q) {
+						if (buf[(size_t)q] == '\n') {
+							if (in_line) done = true;
+							else if (++seen == want) in_line = true;
+						} else if (in_line) text.push_back(buf[(size_t)q]);
+					}
+					pos += (unsigned long long)got;
+				}
+				close(fd);
+			}
+			return fail(LSQ_E_PARSE, "#%llu:%s", err[0], text.c_str());
+		}
+		if (err[1]) return fail(LSQ_E_UNSUPPORTED, "a strand string longer than 7 bytes: outside the device parser's range (lsq_mrf_parse handles it)");
+		if (err[2]) return fail(LSQ_E_RANGE, "more than 256 distinct strand strings");
+		for (size_t i = n_seed; i < 256 && h_strand[i] != STRAND_EMPTY; ++i) {
+			const unsigned long long k = h_strand[i];
+			std::string s;
+			for (unsigned j = 0; j < (unsigned)(k & 0xFF); ++j) s.push_back((char)(k >> (56 - 8 * j)));
+			const int id = E.strands.intern(s);
+			if (id != (int)i) return fail(LSQ_E_STATE, "strand dictionary changed while a reads file was being parsed");
+		}
+		n_seed = E.strands.names.size();
+		return LSQ_OK;
+	}
+};
+
+// Parses staged text on the device into the arrays of lsq_mrf_parse (file order): lsq_mrf_parse_device.
 static int parse_staged_text(lsq_ctx *c, const char *read_format, lsq_text &T, unsigned has_header, unsigned long long first_line, DevParsed &out, float *h2d_ms, float *parse_ms) {
 	if (!read_format) return fail(LSQ_E_ARG, "null argument");
 	if (!c->E) return fail(LSQ_E_STATE, "lsq_events_upload must come first");
 	if (strcmp(read_format, "MRF_SINGLE") != 0) return fail(LSQ_E_FORMAT, "Unknown file format error: %s", read_format);
-	lsq_events &E = *c->E;
-	HostStopwatch SW;
 	hipStream_t st = c->stream;
 	int rc;
-	const unsigned long long len = T.len;
-	DevBuf<unsigned char> &d_text = T.d_text;
 	const unsigned long long zero_off = 0;
 	out.n_reads = out.n_blocks = 0;
 	auto empty_result = [&]() -> int {
@@ -352,118 +593,47 @@ static int parse_staged_text(lsq_ctx *c, const char *read_format, lsq_text &T, u
 	};
 	if (h2d_ms) *h2d_ms = T.h2d_ms;
 	if (parse_ms) *parse_ms = 0;
-	if (len == 0) return empty_result();
+	if (T.len == 0) return empty_result();
 	HIP_TRY(hipEventRecord(c->ev1, st));
 	if ((rc = scan_newlines(c, T))) return rc;
 	const unsigned long long n_nl = T.n_nl;
 	if (n_nl < 1 + has_header) return empty_result();   // header only (or no terminated line at all)
 	const unsigned long long n_lines = n_nl - has_header;
 	if (first_line + n_lines > 0xFFFFFFFFull) return fail(LSQ_E_RANGE, "more than 2^32 lines");
-	DevBuf<unsigned long long> &d_nl_pos = T.d_nl_pos;
-	const unsigned long long n_wg = (n_lines + 255) / 256;
-	DevBuf<unsigned> d_line_nb, d_wg_reads, d_wg_blocks;
-	DevBuf<unsigned long long> d_rd_base, d_bk_base, d_err;
-	if ((rc = d_line_nb.alloc(n_lines)) || (rc = d_wg_reads.alloc(n_wg)) || (rc = d_wg_blocks.alloc(n_wg)) ||
-	    (rc = d_rd_base.alloc(n_wg + 1)) || (rc = d_bk_base.alloc(n_wg + 1)) || (rc = d_err.alloc(4))) return rc;
-	unsigned long long err[4] = {MRF_NO_ERR, 0, 0, 0};
-	HIP_TRY(hipMemcpyAsync(d_err.p, err, sizeof(err), hipMemcpyHostToDevice, st));
-	hipLaunchKernelGGL(lsq_mrf_count_kernel, dim3((unsigned)n_wg), dim3(256), 0, st, d_text.p, d_nl_pos.p, n_lines, has_header, first_line,
-	                   d_line_nb.p, d_wg_reads.p, d_wg_blocks.p, d_err.p);
+	const unsigned n_tiles = (unsigned)((T.len + MRF_TILE - 1) / MRF_TILE);
+	DevBuf<unsigned> d_line_nb;
+	DevBuf<unsigned long long> d_rd_idx, d_bk_off;
+	ScanScratch SS;
+	MrfDictDev DD;
+	if ((rc = d_line_nb.alloc(n_lines)) || (rc = d_rd_idx.alloc(n_lines + 1)) || (rc = d_bk_off.alloc(n_lines + 1)) || (rc = SS.reserve(n_lines)) || (rc = DD.build(c, st))) return rc;
+	MrfText X{T.d_text.p, T.len, T.d_tile_base.p, has_header, first_line, n_lines};
+	hipLaunchKernelGGL(lsq_mrf_count_kernel, dim3(n_tiles), dim3(256), 0, st, X, d_line_nb.p, DD.d_err.p);
 	HIP_TRY(hipGetLastError());
-	hipLaunchKernelGGL(lsq_scan_u32_kernel<1>, dim3(1), dim3(1024), 0, st, d_wg_reads.p, n_wg, d_rd_base.p);
-	hipLaunchKernelGGL(lsq_scan_u32_kernel<1>, dim3(1), dim3(1024), 0, st, d_wg_blocks.p, n_wg, d_bk_base.p);
-	HIP_TRY(hipGetLastError());
+	if ((rc = device_scan<1, true>(SS, d_line_nb.p, n_lines, d_rd_idx.p, st)) || (rc = device_scan<1, false>(SS, d_line_nb.p, n_lines, d_bk_off.p, st))) return rc;
 	unsigned long long n_reads = 0, n_blocks = 0;
-	HIP_TRY(hipMemcpyAsync(err, d_err.p, sizeof(err), hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(&n_reads, d_rd_base.p + n_wg, 8, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(&n_blocks, d_bk_base.p + n_wg, 8, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipStreamSynchronize(st));
-	if (err[0] != MRF_NO_ERR) {
-		const unsigned long long ei = err[0] - first_line + has_header;      // newline that ends the failing line
-		unsigned long long ab[2] = {~0ull, 0};                                  // ab[0] + 1 = first byte of the line
-		if (ei > 0) HIP_TRY(hipMemcpy(&ab[0], d_nl_pos.p + (ei - 1), 8, hipMemcpyDeviceToHost));
-		HIP_TRY(hipMemcpy(&ab[1], d_nl_pos.p + ei, 8, hipMemcpyDeviceToHost));
-		std::string text((size_t)(ab[1] - ab[0] - 1), '\0');
-		size_t got_all = 0;
-		const int fd = open(T.path.c_str(), O_RDONLY);
-		while (fd >= 0 && got_all < text.size()) {
-			const ssize_t got = pread(fd, &text[got_all], text.size() - got_all, (off_t)(T.offset + ab[0] + 1 + got_all));
-			if (got <= 0) break;
-			got_all += (size_t)got;
-		}
-		if (fd >= 0) close(fd);
-		return fail(LSQ_E_PARSE, "#%llu:%s", err[0], text.c_str());
-	}
-	// dictionaries
-	const size_t nc = E.covered.size();
-	size_t tab = 2;
-	while (tab < 4 * nc) tab <<= 1;
-	std::vector<unsigned long long> h_hash(tab, 0);
-	std::vector<unsigned> h_id(tab, 0), h_off(nc + 1, 0);
-	std::string h_names;
-	for (size_t id = 0; id < nc; ++id) {
-		const std::string &nm = E.chroms.names[id];
-		unsigned long long h = 0xcbf29ce484222325ull;
-		for (unsigned char ch : nm) { h ^= ch; h *= 0x100000001b3ull; }
-		if (h == 0) h = 1;
-		size_t i = (size_t)((unsigned)h & (unsigned)(tab - 1));
-		while (h_hash[i] != 0) i = (i + 1) & (tab - 1);
-		h_hash[i] = h; h_id[i] = (unsigned)id;
-		h_names += nm;
-		h_off[id + 1] = (unsigned)h_names.size();
-	}
-	if (E.strands.names.size() > 256) return fail(LSQ_E_RANGE, "more than 256 distinct strand strings");
-	const size_t n_seed = E.strands.names.size();
-	std::vector<unsigned long long> h_strand(256, STRAND_EMPTY);
-	for (size_t i = 0; i < n_seed; ++i) {
-		const std::string &s = E.strands.names[i];
-		h_strand[i] = s.size() <= 7 ? mrf_strand_key(s.data(), s.size()) : STRAND_UNMATCHABLE;
-	}
-	DevBuf<unsigned long long> d_hash, d_strand;
-	DevBuf<unsigned> d_id, d_off;
-	DevBuf<char> d_names;
-	if ((rc = d_hash.upload(h_hash.data(), tab, st)) || (rc = d_id.upload(h_id.data(), tab, st)) || (rc = d_off.upload(h_off.data(), nc + 1, st)) ||
-	    (rc = d_names.upload(h_names.data(), h_names.size(), st)) || (rc = d_strand.upload(h_strand.data(), 256, st))) return rc;
+	HIP_TRY(hipMemcpyAsync(&n_reads, d_rd_idx.p + n_lines, 8, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(&n_blocks, d_bk_off.p + n_lines, 8, hipMemcpyDeviceToHost, st));
+	if ((rc = DD.settle(c, T, has_header, first_line, st))) return rc;          // (waits for the stream) the first failing line ends the run here
 	if ((rc = out.blk_off.alloc(n_reads + 1)) || (rc = out.line_no.alloc(n_reads)) || (rc = out.bs.alloc(n_blocks)) || (rc = out.be.alloc(n_blocks)) ||
 	    (rc = out.bc.alloc(n_blocks)) || (rc = out.bst.alloc(n_blocks))) return rc;
-	MrfDict D{};
-	D.chrom_hash = d_hash.p; D.chrom_id = d_id.p; D.name_off = d_off.p; D.names = d_names.p; D.mask = (unsigned)(tab - 1); D.strand_tab = d_strand.p;
 	MrfOut O{};
 	O.blk_off = out.blk_off.p; O.line_no = out.line_no.p; O.blk_start = out.bs.p; O.blk_end = out.be.p; O.blk_chrom = out.bc.p; O.blk_strand = out.bst.p;
-	hipLaunchKernelGGL(lsq_mrf_write_kernel, dim3((unsigned)n_wg), dim3(256), 0, st, d_text.p, d_nl_pos.p, n_lines, has_header, first_line, d_line_nb.p,
-	                   d_rd_base.p, d_bk_base.p, D, O, d_err.p);
+	hipLaunchKernelGGL(lsq_mrf_write_kernel, dim3(n_tiles), dim3(256), 0, st, X, (const unsigned *)d_line_nb.p, (const unsigned long long *)d_rd_idx.p,
+	                   (const unsigned long long *)d_bk_off.p, DD.D, O, DD.d_err.p);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(c->ev2, st));
-	HIP_TRY(hipMemcpyAsync(err, d_err.p, sizeof(err), hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(h_strand.data(), d_strand.p, 256 * 8, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipStreamSynchronize(st));
-	SW.mark("parse: kernels");
+	if ((rc = DD.settle(c, T, has_header, first_line, st))) return rc;
 	if (parse_ms) (void)hipEventElapsedTime(parse_ms, c->ev1, c->ev2);
-	if (err[1]) return fail(LSQ_E_UNSUPPORTED, "a strand string longer than 7 bytes: outside the device parser's range (lsq_mrf_parse handles it)");
-	if (err[2]) return fail(LSQ_E_RANGE, "more than 256 distinct strand strings");
-	for (size_t i = n_seed; i < 256 && h_strand[i] != STRAND_EMPTY; ++i) {
-		const unsigned long long k = h_strand[i];
-		std::string s;
-		for (unsigned j = 0; j < (unsigned)(k & 0xFF); ++j) s.push_back((char)(k >> (56 - 8 * j)));
-		const int id = E.strands.intern(s);
-		if (id != (int)i) return fail(LSQ_E_STATE, "strand dictionary changed while a reads file was being parsed");
-	}
 	out.n_reads = n_reads; out.n_blocks = n_blocks;
 	return LSQ_OK;
 }
 
-// open -> format literal -> copy -> parse: the order in which the reference meets a bad file or literal
-static int device_parse_mrf(lsq_ctx *c, const char *read_format, const char *path, DevParsed &out, float *h2d_ms, float *parse_ms) {
+// open -> format literal: the order in which the reference meets a bad file or literal
+static int check_mrf_file(const char *read_format, const char *path) {
 	if (!read_format || !path) return fail(LSQ_E_ARG, "null argument");
-	if (!c->E) return fail(LSQ_E_STATE, "lsq_events_upload must come first");
-	{
-		FILE *f = fopen(path, "rb");
-		if (!f) return fail(LSQ_E_IO, "cannot open reads file %s", path);
-		fclose(f);
-	}
+	FILE *f = fopen(path, "rb");
+	if (!f) return fail(LSQ_E_IO, "cannot open reads file %s", path);
+	fclose(f);
 	if (strcmp(read_format, "MRF_SINGLE") != 0) return fail(LSQ_E_FORMAT, "Unknown file format error: %s", read_format);
-	lsq_text T;
-	int rc = stage_text_file(c, path, 0, ~0ull, T);
-	if (rc) return rc;
-	return parse_staged_text(c, read_format, T, 1u, 1ull, out, h2d_ms, parse_ms);
+	return LSQ_OK;
 }
