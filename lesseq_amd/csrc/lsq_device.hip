@@ -251,69 +251,88 @@ int lsq_events_upload(lsq_ctx *c, lsq_events *E) LSQ_API_TRY {
 	}
 	select_counter_set(c, 0);
 	{
-		// ingest tables: covered regions (by chromosome id) and the bucket cuts
+		// ingest tables (lsq_device.hpp: RouteChrom): per chromosome id the covered regions (count/count.cpp:244) as (start, end)
+		// pairs, the spans of the planned events ("clusters") with the bucket each lies in, and the locator grid over both
 		const size_t nc = E->covered.size();
-		std::vector<unsigned> cov_off(nc + 1, 0), cut_off(nc + 1, 0), clu_off(nc + 1, 0);
-		std::vector<int> cs, ce, cl, cfb(std::max<size_t>(nc, 1), -1), us, ue;
+		std::vector<RouteChrom> chrom(std::max<size_t>(nc, 1));
+		std::vector<int2> cov;
+		std::vector<int4> clu;
 		for (size_t ch = 0; ch < nc; ++ch) {
-			for (size_t q = 0; q < E->covered[ch].s.size(); ++q) { cs.push_back((int)E->covered[ch].s[q]); ce.push_back((int)E->covered[ch].e[q]); }
-			cov_off[ch + 1] = (unsigned)cs.size();
-			if (ch < E->cut_lo.size()) for (int32_t v : E->cut_lo[ch]) cl.push_back(v);
-			cut_off[ch + 1] = (unsigned)cl.size();
-			if (ch < E->clu_s.size()) for (size_t q = 0; q < E->clu_s[ch].size(); ++q) { us.push_back(E->clu_s[ch][q]); ue.push_back(E->clu_e[ch][q]); }
-			clu_off[ch + 1] = (unsigned)us.size();
-			if (ch < E->chrom_first_bucket.size()) cfb[ch] = E->chrom_first_bucket[ch];
+			RouteChrom &R = chrom[ch];
+			memset(&R, 0, sizeof(R));
+			R.cov0 = (unsigned)cov.size();
+			for (size_t q = 0; q < E->covered[ch].s.size(); ++q) cov.push_back(make_int2((int)E->covered[ch].s[q], (int)E->covered[ch].e[q]));
+			R.cov1 = (unsigned)cov.size();
+			R.clu0 = (unsigned)clu.size();
+			// A cluster with the bucket of its bases.  Buckets are cut where no span crosses, so a cluster lies in one; the records are
+			// cut at the bucket cuts all the same, and a stretch left of the chromosome's first cut (in no bucket) gets none: a
+			// look-up of "the last record that starts at or left of p" then IS the bucket search and the cluster test of p.
+			const int first = ch < E->chrom_first_bucket.size() ? E->chrom_first_bucket[ch] : -1;
+			if (first >= 0 && ch < E->clu_s.size() && ch < E->cut_lo.size()) {
+				const std::vector<int32_t> &cuts = E->cut_lo[ch];
+				for (size_t q = 0; q < E->clu_s[ch].size(); ++q) {
+					long long s = E->clu_s[ch][q];
+					const long long e = E->clu_e[ch][q];           // (inclusive: a read whose first base is e is still inside)
+					while (s <= e) {
+						const size_t ub = (size_t)(std::upper_bound(cuts.begin(), cuts.end(), (int32_t)s) - cuts.begin());
+						const long long next_cut = ub < cuts.size() ? (long long)cuts[ub] : e + 1;
+						const long long stop = std::min(e, next_cut - 1);
+						if (ub > 0) {
+							const unsigned b = (unsigned)first + (unsigned)(ub - 1);
+							clu.push_back(make_int4((int)s, (int)std::min<long long>(stop, E->buckets[b].hi), (int)b, E->buckets[b].lo));
+						}
+						s = stop + 1;
+					}
+				}
+			}
+			R.clu1 = (unsigned)clu.size();
 		}
 		c->n_chrom_tables = (unsigned)nc;
-		if ((rc = c->cov_off.upload(cov_off.data(), cov_off.size(), c->stream))) return rc;
-		if ((rc = c->cut_off.upload(cut_off.data(), cut_off.size(), c->stream))) return rc;
-		if ((rc = c->clu_off.upload(clu_off.data(), clu_off.size(), c->stream))) return rc;
-		if ((rc = c->clu_s.upload(us.data(), us.size(), c->stream))) return rc;
-		if ((rc = c->clu_e.upload(ue.data(), ue.size(), c->stream))) return rc;
-		if ((rc = c->cov_s.upload(cs.data(), cs.size(), c->stream))) return rc;
-		if ((rc = c->cov_e.upload(ce.data(), ce.size(), c->stream))) return rc;
-		if ((rc = c->cut_lo.upload(cl.data(), cl.size(), c->stream))) return rc;
-		if ((rc = c->chrom_first_bucket.upload(cfb.data(), cfb.size(), c->stream))) return rc;
 		{
-			// the locator of the three searches (lsq_device.hpp: lsq_ctx::loc): bins of 2^shift bases over each chromosome's
-			// range of table values, the shift raised until all chromosomes together take at most 2^20 entries
-			unsigned shift = 12;
+			// the locator: bins of 2^shift bases over each chromosome's range of starts (covered regions and cluster records), the
+			// shift raised until all chromosomes together take at most 2^22 entries.  Entry k of a chromosome, for the bin's first
+			// base x and the next bin's first base y: lower bounds of x and of y among the covered starts (.x, .y) and among the
+			// cluster starts (.z, .w): a search starts one 16-byte load away from a handful of candidates.
+			unsigned shift = 10;
 			std::vector<long long> lo(nc, 0), hi(nc, -1);
 			for (size_t ch = 0; ch < nc; ++ch) {
 				bool any = false;
-				auto see = [&](const int *p, size_t a, size_t b) { for (size_t q = a; q < b; ++q) { if (!any) { lo[ch] = hi[ch] = p[q]; any = true; } lo[ch] = std::min<long long>(lo[ch], p[q]); hi[ch] = std::max<long long>(hi[ch], p[q]); } };
-				see(cs.data(), cov_off[ch], cov_off[ch + 1]); see(cl.data(), cut_off[ch], cut_off[ch + 1]); see(us.data(), clu_off[ch], clu_off[ch + 1]);
-				if (!any) { lo[ch] = 0; hi[ch] = -1; }
+				auto see = [&](long long v) { if (!any) { lo[ch] = hi[ch] = v; any = true; } lo[ch] = std::min(lo[ch], v); hi[ch] = std::max(hi[ch], v); };
+				for (unsigned q = chrom[ch].cov0; q < chrom[ch].cov1; ++q) see(cov[q].x);
+				for (unsigned q = chrom[ch].clu0; q < chrom[ch].clu1; ++q) see(clu[q].x);
 			}
 			for (;; ++shift) {
 				unsigned long long total = 0;
-				for (size_t ch = 0; ch < nc; ++ch) if (hi[ch] >= lo[ch]) total += (unsigned long long)(((hi[ch] >> shift) - (lo[ch] >> shift)) + 2);
-				if (total <= (1ull << 20) || shift >= 30) break;
+				for (size_t ch = 0; ch < nc; ++ch) if (hi[ch] >= lo[ch]) total += (unsigned long long)(((hi[ch] >> shift) - (lo[ch] >> shift)) + 1);
+				if (total <= (1ull << 22) || shift >= 30) break;
 			}
 			std::vector<uint4> loc;
-			std::vector<unsigned> lf(nc + 1, 0);
-			std::vector<int> lb(std::max<size_t>(nc, 1), 0);
 			for (size_t ch = 0; ch < nc; ++ch) {
-				lf[ch] = (unsigned)loc.size();
+				RouteChrom &R = chrom[ch];
+				R.loc_first = (unsigned)loc.size();
 				if (hi[ch] < lo[ch]) continue;
 				const long long base = (lo[ch] >> shift) << shift;          // (arithmetic shift: rounds towards minus infinity)
 				const long long nb = ((hi[ch] - base) >> shift) + 1;
-				lb[ch] = (int)base;
-				unsigned a = cov_off[ch], b = cut_off[ch], u = clu_off[ch];
-				for (long long k = 0; k <= nb; ++k) {
-					const long long x = base + (k << shift);
-					while (a < cov_off[ch + 1] && cs[a] < x) ++a;
-					while (b < cut_off[ch + 1] && cl[b] < x) ++b;
-					while (u < clu_off[ch + 1] && us[u] < x) ++u;
-					loc.push_back(make_uint4(a, b, u, 0u));
+				R.loc_base = (int)base; R.loc_nb = (unsigned)nb;
+				unsigned a = R.cov0, u = R.clu0;
+				for (long long k = 0; k < nb; ++k) {
+					const long long x = base + (k << shift), y = x + (1ll << shift);
+					while (a < R.cov1 && cov[a].x < x) ++a;
+					while (u < R.clu1 && clu[u].x < x) ++u;
+					unsigned a2 = a, u2 = u;
+					while (a2 < R.cov1 && cov[a2].x < y) ++a2;
+					while (u2 < R.clu1 && clu[u2].x < y) ++u2;
+					loc.push_back(make_uint4(a, a2, u, u2));
 				}
 			}
-			lf[nc] = (unsigned)loc.size();
 			if (loc.empty()) loc.push_back(make_uint4(0, 0, 0, 0));
+			if (cov.empty()) cov.push_back(make_int2(0, 0));
+			if (clu.empty()) clu.push_back(make_int4(0, 0, 0, 0));
 			c->loc_shift = shift;
 			if ((rc = c->loc.upload(loc.data(), loc.size(), c->stream))) return rc;
-			if ((rc = c->loc_first.upload(lf.data(), lf.size(), c->stream))) return rc;
-			if ((rc = c->loc_base.upload(lb.data(), lb.size(), c->stream))) return rc;
+			if ((rc = c->route_chrom.upload(chrom.data(), chrom.size(), c->stream))) return rc;
+			if ((rc = c->cov.upload(cov.data(), cov.size(), c->stream))) return rc;
+			if ((rc = c->clu.upload(clu.data(), clu.size(), c->stream))) return rc;
 			HIP_TRY(hipStreamSynchronize(c->stream));          // the host vectors go out of scope
 		}
 		std::vector<unsigned> bb(E->buckets.size() + 1, 0);

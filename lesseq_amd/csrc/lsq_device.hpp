@@ -77,6 +77,15 @@ struct DevBuf {
 template <class T>
 struct DevView { T *p = nullptr; size_t n = 0; };     // a slice of somebody else's allocation
 
+// what the loader's routing pass knows about one chromosome: its stretch of the locator grid, of the covered regions and of the clusters
+struct RouteChrom {
+	unsigned loc_first, loc_nb;              // its bins of the grid
+	int loc_base;                            // first base of bin 0
+	unsigned cov0, cov1, clu0, clu1;
+	unsigned pad;
+};
+static_assert(sizeof(RouteChrom) == 32, "RouteChrom is staged in LDS as two 16-byte words");
+
 // What a workgroup of the count kernel needs to know about one visit to a bucket, in one 128-byte record per (read file,
 // bucket), written once per read set (ingest): the bucket's description, where its slots and its one- and two-block
 // records lie, and the next packed bucket that holds any.  A wave reads it with scalar loads -- one memory round trip
@@ -212,16 +221,15 @@ struct lsq_ctx {
 	DevBuf<unsigned long long> wg_trace;   // developer build (LSQ_ABLATE 4194304): lsq_debug_wg_trace
 	unsigned long long wg_trace_n = 0, wg_trace_workers = 0;
 	DevView<unsigned> exc_count;           // per method: [2m] appended, [2m+1] overflow flag
-	DevBuf<unsigned> cov_off, cut_off, clu_off;     // ingest tables: covered regions, bucket cuts and event clusters per chromosome id
-	// locator of the three (round 4): per chromosome a grid of 2^loc_shift-base bins; entry k holds, for the bin's first base x,
-	// the lower bounds of x among the chromosome's covered starts (.x), bucket cuts (.y) and cluster starts (.z) -- indices into
-	// the concatenated arrays -- so a search starts one probe away from its answer instead of at the chromosome's whole range
+	// ingest tables (round 4 form): per chromosome id a RouteChrom; the covered regions as (start, end) pairs; the clusters (spans of
+	// the planned events) as (start, end, bucket, bucket's first base), cut at the bucket cuts; and the locator grid over both:
+	// per chromosome bins of 2^loc_shift bases, entry k = lower bounds of the bin's first base and of the next bin's among the
+	// covered starts (.x, .y) and the cluster starts (.z, .w) -- a search is one 16-byte load and a handful of neighbouring records
+	DevBuf<RouteChrom> route_chrom;
+	DevBuf<int2> cov;
+	DevBuf<int4> clu;
 	DevBuf<uint4> loc;
-	DevBuf<unsigned> loc_first;            // per chromosome id: its first entry (n_chrom + 1; a chromosome has bins + 1 entries, or none)
-	DevBuf<int> loc_base;                  // per chromosome id: first base of bin 0
-	unsigned loc_shift = 12;
-	DevBuf<int> clu_s, clu_e;
-	DevBuf<int> cov_s, cov_e, cut_lo, chrom_first_bucket;
+	unsigned loc_shift = 10;
 	DevBuf<unsigned> bin_base;             // per bucket: first of its bins among all bins (n_buckets + 1)
 	size_t n_fine = 0;
 	// The one-block pool is laid out by cell (lsq_internal.hpp: Cell), not by bin: per bucket its cells in order and one more

@@ -47,23 +47,18 @@ struct HostStopwatch {
 };
 
 constexpr int INGEST_MAX_BLOCKS = 16;                  // merged blocks per read the device ingest handles
+constexpr int LSQ_RETRY = 1;                           // a front end's settle(): route the file again (it has changed its own mode)
 
 // ---- what the routing pass knows and what it leaves behind ------------------------------------------------------------
 struct RouteTables {
-	const unsigned *cov_off;       // per chromosome id: range of its covered intervals
-	const int *cov_s, *cov_e;
-	const unsigned *cut_off;       // per chromosome id: range of its bucket cuts
-	const int *cut_lo;
-	const int *chrom_first_bucket;
-	const unsigned *clu_off;       // per chromosome id: range of its event clusters (merged spans of the planned events)
-	const int *clu_s, *clu_e;
-	const BucketDesc *buckets;
-	const uint4 *loc;              // locator grid (lsq_ctx::loc): .x covered, .y cuts, .z clusters
-	const unsigned *loc_first;
-	const int *loc_base;
+	const RouteChrom *chrom;       // per chromosome id (lsq_device.hpp); a kernel may point this at its own copy in LDS
+	const int2 *cov;               // covered regions: (start, end), ascending per chromosome
+	const int4 *clu;               // clusters (spans of the planned events) cut at the bucket cuts: (start, end -- inclusive --, bucket, bucket's first base)
+	const uint4 *loc;              // locator grid (lsq_ctx::loc)
 	unsigned loc_shift;
 	unsigned n_chrom;
 };
+constexpr unsigned ROUTE_CHROM_LDS = 64;      // chromosome records a kernel stages in LDS (more chromosomes: read from global memory)
 
 // A read's key: pool in bits 0-1 (0 one merged block, 1 two, 2 three or more, 3 one or two that do not fit compact
 // records), bucket in bits 2-23, strand id in bits 24-31.  Bucket 0x3FFFFF: not routed -- dropped (all ones), or
@@ -86,41 +81,96 @@ struct RouteOut {
 	unsigned compact;              // compact pool records: one- and two-block reads that do not fit them go to pool 3
 };
 
-// lower bound of x among the sorted values of one chromosome, narrowed by the locator: field 0 covered starts, 1 cuts, 2 cluster starts
-struct LocProbe { uint4 a, b; int state; };      // state: -1 below the grid, 1 beyond it (or no grid), 0 inside
-__device__ inline LocProbe loc_probe(const RouteTables &T, const unsigned chrom, const int x) {
-	LocProbe P;
-	const unsigned f0 = T.loc_first[chrom], f1 = T.loc_first[chrom + 1];
-	P.a = P.b = make_uint4(0, 0, 0, 0);
-	if (f1 == f0) { P.state = 1; return P; }
-	const long long d = (long long)x - (long long)T.loc_base[chrom];
-	if (d <= 0) { P.state = -1; return P; }
-	const long long k = d >> T.loc_shift;
-	if (k >= (long long)(f1 - f0 - 1u)) { P.state = 1; return P; }
-	P.a = T.loc[f0 + (unsigned)k]; P.b = T.loc[f0 + (unsigned)k + 1u];
-	P.state = 0;
-	return P;
-}
-__device__ inline unsigned loc_lower_bound(const LocProbe &P, const unsigned lo_f, const unsigned hi_f, const int *vals, const unsigned c0, const unsigned c1, const int x) {
-	if (P.state < 0) return c0;
-	if (P.state > 0) {
-		// beyond the grid every value is smaller; a chromosome without a grid has no values
-		return c1;
-	}
-	unsigned lo = lo_f, hi = hi_f;
-	while (lo < hi) { const unsigned mid = (lo + hi) >> 1; if (vals[mid] < x) lo = mid + 1; else hi = mid; }
-	return lo;
+// The locator entry of base x on a chromosome: where, among the chromosome's covered regions and clusters, the records that
+// start inside x's bin lie.  Kept per lane from one look-up to the next: a read's blocks and its first base mostly share a bin.
+struct LocProbe {
+	int chrom; long long bin;
+	unsigned cov_a, cov_b, clu_a, clu_b;       // lower_bound(starts, x) lies in [a, b]
+};
+__device__ inline void loc_probe(const RouteTables &T, const RouteChrom &R, const int chrom, const int x, LocProbe &P) {
+	const long long d = (long long)x - (long long)R.loc_base;
+	long long k = d >> T.loc_shift;
+	if (R.loc_nb == 0u || d <= 0) k = -1;                       // at or below the first bin's first base: nothing starts left of x
+	else if (k >= (long long)R.loc_nb) k = (long long)R.loc_nb; // beyond the last bin: everything does
+	if (P.chrom == chrom && P.bin == k) return;
+	P.chrom = chrom; P.bin = k;
+	if (k < 0) { P.cov_a = P.cov_b = R.cov0; P.clu_a = P.clu_b = R.clu0; }
+	else if (k >= (long long)R.loc_nb) { P.cov_a = P.cov_b = R.cov1; P.clu_a = P.clu_b = R.clu1; }
+	else { const uint4 e = T.loc[R.loc_first + (unsigned)k]; P.cov_a = e.x; P.cov_b = e.y; P.clu_a = e.z; P.clu_b = e.w; }
 }
 
-// interval_list::contains_interval against the covered regions of the block's chromosome (interval_list.hpp:396-422)
-__device__ inline bool route_covered(const RouteTables &T, const unsigned chrom, const int start, const int end) {
+// interval_list::contains_interval against the covered regions of the block's chromosome (interval_list.hpp:396-422):
+// lo = lower_bound(starts, start); the interval at lo (when it starts exactly there) or the one before it must reach `end`
+__device__ inline bool route_covered(const RouteTables &T, const RouteChrom &R, const int chrom, const int start, const int end, LocProbe &P) {
 	if (!(start < end)) return true;
-	const unsigned lo0 = T.cov_off[chrom], hi0 = T.cov_off[chrom + 1];
-	const LocProbe P = loc_probe(T, chrom, start);
-	const unsigned lo = loc_lower_bound(P, P.a.x, P.b.x, T.cov_s, lo0, hi0, start);       // lower_bound(starts, start)
-	if (lo < hi0 && T.cov_s[lo] <= start && end <= T.cov_e[lo]) return true;
-	if (lo > lo0 && T.cov_s[lo - 1] <= start && end <= T.cov_e[lo - 1]) return true;
+	loc_probe(T, R, chrom, start, P);
+	const unsigned a = P.cov_a, b = P.cov_b;
+	int2 at, before;                        // the records at lo and at lo - 1
+	bool has_at, has_before;
+	if (b - a <= 3u) {
+		// records a - 1 .. a + 3 hold both, wherever in [a, b] lo falls: five loads in flight at once, no dependent probe
+		int2 c[5];
+		unsigned below = 0;
+#pragma unroll
+		for (unsigned q = 0; q < 5; ++q) {
+			const unsigned idx = a + q - 1u;
+			const bool ok = idx + 1u > R.cov0 && idx < R.cov1 && idx <= b;     // (a - 1 may be R.cov0 - 1, or wrap below zero: both fail here)
+			c[q] = ok ? T.cov[idx] : make_int2(0, 0);
+			below += (unsigned)(ok && q >= 1u && idx < b && c[q].x < start);
+		}
+		const unsigned lo = a + below;
+		at = make_int2(0, 0); before = make_int2(0, 0);
+#pragma unroll
+		for (unsigned q = 0; q < 5; ++q) { if (a + q - 1u == lo) at = c[q]; if (a + q == lo) before = c[q]; }
+		has_at = lo < R.cov1; has_before = lo > R.cov0;
+	} else {
+		unsigned lo = a, hi = b;
+		while (lo < hi) { const unsigned mid = (lo + hi) >> 1; if (T.cov[mid].x < start) lo = mid + 1; else hi = mid; }
+		has_at = lo < R.cov1; has_before = lo > R.cov0;
+		at = has_at ? T.cov[lo] : make_int2(0, 0);
+		before = has_before ? T.cov[lo - 1u] : make_int2(0, 0);
+	}
+	if (has_at && at.x <= start && end <= at.y) return true;
+	if (has_before && before.x <= start && end <= before.y) return true;
 	return false;
+}
+
+// the cluster record of base p: the last one that starts at or left of p, if p is inside it -- its bucket is p's bucket
+// (what the reference's candidate window comes to for a read's first base: count/count.cpp:429-432,463)
+__device__ inline bool route_cluster(const RouteTables &T, const RouteChrom &R, const int chrom, const int p, LocProbe &P, int4 &rec) {
+	if (p >= 0x7FFFFFFF) return false;
+	loc_probe(T, R, chrom, p + 1, P);
+	const unsigned a = P.clu_a, b = P.clu_b;       // upper_bound(starts, p) = lower_bound(starts, p + 1) lies in [a, b]
+	if (b - a <= 3u) {
+		int4 c[4];                                   // records a - 1 .. a + 2: the one before the upper bound is among them
+		unsigned below = 0;
+#pragma unroll
+		for (unsigned q = 0; q < 4; ++q) {
+			const unsigned idx = a + q - 1u;
+			const bool ok = idx + 1u > R.clu0 && idx < R.clu1 && idx < b;      // (q = 0: a - 1 < b unless it wrapped, which the first test catches)
+			c[q] = ok ? T.clu[idx] : make_int4(0, 0, 0, 0);
+			below += (unsigned)(ok && q >= 1u && c[q].x <= p);
+		}
+		const unsigned ub = a + below;
+		if (ub == R.clu0) return false;
+		rec = make_int4(0, -1, 0, 0);
+#pragma unroll
+		for (unsigned q = 0; q < 4; ++q) if (a + q == ub) rec = c[q];
+		return p <= rec.y;
+	}
+	unsigned lo = a, hi = b;
+	while (lo < hi) { const unsigned mid = (lo + hi) >> 1; if (T.clu[mid].x <= p) lo = mid + 1; else hi = mid; }
+	if (lo == R.clu0) return false;
+	rec = T.clu[lo - 1u];
+	return p <= rec.y;
+}
+
+// the chromosome records into a workgroup's LDS when they are few (every workgroup of the routing kernels starts with this)
+__device__ inline const RouteChrom *route_stage_chroms(const RouteTables &T, RouteChrom *lds) {
+	if (T.n_chrom > ROUTE_CHROM_LDS) return T.chrom;
+	for (unsigned q = threadIdx.x; q < 2u * T.n_chrom; q += blockDim.x) reinterpret_cast<uint4 *>(lds)[q] = reinterpret_cast<const uint4 *>(T.chrom)[q];
+	__syncthreads();
+	return lds;
 }
 
 // interval_list::add_interval on a small sorted array (see lsq::IntervalList::add)
@@ -185,7 +235,7 @@ struct ReadAcc {
 		else { bs[0] = a0; bs[1] = a1; bs[2] = a2; be[0] = b0; be[1] = b1; be[2] = b2; n = 3; big = true; }
 	}
 	// the read is complete: its key and blocks to their place (index i of the pass)
-	__device__ inline void finish(const RouteTables &T, const RouteOut &O, const unsigned i) {
+	__device__ inline void finish(const RouteTables &T, const RouteChrom *chroms, LocProbe &P, const RouteOut &O, const unsigned i) {
 		unsigned key = ROUTE_KEY_DROPPED;
 		int4 rec = make_int4(0, 0, 0, 0);
 		if (any && n > 0) {
@@ -198,37 +248,27 @@ struct ReadAcc {
 			if (!ok || tot >= (1 << 18)) atomicMax(&O.nb_tot[2], 1ull);
 			key = route_key_unrouted((unsigned)n);
 			rec = make_int4(s0, e0, n > 1 ? s1 : 0, n > 1 ? e1 : 0);
-			// bucket of the first merged base
-			const int first = T.chrom_first_bucket[chrom];
-			if (first >= 0 && s0 < 0x7FFFFFFF) {
-				const LocProbe P = loc_probe(T, (unsigned)chrom, s0 + 1);
-				const unsigned c0 = T.cut_off[chrom], c1 = T.cut_off[chrom + 1];
-				const unsigned ub = loc_lower_bound(P, P.a.y, P.b.y, T.cut_lo, c0, c1, s0 + 1);        // upper_bound(cuts, p)
-				if (ub > c0) {
-					const unsigned b = (unsigned)first + (ub - c0 - 1u);
-					// the first base must lie in the span of some planned event (a cluster): otherwise the read is a
-					// candidate of none of them (count/count.cpp:429-432,463) -- with a shard, the other shards' reads
-					const unsigned u0 = T.clu_off[chrom], u1 = T.clu_off[chrom + 1];
-					const unsigned ul = loc_lower_bound(P, P.a.z, P.b.z, T.clu_s, u0, u1, s0 + 1);    // upper_bound(cluster starts, p)
-					const bool in_cluster = ul > u0 && s0 <= T.clu_e[ul - 1];
-					if (in_cluster && s0 <= T.buckets[b].hi) {
-						const int lo = T.buckets[b].lo;
-						unsigned pool = n == 1 ? 0u : (n == 2 ? 1u : 2u);
-						if (pool < 2u && O.compact) {
-							bool fits = lsq::compact_block_fits((long long)s0 - lo + lsq::COMPACT_BIAS, (long long)e0 - s0);
-							if (n == 2) fits = fits && lsq::compact_block_fits((long long)s1 - e0, (long long)e1 - s1);
-							if (!fits) pool = 3u;
-						}
-						key = route_key(b, pool, strand);
-						if (pool >= 2u) {
-							const unsigned long long idx = atomicAdd(&O.nb_tot[0], 1ull), boff = atomicAdd(&O.nb_tot[1], (unsigned long long)n);
-							atomicAdd(&O.cntn[b], 1u); atomicAdd(&O.cntnb[b], (unsigned)n);
-							if (idx < O.nb_cap && boff + (unsigned)n <= O.nbb_cap) {
-								O.nb_ent[idx] = make_uint4(i, b, (unsigned)n | (strand << 8), (unsigned)boff);
-								if (big) { for (int q = 0; q < n; ++q) O.nb_blk[boff + q] = make_int2(bs[q], be[q]); }
-								else { O.nb_blk[boff] = make_int2(s0, e0); if (n > 1) O.nb_blk[boff + 1] = make_int2(s1, e1); }
-							}
-						}
+			const RouteChrom R = chroms[chrom];
+			// the bucket of the first merged base, if that base lies in the span of some planned event (a cluster): otherwise the
+			// read is a candidate of none of them (count/count.cpp:429-432,463) -- with a shard, the other shards' reads
+			int4 cl;
+			if (route_cluster(T, R, chrom, s0, P, cl)) {
+				const unsigned b = (unsigned)cl.z;
+				const int lo = cl.w;
+				unsigned pool = n == 1 ? 0u : (n == 2 ? 1u : 2u);
+				if (pool < 2u && O.compact) {
+					bool fits = lsq::compact_block_fits((long long)s0 - lo + lsq::COMPACT_BIAS, (long long)e0 - s0);
+					if (n == 2) fits = fits && lsq::compact_block_fits((long long)s1 - e0, (long long)e1 - s1);
+					if (!fits) pool = 3u;
+				}
+				key = route_key(b, pool, strand);
+				if (pool >= 2u) {
+					const unsigned long long idx = atomicAdd(&O.nb_tot[0], 1ull), boff = atomicAdd(&O.nb_tot[1], (unsigned long long)n);
+					atomicAdd(&O.cntn[b], 1u); atomicAdd(&O.cntnb[b], (unsigned)n);
+					if (idx < O.nb_cap && boff + (unsigned)n <= O.nbb_cap) {
+						O.nb_ent[idx] = make_uint4(i, b, (unsigned)n | (strand << 8), (unsigned)boff);
+						if (big) { for (int q = 0; q < n; ++q) O.nb_blk[boff + q] = make_int2(bs[q], be[q]); }
+						else { O.nb_blk[boff] = make_int2(s0, e0); if (n > 1) O.nb_blk[boff + 1] = make_int2(s1, e1); }
 					}
 				}
 			}
@@ -281,7 +321,11 @@ struct IngestRaw {
 };
 
 __global__ void __launch_bounds__(256) lsq_route_raw_kernel(RouteTables T, IngestRaw R, RouteOut O) {
+	__shared__ RouteChrom chrom_lds[ROUTE_CHROM_LDS];
+	const RouteChrom *chroms = route_stage_chroms(T, chrom_lds);
 	const unsigned long long gsz = (unsigned long long)gridDim.x * blockDim.x;
+	LocProbe P;
+	P.chrom = -1; P.bin = 0;
 	for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < R.n_reads; i += gsz) {
 		const unsigned long long b0 = R.blk_off[i], b1 = R.blk_off[i + 1];
 		ReadAcc A;
@@ -290,10 +334,10 @@ __global__ void __launch_bounds__(256) lsq_route_raw_kernel(RouteTables T, Inges
 			const unsigned c = R.blk_chrom[j];
 			if (c >= T.n_chrom) continue;
 			const int bs = R.blk_start[j], be = R.blk_end[j];
-			if (!route_covered(T, c, bs, be)) continue;
+			if (!route_covered(T, chroms[c], (int)c, bs, be, P)) continue;
 			A.add(c, R.blk_strand[j], bs, be);
 		}
-		A.finish(T, O, (unsigned)i);
+		A.finish(T, chroms, P, O, (unsigned)i);
 	}
 }
 
@@ -664,11 +708,7 @@ struct Front {
 
 static RouteTables route_tables(lsq_ctx *c) {
 	RouteTables T{};
-	T.cov_off = c->cov_off.p; T.cov_s = c->cov_s.p; T.cov_e = c->cov_e.p;
-	T.cut_off = c->cut_off.p; T.cut_lo = c->cut_lo.p; T.chrom_first_bucket = c->chrom_first_bucket.p;
-	T.clu_off = c->clu_off.p; T.clu_s = c->clu_s.p; T.clu_e = c->clu_e.p;
-	T.buckets = c->buckets.p; T.n_chrom = c->n_chrom_tables;
-	T.loc = c->loc.p; T.loc_first = c->loc_first.p; T.loc_base = c->loc_base.p; T.loc_shift = c->loc_shift;
+	T.chrom = c->route_chrom.p; T.cov = c->cov.p; T.clu = c->clu.p; T.loc = c->loc.p; T.loc_shift = c->loc_shift; T.n_chrom = c->n_chrom_tables;
 	return T;
 }
 
@@ -766,7 +806,7 @@ static int ingest_device(lsq_ctx *c, int method, Front &F) {
 		HIP_TRY(hipMemcpyAsync(&sums[4], mr.pnb_off.p + B, 8, hipMemcpyDeviceToHost, st));
 		HIP_TRY(hipStreamSynchronize(st));
 		SW.mark("ingest: route + partition counts");
-		if (F.settle && (rc = F.settle(st))) return rc;
+		if (F.settle && (rc = F.settle(st))) { if (rc == LSQ_RETRY) continue; return rc; }
 		// compact records pay when nearly every one- and two-block read fits them (the others are counted a lane a read, tables
 		// in L2); a read set of long blocks -- more than 1 in 16 does not fit -- is routed again for wide records.  So is one
 		// whose many-block reads did not fit the list (a file of long spliced reads), with a list of the size it asked for.
@@ -977,19 +1017,61 @@ static int ingest_text(lsq_ctx *c, int method, const char *read_format, lsq_text
 	F.n = n_lines; F.line_no = nullptr; F.first_line = first_line; F.in_bytes = T.len;
 	const unsigned n_tiles = (unsigned)((T.len + MRF_TILE - 1) / MRF_TILE);
 	const MrfText X{T.d_text.p, T.len, T.d_tile_base.p, has_header, first_line, n_lines};
-	DevBuf<MrfLongLine> d_long;           // lines that began far ahead of their tiles: at most one a tile
-	DevBuf<unsigned> d_n_long;
-	if ((rc = d_long.alloc(n_tiles)) || (rc = d_n_long.alloc(1))) return rc;
+	// what the fast kernel hands on: tiles with more delimiters than its tables hold, lines of another shape than a read's
+	// (at most one a tile begins ahead of its window; the rest is whatever the file holds -- when the list runs over, the
+	// whole file goes through the kernel that walks bytes)
+	unsigned long long list_cap = 1ull << 22;
+	if (const char *e = getenv("LSQ_MRF_LINE_LIST")) { const long long v = atoll(e); if (v >= 0) list_cap = (unsigned long long)v; }      // tests: the run-over path on a small file
+	const unsigned line_cap = (unsigned)std::min<unsigned long long>(n_lines, list_cap) + n_tiles + 1u;
+	DevBuf<MrfLongLine> d_lines;
+	DevBuf<unsigned> d_tiles, d_counts;
+	DevBuf<unsigned long long> d_ckey;
+	DevBuf<unsigned short> d_cid;
+	if ((rc = d_lines.alloc(line_cap)) || (rc = d_tiles.alloc(n_tiles)) || (rc = d_counts.alloc(4))) return rc;
+	HIP_TRY(hipMemsetAsync(d_counts.p, 0, 16, st));          // (a file without lines launches nothing; the verdict below still reads these)
+	MrfHandOff H{d_counts.p, d_tiles.p, n_tiles, d_lines.p, line_cap};
+	// the chromosomes' names as 64-bit keys (names of at most seven bytes; a longer one has no slot and its lines go to the list)
+	MrfFastDict FD{};
+	{
+		const lsq_events &E = *c->E;
+		const size_t nc = E.covered.size();
+		std::vector<unsigned long long> ck(FP_DICT, 0);
+		std::vector<unsigned short> ci(FP_DICT, 0);
+		bool usable = nc <= ROUTE_CHROM_LDS && getenv("LSQ_MRF_SLOW") == nullptr;       // (LSQ_MRF_SLOW: the tests run the byte-walking kernel over whole files with it)
+		for (size_t id = 0; usable && id < nc; ++id) {
+			const std::string &nm = E.chroms.names[id];
+			if (nm.empty() || nm.size() > 7) continue;
+			const unsigned long long key = mrf_strand_key(nm.data(), nm.size());
+			unsigned sl = mrf_key_slot(key);
+			while (ck[sl] != 0) sl = (sl + 1u) & (FP_DICT - 1u);
+			ck[sl] = key; ci[sl] = (unsigned short)id;
+		}
+		if ((rc = d_ckey.upload(ck.data(), FP_DICT, st)) || (rc = d_cid.upload(ci.data(), FP_DICT, st))) return rc;
+		HIP_TRY(hipStreamSynchronize(st));
+		FD.ckey = d_ckey.p; FD.cid = d_cid.p; FD.usable = usable ? 1u : 0u;
+	}
+	bool all_slow = !FD.usable;
+	const unsigned side_grid = std::min(std::max(n_tiles, 1u), 4u * (unsigned)c->n_cu);
 	F.launch = [&](const RouteTables &RT, const RouteOut &O, hipStream_t s) -> int {
 		int r2 = DD.reset_errors(s);
 		if (r2) return r2;
-		HIP_TRY(hipMemsetAsync(d_n_long.p, 0, 4, s));
-		hipLaunchKernelGGL(lsq_mrf_route_kernel, dim3(n_tiles), dim3(256), 0, s, X, DD.D, RT, O, DD.d_err.p, d_long.p, d_n_long.p);
-		hipLaunchKernelGGL(lsq_mrf_route_long_kernel, dim3(std::min(n_tiles / 256u + 1u, 1024u)), dim3(256), 0, s, X, DD.D, RT, O, DD.d_err.p, (const MrfLongLine *)d_long.p, (const unsigned *)d_n_long.p);
+		HIP_TRY(hipMemsetAsync(d_counts.p, 0, 16, s));
+		if (!all_slow) {
+			hipLaunchKernelGGL(lsq_mrf_route_fast_kernel, dim3(n_tiles), dim3(256), 0, s, X, DD.D, FD, RT, O, DD.d_err.p, H);
+			hipLaunchKernelGGL(lsq_mrf_route_kernel, dim3(std::min(side_grid, 256u)), dim3(256), 0, s, X, DD.D, RT, O, DD.d_err.p, H, n_tiles, 1u);
+		} else hipLaunchKernelGGL(lsq_mrf_route_kernel, dim3(n_tiles), dim3(256), 0, s, X, DD.D, RT, O, DD.d_err.p, H, n_tiles, 0u);
+		hipLaunchKernelGGL(lsq_mrf_route_lines_kernel, dim3(std::min(line_cap / 256u + 1u, 1024u)), dim3(256), 0, s, X, DD.D, RT, O, DD.d_err.p, H);
 		HIP_TRY(hipGetLastError());
 		return LSQ_OK;
 	};
-	F.settle = [&](hipStream_t s) -> int { return DD.settle(c, T, has_header, first_line, s); };
+	F.settle = [&](hipStream_t s) -> int {
+		// the line list ran over (a file of lines of another shape than a read's): once more, every tile through the byte-walking kernel
+		unsigned counts[4] = {0, 0, 0, 0};
+		HIP_TRY(hipMemcpy(counts, d_counts.p, 16, hipMemcpyDeviceToHost));
+		if (counts[2] && !all_slow) { all_slow = true; return LSQ_RETRY; }
+		if (counts[2]) return fail(LSQ_E_INTERNAL, "the device parser's line list ran over");
+		return DD.settle(c, T, has_header, first_line, s);
+	};
 	c->reads[method].named = false;
 	rc = ingest_device(c, method, F);
 	if (rc) return rc;

@@ -20,7 +20,8 @@
 //     atomicCAS (strings of at most 7 bytes; longer ones give LSQ_E_UNSUPPORTED -- use lsq_mrf_parse)
 #pragma once
 
-constexpr unsigned MRF_TILE = 8192;                 // text bytes per workgroup: 256 lanes x 2 x 16
+constexpr unsigned MRF_TILE = 7680;                 // text bytes per workgroup (480 words of 16: with the 512 bytes ahead, a window of 8 KiB)
+constexpr unsigned MRF_TILE_Q = (MRF_TILE + 4095) / 4096;      // 16-byte words a lane of 256 takes
 constexpr unsigned MRF_LB = 512;                    // bytes ahead of the tile that are staged with it
 constexpr unsigned MRF_NLCAP = 1024;                // newline positions held at a time (a tile of shorter lines takes several rounds)
 constexpr unsigned long long MRF_NO_ERR = ~0ull;
@@ -52,6 +53,7 @@ struct MrfTileLds {
 	unsigned long long strand[256];
 	unsigned d_hash[MRF_DICT_LDS_SLOTS], d_id[MRF_DICT_LDS_SLOTS], d_off[MRF_DICT_LDS_SLOTS / 4 + 1];
 	char d_names[MRF_DICT_LDS_NAMES];
+	__align__(16) RouteChrom chrom[ROUTE_CHROM_LDS];      // the routing pass's chromosome records (lsq_mrf_route_kernel)
 };
 
 __device__ inline unsigned mrf_wave_incl_scan(unsigned v) {
@@ -96,9 +98,10 @@ __global__ void __launch_bounds__(256) lsq_mrf_newline_count_kernel(const unsign
 	const unsigned long long t0 = (unsigned long long)blockIdx.x * MRF_TILE;
 	unsigned n = 0;
 #pragma unroll
-	for (unsigned q = 0; q < MRF_TILE / 4096; ++q) {
-		unsigned valid;
-		const uint4 v = mrf_load16(text, len, t0 + q * 4096ull + threadIdx.x * 16ull, valid);
+	for (unsigned q = 0; q < MRF_TILE_Q; ++q) {
+		unsigned valid = 0;
+		const unsigned off = q * 4096u + threadIdx.x * 16u;
+		const uint4 v = off < MRF_TILE ? mrf_load16(text, len, t0 + off, valid) : make_uint4(0, 0, 0, 0);
 		n += (unsigned)__popc(mrf_newline_bits16(v, valid));
 	}
 	unsigned total;
@@ -113,24 +116,25 @@ __global__ void __launch_bounds__(256) lsq_mrf_newline_count_kernel(const unsign
 struct MrfLongLine { unsigned long long i, start, n; };
 
 template <bool DEFER, class Fn>
-__device__ inline void mrf_tile_lines(MrfTileLds &S, const unsigned char *text, const unsigned long long len, const unsigned long long *tile_base,
-                                      const unsigned has_header, MrfLongLine *long_lines, unsigned *n_long, Fn &&fn) {
+__device__ inline void mrf_tile_lines(MrfTileLds &S, const unsigned tile, const unsigned char *text, const unsigned long long len, const unsigned long long *tile_base,
+                                      const unsigned has_header, MrfLongLine *long_lines, unsigned *n_long, const unsigned long_cap, unsigned *long_over, Fn &&fn) {
 	const unsigned tid = threadIdx.x;
-	const unsigned long long t0 = (unsigned long long)blockIdx.x * MRF_TILE;
-	unsigned bits[MRF_TILE / 4096];
+	const unsigned long long t0 = (unsigned long long)tile * MRF_TILE;
+	unsigned bits[MRF_TILE_Q];
 #pragma unroll
-	for (unsigned q = 0; q < MRF_TILE / 4096; ++q) {
-		unsigned valid;
-		const uint4 v = mrf_load16(text, len, t0 + q * 4096ull + tid * 16ull, valid);
-		*reinterpret_cast<uint4 *>(&S.text[MRF_LB + q * 4096u + tid * 16u]) = v;
+	for (unsigned q = 0; q < MRF_TILE_Q; ++q) {
+		unsigned valid = 0;
+		const unsigned off = q * 4096u + tid * 16u;
+		const uint4 v = off < MRF_TILE ? mrf_load16(text, len, t0 + off, valid) : make_uint4(0, 0, 0, 0);
+		if (off < MRF_TILE) *reinterpret_cast<uint4 *>(&S.text[MRF_LB + off]) = v;
 		bits[q] = mrf_newline_bits16(v, valid);
 	}
 	if (tid < MRF_LB / 16u && t0 >= MRF_LB)
 		*reinterpret_cast<uint4 *>(&S.text[tid * 16u]) = *reinterpret_cast<const uint4 *>(text + (t0 - MRF_LB) + tid * 16ull);
 	// ordinals of the newlines: the lanes' first words cover bytes 0..4095 of the tile, their second words the rest
-	unsigned ord[MRF_TILE / 4096], nt = 0;
+	unsigned ord[MRF_TILE_Q], nt = 0;
 #pragma unroll
-	for (unsigned q = 0; q < MRF_TILE / 4096; ++q) {
+	for (unsigned q = 0; q < MRF_TILE_Q; ++q) {
 		unsigned total;
 		ord[q] = nt + mrf_block_excl_scan((unsigned)__popc(bits[q]), S.scan4, total);
 		nt += total;
@@ -150,11 +154,11 @@ __device__ inline void mrf_tile_lines(MrfTileLds &S, const unsigned char *text, 
 		}
 		if (tid == 0) S.first_start = found + 1;
 	}
-	const unsigned long long g0 = tile_base[blockIdx.x];
+	const unsigned long long g0 = tile_base[tile];
 	const mrf_lds_cptr lds_text = (mrf_lds_cptr)(const char *)S.text;
 	for (unsigned rb = 0; rb < nt; rb += MRF_NLCAP) {
 #pragma unroll
-		for (unsigned q = 0; q < MRF_TILE / 4096; ++q) {
+		for (unsigned q = 0; q < MRF_TILE_Q; ++q) {
 			unsigned b = bits[q], o = ord[q];
 			while (b) {
 				const unsigned j = (unsigned)__ffs((int)b) - 1u; b &= b - 1u;
@@ -174,7 +178,10 @@ __device__ inline void mrf_tile_lines(MrfTileLds &S, const unsigned char *text, 
 			else start_rel = (long long)S.carry + 1;
 			const unsigned long long i = g - has_header;
 			if (start_rel >= -(long long)MRF_LB) fn(i, MrfLdsView{lds_text + (MRF_LB + (int)start_rel), (unsigned)(end_rel - (int)start_rel)});
-			else if constexpr (DEFER) long_lines[atomicAdd(n_long, 1u)] = MrfLongLine{i, (unsigned long long)((long long)t0 + start_rel), (unsigned long long)((long long)end_rel - start_rel)};
+			else if constexpr (DEFER) {
+				const unsigned at = atomicAdd(n_long, 1u);
+				if (at < long_cap) long_lines[at] = MrfLongLine{i, (unsigned long long)((long long)t0 + start_rel), (unsigned long long)((long long)end_rel - start_rel)}; else *long_over = 1u;
+			}
 			else fn(i, lsq::MrfView{reinterpret_cast<const char *>(text) + (t0 + start_rel), (size_t)((long long)end_rel - start_rel)});
 		}
 		__syncthreads();
@@ -263,45 +270,280 @@ struct MrfText {
 };
 
 // ---- the parse that feeds the load-time filter (the product path): per line, every block through the covered regions and
-// the merge as it is split off; the routed read to key[i] / rec[i], i the data line's index
+// the merge as it is split off; the routed read to key[i] / rec[i], i the data line's index.  Three kernels:
+//   lsq_mrf_route_fast_kernel   every tile; settles the lines of the usual shape (below) and lists the others
+//   lsq_mrf_route_kernel        the tiles the fast kernel could not table (more delimiters than its LDS tables hold), or every
+//                               tile when the fast kernel does not apply: the shared splitter over LDS bytes, a lane a line
+//   lsq_mrf_route_lines_kernel  the listed lines, a lane a line, the shared splitter over the bytes in HBM
 template <class V>
-__device__ inline void mrf_route_line(const MrfText &X, const MrfDict &D, const unsigned long long *lds_strand, const RouteTables &T, const RouteOut &O,
+__device__ inline void mrf_route_line(const MrfText &X, const MrfDict &D, const unsigned long long *lds_strand, const RouteTables &T, const RouteChrom *chroms, const RouteOut &O,
                                       unsigned long long *err, const unsigned long long i, const V line) {
 	const long long LIM = 1ll << 30;
 	if (lsq::mrf_line_is_skipped(line)) { O.key[i] = ROUTE_KEY_DROPPED; return; }
 	ReadAcc A;
 	A.init();
+	LocProbe P;
+	P.chrom = -1; P.bin = 0;
 	const bool ok = lsq::mrf_split_line(line, [&](const V chr, const V strand, const int64_t start, const int64_t end) {
 		const unsigned cid = mrf_chrom_lookup(D, chr);
 		const long long s0 = start - 1, e0 = end;
 		if (cid >= T.n_chrom || s0 <= -LIM || e0 >= LIM || s0 >= LIM || e0 <= -LIM) return;
-		if (!route_covered(T, cid, (int)s0, (int)e0)) return;
+		if (!route_covered(T, chroms[cid], (int)cid, (int)s0, (int)e0, P)) return;
 		A.add(cid, mrf_strand_slot(lds_strand, D.strand_tab, strand, err), (int)s0, (int)e0);
 	});
 	if (!ok) { atomicMin(&err[0], X.first_line + i); O.key[i] = ROUTE_KEY_DROPPED; return; }
-	A.finish(T, O, (unsigned)i);
+	A.finish(T, chroms, P, O, (unsigned)i);
 }
 
-__global__ void __launch_bounds__(256) lsq_mrf_route_kernel(MrfText X, MrfDict G, RouteTables T, RouteOut O, unsigned long long *err, MrfLongLine *long_lines, unsigned *n_long) {
+// lists of work the fast kernel hands on: counts[0] tiles, counts[1] lines, counts[2] set when the line list ran over
+struct MrfHandOff {
+	unsigned *counts;
+	unsigned *tiles; unsigned tile_cap;
+	MrfLongLine *lines; unsigned line_cap;
+};
+
+__global__ void __launch_bounds__(256) lsq_mrf_route_kernel(MrfText X, MrfDict G, RouteTables T, RouteOut O, unsigned long long *err, MrfHandOff H, unsigned n_tiles, unsigned listed) {
 	__shared__ MrfTileLds S;
 	const MrfDict D = mrf_stage_dict(S, G);
-	mrf_tile_lines<true>(S, X.text, X.len, X.tile_base, X.has_header, long_lines, n_long, [&](const unsigned long long i, const MrfLdsView line) {
-		mrf_route_line(X, D, S.strand, T, O, err, i, line);
-	});
+	const RouteChrom *chroms = route_stage_chroms(T, S.chrom);
+	const unsigned n = listed ? min(H.counts[0], H.tile_cap) : n_tiles;
+	for (unsigned t = blockIdx.x; t < n; t += gridDim.x) {
+		const unsigned tile = listed ? H.tiles[t] : t;
+		mrf_tile_lines<true>(S, tile, X.text, X.len, X.tile_base, X.has_header, H.lines, H.counts + 1, H.line_cap, H.counts + 2, [&](const unsigned long long i, const MrfLdsView line) {
+			mrf_route_line(X, D, S.strand, T, chroms, O, err, i, line);
+		});
+		__syncthreads();
+	}
 }
-// the lines that began far ahead of their tiles (none in a file of reads), one lane each, straight from HBM
-__global__ void __launch_bounds__(256) lsq_mrf_route_long_kernel(MrfText X, MrfDict G, RouteTables T, RouteOut O, unsigned long long *err, const MrfLongLine *long_lines, const unsigned *n_long) {
-	const unsigned n = *n_long;
+// listed lines, one lane each, straight from HBM.  A line listed without its start (n = ~0: it began ahead of a tile's
+// window) is walked back to the newline before it first.
+__global__ void __launch_bounds__(256) lsq_mrf_route_lines_kernel(MrfText X, MrfDict G, RouteTables T, RouteOut O, unsigned long long *err, MrfHandOff H) {
+	const unsigned n = min(H.counts[1], H.line_cap);
 	for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
-		const MrfLongLine L = long_lines[t];
-		mrf_route_line(X, G, nullptr, T, O, err, L.i, lsq::MrfView{reinterpret_cast<const char *>(X.text) + L.start, (size_t)L.n});
+		MrfLongLine L = H.lines[t];
+		if (L.n == ~0ull) {
+			// L.start: the line's newline
+			unsigned long long a = L.start;
+			while (a > 0 && X.text[a - 1] != '\n') --a;
+			L.n = L.start - a; L.start = a;
+		}
+		mrf_route_line(X, G, nullptr, T, T.chrom, O, err, L.i, lsq::MrfView{reinterpret_cast<const char *>(X.text) + L.start, (size_t)L.n});
+	}
+}
+
+// ---- the fast kernel.  A workgroup takes a window of 8 KiB of text -- a tile of 7 680 bytes and the 512 ahead of it -- 32
+// bytes a lane, in registers: three exact zero-byte tests (word ^ 0x0A.., ^ 0x3A.., ^ 0x2C..) give every lane the newlines,
+// colons and commas among its bytes as bit masks; one prefix sum over the lanes' counts numbers them; the lanes write the
+// window's delimiters, in text order, into an LDS table (position | kind) and, per newline, the index of its entry.  Then one
+// lane per line that ends in the tile walks its entries instead of its bytes.  A block whose next four delimiters are colons
+// is exactly what the reference's find / substr walk (count/count.cpp:297-326) takes it for: chr = [block start, colon 1),
+// strand, start, end = the stretches between the colons, the next block behind the first comma after colon 4 (colons in
+// between -- the query fields -- are passed over).  The two coordinates are at most nine decimal digits (what
+// lexical_cast<long> takes without a sign, and no overflow possible): eight bytes that END at the delimiter, bytes ahead of
+// the field replaced by '0', summed pairwise (1 x 10 + 1, 2 x 100 + 2, 4 x 10000 + 4 digits) -- and a ninth digit.  The
+// chromosome (at most seven bytes) is looked up by its bytes as one 64-bit key in an LDS table, the strand likewise.
+// Whatever does not fit this shape -- fewer than four colons before the next comma or the line's end, a sign or a stray
+// byte in a coordinate, ten digits, a chromosome or strand of eight bytes or more, a line that starts ahead of the window
+// -- is not decided here: the line goes on a list and lsq_mrf_route_lines_kernel runs the shared splitter on it.
+constexpr unsigned FP_WIN = MRF_LB + MRF_TILE;          // 8 192
+constexpr unsigned FP_PAD = 16;                          // bytes of LDS ahead of the window (a coordinate's eight bytes may begin there)
+constexpr unsigned FP_DCAP = 3072, FP_NCAP = 1024;       // delimiters / newlines a window may hold (a tile of reads: ~1 500 / ~220)
+constexpr unsigned FP_KIND_SHIFT = 13;                   // entry: position in the window | kind << 13 (0 colon, 1 comma, 2 newline)
+constexpr unsigned FP_DICT = 256;
+
+struct MrfFastDict {
+	const unsigned long long *ckey;       // FP_DICT slots: the chromosome's bytes as a key (mrf_strand_key), 0 = empty
+	const unsigned short *cid;
+	unsigned usable;                       // every chromosome name has a slot (names of eight bytes and more have none: their lines go to the list)
+};
+__host__ __device__ inline unsigned mrf_key_slot(unsigned long long k) {
+	unsigned x = (unsigned)k ^ (unsigned)(k >> 32);
+	x ^= x >> 16; x ^= x >> 8;
+	return x & (FP_DICT - 1u);
+}
+
+struct MrfFastLds {
+	__align__(16) unsigned char text[FP_PAD + FP_WIN + 16];
+	__align__(8) unsigned short delim[FP_DCAP + 8];
+	unsigned short nl_dord[FP_NCAP];
+	unsigned scan4[4];
+	unsigned nl_ahead;                      // newlines in the 512 bytes ahead of the tile
+	__align__(8) unsigned long long strand[256];
+	unsigned long long ckey[FP_DICT];
+	unsigned short cid[FP_DICT];
+	__align__(16) RouteChrom chrom[ROUTE_CHROM_LDS];
+};
+
+// 0x80 in every byte of w that equals c
+__device__ inline unsigned fp_eq_bytes(const unsigned w, const unsigned c4) {
+	const unsigned x = w ^ c4;
+	return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+}
+__device__ inline unsigned fp_pack4(const unsigned z) { return ((z >> 7) & 1u) | ((z >> 14) & 2u) | ((z >> 21) & 4u) | ((z >> 28) & 8u); }
+
+// the decimal number in the eight bytes of `w` (first byte lowest), the last `len` of them digits (1 <= len <= 8): bytes ahead of the
+// field count as '0'.  false when a byte of the field is no digit.
+__device__ inline bool fp_number8(const unsigned long long w, const unsigned len, unsigned &out) {
+	unsigned lo = (unsigned)w, hi = (unsigned)(w >> 32);                     // lo: the four bytes ahead, hi: the last four
+	const unsigned keep_hi = len >= 4u ? 0xFFFFFFFFu : 0xFFFFFFFFu << (8u * (4u - len));
+	const unsigned keep_lo = len >= 8u ? 0xFFFFFFFFu : (len > 4u ? 0xFFFFFFFFu << (8u * (8u - len)) : 0u);
+	hi = (hi & keep_hi) | (0x30303030u & ~keep_hi);
+	lo = (lo & keep_lo) | (0x30303030u & ~keep_lo);
+	// every byte of the eight in '0'..'9': on the low seven bits of each byte, + 0x46 must not reach the top bit (<= '9') and + 0x50 must (>= '0')
+	const unsigned lo7 = lo & 0x7F7F7F7Fu, hi7 = hi & 0x7F7F7F7Fu;
+	const bool digits = ((lo | hi) & 0x80808080u) == 0u && (((lo7 + 0x46464646u) | (hi7 + 0x46464646u)) & 0x80808080u) == 0u &&
+	                    (((lo7 + 0x50505050u) & (hi7 + 0x50505050u)) & 0x80808080u) == 0x80808080u;
+	unsigned a = lo - 0x30303030u, b = hi - 0x30303030u;       // (no borrow between bytes when they are digits; otherwise the result is not used)
+	// first byte = most significant digit: pairs, then fours
+	a = (a * 10u + (a >> 8)) & 0x00FF00FFu; b = (b * 10u + (b >> 8)) & 0x00FF00FFu;
+	a = (__umul24(a & 0xFFFFu, 100u) + (a >> 16)); b = (__umul24(b & 0xFFFFu, 100u) + (b >> 16));
+	out = __umul24(a, 10000u) + b;
+	return digits;
+}
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) lsq_mrf_route_fast_kernel(MrfText X, MrfDict G, MrfFastDict FD, RouteTables T, RouteOut O, unsigned long long *err, MrfHandOff H) {
+	__shared__ MrfFastLds S;
+	const unsigned tid = threadIdx.x;
+	const unsigned long long t0 = (unsigned long long)blockIdx.x * MRF_TILE;
+	// ---- the dictionaries
+	S.strand[tid] = __hip_atomic_load(&G.strand_tab[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	S.ckey[tid] = FD.ckey[tid]; S.cid[tid] = FD.cid[tid];
+	for (unsigned q = tid; q < 2u * T.n_chrom; q += 256u) reinterpret_cast<uint4 *>(S.chrom)[q] = reinterpret_cast<const uint4 *>(T.chrom)[q];
+	// ---- the window: 32 bytes a lane, in text order (window byte 32 x lane); bytes ahead of the text or behind it count as none
+	unsigned w[8];
+	unsigned valid = 0;                       // bytes of the lane's 32 that are text
+	{
+		const long long at = (long long)t0 - (long long)MRF_LB + 32ll * tid;
+		uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
+		if (at >= 0 && (unsigned long long)at < X.len) {
+			v0 = *reinterpret_cast<const uint4 *>(X.text + at);
+			if ((unsigned long long)at + 16u < X.len) v1 = *reinterpret_cast<const uint4 *>(X.text + at + 16);
+			valid = (unsigned)min(32ull, X.len - (unsigned long long)at);
+		}
+		*reinterpret_cast<uint4 *>(&S.text[FP_PAD + 32u * tid]) = v0;
+		*reinterpret_cast<uint4 *>(&S.text[FP_PAD + 32u * tid + 16u]) = v1;
+		w[0] = v0.x; w[1] = v0.y; w[2] = v0.z; w[3] = v0.w; w[4] = v1.x; w[5] = v1.y; w[6] = v1.z; w[7] = v1.w;
+	}
+	unsigned m_nl = 0, m_colon = 0, m_comma = 0;
+#pragma unroll
+	for (int q = 0; q < 8; ++q) {
+		m_nl |= fp_pack4(fp_eq_bytes(w[q], 0x0A0A0A0Au)) << (4 * q);
+		m_colon |= fp_pack4(fp_eq_bytes(w[q], 0x3A3A3A3Au)) << (4 * q);
+		m_comma |= fp_pack4(fp_eq_bytes(w[q], 0x2C2C2C2Cu)) << (4 * q);
+	}
+	const unsigned live = valid >= 32u ? 0xFFFFFFFFu : ((1u << valid) - 1u);
+	m_nl &= live; m_colon &= live; m_comma &= live;
+	const unsigned m_any = m_nl | m_colon | m_comma;
+	unsigned total;
+	const unsigned ex = mrf_block_excl_scan(((unsigned)__popc(m_any) << 16) | (unsigned)__popc(m_nl), S.scan4, total);
+	const unsigned n_delim = total >> 16, n_nl = total & 0xFFFFu;
+	if (tid == MRF_LB / 32u) S.nl_ahead = ex & 0xFFFFu;          // (the first lane of the tile proper: what lies ahead of it is the 512 bytes)
+	if (n_delim > FP_DCAP || n_nl > FP_NCAP) {
+		// more delimiters than the tables hold: the tile goes to the kernel that walks bytes
+		if (tid == 0) { const unsigned at = atomicAdd(&H.counts[0], 1u); if (at < H.tile_cap) H.tiles[at] = blockIdx.x; }
+		return;
+	}
+	{
+		unsigned b = m_any, od = ex >> 16, on = ex & 0xFFFFu;
+		while (b) {
+			const unsigned j = (unsigned)__ffs((int)b) - 1u; b &= b - 1u;
+			const unsigned kind = ((m_nl >> j) & 1u) * 2u + ((m_comma >> j) & 1u);
+			S.delim[od] = (unsigned short)((32u * tid + j) | (kind << FP_KIND_SHIFT));
+			if (kind == 2u) S.nl_dord[on++] = (unsigned short)od;
+			++od;
+		}
+	}
+	__syncthreads();
+	const unsigned nl_ahead = S.nl_ahead;
+	if (n_nl == nl_ahead) return;                 // no line ends in the tile
+	const unsigned long long g0 = X.tile_base[blockIdx.x];
+	const mrf_lds_cptr text = (mrf_lds_cptr)(const char *)S.text + FP_PAD;      // window byte 0
+	const unsigned POS = (1u << FP_KIND_SHIFT) - 1u;
+	auto defer = [&](const unsigned long long i, const unsigned long long start, const unsigned long long n) {
+		const unsigned at = atomicAdd(&H.counts[1], 1u);
+		if (at < H.line_cap) H.lines[at] = MrfLongLine{i, start, n}; else H.counts[2] = 1u;
+	};
+	for (unsigned m = nl_ahead + tid; m < n_nl; m += 256u) {
+		const unsigned long long g = g0 + (m - nl_ahead);        // the newline's ordinal in the text = the 0-based number of the line it ends
+		if (X.has_header && g == 0) continue;
+		const unsigned long long i = g - X.has_header;
+		const unsigned dE = S.nl_dord[m];
+		const unsigned eol = S.delim[dE] & POS;
+		const unsigned long long w0 = t0 - MRF_LB;                 // (window byte 0 in the text; wraps below zero for tile 0, whose window bytes < 512 hold nothing)
+		unsigned dS, start;
+		if (m == 0) {
+			if (t0 != 0) { defer(i, w0 + eol, ~0ull); continue; }  // began ahead of the window
+			dS = 0; start = MRF_LB;
+		} else { const unsigned dp = S.nl_dord[m - 1]; dS = dp + 1u; start = (S.delim[dp] & POS) + 1u; }
+		bool odd = false, dropped = false;
+		if (eol > start && text[start] == '#') dropped = true;       // a comment line takes a line number only (count.cpp:288)
+		ReadAcc A;
+		A.init();
+		LocProbe P;
+		P.chrom = -1; P.bin = 0;
+		unsigned cpos = start, d = dS;
+		while (!dropped) {
+			// the block's four colons
+			unsigned long long e4;
+			__builtin_memcpy(&e4, &S.delim[d], 8);
+			// (or three and the line's end: a block without query fields, whose end field runs to the end of the line -- count.cpp:313-316 with
+			// find() == npos -- and after which nothing follows)
+			const bool to_eol = (e4 & 0xE000600060006000ull) == 0x4000000000000000ull;
+			if ((e4 & 0x6000600060006000ull) != 0ull && !to_eol) { odd = true; break; }
+			const unsigned p1 = (unsigned)e4 & POS, p2 = (unsigned)(e4 >> 16) & POS, p3 = (unsigned)(e4 >> 32) & POS, p4 = (unsigned)(e4 >> 48) & POS;
+			const unsigned l_chr = p1 - cpos, l_str = p2 - p1 - 1u, l_s = p3 - p2 - 1u, l_e = p4 - p3 - 1u;
+			if (l_chr > 7u || l_str > 7u || l_s - 1u > 8u || l_e - 1u > 8u) { odd = true; break; }
+			// the coordinates: the eight bytes that end at the delimiter, and the byte ahead of them
+			unsigned long long ws, we, wc, wt;
+			__builtin_memcpy(&ws, &S.text[FP_PAD + p3 - 8u], 8);
+			__builtin_memcpy(&we, &S.text[FP_PAD + p4 - 8u], 8);
+			__builtin_memcpy(&wc, &S.text[FP_PAD + cpos], 8);
+			__builtin_memcpy(&wt, &S.text[FP_PAD + p1 + 1u], 8);
+			const unsigned s9 = (unsigned)(unsigned char)text[(int)p3 - 9] - (unsigned)'0', e9 = (unsigned)(unsigned char)text[(int)p4 - 9] - (unsigned)'0';
+			unsigned vs, ve;
+			const bool good_s = fp_number8(ws, min(l_s, 8u), vs), good_e = fp_number8(we, min(l_e, 8u), ve);
+			bool good = good_s && good_e;
+			if (l_s == 9u) { good = good && s9 <= 9u; vs += s9 * 100000000u; }
+			if (l_e == 9u) { good = good && e9 <= 9u; ve += e9 * 100000000u; }
+			if (!good) { odd = true; break; }
+			// the next block, if any: behind the first comma after colon 4
+			unsigned dn = d + 4u, kind = 2u;
+			if (!to_eol) while ((kind = S.delim[dn] >> FP_KIND_SHIFT) == 0u) ++dn;
+			// chromosome, containment, strand, merge
+			if (l_chr != 0u) {
+				const unsigned long long mask = l_chr >= 8u ? ~0ull : ((1ull << (8u * l_chr)) - 1ull);
+				const unsigned long long kb = wc & mask;
+				const unsigned long long key = ((unsigned long long)__builtin_bswap32((unsigned)kb) << 32) | (unsigned long long)__builtin_bswap32((unsigned)(kb >> 32)) | (unsigned long long)l_chr;
+				unsigned cid = MRF_NOCHROM;
+				for (unsigned sl = mrf_key_slot(key);; sl = (sl + 1u) & (FP_DICT - 1u)) {
+					const unsigned long long k = S.ckey[sl];
+					if (k == key) { cid = S.cid[sl]; break; }
+					if (k == 0ull) break;
+				}
+				const int s0 = (int)vs - 1, e0 = (int)ve;
+				if (cid < T.n_chrom && route_covered(T, S.chrom[cid], (int)cid, s0, e0, P)) {
+					const unsigned long long tmask = l_str >= 8u ? ~0ull : ((1ull << (8u * l_str)) - 1ull);
+					const unsigned long long tb = wt & tmask;
+					const unsigned long long tkey = ((unsigned long long)__builtin_bswap32((unsigned)tb) << 32) | (unsigned long long)__builtin_bswap32((unsigned)(tb >> 32)) | (unsigned long long)l_str;
+					unsigned sid = 256u;
+					for (unsigned q = 0; q < 256u; ++q) { const unsigned long long cur = S.strand[q]; if (cur == tkey) { sid = q; break; } if (cur == STRAND_EMPTY) break; }
+					if (sid == 256u) sid = mrf_strand_slot(nullptr, G.strand_tab, MrfLdsView{text + (p1 + 1u), l_str}, err);
+					A.add(cid, sid, s0, e0);
+				}
+			}
+			if (kind != 1u) break;                       // the line's end
+			cpos = (S.delim[dn] & POS) + 1u; d = dn + 1u;
+		}
+		if (odd) { defer(i, w0 + start, eol - start); continue; }
+		if (dropped) { O.key[i] = ROUTE_KEY_DROPPED; continue; }
+		A.finish(T, S.chrom, P, O, (unsigned)i);
 	}
 }
 
 // ---- the same walk for lsq_mrf_parse_device: pass 1, blocks per data line (0 for skipped lines), first failing line
 __global__ void __launch_bounds__(256) lsq_mrf_count_kernel(MrfText X, unsigned *line_nb, unsigned long long *err) {
 	__shared__ MrfTileLds S;
-	mrf_tile_lines<false>(S, X.text, X.len, X.tile_base, X.has_header, nullptr, nullptr, [&](const unsigned long long i, auto line) {
+	mrf_tile_lines<false>(S, blockIdx.x, X.text, X.len, X.tile_base, X.has_header, nullptr, nullptr, 0u, nullptr, [&](const unsigned long long i, auto line) {
 		unsigned nb = 0;
 		if (!lsq::mrf_line_is_skipped(line)) {
 			const bool ok = lsq::mrf_split_line(line, [&](auto, auto, int64_t, int64_t) { ++nb; });
@@ -325,7 +567,7 @@ __global__ void __launch_bounds__(256) lsq_mrf_write_kernel(MrfText X, const uns
 	__shared__ MrfTileLds S;
 	const MrfDict D = mrf_stage_dict(S, G);
 	const long long LIM = 1ll << 30;
-	mrf_tile_lines<false>(S, X.text, X.len, X.tile_base, X.has_header, nullptr, nullptr, [&](const unsigned long long i, auto line) {
+	mrf_tile_lines<false>(S, blockIdx.x, X.text, X.len, X.tile_base, X.has_header, nullptr, nullptr, 0u, nullptr, [&](const unsigned long long i, auto line) {
 		const unsigned nb = line_nb[i];
 		const unsigned long long r = rd_idx[i], o = bk_off[i];
 		if (i + 1 == X.n_lines) O.blk_off[r + (nb ? 1u : 0u)] = o + nb;

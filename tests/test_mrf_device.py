@@ -190,3 +190,128 @@ def test_two_million_lines_tile_boundaries_and_results(tmp_path, monkeypatch):
     monkeypatch.delenv("LSQ_PINNED_COPY_MIN")
     print("device parse of %d MB: h2d %.1f ms, kernels %.1f ms" % (os.path.getsize(mrf) >> 20, t["h2d_ms"], t["parse_ms"]))
     ctx.close()
+
+
+# ---- the three ways a line gets parsed on the way into the pools (round 4): the fast kernel's delimiter tables, the line list
+# for lines of another shape than a read's, the byte-walking kernel for tiles (or files) the fast kernel does not take
+
+def pools_and_counts(ctx, path=None, reads=None):
+    if reads is not None:
+        ctx.upload_reads(0, reads)
+    else:
+        ctx.upload_reads_mrf(0, path)
+    ctx.count()
+    c = ctx.counts()
+    return ctx.retained(0), ctx.retained_blocks(0), ctx.pooled(0), c[0].copy(), c[1].copy()
+
+
+def same(a, b):
+    return a[:3] == b[:3] and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+
+
+def random_valid_lines(rng, n):
+    """lines the reference accepts, in every shape its find / substr walk makes sense of: coordinates of 1-9 digits with leading
+    zeros and signs, ten and more digits, blocks without query fields, trailing text, unknown and long chromosome names,
+    strands of 0-7 bytes, comments; blocks in and around the exons of ANNOT"""
+    out = []
+    for _ in range(n):
+        r = rng.random()
+        if r < 0.03:
+            out.append("#" + ":" * int(rng.integers(0, 9)) + "," * int(rng.integers(0, 3)) + "x")
+            continue
+        blocks = []
+        for _b in range(int(rng.choice([1, 1, 1, 2, 2, 3, 5]))):
+            chrom = rng.choice(["c1", "c1", "c1", "c2", "c2", "zz", "", "chromosome_with_a_long_name", "c1x4567", "c12345678"])
+            strand = rng.choice(["+", "+", "-", "-", ".", "*", "", "ab", "strand7"])
+            if chrom == "c2":
+                a = int(rng.integers(990, 1500)); b = a + int(rng.integers(0, 60))
+            else:
+                a = int(rng.integers(90, 400)); b = a + int(rng.integers(0, 60))
+            if rng.random() < 0.05:
+                a = int(rng.choice([0, 1, 9, 99999999, 100000000, 999999999, 1000000000, 2147483647, 2147483648, 5000000000]))
+                b = a + int(rng.integers(0, 50))
+
+            def fmt(v):
+                q = rng.random()
+                if q < 0.70:
+                    return str(v)
+                if q < 0.80:
+                    return "+" + str(v)
+                if q < 0.95:
+                    return str(v).zfill(int(rng.integers(1, 12)))
+                return "-" + str(v) if v and rng.random() < 0.5 else "-0"
+            blk = "%s:%s:%s:%s" % (chrom, strand, fmt(a), fmt(b))
+            blocks.append(blk)
+        # query fields: on every block but possibly the last (a block without them swallows what follows into its end field)
+        line = ",".join(b + ":1:%d" % int(rng.integers(1, 100)) for b in blocks[:-1])
+        last = blocks[-1]
+        q = rng.random()
+        if q < 0.75:
+            last += ":1:50"
+        elif q < 0.85:
+            last += ":1:50\tACGT\tIIII"
+        elif q < 0.90:
+            last += ":"
+        line = (line + "," if line else "") + last
+        out.append(line)
+    return out
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_fast_kernel_line_list_and_byte_walking_kernel_agree_with_the_host_parser(seed, tmp_path, monkeypatch):
+    iv, mp = write_annot(tmp_path)
+    rng = np.random.default_rng(seed)
+    lines = random_valid_lines(rng, 30000) + good_odd_lines()
+    p = tmp_path / "r.mrf"
+    p.write_text("AlignmentBlocks\n" + "\n".join(lines) + "\n")
+    ev, ctx = setup(iv, mp)
+    want = pools_and_counts(ctx, reads=L.Reads.from_mrf(str(p), ev))
+    assert want[0] > 5000 and int(want[3].sum()) > 1000
+    fast = pools_and_counts(ctx, path=str(p))
+    assert same(want, fast)
+    monkeypatch.setenv("LSQ_MRF_LINE_LIST", "50")          # the list runs over: the file goes through the byte-walking kernel
+    assert same(want, pools_and_counts(ctx, path=str(p)))
+    monkeypatch.delenv("LSQ_MRF_LINE_LIST")
+    monkeypatch.setenv("LSQ_MRF_SLOW", "1")                # ... which this asks for outright
+    assert same(want, pools_and_counts(ctx, path=str(p)))
+    ctx.close()
+
+
+def test_windows_with_more_delimiters_than_the_tables_hold(tmp_path):
+    """comment lines of thousands of colons and commas (longer than the 512 bytes a tile sees ahead of itself, too) between
+    reads: their tiles go to the byte-walking kernel, the reads around them keep their line numbers"""
+    iv, mp = write_annot(tmp_path)
+    rng = np.random.default_rng(5)
+    lines = []
+    for k in range(4000):
+        if k % 97 == 13:
+            lines.append("#" + "".join(rng.choice([":", ",", "x"], size=int(rng.integers(3000, 9000)))))
+        else:
+            a = int(rng.integers(100, 350))
+            lines.append("c1:+:%d:%d:1:50" % (a + 1, a + 50))
+    p = tmp_path / "d.mrf"
+    p.write_text("AlignmentBlocks\n" + "\n".join(lines) + "\n")
+    ev, ctx = setup(iv, mp)
+    want = pools_and_counts(ctx, reads=L.Reads.from_mrf(str(p), ev))
+    assert want[0] > 3000
+    assert same(want, pools_and_counts(ctx, path=str(p)))
+    parsed_equal(ev, L.Reads.from_mrf(str(p), ev), ctx.parse_mrf_device(str(p)))
+    ctx.close()
+
+
+@pytest.mark.parametrize("bad", ["c1:+:10x:20:1:10", "c1:+:99999999999999999999:5:1:1", "c1:+:1:5,c1:+:7:9", "", "c1:+"])
+def test_first_failing_line_through_the_ingest_path(bad, tmp_path):
+    """the same verdict and the same line number whether the fast kernel meets the line or the list does"""
+    iv, mp = write_annot(tmp_path)
+    lines = ["c1:+:101:150:1:50"] * 900
+    lines[300] = bad
+    lines[650] = "c1:+:x:150:1:50"
+    p = tmp_path / "bad.mrf"
+    p.write_text("AlignmentBlocks\n" + "\n".join(lines) + "\n")
+    ev, ctx = setup(iv, mp)
+    with pytest.raises(L.LsqError) as eh:
+        L.Reads.from_mrf(str(p), ev)
+    with pytest.raises(L.LsqError) as ed:
+        ctx.upload_reads_mrf(0, str(p))
+    assert eh.value.status == ed.value.status == -4 and str(eh.value) == str(ed.value) and "#301:" in str(ed.value)
+    ctx.close()
