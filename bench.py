@@ -66,6 +66,16 @@ WORKLOADS = {
                desc="BASELINE configs[4] whole: 1B synthetic 100bp reads over 200k mixed events, Zipf read depth (hot genes), 24 chromosomes"),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 measured copy rate
+# the loader chain's passes (lsq_ingest_stage_name) and the kernels each launches, for the PMC rows of the traffic pass
+INGEST_STAGE_KERNELS = {
+    "newline_count": ("lsq_mrf_newline_count_kernel",),
+    "route": ("lsq_mrf_route_fast_kernel", "lsq_mrf_route_kernel", "lsq_mrf_route_lines_kernel", "lsq_route_raw_kernel"),
+    "partition_count": ("lsq_part_hist_kernel",),
+    "partition_scatter": ("lsq_part_scatter_kernel", "lsq_piece_expand_kernel"),
+    "group_classify": ("lsq_group_classify_kernel",),
+    "group_offsets": ("lsq_ingest_offsets_kernel",),
+    "group_place": ("lsq_group_place_kernel", "lsq_ingest_pad_kernel", "lsq_ingest_nblock_kernel"),
+}
 
 
 def shared_dir(tag):
@@ -82,10 +92,11 @@ def measure_traffic_live(wl_name, timeout=300):
     import csv, glob, shutil
     prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(prof):
-        return None, "rocprofv3 not found"
+        return None, "rocprofv3 not found", None
     base = tempfile.mkdtemp(prefix="lsq_traffic_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp", LSQ_BENCH_TAG="_traffic%d" % os.getpid())
     means = {}
+    ingest = {}
     try:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(base, ctr)
@@ -94,22 +105,31 @@ def measure_traffic_live(wl_name, timeout=300):
             try:
                 p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout)
             except subprocess.TimeoutExpired:
-                return None, "the %s pass did not finish in %d s" % (ctr, timeout)
+                return None, "the %s pass did not finish in %d s" % (ctr, timeout), None
             if p.returncode != 0:
-                return None, "the %s pass ended with %d: %s" % (ctr, p.returncode, p.stderr.decode(errors="replace")[-300:])
+                return None, "the %s pass ended with %d: %s" % (ctr, p.returncode, p.stderr.decode(errors="replace")[-300:]), None
             tot, n = 0.0, 0
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if "lsq_count_fast_kernel" in row.get("Kernel_Name", "") and row.get("Counter_Name") == ctr:
+                    if row.get("Counter_Name") != ctr:
+                        continue
+                    kn = row.get("Kernel_Name", "")
+                    if "lsq_count_fast_kernel" in kn:
                         tot += float(row["Counter_Value"]); n += 1
+                    for stage, pats in INGEST_STAGE_KERNELS.items():
+                        if any(p_ in kn for p_ in pats):
+                            # the first ingest of the child run is the text's (the only one under --no-e2e); a later one would be added to it
+                            ingest.setdefault(stage, {}).setdefault(ctr, 0.0)
+                            ingest[stage][ctr] += float(row["Counter_Value"])
             if n == 0:
-                return None, "no %s rows for the count kernel" % ctr
+                return None, "no %s rows for the count kernel" % ctr, None
             means[ctr] = (tot / n, n)
     finally:
         shutil.rmtree(base, ignore_errors=True)
     b = (2.0 * means["FETCH_SIZE"][0] + means["WRITE_SIZE"][0]) * 1024.0
+    ingest_bytes = {st: (2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024.0 for st, v in ingest.items()}
     return b, ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, one pass each over a 6-step child run of this command on this device "
-               "(%d / %d launches); 2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes (gfx950 counts a wide coalesced read at half its bytes)" % (means["FETCH_SIZE"][1], means["WRITE_SIZE"][1]))
+               "(%d / %d launches); 2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes (gfx950 counts a wide coalesced read at half its bytes)" % (means["FETCH_SIZE"][1], means["WRITE_SIZE"][1])), ingest_bytes
 
 
 def main():
@@ -177,7 +197,7 @@ def main():
             if rank == 0:
                 out["config"]["c5_error"] = why
                 os.write(json_fd, (json.dumps(out) + "\n").encode())
-            os._exit(0)
+            os._exit(3)           # the c3 line is out; the run itself did not end well and says so
         limit = float(os.environ.get("LSQ_BENCH_C5_LIMIT", "300"))
         dog = threading.Timer(limit, give_up, args=("the configs[4] leg did not finish within %.0f s" % limit,))
         dog.daemon = True
@@ -195,6 +215,8 @@ def main():
                 "c5_count_launch_rank0": c5["config"]["count_launch_rank0"],
                 "c5_per_rank": c5["config"]["per_rank"], "c5_gather_ms_alone": c5["config"]["gather_ms_alone"],
                 "c5_gather_through": c5["config"]["gather_through"], "c5_lsq_comm_size": c5["config"]["lsq_comm_size"],
+                "c5_n1_ms_per_step_same_box": c5["config"]["n1_ms_per_step_same_box"], "c5_speedup_vs_n1": c5["config"]["speedup_vs_n1"],
+                "c5_efficiency": c5["config"]["efficiency"],
                 "c5_tables_equal_unsharded_run": c5["config"]["tables_equal_unsharded_run"],
                 "c5_generate_s": c5["config"]["generate_s"], "c5_ingest_from_text_s": c5["config"]["ingest_from_text_s"],
                 "c5_em_replayed_events": c5["config"]["em_replayed_events"],
@@ -235,6 +257,8 @@ def setup_lsq_comm(env):
         rccl.lsq_comm_abort.argtypes = [C.c_void_p]
         rccl.lsq_comm_size.argtypes = [C.c_void_p]
         rccl.lsq_rccl_last_error.restype = C.c_char_p
+        v = int(rccl.lsq_rccl_version())
+        env["rccl_version"] = "%d.%d.%d" % (v // 10000, (v // 100) % 100, v % 100) if v else None
     except Exception as e:
         ok, rccl, why = 0, None, "liblesseq_rccl.so: %s" % e
     # every rank takes part in the exchanges below whatever happened above (a rank that skipped one would leave the
@@ -361,6 +385,7 @@ def run_workload(env, a, wl_name, primary):
                 res["e2e_cli_gpus_1_phases"] = ph1
                 if rcn == 0:
                     res["e2e_cli_gpus_n_mrf_reads_per_s"] = W["n_reads"] / dtn
+                    res["e2e_cli_gpus_n_speedup_over_one_gpu_executable"] = (dt1 / dtn) if rc1 == 0 else None
                 # ... and the same job sharded by READS (LSQ_SHARD=reads: every GPU copies and parses a byte range of the text, one
                 # all-reduce of the class counts, GPU 0 solves): the mode in which the loader scales with the GPUs
                 rcr, dtr, outr, phr, errr = run_cli("solve", argv_solve, dict(menv, LSQ_SHARD="reads"), timeout=300)
@@ -370,6 +395,7 @@ def run_workload(env, a, wl_name, primary):
                     res["e2e_cli_gpus_n_by_reads_error"] = errr[-600:]
                 else:
                     res["e2e_cli_gpus_n_by_reads_mrf_reads_per_s"] = W["n_reads"] / dtr
+                    res["e2e_cli_gpus_n_by_reads_speedup_over_one_gpu_executable"] = (dt1 / dtr) if rc1 == 0 else None
                 res["e2e_cli_gpus_n_by_reads_table_equals_one_gpu_table"] = bool(rc1 == 0 and rcr == 0 and out1 == outr)
                 res["e2e_cli_gpus_n_by_reads_phases"] = phr
                 res["e2e_cli_gpus_n_note"] = ("LSQ_GPUS=%d lesseq_amd/bin/solve as a child process on the MRF text: pre-pass count on GPU 0, slices of equal read weight, every "
@@ -397,6 +423,8 @@ def run_workload(env, a, wl_name, primary):
     ctx.upload_events(ev)
     ctx.upload_reads_text(0, text, free=False)
     t_ingest = time.perf_counter() - t0
+    ingest_stages = ctx.ingest_stages()                # device time and minimum bytes of every pass of the loader chain, this ingest
+    ingest_h2d_ms = ctx.mrf_timing()["h2d_ms"]
     ctx.count()
     ctx.solve()
     cnt_full, bases_full = [x.copy() for x in ctx.counts()]
@@ -411,6 +439,22 @@ def run_workload(env, a, wl_name, primary):
         e2e["e2e_from_text_note"] = "in-process: lsq_text_stage (H2D of the text) + event upload + device parse + ingest + count + EM + fetch + lsq_format_solve"
         e2e["e2e_from_text_table_matches_cli"] = hashlib.sha256(table.encode()).hexdigest() == e2e.get("e2e_cli_solve_table_sha256")
     bounds = [(0, n_ev)]
+    n1_same_box = None
+    if strong:
+        # N > 1: the whole job is resident on every GPU at this point (the pre-pass count that weighs the slices).  Twenty unsharded
+        # steps of it -- count + EM + pack, no gather -- give the one-GPU step time of THIS box, so the line's speed-up does not
+        # rest on another box's one-GPU run (boxes differ by ~5 %).  Every rank runs them (same work everywhere); rank 0's counts.
+        blk1 = torch.zeros(max(ev.record_words(0, n_ev), 1), dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        for k in range(5):
+            ctx.count(); ctx.solve(); ctx.pack_results_device(blk1.data_ptr())
+        ctx.synchronize()
+        t_n1 = time.perf_counter()
+        for k in range(20):
+            ctx.count(); ctx.solve(); ctx.pack_results_device(blk1.data_ptr())
+        ctx.synchronize()
+        n1_same_box = (time.perf_counter() - t_n1) / 20 * 1e3
+        del blk1
     if strong:
         # slices of equal read weight; then this rank's slice only: event tables re-planned, reads re-ingested
         bounds = ev.shard_bounds(world, ld.event_weights(ev, cnt_full))
@@ -435,7 +479,28 @@ def run_workload(env, a, wl_name, primary):
         e2e["e2e_device_resident_reads_per_s"] = W["n_reads"] / e2e["e2e_device_resident_s"]
         e2e["e2e_device_resident_note"] = "parsed blocks in host memory -> H2D -> ingest kernels -> count -> EM -> D2H of the tables (PCIe-inclusive; never `value`)"
         assert np.array_equal(c2, cnt_full) and np.array_equal(b2, bases_full) and np.array_equal(th2, theta_full)
+        e2e["ingest_stages_from_parsed_arrays"] = ctx.ingest_stages()
         del reads
+        # the same reads in coordinate order (what an aligner's sorted output looks like): neighbouring lines fall into the same
+        # bucket and the same cell.  The ingest of that file beside the shuffled one's (device time, per pass).
+        sdir = os.path.join(tmp, "sorted")
+        os.makedirs(sdir, exist_ok=True)
+        t_s = time.perf_counter()
+        L.synth_write(L.SynthSpec(W["seed"], W["n_events"], W["n_reads"], W["R"], W["n_chrom"], types, W.get("zipf", False), sorted_reads=True), sdir, "w", write_mrf=True)
+        e2e["sorted_generate_s"] = time.perf_counter() - t_s
+        stext = ctx.stage_text(os.path.join(sdir, "w.mrf"))
+        ctx.upload_reads_text(0, stext, free=True)
+        sst = ctx.ingest_stages()
+        assert ctx.retained(0) == job_retained, "the sorted file holds other reads than the shuffled one"
+        ctx.count()
+        cs, bs_ = ctx.counts()
+        # (read names are line numbers, so the handful of reads that tie with an event's span start may fall the other way: not compared bit for bit)
+        e2e["ingest_sorted_input"] = {"device_ms": sum(x["ms"] for x in sst), "stages_ms": {x["stage"]: x["ms"] for x in sst},
+                                      "device_ms_shuffled": sum(x["ms"] for x in ingest_stages),
+                                      "valid_assignments": int(cs.sum()), "valid_assignments_shuffled": int(cnt_full.sum())}
+        e2e["ingest_sorted_input"]["sorted_over_shuffled"] = e2e["ingest_sorted_input"]["device_ms"] / max(e2e["ingest_sorted_input"]["device_ms_shuffled"], 1e-9)
+        os.remove(os.path.join(sdir, "w.mrf"))
+        ctx.upload_reads_text(0, ctx.stage_text(mrf), free=True)          # the job's own reads again, for the timed loop
 
     # ---- the records a step hands over: packed in output order; all-gathered with N > 1
     stride = max(max(ev.record_words(f, c) for f, c in bounds), 1)
@@ -680,9 +745,9 @@ def run_workload(env, a, wl_name, primary):
                              "source": "profiles/%s_traffic_%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; 2 x FETCH_SIZE + WRITE_SIZE)" % (rr, wl_name)}
                 break
         # ... and by this run, when it is the one-GPU default: two short child runs under the profiler's counters (after the timed loop)
-        traffic_live, traffic_note = (None, "not measured by this run")
+        traffic_live, traffic_note, ingest_traffic = (None, "not measured by this run", None)
         if world == 1 and primary and not a.no_traffic:
-            traffic_live, traffic_note = measure_traffic_live(wl_name)
+            traffic_live, traffic_note, ingest_traffic = measure_traffic_live(wl_name)
         # what a plain streaming read of the same number of bytes reaches on this device (state both ceilings)
         import ctypes as C
         L.lib.lsq_debug_stream_read_rate.argtypes = [C.c_void_p, C.c_ulonglong, C.POINTER(C.c_double)]
@@ -735,6 +800,12 @@ def run_workload(env, a, wl_name, primary):
                 "em_max_iters": int(iters_full.max()) if n_ev else 0,
                 "generate_s": t_gen, "ingest_from_text_s": t_ingest, "first_count_solve_fetch_s": t_first - t_ingest,
                 "gather_ms_alone": gather_ms,
+                "n1_ms_per_step_same_box": n1_same_box,
+                "speedup_vs_n1": ((n1_same_box / (1e3 * elapsed / a.steps)) if (n1_same_box and strong) else None),
+                "efficiency": ((n1_same_box / (1e3 * elapsed / a.steps) / world) if (n1_same_box and strong) else None),
+                "n1_same_box_note": ("20 unsharded steps (count + EM + pack, no gather) of the same job on rank 0's GPU before the events were sharded; speedup_vs_n1 = that / "
+                                     "ms_per_step, efficiency = speedup / N -- informational, from this run's own clock on one box; the driver computes its own from the per-N lines" if strong else None),
+                "rccl_version": env.get("rccl_version"),
                 "gather_through": ("liblesseq_rccl lsq_gather (ncclAllGather on the step's result lane)" if use_lsq_gather else
                                    ("torch.distributed all_gather_into_tensor (%s)" % ("gloo, host tensors: rehearsal" if on_host else "RCCL through torch") if world > 1 else None)),
                 "lsq_comm_size": (int(rccl.lsq_comm_size(comm)) if use_lsq_gather else 0),
@@ -748,6 +819,11 @@ def run_workload(env, a, wl_name, primary):
             "roofline": {
                 "bound": "hbm", "kernel": "lsq_count_fast_kernel<%s, %d>" % ("true" if pool_fmt[0] else "false", launch_info[0] // 2) + (" (rank 0's launch)" if world > 1 else ""),
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "frac_algorithmic": achieved / HBM_PEAK_GBS,
+                # what the HBM actually moved over the same kernel time: the PMC traffic when this run measured it, else the pools' resident bytes
+                "frac_on_bytes_moved": ((traffic_live if traffic_live else float(pool_fmt[1] + ev_bytes)) / (fk * 1e-3) / 1e9 / HBM_PEAK_GBS),
+                "frac_note": "`achieved` / `frac` count SURVEY 8(d)'s ALGORITHMIC 8 bytes per read block, as the bench contract prescribes; the compact pools hold and stream "
+                             "4 bytes per block, so the HBM moves about half of that: `frac_on_bytes_moved` is the device's real bandwidth use by this kernel",
                 # the same kernel on an otherwise idle device (steps synchronised one by one, no EM beside it)
                 "frac_alone": alg_bytes / (float(np.mean(alone_fast_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 # consecutive counts run on two streams and overlap at their ends (the next one fills the tail of this one), so a
@@ -766,6 +842,26 @@ def run_workload(env, a, wl_name, primary):
             },
         }
         out["config"].update(e2e)
+        # ---- the loader chain on the same roofline: what a job spends once per read file (count/count.cpp:279-364 on the device)
+        ing_ms = sum(x["ms"] for x in ingest_stages)
+        stages = []
+        for x in ingest_stages:
+            tr = (ingest_traffic or {}).get(x["stage"])
+            gb = x["bytes"] / (x["ms"] * 1e-3) / 1e9 if x["ms"] > 0 else None
+            stages.append({"stage": x["stage"], "ms": x["ms"], "algorithmic_bytes": x["bytes"], "achieved": gb, "frac": (gb / HBM_PEAK_GBS if gb else None),
+                           "traffic": tr, "traffic_over_algorithmic": (tr / x["bytes"] if tr and x["bytes"] else None)})
+        out["roofline_ingest"] = {
+            "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "what": "the passes of the loader chain over this job's MRF text in HBM (lsq_last_ingest_stages): ms = HIP events on the library's stream around the pass's "
+                    "launches; algorithmic_bytes = the pass's input read once + its output written once; traffic = 2 x FETCH_SIZE + WRITE_SIZE of the pass's kernels "
+                    "in the same rocprofv3 --pmc child runs that measure the count kernel (null when those did not run)",
+            "text_bytes": os.path.getsize(mrf) if os.path.exists(mrf) else None, "lines": W["n_reads"], "h2d_ms": ingest_h2d_ms,
+            "device_ms": ing_ms, "stages": stages,
+            "frac_whole_chain": (sum(x["bytes"] for x in ingest_stages) / (ing_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ing_ms > 0 else None,
+        }
+        out["config"]["one_shot_device_ms"] = ing_ms + float(np.mean(count_ms)) + float(np.mean(solve_ms))
+        out["config"]["one_shot_device_note"] = ("device time of ONE fresh read set: the loader chain (parse + filter + partition + groups + pools) + one count + one EM, "
+                                                 "each on an idle device; %.0f reads/s of MRF text" % (W["n_reads"] / max((ing_ms + float(np.mean(count_ms)) + float(np.mean(solve_ms))) * 1e-3, 1e-9)))
         # ---- cpu_baseline: the oracle on a bounded prefix of the same stream (rank 0, N = 1 only)
         if world == 1 and cpu_sample > 0:
             sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -434,6 +434,9 @@ typedef struct {
 	double overlap_frac;       /* fraction of events that overlap their left neighbour */
 	uint64_t first_read;       /* reads are numbered first_read .. first_read+n_reads-1 in the spec's
 	                              read stream (counter-based), so chunks of one stream can be made */
+	uint32_t sorted;           /* 1: the reads in coordinate order (chromosome, first base, then their number in the stream) -- what an
+	                              aligner's sorted output looks like -- instead of the stream's own (shuffled) order; line numbers follow the file */
+	uint32_t reserved;
 } lsq_synth_spec;
 
 /* Writes <stem>.interval, <stem>.map and (if write_mrf) <stem>.mrf under dir. */

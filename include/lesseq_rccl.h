@@ -42,6 +42,7 @@ int lsq_comm_init_all_for(int n, const int *devices, double seconds, lsq_comm **
 /* Ends whatever the communicator has in flight (ncclCommAbort) and frees it: the way out when a collective does not
  * complete (lsq_ctx_synchronize_for returned LSQ_E_TIMEOUT).  The other ranks' collectives fail or are aborted likewise. */
 void lsq_comm_abort(lsq_comm *comm);
+int lsq_rccl_version(void);           /* ncclGetVersion's integer of the RCCL this library runs on (0: the call failed) */
 int lsq_comm_rank(const lsq_comm *comm);
 int lsq_comm_size(const lsq_comm *comm);
 

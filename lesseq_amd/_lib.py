@@ -38,7 +38,8 @@ cs = C.c_char_p
 
 class SynthSpecStruct(C.Structure):
     _fields_ = [("seed", u64), ("n_events", u64), ("n_reads", u64), ("read_length", u32), ("n_chrom", u32),
-                ("event_types", u32), ("zipf", u32), ("overlap_frac", C.c_double), ("first_read", u64)]
+                ("event_types", u32), ("zipf", u32), ("overlap_frac", C.c_double), ("first_read", u64),
+                ("sorted", u32), ("reserved", u32)]
 
 
 def _sig(name, res, *args):

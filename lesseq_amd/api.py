@@ -438,11 +438,11 @@ class Context:
 
 
 class SynthSpec:
-    def __init__(self, seed, n_events, n_reads, read_length=100, n_chrom=1, event_types=EVENT_TYPES, zipf=False, overlap_frac=0.10, first_read=0):
+    def __init__(self, seed, n_events, n_reads, read_length=100, n_chrom=1, event_types=EVENT_TYPES, zipf=False, overlap_frac=0.10, first_read=0, sorted_reads=False):
         mask = 0
         for t in event_types:
             mask |= 1 << EVENT_TYPES.index(t)
-        self.c = SynthSpecStruct(seed, n_events, n_reads, read_length, n_chrom, mask, 1 if zipf else 0, overlap_frac, first_read)
+        self.c = SynthSpecStruct(seed, n_events, n_reads, read_length, n_chrom, mask, 1 if zipf else 0, overlap_frac, first_read, 1 if sorted_reads else 0, 0)
 
 
 def synth_write(spec, directory, stem, write_mrf=True):

@@ -185,6 +185,8 @@ int lsq_comm_init_all_for(int n, const int *devices, double seconds, lsq_comm **
 	return LSQ_OK;
 } LSQ_API_CATCH
 
+// the RCCL this library runs on, as ncclGetVersion's integer (e.g. 22203 = 2.22.3); 0 when the call fails
+int lsq_rccl_version(void) { int v = 0; return ncclGetVersion(&v) == ncclSuccess ? v : 0; }
 int lsq_comm_rank(const lsq_comm *comm) { return comm ? comm->rank : -1; }
 int lsq_comm_size(const lsq_comm *comm) { return comm ? comm->size : 0; }
 

@@ -204,6 +204,64 @@ void gen_read(const lsq_synth_spec &S, const SynModel &Mo, uint64_t i, OneRead &
 
 std::string chrom_name(int c) { return "chr" + std::to_string(c + 1); }
 
+// spec.sorted: the reads' numbers in coordinate order -- chromosome, first base of the first block, number.  A counting sort on
+// (chromosome, first base / 65 536) by all threads, then every bin sorted on its own.
+int sorted_order(const lsq_synth_spec &S, const SynModel &Mo, std::vector<uint32_t> &order) {
+	const uint64_t n = S.n_reads;
+	if (n > 0xFFFFFFF0ull) return fail(LSQ_E_RANGE, "more than 2^32 reads in one read set");
+	const int T = n < 100000 ? 1 : host_threads(0);
+	std::vector<uint64_t> key(n);              // chromosome << 40 | first base + 2^31 (reads may start left of base 0)
+	auto range = [&](int t, uint64_t &a, uint64_t &b) { a = n * (uint64_t)t / (uint64_t)T; b = n * (uint64_t)(t + 1) / (uint64_t)T; };
+	const uint64_t n_bins = (uint64_t)S.n_chrom << 16;       // chromosome, bits 31..16 of the biased base
+	auto bin_of = [](uint64_t k) { return (size_t)(((k >> 40) << 16) | ((k >> 16) & 0xFFFFu)); };
+	std::vector<std::vector<uint32_t>> cnt((size_t)T);
+	{
+		ThreadGroup th;
+		for (int t = 0; t < T; ++t) th.spawn([&, t] {
+			uint64_t a, b; range(t, a, b);
+			cnt[(size_t)t].assign(n_bins, 0);
+			OneRead r;
+			for (uint64_t i = a; i < b; ++i) {
+				gen_read(S, Mo, S.first_read + i, r);
+				key[i] = ((uint64_t)r.chrom << 40) | (uint64_t)((int64_t)r.bs[0] + (1ll << 31));
+				++cnt[(size_t)t][bin_of(key[i])];
+			}
+		});
+		th.join();
+		if (th.failed()) return fail(LSQ_E_INTERNAL, "a helper thread failed: %s", th.error().c_str());
+	}
+	std::vector<uint64_t> bin_first(n_bins + 1, 0);
+	{
+		uint64_t run = 0;
+		for (uint64_t bq = 0; bq < n_bins; ++bq) {
+			bin_first[bq] = run;
+			for (int t = 0; t < T; ++t) { const uint32_t c = cnt[(size_t)t][bq]; cnt[(size_t)t][bq] = (uint32_t)(run - bin_first[bq]); run += c; }
+		}
+		bin_first[n_bins] = run;
+	}
+	order.resize(n);
+	{
+		ThreadGroup th;
+		for (int t = 0; t < T; ++t) th.spawn([&, t] {
+			uint64_t a, b; range(t, a, b);
+			for (uint64_t i = a; i < b; ++i) { const size_t bq = bin_of(key[i]); order[bin_first[bq] + cnt[(size_t)t][bq]++] = (uint32_t)i; }
+		});
+		th.join();
+		if (th.failed()) return fail(LSQ_E_INTERNAL, "a helper thread failed: %s", th.error().c_str());
+	}
+	{
+		ThreadGroup th;
+		for (int t = 0; t < T; ++t) th.spawn([&, t] {
+			for (uint64_t bq = (uint64_t)t; bq < n_bins; bq += (uint64_t)T)
+				std::sort(order.begin() + (ptrdiff_t)bin_first[bq], order.begin() + (ptrdiff_t)bin_first[bq + 1],
+				          [&](uint32_t x, uint32_t y) { return key[x] != key[y] ? key[x] < key[y] : x < y; });
+		});
+		th.join();
+		if (th.failed()) return fail(LSQ_E_INTERNAL, "a helper thread failed: %s", th.error().c_str());
+	}
+	return LSQ_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -239,6 +297,8 @@ int lsq_synth_write(const lsq_synth_spec *S, const char *dir, const char *stem, 
 		const int T = host_threads(0);
 		const uint64_t CHUNK = 1u << 18;
 		std::vector<std::string> bufs((size_t)T);
+		std::vector<uint32_t> order;             // spec.sorted: the read written at each place
+		if (S->sorted && (rc = sorted_order(*S, Mo, order))) { fclose(fr); return rc; }
 		auto put_int = [](std::string &o, long long v) {
 			char tmp[24]; int n = 0;
 			if (v < 0) { o.push_back('-'); v = -v; }
@@ -255,7 +315,7 @@ int lsq_synth_write(const lsq_synth_spec *S, const char *dir, const char *stem, 
 					const uint64_t i0 = round0 + CHUNK * (uint64_t)t, i1 = std::min<uint64_t>(i0 + CHUNK, S->n_reads);
 					OneRead r;
 					for (uint64_t i = i0; i < i1; ++i) {
-						gen_read(*S, Mo, S->first_read + i, r);
+						gen_read(*S, Mo, S->first_read + (order.empty() ? i : (uint64_t)order[i]), r);
 						int q = 1;
 						for (int b = 0; b < r.nb; ++b) {
 							const int ln = r.be[b] - r.bs[b];
@@ -296,6 +356,9 @@ int lsq_synth_reads(const lsq_synth_spec *S, lsq_events *E, int n_threads, lsq_r
 	const uint64_t n = S->n_reads;
 	int T = host_threads(n_threads);
 	if (n < 100000) T = 1;
+	std::vector<uint32_t> order;
+	if (S->sorted && (rc = sorted_order(*S, Mo, order))) return rc;
+	auto at = [&](uint64_t i) { return S->first_read + (order.empty() ? i : (uint64_t)order[i]); };
 	// pass 1: block counts
 	Rd->o_blk_off.assign(n + 1, 0);
 	Rd->o_line_no.resize(n);
@@ -305,7 +368,7 @@ int lsq_synth_reads(const lsq_synth_spec *S, lsq_events *E, int n_threads, lsq_r
 		for (int t = 0; t < T; ++t) th.spawn([&, t] {
 			uint64_t a, b; range(t, a, b);
 			OneRead r;
-			for (uint64_t i = a; i < b; ++i) { gen_read(*S, Mo, S->first_read + i, r); Rd->o_blk_off[i + 1] = (uint64_t)r.nb; Rd->o_line_no[i] = (uint32_t)(i + 1); }
+			for (uint64_t i = a; i < b; ++i) { gen_read(*S, Mo, at(i), r); Rd->o_blk_off[i + 1] = (uint64_t)r.nb; Rd->o_line_no[i] = (uint32_t)(i + 1); }
 		});
 		th.join();
 		if (th.failed()) return fail(LSQ_E_INTERNAL, "a helper thread failed: %s", th.error().c_str());
@@ -319,7 +382,7 @@ int lsq_synth_reads(const lsq_synth_spec *S, lsq_events *E, int n_threads, lsq_r
 			uint64_t a, b; range(t, a, b);
 			OneRead r;
 			for (uint64_t i = a; i < b; ++i) {
-				gen_read(*S, Mo, S->first_read + i, r);
+				gen_read(*S, Mo, at(i), r);
 				uint64_t o = Rd->o_blk_off[i];
 				for (int k = 0; k < r.nb; ++k) {
 					Rd->o_start[o + k] = r.bs[k]; Rd->o_end[o + k] = r.be[k];
