@@ -661,6 +661,74 @@ def run_workload(env, a, wl_name, primary):
             step(k)
         fence()
         ms_other_batch = (time.perf_counter() - t_ob) / n_ob * 1e3
+    # ---- the wide-record kernel (lsq_count_fast_kernel<false, ..>: 8 bytes a block in HBM, so its algorithmic bytes ARE its resident
+    # bytes): (a) this job with compact records switched off; (b) a long-read job -- reads of 1 500 bases, single blocks of 1-1.5 kb and
+    # junction reads -- whose blocks do not fit compact records, so the ingest chooses wide records by itself
+    wide = {}
+    if world == 1 and not no_e2e:
+        def kernel_and_step_ms():
+            for k in range(10):
+                step(k)
+            fence()
+            tw = time.perf_counter()
+            for k in range(50):
+                step(k)
+            fence()
+            ms = (time.perf_counter() - tw) / 50 * 1e3
+            ks = []
+            ctx.set_timing(True)
+            for _ in range(5):
+                for k in range(3):
+                    step(k)
+                ctx.synchronize()
+                ks.append(ctx.fast_kernel_ms())
+            ctx.set_timing(False)
+            fence()
+            return ms, float(np.mean(ks))
+        saved_gather, in_loop_gather = in_loop_gather, False
+        ctx.set_option("compact_pools", 0)
+        ctx.upload_reads_text(0, ctx.stage_text(mrf), free=True)
+        fmt_w = ctx.pool_format(0)
+        ms_w, k_w = kernel_and_step_ms()
+        assert not fmt_w[0]
+        ev_b = sum(8 * ev.N(i) + 8 * ev.K(i) + 16 + 8 * ((1 << ev.K(i)) - 1) + 8 for i in range(n_ev))
+        wide.update({"wide_ms_per_step": ms_w, "wide_count_fast_kernel_ms": k_w, "wide_resident_bytes": float(fmt_w[1] + ev_b),
+                     "wide_frac": (fmt_w[1] + ev_b) / (k_w * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "wide_note": "this job with option compact_pools = 0: lsq_count_fast_kernel<false, ..> streams (start, end) pairs, 8 bytes a block -- algorithmic bytes = "
+                                  "resident bytes, so wide_frac is that kernel's plain HBM fraction (resident bytes / HIP-event kernel time / 8 TB/s)"})
+        ctx.set_option("compact_pools", 1)
+        # (b)
+        lr = dict(n_events=W["n_events"], n_reads=min(W["n_reads"], 20_000_000), R=1500)
+        ldir = os.path.join(tmp, "long")
+        os.makedirs(ldir, exist_ok=True)
+        lspec = L.SynthSpec(W["seed"] + 77, lr["n_events"], lr["n_reads"], lr["R"], W["n_chrom"], types, W.get("zipf", False))
+        L.synth_write(lspec, ldir, "l", write_mrf=True)
+        lev = L.Events(L.Annotation(os.path.join(ldir, "l.interval"), os.path.join(ldir, "l.map")), ("SHORT_READ",), (lr["R"],))
+        ctx.upload_events(lev)
+        ctx.upload_reads_text(0, ctx.stage_text(os.path.join(ldir, "l.mrf")), free=True)
+        lst = ctx.ingest_stages()
+        fmt_l = ctx.pool_format(0)
+        ev_keep, ev = ev, lev                     # (step() packs with the context's events)
+        stride_l = max(lev.record_words(0, len(lev)), 1)
+        blocks_keep = blocks
+        blocks = [torch.zeros(stride_l, dtype=torch.int64, device=dev) for _ in range(2)]
+        torch.cuda.synchronize()
+        ms_l, k_l = kernel_and_step_ms()
+        lev_b = sum(8 * lev.N(i) + 8 * lev.K(i) + 16 + 8 * ((1 << lev.K(i)) - 1) + 8 for i in range(len(lev)))
+        wide.update({"long_reads_workload": "%d synthetic reads of %d bases over %d mixed events (flank exons %d bases), %d chromosomes" % (lr["n_reads"], lr["R"], lr["n_events"], lr["R"] + 1, W["n_chrom"]),
+                     "long_reads_compact_records_chosen": bool(fmt_l[0]), "long_reads_pool_reads_one_two_many": list(fmt_l[2]),
+                     "long_reads_retained": ctx.retained(0), "long_reads_ms_per_step": ms_l, "long_reads_count_fast_kernel_ms": k_l,
+                     "long_reads_frac": (fmt_l[1] + lev_b) / (k_l * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "long_reads_ingest_device_ms": sum(x["ms"] for x in lst)})
+        ev, blocks = ev_keep, blocks_keep
+        in_loop_gather = saved_gather
+        shutil.rmtree(ldir, ignore_errors=True)
+        # the job's own events and reads again: what follows (tables of the last step, counters) speaks of them
+        ctx.upload_events(ev)
+        ctx.upload_reads_text(0, ctx.stage_text(mrf), free=True)
+        for k in range(2):
+            step(k)
+        fence()
     # what the gather costs on its own (N > 1): submitted alone, timed on the host
     gather_ms = None
     if world > 1:
@@ -842,6 +910,7 @@ def run_workload(env, a, wl_name, primary):
             },
         }
         out["config"].update(e2e)
+        out["config"].update(wide)
         # ---- the loader chain on the same roofline: what a job spends once per read file (count/count.cpp:279-364 on the device)
         ing_ms = sum(x["ms"] for x in ingest_stages)
         stages = []

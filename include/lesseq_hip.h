@@ -58,6 +58,10 @@ typedef enum {
 
 const char *lsq_last_error(void);
 int lsq_abi_version(void);
+/* The library's own warnings (e.g. "the exception list of read file m overflowed: every read was counted again") go to stderr in
+ * the reference's log format (jsc/util/log.hpp:22-79, "[LOG date time WARNING] text") when level >= 1; default 2, like the
+ * reference's reporting level; the executables pass their log_level argument on. */
+void lsq_set_log_level(int level);
 
 /* ------------------------------------------------------------------------------------
  * Host-only group

@@ -105,6 +105,7 @@ _sig("lsq_text_free", None, vp)
 _sig("lsq_reads_upload_text", C.c_int, vp, C.c_int, cs, vp)
 _sig("lsq_mrf_parse_device", C.c_int, vp, cs, cs, P(vp))
 _sig("lsq_last_mrf_timing", C.c_int, vp, P(C.c_float), P(C.c_float))
+_sig("lsq_set_log_level", None, C.c_int)
 _sig("lsq_ingest_stage_count", C.c_int)
 _sig("lsq_ingest_stage_name", cs, C.c_int)
 _sig("lsq_last_ingest_stages", C.c_int, vp, P(C.c_float), P(u64), C.c_int)

@@ -1,6 +1,8 @@
 // Host side of the path, part 1: annotation loading, event compilation and the device plan
 // (buckets + LDS images).  Semantics restated from the reference lines cited at each step.
 #include <algorithm>
+#include <atomic>
+#include <ctime>
 #include <cerrno>
 #include <climits>
 #include <cstdarg>
@@ -26,6 +28,23 @@ int fail(int status, const char *fmt, ...) {
 	try { g_err = buf; } catch (...) { g_err.clear(); }      // (the text is lost before the status is)
 	return status;
 }
+
+// a warning of the library itself, in the reference's log format (jsc/util/log.hpp:22-79) on stderr, when the reporting level lets
+// warnings through (lsq_set_log_level; the executables pass their log_level argument on)
+static std::atomic<int> g_log_level{2};
+void warn(const char *fmt, ...) {
+	if (g_log_level.load() < 1) return;
+	char buf[1024];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof buf, fmt, ap);
+	va_end(ap);
+	time_t raw; time(&raw);
+	struct tm tmv; localtime_r(&raw, &tmv);
+	fprintf(stderr, "[LOG %d-%02d-%02d %02d:%02d:%02d WARNING] %s\n", tmv.tm_year + 1900, tmv.tm_mon + 1, tmv.tm_mday, tmv.tm_hour, tmv.tm_min, tmv.tm_sec, buf);
+	fflush(stderr);
+}
+void set_log_level(int level) { g_log_level.store(level); }
 
 // the catch-all of an extern "C" entry (LSQ_API_CATCH): called from inside a catch block, rethrows to read the exception
 int fail_exception(const char *where) noexcept {
@@ -219,6 +238,7 @@ int lsq_debug_throw(int kind) LSQ_API_TRY {
 	return LSQ_OK;
 } LSQ_API_CATCH
 int lsq_abi_version(void) { return LSQ_ABI_VERSION; }
+void lsq_set_log_level(int level) { lsq::set_log_level(level); }
 void lsq_free(void *p) { free(p); }
 
 // count/count.cpp:135-216; the formats beyond LH_GENE_TXT / UCSC_GENE2ISOFORM are solve's (solve/solve.cpp:152-329)

@@ -129,6 +129,7 @@ int run_classify(int argc, const char *const *argv) {
 	long lvl;
 	if (!cast_long(argv[1], lvl)) return EXIT_ABORT;
 	g_log_level = (int)lvl;
+	lsq_set_log_level(g_log_level);
 	std::string out_prefix = argv[3];
 	unsigned long gb, ge;
 	if (!cast_ulong(argv[8], gb) || !cast_ulong(argv[9], ge)) { logf(0, "Lexical_cast error when converting arguments to numeric values"); return 1; }
@@ -539,6 +540,7 @@ int run_count_solve(bool solve, int argc, const char *const *argv, std::string &
 	long lvl;
 	if (!cast_long(argv[1], lvl)) return EXIT_ABORT;      // lexical_cast outside the try block (count/count.cpp:99)
 	g_log_level = (int)lvl;
+	lsq_set_log_level(g_log_level);
 	unsigned long gb, ge;
 	if (!cast_ulong(argv[8], gb) || !cast_ulong(argv[9], ge)) { logf(0, "Lexical_cast error when converting arguments to numeric values"); return 1; }
 	std::vector<const char *> fmts, types, paths;

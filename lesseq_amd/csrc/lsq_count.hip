@@ -1485,24 +1485,11 @@ __global__ void __launch_bounds__(256) lsq_count_cleanup_kernel(const CountArgs 
 	// counted again, from zero (below; lsq_count_status reports it)
 	if (n_raw > exc_cap || force_recount) {
 		if (gtid == 0) A.exc_count[1] = 1u;
-		// ... and this launch clears what the fast kernel and its workers added to the packed buckets' class counters
-		const unsigned lane = threadIdx.x & 63u, wave_id = (unsigned)(gtid >> 6), n_waves = (unsigned)(gsz >> 6);
-		for (unsigned b = wave_id; b < A.n_buckets; b += n_waves) {
-			const BucketDesc &d = A.buckets[b];
-			if (d.kind != 1) continue;
-			for (unsigned i = lane; i < d.n_cls; i += 64u) { A.cnt[d.cls_base + i] = 0; A.bases[d.cls_base + i] = 0; }
-		}
-		// ... and, once every workgroup of this launch has done its part of that (a barrier over the launch's few workgroups: a
-		// word of the counter set, zeroed with it before every count), counts every read of those buckets again.  The rare way
+		// ... every packed bucket's class counters are cleared of what the fast kernel and its workers added, and every read of the
+		// bucket is counted again -- BY THE SAME WAVE, bucket by bucket: a bucket's reads add to that bucket's counters only, so no
+		// workgroup waits for another (until round 4 the launch cleared everything, met at a spin barrier over its workgroups -- which
+		// held only for as many workgroups as are resident together, so the launch was kept at 16 -- and then counted).  The rare way
 		// through this kernel; it used to be a launch of its own behind this one, which found nothing to do step after step.
-		__threadfence();
-		__syncthreads();
-		if (threadIdx.x == 0) {
-			atomicAdd(A.bar, 1ull);
-			while (__hip_atomic_load(A.bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned long long)gridDim.x) __builtin_amdgcn_s_sleep(8);
-		}
-		__syncthreads();
-		__threadfence();
 		recount_all_reads(A, n_pn);
 		return;
 	}
@@ -1530,16 +1517,17 @@ __device__ void recount_all_reads(const CountArgs &A, unsigned long long n_pn) {
 	const unsigned long long gsz = (unsigned long long)gridDim.x * blockDim.x;
 	const unsigned lane = threadIdx.x & 63u;
 	const unsigned wave_id = (unsigned)(gtid >> 6), n_waves = (unsigned)(gsz >> 6);
-	for (unsigned long long g = gtid; g < n_pn; g += gsz) {
-		const unsigned b = A.pn_bucket[g];
-		if (A.buckets[b].kind != 1) continue;
-		const GlobalBucket G = global_bucket(A, b);
-		const unsigned o0 = A.pn_blk_off[g], o1 = o0 + A.pn_nblk[g];
-		eval_read_global(A, G, A.pn_se + o0, (int)(o1 - o0), first_event_for(G, A.pn_se[o0].x), true, A.pn_strand[g], A.pn_line[g]);
-	}
+	(void)n_pn;
 	for (unsigned b = wave_id; b < A.n_buckets; b += n_waves) {
-		if (A.buckets[b].kind != 1) continue;
+		const BucketDesc &d = A.buckets[b];
+		if (d.kind != 1) continue;
+		for (unsigned i = lane; i < d.n_cls; i += 64u) { A.cnt[d.cls_base + i] = 0; A.bases[d.cls_base + i] = 0; }
+		__threadfence();                           // the zeros are in place before this wave's own atomics on the same words
 		const GlobalBucket G = global_bucket(A, b);
+		for (unsigned long long g = A.pn_off[b] + lane; g < A.pn_off[b + 1]; g += 64u) {
+			const unsigned o0 = A.pn_blk_off[g], o1 = o0 + A.pn_nblk[g];
+			eval_read_global(A, G, A.pn_se + o0, (int)(o1 - o0), first_event_for(G, A.pn_se[o0].x), true, A.pn_strand[g], A.pn_line[g]);
+		}
 		for (unsigned long long g = A.p1_off[b] + lane; g < A.p1_off[b + 1]; g += 64u) {
 			int2 blk[1] = {pool1_read(A, g, A.buckets[b].lo)};
 			if (blk[0].y == blk[0].x) continue;      // padding of a cell's group
@@ -1859,7 +1847,9 @@ int run_count(lsq_ctx *c) {
 	// (it turns into the recount where the exception list overflowed)
 	if (!counted_signalled) HIP_TRY(hipEventRecord(c->ev_counted2[set], st));
 	HIP_TRY(hipStreamWaitEvent(st_em, c->ev_counted2[set], 0));
-	// few workgroups: these launches normally find the flag clear and return, beside the next count's kernel on a full device
+	// few workgroups: these launches normally find a handful of pairs to settle, beside the next count's kernel on a full device;
+	// when the list has overflowed the same workgroups count every read again, so not too few either (a quarter of the compute units:
+	// a C3 recount in a few milliseconds, where the sixteen of round 3 took four times as long; no workgroup waits for another)
 	const unsigned rgrid = std::max(16u, (unsigned)c->n_cu / 4u);
 	if (c->recount_args.n < 2 * (size_t)LSQ_MAX_METHODS * sizeof(CountArgs)) {
 		int rc = c->recount_args.alloc(2 * (size_t)LSQ_MAX_METHODS * sizeof(CountArgs));
@@ -1874,7 +1864,7 @@ int run_count(lsq_ctx *c) {
 			HIP_TRY(hipMemcpyAsync(c->recount_args.p + slot, c->recount_args_host.data() + slot, sizeof(CountArgs), hipMemcpyHostToDevice, st_em));
 		}
 		const CountArgs *dA = reinterpret_cast<const CountArgs *>(c->recount_args.p + slot);
-		hipLaunchKernelGGL(lsq_count_cleanup_kernel, dim3(c->opt_recount ? rgrid : 16u), dim3(256), 0, st_em, dA, c->opt_recount ? 1 : 0, u.n_pn,
+		hipLaunchKernelGGL(lsq_count_cleanup_kernel, dim3(c->opt_cleanup_grid ? c->opt_cleanup_grid : rgrid), dim3(256), 0, st_em, dA, c->opt_recount ? 1 : 0, u.n_pn,
 		                   (const ExcEntry *)u.A.exc, (const unsigned *)u.A.exc_count, u.A.exc_cap);
 		HIP_TRY(hipGetLastError());
 	}
@@ -1893,6 +1883,7 @@ int lsq_count_status(lsq_ctx *c, uint32_t *exceptions, uint32_t *recounted) LSQ_
 	{ int rc = sync_all(c); if (rc) return rc; }
 	std::vector<unsigned> h(c->exc_count.n);
 	HIP_TRY(hipMemcpy(h.data(), c->exc_count.p, h.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+	note_overflow(c, h);
 	for (int m = 0; m < c->E->n_methods; ++m) {
 		if (exceptions) exceptions[m] = h[2 * (size_t)m];
 		if (recounted) recounted[m] = h[2 * (size_t)m + 1];

@@ -55,6 +55,19 @@ void select_counter_set(lsq_ctx *c, int set) {
 	c->dbg.p = base + 2 * per + LSQ_MAX_METHODS;
 }
 
+// An exception list that overflowed is no error -- the exception pass then counts every read of the file again, on the device,
+// and the tables are whole -- but it costs a count of its own per step: the host says so the first time it looks at that count
+// (lsq_count_status, lsq_results_counts), with what to raise (lsq_ctx_set_option "exception_capacity").
+void note_overflow(lsq_ctx *c, const std::vector<unsigned> &h) {
+	for (int m = 0; m < c->E->n_methods; ++m) {
+		if (!h[2 * (size_t)m + 1] || c->overflow_logged[m]) continue;
+		c->overflow_logged[m] = true;
+		if (c->opt_recount) continue;            // asked for (option recount_every_read): nothing to report
+		warn("read file %d: the exception list overflowed (%u pairs for %zu entries); every read of the file was counted again on the device. "
+		     "Tables are complete; raise lsq_ctx_set_option \"exception_capacity\" to avoid the second pass", m, h[2 * (size_t)m], c->reads[m].exc_cap);
+	}
+}
+
 } // namespace lsq
 
 extern "C" {
@@ -369,6 +382,7 @@ int lsq_count(lsq_ctx *c) LSQ_API_TRY {
 #endif
 	int rc = run_count(c);
 	if (rc) return rc;
+	for (bool &f : c->overflow_logged) f = false;
 	if (c->has_host && (rc = host_count(c))) return rc;        // genes beyond the kernels' limits: evaluated here (blocks)
 	c->counted = true;
 	c->solved = false;
@@ -490,6 +504,11 @@ int lsq_results_counts(lsq_ctx *c, uint64_t *class_count, uint64_t *class_bases)
 	const size_t n_cls = E.n_cls_total, n_out = (size_t)E.class_off.back(), M = (size_t)E.n_methods;
 	std::vector<unsigned long long> hc(std::max<size_t>(M * n_cls, 1)), hb(std::max<size_t>(M * n_cls, 1));
 	{ int rc = sync_all(c); if (rc) return rc; }
+	if (!c->counts_external && c->exc_count.n) {
+		std::vector<unsigned> h(c->exc_count.n);
+		HIP_TRY(hipMemcpy(h.data(), c->exc_count.p, h.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+		note_overflow(c, h);
+	}
 	if (M * n_cls) {
 		HIP_TRY(hipMemcpy(hc.data(), c->cnt.p, M * n_cls * sizeof(unsigned long long), hipMemcpyDeviceToHost));
 		HIP_TRY(hipMemcpy(hb.data(), c->bases.p, M * n_cls * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -832,6 +851,9 @@ int lsq_ctx_set_option(lsq_ctx *c, const char *name, double value) LSQ_API_TRY {
 		c->em_order_lane_valid[0] = c->em_order_lane_valid[1] = false;
 	} else if (n == "recount_every_read") {
 		c->opt_recount = value != 0;
+	} else if (n == "cleanup_workgroups") {
+		if (value < 0 || value > 4096) return fail(LSQ_E_ARG, "cleanup_workgroups out of range");
+		c->opt_cleanup_grid = (unsigned)value;
 	} else if (n == "em_guard_band") {
 		return lsq_set_em_guard_band(c, value);
 	} else

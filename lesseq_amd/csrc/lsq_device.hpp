@@ -249,6 +249,8 @@ struct lsq_ctx {
 	size_t opt_exc_cap = 0;
 	bool opt_compact_pools = true;          // "compact_pools": 0 keeps wide pool records whatever the reads look like
 	bool opt_recount = false;
+	unsigned opt_cleanup_grid = 0;          // "cleanup_workgroups": workgroups of the exception pass (0: a quarter of the compute units)
+	bool overflow_logged[LSQ_MAX_METHODS] = {};      // the warning about an overflowed exception list has been written for the latest count
 	bool opt_snap_shares = true;            // workgroup shares cut on bucket boundaries where one is near
 	bool opt_share_weighted = true;         // "share_weighted": the shares equal in cost, not in reads (run_count's plan)
 	double opt_share_cost_p2 = 4.3;         // "share_cost_two_block": a two-block record, in one-block records
@@ -293,6 +295,7 @@ int run_count(lsq_ctx *c);                           // lsq_count.hip
 int run_solve(lsq_ctx *c);
 int run_fim(lsq_ctx *c);
 int sync_all(lsq_ctx *c);                 // both streams
+void note_overflow(lsq_ctx *c, const std::vector<unsigned> &exc_count);      // lsq_device.hip: the warning about an overflowed exception list, once per count
 int host_count(lsq_ctx *c);                          // lsq_replay.hip: host buckets (genes beyond the kernels' limits)
 int host_solve(lsq_ctx *c);
 int replay_flagged(lsq_ctx *c, unsigned *n_done);    // lsq_replay.hip: the EM of guard-band events in the reference's per-read order

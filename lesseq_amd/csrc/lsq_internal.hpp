@@ -20,6 +20,8 @@ namespace lsq {
 
 // ---- error text for the calling thread -------------------------------------------------
 int fail(int status, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+void warn(const char *fmt, ...) __attribute__((format(printf, 1, 2)));      // "[LOG ... WARNING] text" on stderr (lsq_set_log_level >= 1)
+void set_log_level(int level);
 
 // ---- no exception crosses the C ABI (include/lesseq_hip.h; the reference's contract for a failure is a logged message
 // and `return 1`, count/count.cpp:20-38) -----------------------------------------------------------------------------

@@ -77,7 +77,7 @@ void make_event(Rng &g, int type, int32_t a, int R, Exons &A, Exons &B, int32_t 
 }
 
 int build_model(const lsq_synth_spec &S, SynModel &Mo) {
-	if (S.n_chrom == 0 || S.n_chrom > 1000 || S.read_length < 20 || S.read_length > 400) return fail(LSQ_E_ARG, "synthetic spec: n_chrom in 1..1000, read_length in 20..400");
+	if (S.n_chrom == 0 || S.n_chrom > 1000 || S.read_length < 20 || S.read_length > 4000) return fail(LSQ_E_ARG, "synthetic spec: n_chrom in 1..1000, read_length in 20..4000");
 	uint32_t types = S.event_types & 0xFF;
 	if (!types) types = 0xFF;
 	std::vector<int> allowed;

@@ -1313,3 +1313,119 @@ def test_whole_reference_runs_of_config0_and_config1(name, tmp_path):
     assert p.returncode == 0 and p.stdout == cexp
     p = subprocess.run([os.path.join(BIN, "solve")] + argv, capture_output=True, text=True)
     assert p.returncode == 0 and ob.solve_text_close(p.stdout, sexp)
+
+
+# ---- round 4 ----------------------------------------------------------------------------------------------------------------
+
+def test_long_reads_choose_wide_records_and_match_the_oracle(tmp_path):
+    """reads of 1 500 bases (single blocks of 1-1.5 kb, junction reads): no block fits a compact record's ten length bits, the
+    ingest routes the file again for wide records by itself (common/read.h:204-274 on multi-kb blocks) -- tables as the oracle's"""
+    spec = L.SynthSpec(77, 300, 60000, 1500, 3, L.EVENT_TYPES)
+    L.synth_write(spec, str(tmp_path), "l")
+    argv = ["0", "l", "./", "LH_GENE_TXT", str(tmp_path / "l.interval"), "UCSC_GENE2ISOFORM", str(tmp_path / "l.map"),
+            "0", "100000000", "MRF_SINGLE", "SHORT_READ", "1500", str(tmp_path / "l.mrf"), str(60000 * 1500)]
+    rc, otext, exact = ob.run("solve", argv)
+    assert rc == 0
+    compare_exact(gpu_exact(argv), exact, "long reads")
+    rc, text = L.cli_run("count", argv[:-1])
+    rc2, ctext, _ = ob.run("count", argv[:-1])
+    assert rc == rc2 == 0 and text == ctext
+    rc, text = L.cli_run("solve", argv)
+    assert rc == 0 and ob.solve_text_close(text, otext)
+    # ... and it was the wide-record kernel that counted, chosen by the ingest, from the text as from parsed arrays
+    ann = L.Annotation(argv[4], argv[6])
+    ev = L.Events(ann, ("SHORT_READ",), (1500,))
+    ctx = L.Context(0)
+    ctx.upload_events(ev)
+    ctx.upload_reads_mrf(0, argv[12])
+    fmt = ctx.pool_format(0)
+    assert fmt[0] is False and fmt[2][0] > 20000 and fmt[2][2] < fmt[2][0] // 4
+    ctx.count()
+    a = [x.copy() for x in ctx.counts()]
+    ctx.upload_reads(0, L.Reads.from_mrf(argv[12], ev))
+    assert ctx.pool_format(0)[0] is False
+    ctx.count()
+    b = ctx.counts()
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and int(a[0].sum()) > 20000
+    ctx.close()
+
+
+@pytest.mark.parametrize("zipf", [False, True], ids=["even_depth", "zipf_depth"])
+def test_coordinate_sorted_file_vs_oracle(zipf, tmp_path):
+    """the same reads in coordinate order, as an aligner's sorted output has them: neighbouring lines share a bucket, a cell and
+    -- with hot genes -- a counter; line numbers (read names) follow the file, so the oracle reads the sorted file too"""
+    spec = L.SynthSpec(83, 1500, 300000, 100, 4, L.EVENT_TYPES, zipf, sorted_reads=True)
+    L.synth_write(spec, str(tmp_path), "s")
+    lines = open(tmp_path / "s.mrf").read().split("\n")[1:-1]
+    keys = [(int(l.split(":")[0][3:]), int(l.split(":")[2])) for l in lines]
+    assert keys == sorted(keys) and len(lines) == 300000
+    argv = ["0", "s", "./", "LH_GENE_TXT", str(tmp_path / "s.interval"), "UCSC_GENE2ISOFORM", str(tmp_path / "s.map"),
+            "0", "100000000", "MRF_SINGLE", "SHORT_READ", "100", str(tmp_path / "s.mrf"), str(300000 * 100)]
+    rc, otext, exact = ob.run("solve", argv)
+    assert rc == 0
+    compare_exact(gpu_exact(argv), exact, "sorted")
+    rc, text = L.cli_run("count", argv[:-1])          # (the executable's loader: the device parser and the chain behind it)
+    rc2, ctext, _ = ob.run("count", argv[:-1])
+    assert rc == rc2 == 0 and text == ctext
+    # the generator's direct read set is the file's
+    ann = L.Annotation(argv[4], argv[6])
+    ev = L.Events(ann, ("SHORT_READ",), (100,))
+    ctx = L.Context(0)
+    ctx.upload_events(ev)
+    ctx.upload_reads(0, L.Reads.synthetic(spec, ev))
+    ctx.count()
+    a = [x.copy() for x in ctx.counts()]
+    ctx.upload_reads_mrf(0, argv[12])
+    ctx.count()
+    b = ctx.counts()
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    ctx.close()
+
+
+def test_overflow_recount_on_any_number_of_workgroups_and_its_warning(tmp_path):
+    """the recount an overflowed exception list ends in is bucket by bucket, each bucket cleared and counted by one wave: the same
+    tables from 1, 16 or 300 workgroups of the exception pass, with a second count in flight behind the first -- and the host says
+    so, once per count, the first time it looks (log format of the reference, jsc/util/log.hpp)"""
+    import golden_inputs as gi
+    info = gi.write_events_case(str(tmp_path), "x", seed=79, n_events=300, n_reads=60000, R=60, n_chrom=3)
+    lines = open(tmp_path / "x.mrf").read().split("\n")
+    extra = []
+    for e in info["events"]:               # reads that cover an event's span exactly: the strand / name order decides (count/count.cpp:64-85)
+        gs = min(f[0][0] for f in e["forms"]); ge = max(f[-1][1] for f in e["forms"])
+        for strand in ("+", "-", e["strand"]):
+            extra.append("%s:%s:%d:%d:1:%d" % (e["chrom"], strand, gs + 1, ge, ge - gs))
+    with open(tmp_path / "x.mrf", "w") as f:
+        f.write("\n".join(lines[:-1] + extra) + "\n")
+    ann = L.Annotation(str(tmp_path / "x.interval"), str(tmp_path / "x.map"), 0, 1000)
+    ev = L.Events(ann, ("SHORT_READ",), (60,))
+    ctx = L.Context(0)
+    ctx.upload_events(ev)
+    reads = L.Reads.from_mrf(str(tmp_path / "x.mrf"), ev)
+    ctx.upload_reads(0, reads)
+    ctx.count(); ctx.solve()
+    cnt0, bases0 = [x.copy() for x in ctx.counts()]
+    assert ctx.count_status()[1] == [0]
+    L.lib.lsq_set_log_level(2)             # (an in-process run of the executables leaves its own log_level argument behind)
+    log = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "native_stderr.log")     # where conftest.py points fd 2 during a GPU test
+    seen = lambda: open(log, errors="replace").read().count("WARNING] read file 0: the exception list overflowed") if os.path.exists(log) else None
+    before = seen()
+    ctx.set_option("exception_capacity", 1)
+    ctx.upload_reads(0, reads)
+    for wgs in (1, 16, 300, 0):
+        ctx.set_option("cleanup_workgroups", wgs)
+        for _ in range(3):                 # (steps submitted back to back: the recount of one runs beside the count of the next)
+            ctx.count(); ctx.solve()
+        cnt1, bases1 = ctx.counts()
+        assert np.array_equal(cnt0, cnt1) and np.array_equal(bases0, bases1), wgs
+        exc, rec = ctx.count_status()
+        assert rec == [1] and exc[0] > 1
+        if before is not None:
+            assert seen() == before + 1, wgs          # once per count the host looked at, however often it looked
+            before += 1
+    L.lib.lsq_set_log_level(0)
+    ctx.count()
+    ctx.counts()
+    if before is not None:
+        assert seen() == before
+    L.lib.lsq_set_log_level(2)
+    ctx.close()
