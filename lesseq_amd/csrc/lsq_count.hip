@@ -1847,10 +1847,10 @@ int run_count(lsq_ctx *c) {
 	// (it turns into the recount where the exception list overflowed)
 	if (!counted_signalled) HIP_TRY(hipEventRecord(c->ev_counted2[set], st));
 	HIP_TRY(hipStreamWaitEvent(st_em, c->ev_counted2[set], 0));
-	// few workgroups: these launches normally find a handful of pairs to settle, beside the next count's kernel on a full device;
-	// when the list has overflowed the same workgroups count every read again, so not too few either (a quarter of the compute units:
-	// a C3 recount in a few milliseconds, where the sixteen of round 3 took four times as long; no workgroup waits for another)
-	const unsigned rgrid = std::max(16u, (unsigned)c->n_cu / 4u);
+	// One workgroup a compute unit: the launch normally finds a handful of pairs to settle beside the next count's kernel (C3: a step
+	// takes 0.107-0.109 ms with 16, 64, 128 or 256 of them, profiles/r04_recount_c3.json), and when the list has overflowed the same
+	// workgroups count every read again -- 14 ms per C3 step on 256, 37 on 64, 90-108 on the 16 of round 3.  No workgroup waits for another.
+	const unsigned rgrid = std::max(16u, (unsigned)c->n_cu);
 	if (c->recount_args.n < 2 * (size_t)LSQ_MAX_METHODS * sizeof(CountArgs)) {
 		int rc = c->recount_args.alloc(2 * (size_t)LSQ_MAX_METHODS * sizeof(CountArgs));
 		if (rc) return rc;

@@ -305,7 +305,9 @@ int lsq_events_upload(lsq_ctx *c, lsq_events *E) LSQ_API_TRY {
 			// the locator: bins of 2^shift bases over each chromosome's range of starts (covered regions and cluster records), the
 			// shift raised until all chromosomes together take at most 2^22 entries.  Entry k of a chromosome, for the bin's first
 			// base x and the next bin's first base y: lower bounds of x and of y among the covered starts (.x, .y) and among the
-			// cluster starts (.z, .w): a search starts one 16-byte load away from a handful of candidates.
+			// cluster starts: entry k holds the lower bounds of x (.x covered, .y clusters), entry k + 1 those of y -- read as one
+			// 16-byte pair, a search starts one load away from a handful of candidates; eight bytes a bin keep the bins of the
+			// events (where the reads are) inside the L2.
 			unsigned shift = 10;
 			std::vector<long long> lo(nc, 0), hi(nc, -1);
 			for (size_t ch = 0; ch < nc; ++ch) {
@@ -316,10 +318,10 @@ int lsq_events_upload(lsq_ctx *c, lsq_events *E) LSQ_API_TRY {
 			}
 			for (;; ++shift) {
 				unsigned long long total = 0;
-				for (size_t ch = 0; ch < nc; ++ch) if (hi[ch] >= lo[ch]) total += (unsigned long long)(((hi[ch] >> shift) - (lo[ch] >> shift)) + 1);
+				for (size_t ch = 0; ch < nc; ++ch) if (hi[ch] >= lo[ch]) total += (unsigned long long)(((hi[ch] >> shift) - (lo[ch] >> shift)) + 2);
 				if (total <= (1ull << 22) || shift >= 30) break;
 			}
-			std::vector<uint4> loc;
+			std::vector<uint2> loc;
 			for (size_t ch = 0; ch < nc; ++ch) {
 				RouteChrom &R = chrom[ch];
 				R.loc_first = (unsigned)loc.size();
@@ -328,17 +330,14 @@ int lsq_events_upload(lsq_ctx *c, lsq_events *E) LSQ_API_TRY {
 				const long long nb = ((hi[ch] - base) >> shift) + 1;
 				R.loc_base = (int)base; R.loc_nb = (unsigned)nb;
 				unsigned a = R.cov0, u = R.clu0;
-				for (long long k = 0; k < nb; ++k) {
-					const long long x = base + (k << shift), y = x + (1ll << shift);
+				for (long long k = 0; k <= nb; ++k) {               // (nb + 1 entries: a bin's upper bounds are the next entry's lower bounds)
+					const long long x = base + (k << shift);
 					while (a < R.cov1 && cov[a].x < x) ++a;
 					while (u < R.clu1 && clu[u].x < x) ++u;
-					unsigned a2 = a, u2 = u;
-					while (a2 < R.cov1 && cov[a2].x < y) ++a2;
-					while (u2 < R.clu1 && clu[u2].x < y) ++u2;
-					loc.push_back(make_uint4(a, a2, u, u2));
+					loc.push_back(make_uint2(a, u));
 				}
 			}
-			if (loc.empty()) loc.push_back(make_uint4(0, 0, 0, 0));
+			loc.push_back(make_uint2(0, 0)); loc.push_back(make_uint2(0, 0));      // (an entry is read as a pair with its successor)
 			if (cov.empty()) cov.push_back(make_int2(0, 0));
 			if (clu.empty()) clu.push_back(make_int4(0, 0, 0, 0));
 			c->loc_shift = shift;

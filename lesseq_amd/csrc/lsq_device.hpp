@@ -223,12 +223,12 @@ struct lsq_ctx {
 	DevView<unsigned> exc_count;           // per method: [2m] appended, [2m+1] overflow flag
 	// ingest tables (round 4 form): per chromosome id a RouteChrom; the covered regions as (start, end) pairs; the clusters (spans of
 	// the planned events) as (start, end, bucket, bucket's first base), cut at the bucket cuts; and the locator grid over both:
-	// per chromosome bins of 2^loc_shift bases, entry k = lower bounds of the bin's first base and of the next bin's among the
-	// covered starts (.x, .y) and the cluster starts (.z, .w) -- a search is one 16-byte load and a handful of neighbouring records
+	// per chromosome bins of 2^loc_shift bases, entry k = lower bounds of the bin's first base among the covered starts (.x) and
+	// the cluster starts (.y); entries k and k + 1, one 16-byte load, bound a search to a handful of neighbouring records
 	DevBuf<RouteChrom> route_chrom;
 	DevBuf<int2> cov;
 	DevBuf<int4> clu;
-	DevBuf<uint4> loc;
+	DevBuf<uint2> loc;
 	unsigned loc_shift = 10;
 	DevBuf<unsigned> bin_base;             // per bucket: first of its bins among all bins (n_buckets + 1)
 	size_t n_fine = 0;
@@ -249,7 +249,7 @@ struct lsq_ctx {
 	size_t opt_exc_cap = 0;
 	bool opt_compact_pools = true;          // "compact_pools": 0 keeps wide pool records whatever the reads look like
 	bool opt_recount = false;
-	unsigned opt_cleanup_grid = 0;          // "cleanup_workgroups": workgroups of the exception pass (0: a quarter of the compute units)
+	unsigned opt_cleanup_grid = 0;          // "cleanup_workgroups": workgroups of the exception pass (0: one a compute unit)
 	bool overflow_logged[LSQ_MAX_METHODS] = {};      // the warning about an overflowed exception list has been written for the latest count
 	bool opt_snap_shares = true;            // workgroup shares cut on bucket boundaries where one is near
 	bool opt_share_weighted = true;         // "share_weighted": the shares equal in cost, not in reads (run_count's plan)

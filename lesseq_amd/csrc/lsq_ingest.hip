@@ -54,7 +54,7 @@ struct RouteTables {
 	const RouteChrom *chrom;       // per chromosome id (lsq_device.hpp); a kernel may point this at its own copy in LDS
 	const int2 *cov;               // covered regions: (start, end), ascending per chromosome
 	const int4 *clu;               // clusters (spans of the planned events) cut at the bucket cuts: (start, end -- inclusive --, bucket, bucket's first base)
-	const uint4 *loc;              // locator grid (lsq_ctx::loc)
+	const uint2 *loc;              // locator grid (lsq_ctx::loc): entries k and k + 1 are read as one 16-byte pair
 	unsigned loc_shift;
 	unsigned n_chrom;
 };
@@ -96,7 +96,11 @@ __device__ inline void loc_probe(const RouteTables &T, const RouteChrom &R, cons
 	P.chrom = chrom; P.bin = k;
 	if (k < 0) { P.cov_a = P.cov_b = R.cov0; P.clu_a = P.clu_b = R.clu0; }
 	else if (k >= (long long)R.loc_nb) { P.cov_a = P.cov_b = R.cov1; P.clu_a = P.clu_b = R.clu1; }
-	else { const uint4 e = T.loc[R.loc_first + (unsigned)k]; P.cov_a = e.x; P.cov_b = e.y; P.clu_a = e.z; P.clu_b = e.w; }
+	else {
+		uint4 e;                                                  // (8-byte aligned: two entries in one load)
+		__builtin_memcpy(&e, T.loc + (R.loc_first + (unsigned)k), 16);
+		P.cov_a = e.x; P.clu_a = e.y; P.cov_b = e.z; P.clu_b = e.w;
+	}
 }
 
 // interval_list::contains_interval against the covered regions of the block's chromosome (interval_list.hpp:396-422):
@@ -606,7 +610,11 @@ __global__ void __launch_bounds__(256) lsq_group_place_kernel(PlaceArgs A) {
 	const unsigned gbase = pool ? A.jgroup_base[b] : A.cell_base[b];
 	const unsigned long long first = (pool ? A.part_off2[b] : A.part_off1[b]) + pc.y;
 	const unsigned *fine = (pool ? A.fine2 : A.fine1) + first;
-	for (unsigned q = threadIdx.x; q < n_groups; q += 256u) cur[q] = 0;
+	// the groups' first places, relative to the bucket's stretch of the pool, beside their cursors: one trip to memory for all of them
+	unsigned *goff = cur + n_groups;
+	const unsigned long long *off = pool ? A.off2 : A.off1;
+	const unsigned long long off0 = off[gbase];
+	for (unsigned q = threadIdx.x; q < n_groups; q += 256u) { cur[q] = 0; goff[q] = (unsigned)(off[gbase + q] - off0); }
 	__syncthreads();
 	if (!pc.w) {
 		for (unsigned r = threadIdx.x; r < pc.z; r += 256u) atomicAdd(&cur[fine[r] - gbase], 1u);
@@ -616,10 +624,9 @@ __global__ void __launch_bounds__(256) lsq_group_place_kernel(PlaceArgs A) {
 		__syncthreads();
 	}
 	const int base = d.lo - lsq::COMPACT_BIAS;
-	const unsigned long long *off = pool ? A.off2 : A.off1;
 	for (unsigned r = threadIdx.x; r < pc.z; r += 256u) {
-		const unsigned g = fine[r];
-		const unsigned long long w = off[g] + atomicAdd(&cur[g - gbase], 1u);
+		const unsigned g = fine[r] - gbase;
+		const unsigned long long w = off0 + goff[g] + atomicAdd(&cur[g], 1u);
 		if (!pool) {
 			const uint4 v = A.part1[first + r];
 			const int2 rec = make_int2((int)v.x, (int)v.y);
@@ -758,7 +765,7 @@ static int ingest_device(lsq_ctx *c, int method, Front &F) {
 		jg_max = std::max(jg_max, n_jg);
 		groups_max = std::max(groups_max, n_jg + n_cells + 1);
 	}
-	const size_t keys_lds = (8 * jg_max + 15) & ~(size_t)15, group_lds = img_max + keys_lds + 8 * groups_max, place_lds = 4 * groups_max;
+	const size_t keys_lds = (8 * jg_max + 15) & ~(size_t)15, group_lds = img_max + keys_lds + 8 * groups_max, place_lds = 8 * groups_max;
 	if (group_lds > 160 * 1024) return fail(LSQ_E_UNSUPPORTED, "a bucket's tables and group counters exceed the CU's LDS");
 	if (part_in_lds && part_lds > 48 * 1024) {
 		HIP_TRY(hipFuncSetAttribute((const void *)lsq_part_hist_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_lds));
