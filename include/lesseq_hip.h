@@ -160,6 +160,11 @@ int lsq_reads_arrays(const lsq_reads *r, const uint64_t **blk_off, const uint32_
 typedef struct lsq_ctx lsq_ctx;
 
 int lsq_ctx_create(int device_id, lsq_ctx **out);
+/* The same with flags.  LSQ_CTX_LANES_IN_BACKGROUND: only the upload stream is made before the call returns; the step lanes' streams
+ * and events (0.04 s of runtime calls) are made by a helper thread, which the first call that needs a lane -- lsq_events_upload
+ * comes ahead of all of them -- or lsq_ctx_destroy joins.  lsq_text_stage needs no lane: an executable copies its reads to HBM meanwhile. */
+#define LSQ_CTX_LANES_IN_BACKGROUND 1u
+int lsq_ctx_create_with(int device_id, unsigned flags, lsq_ctx **out);
 void lsq_ctx_destroy(lsq_ctx *c);
 /* The context works on HIP streams of its own.  Uploads and ingest run on one (returned here as hipStream_t in a
  * void*).  A step -- lsq_count, lsq_solve, the hand-off of its results -- runs on one of two LANES that consecutive

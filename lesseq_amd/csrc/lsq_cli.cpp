@@ -4,6 +4,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cctype>
 #include <cerrno>
 #include <cstdarg>
@@ -581,11 +582,13 @@ int run_count_solve(bool solve, int argc, const char *const *argv, std::string &
 	// ... and the same thread goes on to copy the MRF text of every read file to HBM (that needs no event
 	// table); a file that does not open or is not MRF_SINGLE is left to the main thread, which reports it
 	std::vector<lsq_text *> texts((size_t)M, nullptr);
+	std::atomic<int> ctx_ready{0};          // 1: the context exists (the thread goes on to stage the reads' text), 2: the thread has given up
 	auto make_context = [&] {
-		ctx_status = lsq_ctx_create(devices[0], &ctx_bg);
-		if (ctx_status) { ctx_error = lsq_last_error(); return; }          // the message lives in that thread
+		ctx_status = lsq_ctx_create_with(devices[0], g_is_executable ? LSQ_CTX_LANES_IN_BACKGROUND : 0u, &ctx_bg);
+		if (ctx_status) { ctx_error = lsq_last_error(); ctx_ready.store(2, std::memory_order_release); return; }          // the message lives in that thread
 		ctx_status = apply_env_options(ctx_bg);
-		if (ctx_status) { ctx_error = lsq_last_error(); return; }
+		if (ctx_status) { ctx_error = lsq_last_error(); ctx_ready.store(2, std::memory_order_release); return; }
+		ctx_ready.store(1, std::memory_order_release);
 		if (shard_reads) return;          // every GPU stages its own byte range later
 		for (int m = 0; m < M; ++m)
 			if (strcmp(fmts[m], "MRF_SINGLE") == 0 && lsq_text_stage(ctx_bg, paths[m], &texts[(size_t)m]) != LSQ_OK) texts[(size_t)m] = nullptr;
@@ -637,13 +640,26 @@ int run_count_solve(bool solve, int argc, const char *const *argv, std::string &
 		st = precheck_reads_file(fmts[m], paths[m], solve);
 		if (st) { logf(0, "%s", lsq_last_error()); return status_to_exit(st); }
 		if (!F.c) {
+			// An executable's second thread is still copying the reads' text to HBM when its context is ready: the event tables go up
+			// beside that copy (small uploads on the same stream, between two slices of the text), then this thread waits for the copy.
+			if (g_is_executable) {
+				while (ctx_ready.load(std::memory_order_acquire) == 0) std::this_thread::yield();
+				T.mark("wait for the device context");
+				if (ctx_ready.load(std::memory_order_acquire) == 1) {
+					st = lsq_events_upload(ctx_bg, F.e);
+					if (st) { const std::string msg = lsq_last_error(); join_context(); logf(0, "%s", msg.c_str()); return 3; }
+					T.mark("event tables upload");
+				}
+			}
 			join_context();
-			T.mark("wait for the device context");
+			T.mark("wait for the text copy");
 			if (ctx_status) { logf(0, "%s", ctx_error.c_str()); return 3; }
 			F.c = ctx_bg;
-			st = lsq_events_upload(F.c, F.e);
-			if (st) { logf(0, "%s", lsq_last_error()); return 3; }
-			T.mark("event tables upload");
+			if (!g_is_executable) {
+				st = lsq_events_upload(F.c, F.e);
+				if (st) { logf(0, "%s", lsq_last_error()); return 3; }
+				T.mark("event tables upload");
+			}
 		}
 		if (shard_reads && lsq_events_host_genes(F.e) > 0) {
 			logf(1, "LSQ_SHARD=reads: %lld gene(s) beyond the device kernels' limits need all of their reads in one place; the job is sharded by events instead", (long long)lsq_events_host_genes(F.e));

@@ -31,7 +31,15 @@ static hipError_t wait_for_stream(hipStream_t s) {
 	}
 }
 
+// the lanes' streams and events exist (a context made with LSQ_CTX_LANES_IN_BACKGROUND: its helper thread is joined here, once)
+int ensure_lanes(lsq_ctx *c) {
+	if (c->lanes_thread.joinable()) c->lanes_thread.join();
+	if (c->lanes_status) return fail(c->lanes_status, "%s", c->lanes_error.c_str());
+	return LSQ_OK;
+}
+
 int sync_all(lsq_ctx *c) {
+	{ const int rc = ensure_lanes(c); if (rc) return rc; }
 	HIP_TRY(wait_for_stream(c->stream_count2[0]));
 	HIP_TRY(wait_for_stream(c->stream_count2[1]));
 	HIP_TRY(wait_for_stream(c->stream_em2[0]));
@@ -72,7 +80,9 @@ void note_overflow(lsq_ctx *c, const std::vector<unsigned> &h) {
 
 extern "C" {
 
-int lsq_ctx_create(int device_id, lsq_ctx **out) LSQ_API_TRY {
+int lsq_ctx_create(int device_id, lsq_ctx **out) { return lsq_ctx_create_with(device_id, 0u, out); }
+
+int lsq_ctx_create_with(int device_id, unsigned flags, lsq_ctx **out) LSQ_API_TRY {
 	if (!out) return fail(LSQ_E_ARG, "null argument");
 	// developer aid: LSQ_CLI_TIMING=1 prints where the start-up goes (stderr)
 	const bool timing = getenv("LSQ_CLI_TIMING") != nullptr;
@@ -98,25 +108,43 @@ int lsq_ctx_create(int device_id, lsq_ctx **out) LSQ_API_TRY {
 	c->device = device_id;
 	c->n_cu = prop.multiProcessorCount;
 	HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-	for (int l = 0; l < 2; ++l) {
-		HIP_TRY(hipStreamCreateWithFlags(&c->stream_em2[l], hipStreamNonBlocking));      // (a higher stream priority changed nothing measurable)
-		HIP_TRY(hipStreamCreateWithFlags(&c->stream_count2[l], hipStreamNonBlocking));
-		HIP_TRY(hipEventCreateWithFlags(&c->ev_counted2[l], hipEventDisableTiming));
-		HIP_TRY(hipEventCreateWithFlags(&c->ev_mark2[l], hipEventDisableTiming));
-	}
-	c->stream_em = c->stream_em2[0];
-	mark("context: streams");
-	HIP_TRY(hipEventCreate(&c->ev0)); HIP_TRY(hipEventCreate(&c->ev1));
-	HIP_TRY(hipEventCreate(&c->ev2)); HIP_TRY(hipEventCreate(&c->ev3));
 	HIP_TRY(hipEventCreate(&c->evt0)); HIP_TRY(hipEventCreate(&c->evt1));
-	for (int m = 0; m < LSQ_MAX_METHODS; ++m) { HIP_TRY(hipEventCreate(&c->evf0[m])); HIP_TRY(hipEventCreate(&c->evf1[m])); }
-	mark("context: events");
+	mark("context: upload stream");
+	// The rest -- the two lanes' streams and events, 0.04 s of the runtime's time -- is not needed by what an executable does first with
+	// its context (copying the MRF text to HBM, lsq_text_stage): with LSQ_CTX_LANES_IN_BACKGROUND a helper thread makes it meanwhile,
+	// and the first call that wants a lane (lsq_events_upload is ahead of every one of them) joins it.
+	lsq_ctx *cp = c.get();
+	auto make_lanes = [cp]() -> int {
+		HIP_TRY(hipSetDevice(cp->device));
+		for (int l = 0; l < 2; ++l) {
+			HIP_TRY(hipStreamCreateWithFlags(&cp->stream_em2[l], hipStreamNonBlocking));      // (a higher stream priority changed nothing measurable)
+			HIP_TRY(hipStreamCreateWithFlags(&cp->stream_count2[l], hipStreamNonBlocking));
+			HIP_TRY(hipEventCreateWithFlags(&cp->ev_counted2[l], hipEventDisableTiming));
+			HIP_TRY(hipEventCreateWithFlags(&cp->ev_mark2[l], hipEventDisableTiming));
+		}
+		cp->stream_em = cp->stream_em2[0];
+		HIP_TRY(hipEventCreate(&cp->ev0)); HIP_TRY(hipEventCreate(&cp->ev1));
+		HIP_TRY(hipEventCreate(&cp->ev2)); HIP_TRY(hipEventCreate(&cp->ev3));
+		for (int m = 0; m < LSQ_MAX_METHODS; ++m) { HIP_TRY(hipEventCreate(&cp->evf0[m])); HIP_TRY(hipEventCreate(&cp->evf1[m])); }
+		return LSQ_OK;
+	};
+	if (flags & LSQ_CTX_LANES_IN_BACKGROUND) {
+		c->lanes_thread = std::thread([cp, make_lanes]() noexcept {
+			try { cp->lanes_status = make_lanes(); if (cp->lanes_status) cp->lanes_error = lsq_last_error(); }
+			catch (...) { cp->lanes_status = LSQ_E_INTERNAL; try { cp->lanes_error = "the lanes' helper thread failed"; } catch (...) {} }
+		});
+	} else {
+		const int rc = make_lanes();
+		if (rc) return rc;
+		mark("context: lanes");
+	}
 	*out = c.release();
 	return LSQ_OK;
 } LSQ_API_CATCH
 
 void lsq_ctx_destroy(lsq_ctx *c) {
 	if (!c) return;
+	if (c->lanes_thread.joinable()) c->lanes_thread.join();
 	(void)hipSetDevice(c->device);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	for (int l = 0; l < 2; ++l) {
@@ -148,6 +176,7 @@ int lsq_ctx_synchronize(lsq_ctx *c) LSQ_API_TRY {
 int lsq_ctx_synchronize_for(lsq_ctx *c, double seconds) LSQ_API_TRY {
 	if (!c) return fail(LSQ_E_ARG, "null context");
 	HIP_TRY(hipSetDevice(c->device));
+	{ const int rc = ensure_lanes(c); if (rc) return rc; }
 	const auto t0 = std::chrono::steady_clock::now();
 	const hipStream_t all[5] = {c->stream_count2[0], c->stream_count2[1], c->stream_em2[0], c->stream_em2[1], c->stream};
 	for (const hipStream_t s : all) {

@@ -11,6 +11,7 @@
 #include <memory>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -143,6 +144,10 @@ struct MethodReads {
 } // namespace lsq
 
 struct lsq_ctx {
+	// lsq_ctx_create_with(LSQ_CTX_LANES_IN_BACKGROUND): the helper thread that makes the lanes' streams and events, and how it ended
+	std::thread lanes_thread;
+	int lanes_status = 0;
+	std::string lanes_error;
 	int device = 0;
 	int n_cu = 256;
 	hipStream_t stream = nullptr;           // uploads, ingest and the count kernels
@@ -295,6 +300,7 @@ int run_count(lsq_ctx *c);                           // lsq_count.hip
 int run_solve(lsq_ctx *c);
 int run_fim(lsq_ctx *c);
 int sync_all(lsq_ctx *c);                 // both streams
+int ensure_lanes(lsq_ctx *c);             // lsq_device.hip: joins a context's helper thread (lanes made in the background), once
 void note_overflow(lsq_ctx *c, const std::vector<unsigned> &exc_count);      // lsq_device.hip: the warning about an overflowed exception list, once per count
 int host_count(lsq_ctx *c);                          // lsq_replay.hip: host buckets (genes beyond the kernels' limits)
 int host_solve(lsq_ctx *c);

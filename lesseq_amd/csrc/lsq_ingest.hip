@@ -207,19 +207,22 @@ __device__ inline void push3(int &a0, int &a1, int &a2, int &k, const int v) {
 
 // The kept blocks of one read as they come, merged by interval_list's rule.  Nearly every read keeps one or two merged
 // blocks: those live in registers (the rule written out for a list of at most two); a third block moves the read to arrays.
+// (the arrays are an object of their own: as members they kept the whole accumulator in the private segment -- every field a
+// scratch store and load per block, 10 GB of scratch traffic per C3 file -- where now only a read's third block touches it)
+struct ReadBig { int bs[INGEST_MAX_BLOCKS], be[INGEST_MAX_BLOCKS]; };
 struct ReadAcc {
 	int s0, e0, s1, e1;
 	int n;                          // merged blocks
 	int chrom;
 	unsigned strand;
 	bool any, ok, big;
-	int bs[INGEST_MAX_BLOCKS], be[INGEST_MAX_BLOCKS];
 	__device__ inline void init() { s0 = e0 = s1 = e1 = 0; n = 0; chrom = -1; strand = 0; any = false; ok = true; big = false; }
 	// a block that passed the containment filter (count/count.cpp:319-323)
-	__device__ inline void add(const unsigned c, const unsigned sid, const int start, const int end) {
+	__device__ inline void add(ReadBig &B, const unsigned c, const unsigned sid, const int start, const int end) {
 		any = true; chrom = (int)c; strand = sid;
 		if (!(start < end)) return;
-		if (big) { ok = small_add_interval(bs, be, n, start, end) && ok; return; }
+		if (big) { ok = small_add_interval(B.bs, B.be, n, start, end) && ok; return; }
+		if (n == 0) { s0 = start; e0 = end; n = 1; return; }
 		const bool h0 = n > 0, h1 = n > 1;
 		const int ss = (int)(h0 && s0 < start) + (int)(h1 && s1 < start), se = (int)(h0 && e0 < start) + (int)(h1 && e1 < start);
 		const int es = (int)(h0 && s0 < end) + (int)(h1 && s1 < end), ee = (int)(h0 && e0 < end) + (int)(h1 && e1 < end);
@@ -236,18 +239,18 @@ struct ReadAcc {
 		if (h0 && 0 >= ee) push3(b0, b1, b2, kb, e0);
 		if (h1 && 1 >= ee) push3(b0, b1, b2, kb, e1);
 		if (ka <= 2) { s0 = a0; s1 = a1; e0 = b0; e1 = b1; n = ka; }
-		else { bs[0] = a0; bs[1] = a1; bs[2] = a2; be[0] = b0; be[1] = b1; be[2] = b2; n = 3; big = true; }
+		else { B.bs[0] = a0; B.bs[1] = a1; B.bs[2] = a2; B.be[0] = b0; B.be[1] = b1; B.be[2] = b2; n = 3; big = true; }
 	}
 	// the read is complete: its key and blocks to their place (index i of the pass)
-	__device__ inline void finish(const RouteTables &T, const RouteChrom *chroms, LocProbe &P, const RouteOut &O, const unsigned i) {
+	__device__ inline void finish(const ReadBig &B, const RouteTables &T, const RouteChrom *chroms, LocProbe &P, const RouteOut &O, const unsigned i) {
 		unsigned key = ROUTE_KEY_DROPPED;
 		int4 rec = make_int4(0, 0, 0, 0);
 		if (any && n > 0) {
 			long long tot = 0;
 			if (big) {
-				s0 = bs[0]; e0 = be[0];
-				if (n > 1) { s1 = bs[1]; e1 = be[1]; }
-				for (int q = 0; q < n; ++q) tot += be[q] - bs[q];
+				s0 = B.bs[0]; e0 = B.be[0];
+				if (n > 1) { s1 = B.bs[1]; e1 = B.be[1]; }
+				for (int q = 0; q < n; ++q) tot += B.be[q] - B.bs[q];
 			} else tot = (long long)(e0 - s0) + (n > 1 ? (long long)(e1 - s1) : 0ll);
 			if (!ok || tot >= (1 << 18)) atomicMax(&O.nb_tot[2], 1ull);
 			key = route_key_unrouted((unsigned)n);
@@ -271,7 +274,7 @@ struct ReadAcc {
 					atomicAdd(&O.cntn[b], 1u); atomicAdd(&O.cntnb[b], (unsigned)n);
 					if (idx < O.nb_cap && boff + (unsigned)n <= O.nbb_cap) {
 						O.nb_ent[idx] = make_uint4(i, b, (unsigned)n | (strand << 8), (unsigned)boff);
-						if (big) { for (int q = 0; q < n; ++q) O.nb_blk[boff + q] = make_int2(bs[q], be[q]); }
+						if (big) { for (int q = 0; q < n; ++q) O.nb_blk[boff + q] = make_int2(B.bs[q], B.be[q]); }
 						else { O.nb_blk[boff] = make_int2(s0, e0); if (n > 1) O.nb_blk[boff + 1] = make_int2(s1, e1); }
 					}
 				}
@@ -324,7 +327,10 @@ struct IngestRaw {
 	const unsigned char *blk_strand;
 };
 
-__global__ void __launch_bounds__(256) lsq_route_raw_kernel(RouteTables T, IngestRaw R, RouteOut O) {
+#ifndef LSQ_RAW_WAVES
+#define LSQ_RAW_WAVES 8
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LSQ_RAW_WAVES))) lsq_route_raw_kernel(RouteTables T, IngestRaw R, RouteOut O) {
 	__shared__ RouteChrom chrom_lds[ROUTE_CHROM_LDS];
 	const RouteChrom *chroms = route_stage_chroms(T, chrom_lds);
 	const unsigned long long gsz = (unsigned long long)gridDim.x * blockDim.x;
@@ -333,15 +339,16 @@ __global__ void __launch_bounds__(256) lsq_route_raw_kernel(RouteTables T, Inges
 	for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < R.n_reads; i += gsz) {
 		const unsigned long long b0 = R.blk_off[i], b1 = R.blk_off[i + 1];
 		ReadAcc A;
+		ReadBig B;
 		A.init();
 		for (unsigned long long j = b0; j < b1; ++j) {
 			const unsigned c = R.blk_chrom[j];
 			if (c >= T.n_chrom) continue;
 			const int bs = R.blk_start[j], be = R.blk_end[j];
 			if (!route_covered(T, chroms[c], (int)c, bs, be, P)) continue;
-			A.add(c, R.blk_strand[j], bs, be);
+			A.add(B, c, R.blk_strand[j], bs, be);
 		}
-		A.finish(T, chroms, P, O, (unsigned)i);
+		A.finish(B, T, chroms, P, O, (unsigned)i);
 	}
 }
 
@@ -731,6 +738,7 @@ static int ingest_device(lsq_ctx *c, int method, Front &F) {
 	if (n > 0xFFFFFFF0ull) return fail(LSQ_E_RANGE, "more than 2^32 reads in one file");
 	hipStream_t st = c->stream;
 	int rc;
+	if ((rc = ensure_lanes(c))) return rc;
 	// the pools of this method are rewritten below: an exception pass of an earlier count may still read them on the result stream
 	HIP_TRY(hipStreamSynchronize(c->stream_em2[0]));
 	HIP_TRY(hipStreamSynchronize(c->stream_em2[1]));

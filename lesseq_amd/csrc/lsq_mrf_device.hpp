@@ -281,6 +281,7 @@ __device__ inline void mrf_route_line(const MrfText &X, const MrfDict &D, const 
 	const long long LIM = 1ll << 30;
 	if (lsq::mrf_line_is_skipped(line)) { O.key[i] = ROUTE_KEY_DROPPED; return; }
 	ReadAcc A;
+	ReadBig B;
 	A.init();
 	LocProbe P;
 	P.chrom = -1; P.bin = 0;
@@ -289,10 +290,10 @@ __device__ inline void mrf_route_line(const MrfText &X, const MrfDict &D, const 
 		const long long s0 = start - 1, e0 = end;
 		if (cid >= T.n_chrom || s0 <= -LIM || e0 >= LIM || s0 >= LIM || e0 <= -LIM) return;
 		if (!route_covered(T, chroms[cid], (int)cid, (int)s0, (int)e0, P)) return;
-		A.add(cid, mrf_strand_slot(lds_strand, D.strand_tab, strand, err), (int)s0, (int)e0);
+		A.add(B, cid, mrf_strand_slot(lds_strand, D.strand_tab, strand, err), (int)s0, (int)e0);
 	});
 	if (!ok) { atomicMin(&err[0], X.first_line + i); O.key[i] = ROUTE_KEY_DROPPED; return; }
-	A.finish(T, chroms, P, O, (unsigned)i);
+	A.finish(B, T, chroms, P, O, (unsigned)i);
 }
 
 // lists of work the fast kernel hands on: counts[0] tiles, counts[1] lines, counts[2] set when the line list ran over
@@ -345,6 +346,18 @@ __global__ void __launch_bounds__(256) lsq_mrf_route_lines_kernel(MrfText X, Mrf
 // Whatever does not fit this shape -- fewer than four colons before the next comma or the line's end, a sign or a stray
 // byte in a coordinate, ten digits, a chromosome or strand of eight bytes or more, a line that starts ahead of the window
 // -- is not decided here: the line goes on a list and lsq_mrf_route_lines_kernel runs the shared splitter on it.
+// Waves a SIMD the compiler is asked to leave room for.  Left alone it takes 156 registers (three waves) and the kernel, a chain of
+// LDS and L2 round trips per line, waits: 10.1 ms per C3 file; held to 128 (four waves, with spills) 13.5; asked for five or more
+// it settles at 75 registers -- six waves, what the 23 KB of LDS tables allow -- with the per-line state it cannot keep in registers
+// in the private segment (L1-resident): 6.4 ms (same box, tools/ingest_bench.py).
+#ifndef LSQ_FAST_WAVES
+#define LSQ_FAST_WAVES 6
+#endif
+#if LSQ_FAST_WAVES
+#define LSQ_FAST_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(LSQ_FAST_WAVES)))
+#else
+#define LSQ_FAST_WAVES_ATTR
+#endif
 constexpr unsigned FP_WIN = MRF_LB + MRF_TILE;          // 8 192
 constexpr unsigned FP_PAD = 16;                          // bytes of LDS ahead of the window (a coordinate's eight bytes may begin there)
 constexpr unsigned FP_DCAP = 3072, FP_NCAP = 1024;       // delimiters / newlines a window may hold (a tile of reads: ~1 500 / ~220)
@@ -401,7 +414,7 @@ __device__ inline bool fp_number8(const unsigned long long w, const unsigned len
 	return digits;
 }
 
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) lsq_mrf_route_fast_kernel(MrfText X, MrfDict G, MrfFastDict FD, RouteTables T, RouteOut O, unsigned long long *err, MrfHandOff H) {
+__global__ void __launch_bounds__(256) LSQ_FAST_WAVES_ATTR lsq_mrf_route_fast_kernel(MrfText X, MrfDict G, MrfFastDict FD, RouteTables T, RouteOut O, unsigned long long *err, MrfHandOff H) {
 	__shared__ MrfFastLds S;
 	const unsigned tid = threadIdx.x;
 	const unsigned long long t0 = (unsigned long long)blockIdx.x * MRF_TILE;
@@ -478,6 +491,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) l
 		bool odd = false, dropped = false;
 		if (eol > start && text[start] == '#') dropped = true;       // a comment line takes a line number only (count.cpp:288)
 		ReadAcc A;
+		ReadBig B;
 		A.init();
 		LocProbe P;
 		P.chrom = -1; P.bin = 0;
@@ -528,7 +542,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) l
 					unsigned sid = 256u;
 					for (unsigned q = 0; q < 256u; ++q) { const unsigned long long cur = S.strand[q]; if (cur == tkey) { sid = q; break; } if (cur == STRAND_EMPTY) break; }
 					if (sid == 256u) sid = mrf_strand_slot(nullptr, G.strand_tab, MrfLdsView{text + (p1 + 1u), l_str}, err);
-					A.add(cid, sid, s0, e0);
+					A.add(B, cid, sid, s0, e0);
 				}
 			}
 			if (kind != 1u) break;                       // the line's end
@@ -536,7 +550,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) l
 		}
 		if (odd) { defer(i, w0 + start, eol - start); continue; }
 		if (dropped) { O.key[i] = ROUTE_KEY_DROPPED; continue; }
-		A.finish(T, S.chrom, P, O, (unsigned)i);
+		A.finish(B, T, S.chrom, P, O, (unsigned)i);
 	}
 }
 
