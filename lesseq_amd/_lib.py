@@ -171,7 +171,16 @@ def hip_versions():
     return comp.value, run.value
 
 
-_warn_on_runtime_mismatch()
+# (not at import: hipRuntimeGetVersion may start the HIP runtime, and importing the package -- build(), the CPU test run, a launcher
+# that goes on to spawn workers -- must make no HIP call.  lesseq_amd.api.Context makes the check when the first context exists.)
+_runtime_checked = False
+
+
+def check_runtime_once():
+    global _runtime_checked
+    if not _runtime_checked:
+        _runtime_checked = True
+        _warn_on_runtime_mismatch()
 
 
 def check(status):

@@ -4,7 +4,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import lib, check, SynthSpecStruct, u64, u32, i32, u16, u8, i64, vp, cs, P
+from ._lib import lib, check, check_runtime_once, SynthSpecStruct, u64, u32, i32, u16, u8, i64, vp, cs, P
 
 EVENT_TYPES = ("SE", "RI", "A5SS", "A3SS", "MXE", "AFE", "ALE", "T3")
 
@@ -230,6 +230,7 @@ class Context:
         check(lib.lsq_ctx_create(device, C.byref(h)))
         self.h = h
         self.events = None
+        check_runtime_once()              # (the HIP runtime is up now: compiled-against and running versions are compared once)
         # LSQ_OPTIONS="name=value,...": the executables pass these to lsq_ctx_set_option (lsq_cli.cpp), so does this class
         for item in filter(None, os.environ.get("LSQ_OPTIONS", "").split(",")):
             if "=" in item:

@@ -824,9 +824,16 @@ int lsq_debug_hip_versions(int *compiled, int *runtime) {
 int lsq_debug_set_em_order(lsq_ctx *c, const uint32_t *order, unsigned n_small_places, unsigned n_places) LSQ_API_TRY {
 	HIP_TRY(hipSetDevice(c->device));
 	{ int rc = sync_all(c); if (rc) return rc; }
+	if (n_small_places > n_places) return fail(LSQ_E_ARG, "more small places than places");
 	int rc = c->em_order.upload(order, n_places, c->stream);
 	if (rc) return rc;
 	HIP_TRY(hipStreamSynchronize(c->stream));
+	{
+		// the closed form's lists are sized by the lean group (lsq_events_upload): a placement that makes the group larger takes larger lists
+		const size_t np = std::max<size_t>(n_small_places, 1);
+		for (int l = 0; l < 2; ++l)
+			if (c->em_tail_flag[l].n < np && ((rc = c->em_tail_u32[l].alloc(2 * np)) || (rc = c->em_tail_flag[l].alloc(np)) || (rc = c->em_tail_f64[l].alloc(3 * np)))) return rc;
+	}
 	c->em_small_places = n_small_places; c->em_places = n_places;
 	c->em_order_lane_valid[0] = c->em_order_lane_valid[1] = false;
 	c->opt_em_regroup = false;            // a placement given by hand stays

@@ -424,18 +424,33 @@ __global__ void __launch_bounds__(PART_WG) lsq_part_scatter_kernel(PartArgs A) {
 		for (unsigned e = threadIdx.x; e < 2u * B; e += PART_WG) { const unsigned c = part_lds[e]; part_lds[e] = c ? atomicAdd(&A.cursor[e], c) : 0u; }
 		__syncthreads();
 	}
-	for (unsigned long long i = c0 + threadIdx.x; i < c1; i += PART_WG) {
-		const unsigned k = A.key[i];
-		if (!route_key_is_routed(k) || (k & 3u) >= 2u) continue;
-		const unsigned pool = k & 3u, b = (k >> 2) & ROUTE_NO_BUCKET, strand = k >> 24;
-		const unsigned at = LDS ? atomicAdd(&part_lds[pool * B + b], 1u) : atomicAdd(&A.cursor[pool * B + b], 1u);
-		const int4 r = A.rec[i];
-		const unsigned line = A.line_no ? A.line_no[i] : (unsigned)(A.first_line + i);
-		if (pool == 0u) A.part1[A.off1[b] + at] = make_uint4((unsigned)r.x, (unsigned)r.y, line, strand);
-		else {
-			const unsigned long long w = 2ull * (A.off2[b] + at);
-			A.part2[w] = make_uint4((unsigned)r.x, (unsigned)r.y, (unsigned)r.z, (unsigned)r.w);
-			A.part2[w + 1] = make_uint4(line, strand, 0u, 0u);
+	// (four reads a lane at a time: their keys and blocks are on their way together, then their places, then their stores)
+	for (unsigned long long i0 = c0 + threadIdx.x; i0 < c1; i0 += 4ull * PART_WG) {
+		unsigned k[4]; int4 r[4]; unsigned line[4]; bool on[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const unsigned long long i = i0 + (unsigned long long)u * PART_WG;
+			on[u] = i < c1;
+			k[u] = on[u] ? A.key[i] : ROUTE_KEY_DROPPED;
+			on[u] = on[u] && route_key_is_routed(k[u]) && (k[u] & 3u) < 2u;
+		}
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const unsigned long long i = i0 + (unsigned long long)u * PART_WG;
+			r[u] = on[u] ? A.rec[i] : make_int4(0, 0, 0, 0);
+			line[u] = on[u] ? (A.line_no ? A.line_no[i] : (unsigned)(A.first_line + i)) : 0u;
+		}
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			if (!on[u]) continue;
+			const unsigned pool = k[u] & 3u, b = (k[u] >> 2) & ROUTE_NO_BUCKET, strand = k[u] >> 24;
+			const unsigned at = LDS ? atomicAdd(&part_lds[pool * B + b], 1u) : atomicAdd(&A.cursor[pool * B + b], 1u);
+			if (pool == 0u) A.part1[A.off1[b] + at] = make_uint4((unsigned)r[u].x, (unsigned)r[u].y, line[u], strand);
+			else {
+				const unsigned long long w = 2ull * (A.off2[b] + at);
+				A.part2[w] = make_uint4((unsigned)r[u].x, (unsigned)r[u].y, (unsigned)r[u].z, (unsigned)r[u].w);
+				A.part2[w + 1] = make_uint4(line[u], strand, 0u, 0u);
+			}
 		}
 	}
 }
@@ -631,19 +646,30 @@ __global__ void __launch_bounds__(256) lsq_group_place_kernel(PlaceArgs A) {
 		__syncthreads();
 	}
 	const int base = d.lo - lsq::COMPACT_BIAS;
-	for (unsigned r = threadIdx.x; r < pc.z; r += 256u) {
-		const unsigned g = fine[r] - gbase;
-		const unsigned long long w = off0 + goff[g] + atomicAdd(&cur[g], 1u);
-		if (!pool) {
-			const uint4 v = A.part1[first + r];
-			const int2 rec = make_int2((int)v.x, (int)v.y);
-			if (A.compact) pool_store<true>(A.p1, w, rec, base); else pool_store<false>(A.p1, w, rec, base);
-			A.p1_strand[w] = (unsigned char)v.w; A.p1_line[w] = v.z;
-		} else {
-			const uint4 v = A.part2[2ull * (first + r)], x = A.part2[2ull * (first + r) + 1];
-			const int4 rec = make_int4((int)v.x, (int)v.y, (int)v.z, (int)v.w);
-			if (A.compact) pool_store<true>(A.p2, w, rec, base); else pool_store<false>(A.p2, w, rec, base);
-			A.p2_strand[w] = (unsigned char)x.y; A.p2_line[w] = x.x;
+	// (four records a lane at a time: loads together, then the places, then the stores)
+	for (unsigned r0 = threadIdx.x; r0 < pc.z; r0 += 1024u) {
+		unsigned g[4]; uint4 v[4], x[4]; bool on[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const unsigned r = r0 + 256u * (unsigned)u;
+			on[u] = r < pc.z;
+			g[u] = on[u] ? fine[r] - gbase : 0u;
+			if (!pool) { v[u] = on[u] ? A.part1[first + r] : make_uint4(0, 0, 0, 0); x[u] = v[u]; }
+			else { v[u] = on[u] ? A.part2[2ull * (first + r)] : make_uint4(0, 0, 0, 0); x[u] = on[u] ? A.part2[2ull * (first + r) + 1] : make_uint4(0, 0, 0, 0); }
+		}
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			if (!on[u]) continue;
+			const unsigned long long w = off0 + goff[g[u]] + atomicAdd(&cur[g[u]], 1u);
+			if (!pool) {
+				const int2 rec = make_int2((int)v[u].x, (int)v[u].y);
+				if (A.compact) pool_store<true>(A.p1, w, rec, base); else pool_store<false>(A.p1, w, rec, base);
+				A.p1_strand[w] = (unsigned char)v[u].w; A.p1_line[w] = v[u].z;
+			} else {
+				const int4 rec = make_int4((int)v[u].x, (int)v[u].y, (int)v[u].z, (int)v[u].w);
+				if (A.compact) pool_store<true>(A.p2, w, rec, base); else pool_store<false>(A.p2, w, rec, base);
+				A.p2_strand[w] = (unsigned char)x[u].y; A.p2_line[w] = x[u].x;
+			}
 		}
 	}
 }
