@@ -161,6 +161,7 @@ void lsq_ctx_destroy(lsq_ctx *c) {
 	if (c->evt1) (void)hipEventDestroy(c->evt1);
 	for (int m = 0; m < LSQ_MAX_METHODS; ++m) { if (c->evf0[m]) (void)hipEventDestroy(c->evf0[m]); if (c->evf1[m]) (void)hipEventDestroy(c->evf1[m]); }
 	for (hipEvent_t e : c->ing_ev) if (e) (void)hipEventDestroy(e);
+	for (int q = 0; q < 2; ++q) { if (c->pin_buf[q]) (void)hipHostFree(c->pin_buf[q]); if (c->pin_ev[q]) (void)hipEventDestroy(c->pin_ev[q]); }
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	for (int l = 0; l < 2; ++l) { if (c->stream_em2[l]) (void)hipStreamDestroy(c->stream_em2[l]); if (c->stream_count2[l]) (void)hipStreamDestroy(c->stream_count2[l]); }
 	delete c;

@@ -275,6 +275,9 @@ struct lsq_ctx {
 	std::map<size_t, std::vector<unsigned short>> host_seq;     // host buckets: [device event * M + method] -> classes of its valid reads, index order
 	float count_ms = 0, solve_ms = 0;
 	float mrf_h2d_ms = 0, mrf_parse_ms = 0;
+	// two pinned 32 MiB host buffers and their "drained" events, made at the first large host-to-device copy (lsq_mrf_device.hpp: pinned_pipeline)
+	unsigned char *pin_buf[2] = {nullptr, nullptr};
+	hipEvent_t pin_ev[2] = {nullptr, nullptr};
 	// device time and bytes of the stages of the latest ingest (lsq_ingest.hip: lsq_last_ingest_stages)
 	hipEvent_t ing_ev[2 * LSQ_INGEST_STAGES] = {};
 	float ing_ms[LSQ_INGEST_STAGES] = {};

@@ -616,6 +616,64 @@ struct MappedFile {
 	~MappedFile() { if (data) munmap((void *)data, len); }
 };
 
+// Host memory (or a file) to HBM through two pinned 32 MiB buffers of the context: a few worker threads fill one -- fill(dst, offset,
+// bytes) of their share of the slice: pread() of a file, memcpy() of an array -- while the DMA engine drains the other.  38-53 GB/s,
+// against 18-20 GB/s of the runtime's own staging of pageable memory on its first pass over it (it pins the pages it is given, which
+// is what a first copy of fresh arrays or of a fresh mapping pays for).  The buffers are made once per context.
+constexpr size_t PIN_SLICE = 32ull << 20;
+static int ensure_pinned_buffers(lsq_ctx *c) {
+	if (c->pin_buf[0] && c->pin_buf[1] && c->pin_ev[0] && c->pin_ev[1]) return LSQ_OK;
+	const bool ok = hipHostMalloc((void **)&c->pin_buf[0], PIN_SLICE, hipHostMallocDefault) == hipSuccess &&
+	                hipHostMalloc((void **)&c->pin_buf[1], PIN_SLICE, hipHostMallocDefault) == hipSuccess &&
+	                hipEventCreateWithFlags(&c->pin_ev[0], hipEventDisableTiming) == hipSuccess &&
+	                hipEventCreateWithFlags(&c->pin_ev[1], hipEventDisableTiming) == hipSuccess;
+	if (!ok) {
+		(void)hipGetLastError();
+		for (int q = 0; q < 2; ++q) { if (c->pin_buf[q]) (void)hipHostFree(c->pin_buf[q]); if (c->pin_ev[q]) (void)hipEventDestroy(c->pin_ev[q]); c->pin_buf[q] = nullptr; c->pin_ev[q] = nullptr; }
+		return fail(LSQ_E_INTERNAL, "no pinned host buffers");
+	}
+	return LSQ_OK;
+}
+template <class Fill>
+static int pinned_pipeline(lsq_ctx *c, unsigned char *d_dst, const size_t len, Fill &&fill, const char *what) {
+	if (len == 0) return LSQ_OK;
+	int rc = ensure_pinned_buffers(c);
+	if (rc) return rc;
+	hipStream_t st = c->stream;
+	unsigned char *const *pin = c->pin_buf;
+	int rc_copy = LSQ_OK;
+	const int T = std::max(1, std::min(16, host_threads(0)));
+	const long n_slices = (long)((len + PIN_SLICE - 1) / PIN_SLICE);
+	std::atomic<long> go{-1}, filled{0};
+	std::atomic<int> io_error{0};
+	std::atomic<bool> give_up{false};         // set on every way out of this function: a worker that still waits for its slice leaves
+	ThreadGroup workers;                      // (joined on every way out, after give_up is set: declared first, destroyed last)
+	struct GiveUp { std::atomic<bool> &f; ~GiveUp() { f.store(true, std::memory_order_release); } } give_up_on_exit{give_up};
+	for (int t = 0; t < T; ++t) workers.spawn([&, t] {
+		for (long sl = 0; sl < n_slices; ++sl) {
+			while (go.load(std::memory_order_acquire) < sl) { if (give_up.load(std::memory_order_acquire)) return; std::this_thread::yield(); }
+			const size_t off = (size_t)sl * PIN_SLICE, nby = std::min<size_t>(PIN_SLICE, len - off);
+			const size_t a = nby * (size_t)t / (size_t)T, b = nby * (size_t)(t + 1) / (size_t)T;
+			if (b > a && !fill(pin[sl & 1] + a, off + a, b - a)) io_error.store(1);
+			filled.fetch_add(1, std::memory_order_release);
+		}
+	});
+	for (long sl = 0; sl < n_slices; ++sl) {
+		const int k = (int)(sl & 1);
+		if (sl >= 2 && rc_copy == LSQ_OK && hipEventSynchronize(c->pin_ev[k]) != hipSuccess) rc_copy = fail(LSQ_E_DEVICE, "hipEventSynchronize failed in the copy of %s", what);
+		go.store(sl, std::memory_order_release);
+		while (filled.load(std::memory_order_acquire) < (long)T * (sl + 1)) std::this_thread::yield();
+		const size_t off = (size_t)sl * PIN_SLICE, nby = std::min<size_t>(PIN_SLICE, len - off);
+		if (rc_copy == LSQ_OK && (hipMemcpyAsync(d_dst + off, pin[k], nby, hipMemcpyHostToDevice, st) != hipSuccess || hipEventRecord(c->pin_ev[k], st) != hipSuccess))
+			rc_copy = fail(LSQ_E_DEVICE, "hipMemcpyAsync failed in the copy of %s", what);
+	}
+	workers.join();
+	if (hipStreamSynchronize(st) != hipSuccess && rc_copy == LSQ_OK) rc_copy = fail(LSQ_E_DEVICE, "the copy of %s failed", what);
+	if (workers.failed() && rc_copy == LSQ_OK) rc_copy = fail(LSQ_E_INTERNAL, "a helper thread failed: %s", workers.error().c_str());
+	if (io_error.load() && rc_copy == LSQ_OK) rc_copy = fail(LSQ_E_IO, "cannot read %s", what);
+	return rc_copy;
+}
+
 static int stage_text_file(lsq_ctx *c, const char *path, unsigned long long byte_begin, unsigned long long byte_end, lsq_text &T) {
 	HostStopwatch SW;
 	int fd = open(path, O_RDONLY);
@@ -624,17 +682,16 @@ static int stage_text_file(lsq_ctx *c, const char *path, unsigned long long byte
 	if (fstat(fd, &sb) != 0) { close(fd); return fail(LSQ_E_IO, "cannot stat %s", path); }
 	// Small files are mapped and copied as they are (the runtime stages pageable memory through its own
 	// pinned buffers on one thread: 18 GB/s measured).  Files of a gigabyte and more are never mapped:
-	// a few worker threads pread() them, a slice at a time, into two pinned 32 MiB buffers of ours while
+	// a few worker threads pread() them, a slice at a time, into the context's two pinned buffers while
 	// the DMA engine drains the other buffer (38 GB/s, and no page-table build-up and tear-down for
 	// gigabytes of mapping).
 	const unsigned long long file_len = (unsigned long long)sb.st_size;
 	byte_end = std::min(byte_end, file_len);
 	byte_begin = std::min(byte_begin, byte_end);
 	const unsigned long long len = byte_end - byte_begin;          // the bytes [byte_begin, byte_end) of the file
-	const size_t SLICE = 32ull << 20;
-	unsigned long long pinned_min = 1ull << 30;           // below a gigabyte allocating the pinned buffers costs more than they save
+	unsigned long long pinned_min = 1ull << 30;           // below a gigabyte making the pinned buffers (once per context) costs more than they save
 	if (const char *e = getenv("LSQ_PINNED_COPY_MIN")) { const long long v = atoll(e); if (v >= 0) pinned_min = (unsigned long long)v; }   // tests
-	bool pinned = len >= pinned_min && len >= 2 * SLICE;
+	bool pinned = len >= pinned_min && len >= 2 * PIN_SLICE;
 	struct FdCloser { int fd; ~FdCloser() { if (fd >= 0) close(fd); } } fdc{fd};
 	MappedFile mf;
 	hipStream_t st = c->stream;
@@ -644,65 +701,31 @@ static int stage_text_file(lsq_ctx *c, const char *path, unsigned long long byte
 	DevBuf<unsigned char> &d_text = T.d_text;
 	if ((rc = d_text.alloc(len + 16))) return rc;
 	HIP_TRY(hipEventRecord(c->evt0, st));
-	{
-		unsigned char *pin[2] = {nullptr, nullptr};
-		hipEvent_t drained[2] = {nullptr, nullptr};
-		if (pinned) {
-			pinned = hipHostMalloc((void **)&pin[0], SLICE, hipHostMallocDefault) == hipSuccess &&
-			         hipHostMalloc((void **)&pin[1], SLICE, hipHostMallocDefault) == hipSuccess &&
-			         hipEventCreateWithFlags(&drained[0], hipEventDisableTiming) == hipSuccess &&
-			         hipEventCreateWithFlags(&drained[1], hipEventDisableTiming) == hipSuccess;
-			(void)hipGetLastError();
-		}
+	if (pinned && ensure_pinned_buffers(c) != LSQ_OK) pinned = false;
+	if (pinned) {
+		rc = pinned_pipeline(c, d_text.p, (size_t)len, [&](unsigned char *dst, size_t off, size_t n) {
+			size_t a = 0;
+			while (a < n) {
+				const ssize_t got = pread(fd, dst + a, n - a, (off_t)(byte_begin + off + a));
+				if (got <= 0) return false;
+				a += (size_t)got;
+			}
+			return true;
+		}, path);
+		if (rc) return rc;
+	} else {
 		int rc_copy = LSQ_OK;
-		if (pinned) {
-			const int T = std::max(1, std::min(16, host_threads(0)));
-			const long n_slices = (long)((len + SLICE - 1) / SLICE);
-			std::atomic<long> go{-1}, filled{0};
-			std::atomic<int> io_error{0};
-			std::atomic<bool> give_up{false};         // set on every way out of this block: a worker that still waits for its slice leaves
-			ThreadGroup workers;                      // (joined on every way out, after give_up is set: declared first, destroyed last)
-			struct GiveUp { std::atomic<bool> &f; ~GiveUp() { f.store(true, std::memory_order_release); } } give_up_on_exit{give_up};
-			for (int t = 0; t < T; ++t) workers.spawn([&, t] {
-				for (long sl = 0; sl < n_slices; ++sl) {
-					while (go.load(std::memory_order_acquire) < sl) { if (give_up.load(std::memory_order_acquire)) return; std::this_thread::yield(); }
-					const size_t off = (size_t)sl * SLICE, nby = std::min<size_t>(SLICE, len - off);
-					size_t a = nby * (size_t)t / (size_t)T;
-					const size_t b = nby * (size_t)(t + 1) / (size_t)T;
-					while (a < b) {
-						const ssize_t got = pread(fd, pin[sl & 1] + a, b - a, (off_t)(byte_begin + off + a));
-						if (got <= 0) { io_error.store(1); break; }
-						a += (size_t)got;
-					}
-					filled.fetch_add(1, std::memory_order_release);
-				}
-			});
-			for (long sl = 0; sl < n_slices; ++sl) {
-				const int k = (int)(sl & 1);
-				if (sl >= 2 && rc_copy == LSQ_OK && hipEventSynchronize(drained[k]) != hipSuccess) rc_copy = fail(LSQ_E_DEVICE, "hipEventSynchronize failed in the text copy");
-				go.store(sl, std::memory_order_release);
-				while (filled.load(std::memory_order_acquire) < (long)T * (sl + 1)) std::this_thread::yield();
-				const size_t off = (size_t)sl * SLICE, nby = std::min<size_t>(SLICE, len - off);
-				if (rc_copy == LSQ_OK && (hipMemcpyAsync(d_text.p + off, pin[k], nby, hipMemcpyHostToDevice, st) != hipSuccess || hipEventRecord(drained[k], st) != hipSuccess))
-					rc_copy = fail(LSQ_E_DEVICE, "hipMemcpyAsync failed in the text copy");
+		void *m = mmap(nullptr, (size_t)file_len, PROT_READ, MAP_PRIVATE, fd, 0);
+		if (m == MAP_FAILED) rc_copy = fail(LSQ_E_IO, "cannot map %s", path);
+		else {
+			mf.data = (const char *)m; mf.len = (size_t)file_len;
+			madvise(m, mf.len, MADV_SEQUENTIAL);
+			for (size_t off = 0; off < len && rc_copy == LSQ_OK; off += PIN_SLICE) {
+				const size_t nby = std::min<size_t>(PIN_SLICE, len - off);
+				if (hipMemcpyAsync(d_text.p + off, mf.data + byte_begin + off, nby, hipMemcpyHostToDevice, st) != hipSuccess) rc_copy = fail(LSQ_E_DEVICE, "hipMemcpyAsync failed in the text copy");
 			}
-			workers.join();
 			if (hipStreamSynchronize(st) != hipSuccess && rc_copy == LSQ_OK) rc_copy = fail(LSQ_E_DEVICE, "text copy failed");
-			if (io_error.load() && rc_copy == LSQ_OK) rc_copy = fail(LSQ_E_IO, "cannot read %s", path);
-		} else {
-			void *m = mmap(nullptr, (size_t)file_len, PROT_READ, MAP_PRIVATE, fd, 0);
-			if (m == MAP_FAILED) rc_copy = fail(LSQ_E_IO, "cannot map %s", path);
-			else {
-				mf.data = (const char *)m; mf.len = (size_t)file_len;
-				madvise(m, mf.len, MADV_SEQUENTIAL);
-				for (size_t off = 0; off < len && rc_copy == LSQ_OK; off += SLICE) {
-					const size_t nby = std::min<size_t>(SLICE, len - off);
-					if (hipMemcpyAsync(d_text.p + off, mf.data + byte_begin + off, nby, hipMemcpyHostToDevice, st) != hipSuccess) rc_copy = fail(LSQ_E_DEVICE, "hipMemcpyAsync failed in the text copy");
-				}
-				if (hipStreamSynchronize(st) != hipSuccess && rc_copy == LSQ_OK) rc_copy = fail(LSQ_E_DEVICE, "text copy failed");
-			}
 		}
-		for (int q = 0; q < 2; ++q) { if (pin[q]) (void)hipHostFree(pin[q]); if (drained[q]) (void)hipEventDestroy(drained[q]); }
 		if (rc_copy) return rc_copy;
 	}
 	HIP_TRY(hipEventRecord(c->evt1, st));
