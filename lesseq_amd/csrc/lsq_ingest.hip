@@ -1095,12 +1095,16 @@ static int ingest_text(lsq_ctx *c, int method, const char *read_format, lsq_text
 	}
 	bool all_slow = !FD.usable;
 	const unsigned side_grid = std::min(std::max(n_tiles, 1u), 4u * (unsigned)c->n_cu);
+	// a workgroup a tile: the kernel can also run as a grid of resident workgroups that stay for many tiles (LSQ_FAST_GRID workgroups a
+	// compute unit; developer aid) -- measured slower on C3: 7.4 ms at 6, 7.0 at 12, 6.7 at 24 against 6.1 with a workgroup a tile
+	unsigned fast_grid = std::max(n_tiles, 1u);
+	if (const char *e = getenv("LSQ_FAST_GRID")) { const int v = atoi(e); if (v > 0) fast_grid = (unsigned)v * (unsigned)c->n_cu; }
 	F.launch = [&](const RouteTables &RT, const RouteOut &O, hipStream_t s) -> int {
 		int r2 = DD.reset_errors(s);
 		if (r2) return r2;
 		HIP_TRY(hipMemsetAsync(d_counts.p, 0, 16, s));
 		if (!all_slow) {
-			hipLaunchKernelGGL(lsq_mrf_route_fast_kernel, dim3(n_tiles), dim3(256), 0, s, X, DD.D, FD, RT, O, DD.d_err.p, H);
+			hipLaunchKernelGGL(lsq_mrf_route_fast_kernel, dim3(std::min(n_tiles, fast_grid)), dim3(256), 0, s, X, DD.D, FD, RT, O, DD.d_err.p, H, n_tiles);
 			hipLaunchKernelGGL(lsq_mrf_route_kernel, dim3(std::min(side_grid, 256u)), dim3(256), 0, s, X, DD.D, RT, O, DD.d_err.p, H, n_tiles, 1u);
 		} else hipLaunchKernelGGL(lsq_mrf_route_kernel, dim3(n_tiles), dim3(256), 0, s, X, DD.D, RT, O, DD.d_err.p, H, n_tiles, 0u);
 		hipLaunchKernelGGL(lsq_mrf_route_lines_kernel, dim3(std::min(line_cap / 256u + 1u, 1024u)), dim3(256), 0, s, X, DD.D, RT, O, DD.d_err.p, H);

@@ -20,7 +20,11 @@
 //     atomicCAS (strings of at most 7 bytes; longer ones give LSQ_E_UNSUPPORTED -- use lsq_mrf_parse)
 #pragma once
 
-constexpr unsigned MRF_TILE = 7680;                 // text bytes per workgroup (480 words of 16: with the 512 bytes ahead, a window of 8 KiB)
+#ifndef LSQ_MRF_TILE
+#define LSQ_MRF_TILE 7680
+#endif
+constexpr unsigned MRF_TILE = LSQ_MRF_TILE;         // text bytes per workgroup: with the 512 bytes ahead, a window of 8 KiB (7 680) or 4 KiB (3 584)
+static_assert(MRF_TILE == 7680 || MRF_TILE == 3584, "the fast kernel's window is 256 lanes x 32 or x 16 bytes");
 constexpr unsigned MRF_TILE_Q = (MRF_TILE + 4095) / 4096;      // 16-byte words a lane of 256 takes
 constexpr unsigned MRF_LB = 512;                    // bytes ahead of the tile that are staged with it
 constexpr unsigned MRF_NLCAP = 1024;                // newline positions held at a time (a tile of shorter lines takes several rounds)
@@ -360,7 +364,10 @@ __global__ void __launch_bounds__(256) lsq_mrf_route_lines_kernel(MrfText X, Mrf
 #endif
 constexpr unsigned FP_WIN = MRF_LB + MRF_TILE;          // 8 192
 constexpr unsigned FP_PAD = 16;                          // bytes of LDS ahead of the window (a coordinate's eight bytes may begin there)
-constexpr unsigned FP_DCAP = 3072, FP_NCAP = 1024;       // delimiters / newlines a window may hold (a tile of reads: ~1 500 / ~220)
+constexpr unsigned FP_LANE = FP_WIN / 256;               // window bytes a lane takes: 32 or 16
+constexpr unsigned FP_DCAP = FP_WIN * 5 / 16, FP_NCAP = FP_WIN / 8;       // delimiters / newlines a window may hold (8 KiB of reads: ~1 500 / ~220)
+constexpr unsigned FP_BCAP = FP_WIN >= 8192 ? 384 : 256;                        // blocks of one round of 256 lines (reads: ~310); a line whose blocks find no room goes to the list
+constexpr unsigned FP_STRANDS = 32;                      // strand keys kept in LDS (the table's first slots: the strands every file has)
 constexpr unsigned FP_KIND_SHIFT = 13;                   // entry: position in the window | kind << 13 (0 colon, 1 comma, 2 newline)
 constexpr unsigned FP_DICT = 256;
 
@@ -381,7 +388,9 @@ struct MrfFastLds {
 	unsigned short nl_dord[FP_NCAP];
 	unsigned scan4[4];
 	unsigned nl_ahead;                      // newlines in the 512 bytes ahead of the tile
-	__align__(8) unsigned long long strand[256];
+	unsigned n_blk;                         // blocks listed in this round
+	__align__(16) uint4 blk[FP_BCAP];       // a block: its five field bounds on the way in, what became of it on the way out
+	__align__(8) unsigned long long strand[FP_STRANDS];
 	unsigned long long ckey[FP_DICT];
 	unsigned short cid[FP_DICT];
 	__align__(16) RouteChrom chrom[ROUTE_CHROM_LDS];
@@ -414,143 +423,220 @@ __device__ inline bool fp_number8(const unsigned long long w, const unsigned len
 	return digits;
 }
 
-__global__ void __launch_bounds__(256) LSQ_FAST_WAVES_ATTR lsq_mrf_route_fast_kernel(MrfText X, MrfDict G, MrfFastDict FD, RouteTables T, RouteOut O, unsigned long long *err, MrfHandOff H) {
+__global__ void __launch_bounds__(256) LSQ_FAST_WAVES_ATTR lsq_mrf_route_fast_kernel(MrfText X, MrfDict G, MrfFastDict FD, RouteTables T, RouteOut O, unsigned long long *err, MrfHandOff H, unsigned n_tiles) {
 	__shared__ MrfFastLds S;
 	const unsigned tid = threadIdx.x;
-	const unsigned long long t0 = (unsigned long long)blockIdx.x * MRF_TILE;
 	// ---- the dictionaries
-	S.strand[tid] = __hip_atomic_load(&G.strand_tab[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	if (tid < FP_STRANDS) S.strand[tid] = __hip_atomic_load(&G.strand_tab[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	S.ckey[tid] = FD.ckey[tid]; S.cid[tid] = FD.cid[tid];
 	for (unsigned q = tid; q < 2u * T.n_chrom; q += 256u) reinterpret_cast<uint4 *>(S.chrom)[q] = reinterpret_cast<const uint4 *>(T.chrom)[q];
-	// ---- the window: 32 bytes a lane, in text order (window byte 32 x lane); bytes ahead of the text or behind it count as none
-	unsigned w[8];
-	unsigned valid = 0;                       // bytes of the lane's 32 that are text
-	{
-		const long long at = (long long)t0 - (long long)MRF_LB + 32ll * tid;
-		uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
-		if (at >= 0 && (unsigned long long)at < X.len) {
-			v0 = *reinterpret_cast<const uint4 *>(X.text + at);
-			if ((unsigned long long)at + 16u < X.len) v1 = *reinterpret_cast<const uint4 *>(X.text + at + 16);
-			valid = (unsigned)min(32ull, X.len - (unsigned long long)at);
-		}
-		*reinterpret_cast<uint4 *>(&S.text[FP_PAD + 32u * tid]) = v0;
-		*reinterpret_cast<uint4 *>(&S.text[FP_PAD + 32u * tid + 16u]) = v1;
-		w[0] = v0.x; w[1] = v0.y; w[2] = v0.z; w[3] = v0.w; w[4] = v1.x; w[5] = v1.y; w[6] = v1.z; w[7] = v1.w;
-	}
-	unsigned m_nl = 0, m_colon = 0, m_comma = 0;
-#pragma unroll
-	for (int q = 0; q < 8; ++q) {
-		m_nl |= fp_pack4(fp_eq_bytes(w[q], 0x0A0A0A0Au)) << (4 * q);
-		m_colon |= fp_pack4(fp_eq_bytes(w[q], 0x3A3A3A3Au)) << (4 * q);
-		m_comma |= fp_pack4(fp_eq_bytes(w[q], 0x2C2C2C2Cu)) << (4 * q);
-	}
-	const unsigned live = valid >= 32u ? 0xFFFFFFFFu : ((1u << valid) - 1u);
-	m_nl &= live; m_colon &= live; m_comma &= live;
-	const unsigned m_any = m_nl | m_colon | m_comma;
-	unsigned total;
-	const unsigned ex = mrf_block_excl_scan(((unsigned)__popc(m_any) << 16) | (unsigned)__popc(m_nl), S.scan4, total);
-	const unsigned n_delim = total >> 16, n_nl = total & 0xFFFFu;
-	if (tid == MRF_LB / 32u) S.nl_ahead = ex & 0xFFFFu;          // (the first lane of the tile proper: what lies ahead of it is the 512 bytes)
-	if (n_delim > FP_DCAP || n_nl > FP_NCAP) {
-		// more delimiters than the tables hold: the tile goes to the kernel that walks bytes
-		if (tid == 0) { const unsigned at = atomicAdd(&H.counts[0], 1u); if (at < H.tile_cap) H.tiles[at] = blockIdx.x; }
-		return;
-	}
-	{
-		unsigned b = m_any, od = ex >> 16, on = ex & 0xFFFFu;
-		while (b) {
-			const unsigned j = (unsigned)__ffs((int)b) - 1u; b &= b - 1u;
-			const unsigned kind = ((m_nl >> j) & 1u) * 2u + ((m_comma >> j) & 1u);
-			S.delim[od] = (unsigned short)((32u * tid + j) | (kind << FP_KIND_SHIFT));
-			if (kind == 2u) S.nl_dord[on++] = (unsigned short)od;
-			++od;
-		}
-	}
-	__syncthreads();
-	const unsigned nl_ahead = S.nl_ahead;
-	if (n_nl == nl_ahead) return;                 // no line ends in the tile
-	const unsigned long long g0 = X.tile_base[blockIdx.x];
 	const mrf_lds_cptr text = (mrf_lds_cptr)(const char *)S.text + FP_PAD;      // window byte 0
 	const unsigned POS = (1u << FP_KIND_SHIFT) - 1u;
 	auto defer = [&](const unsigned long long i, const unsigned long long start, const unsigned long long n) {
 		const unsigned at = atomicAdd(&H.counts[1], 1u);
 		if (at < H.line_cap) H.lines[at] = MrfLongLine{i, start, n}; else H.counts[2] = 1u;
 	};
-	for (unsigned m = nl_ahead + tid; m < n_nl; m += 256u) {
-		const unsigned long long g = g0 + (m - nl_ahead);        // the newline's ordinal in the text = the 0-based number of the line it ends
-		if (X.has_header && g == 0) continue;
-		const unsigned long long i = g - X.has_header;
-		const unsigned dE = S.nl_dord[m];
-		const unsigned eol = S.delim[dE] & POS;
+	// a workgroup stays for many tiles (the dictionaries above are staged once: 4 KB per workgroup beside 8 KB of text per tile otherwise)
+	for (unsigned tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+	const unsigned long long t0 = (unsigned long long)tile * MRF_TILE;
+	__syncthreads();                          // (the tile before is done with the tables below)
+	// ---- the window: FP_LANE bytes a lane, in text order (window byte FP_LANE x lane); bytes ahead of the text or behind it count as none
+	unsigned w[FP_LANE / 4];
+	unsigned valid = 0;                       // bytes of the lane's that are text
+	{
+		const long long at = (long long)t0 - (long long)MRF_LB + (long long)FP_LANE * tid;
+		uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
+		if (at >= 0 && (unsigned long long)at < X.len) {
+			v0 = *reinterpret_cast<const uint4 *>(X.text + at);
+			if (FP_LANE > 16 && (unsigned long long)at + 16u < X.len) v1 = *reinterpret_cast<const uint4 *>(X.text + at + 16);
+			valid = (unsigned)min((unsigned long long)FP_LANE, X.len - (unsigned long long)at);
+		}
+		*reinterpret_cast<uint4 *>(&S.text[FP_PAD + FP_LANE * tid]) = v0;
+		w[0] = v0.x; w[1] = v0.y; w[2] = v0.z; w[3] = v0.w;
+		if constexpr (FP_LANE > 16) {
+			*reinterpret_cast<uint4 *>(&S.text[FP_PAD + FP_LANE * tid + 16u]) = v1;
+			w[4] = v1.x; w[5] = v1.y; w[6] = v1.z; w[7] = v1.w;
+		}
+	}
+	unsigned m_nl = 0, m_colon = 0, m_comma = 0;
+#pragma unroll
+	for (int q = 0; q < (int)(FP_LANE / 4); ++q) {
+		m_nl |= fp_pack4(fp_eq_bytes(w[q], 0x0A0A0A0Au)) << (4 * q);
+		m_colon |= fp_pack4(fp_eq_bytes(w[q], 0x3A3A3A3Au)) << (4 * q);
+		m_comma |= fp_pack4(fp_eq_bytes(w[q], 0x2C2C2C2Cu)) << (4 * q);
+	}
+	const unsigned live = valid >= 32u ? 0xFFFFFFFFu : ((1u << valid) - 1u);            // (valid <= FP_LANE)
+	m_nl &= live; m_colon &= live; m_comma &= live;
+	const unsigned m_any = m_nl | m_colon | m_comma;
+	unsigned total;
+	const unsigned ex = mrf_block_excl_scan(((unsigned)__popc(m_any) << 16) | (unsigned)__popc(m_nl), S.scan4, total);
+	const unsigned n_delim = total >> 16, n_nl = total & 0xFFFFu;
+	if (tid == MRF_LB / FP_LANE) S.nl_ahead = ex & 0xFFFFu;          // (the first lane of the tile proper: what lies ahead of it is the 512 bytes)
+	if (n_delim > FP_DCAP || n_nl > FP_NCAP) {
+		// more delimiters than the tables hold: the tile goes to the kernel that walks bytes
+		if (tid == 0) { const unsigned at = atomicAdd(&H.counts[0], 1u); if (at < H.tile_cap) H.tiles[at] = tile; }
+		continue;
+	}
+	{
+		// (one loop over the lane's delimiters of all kinds: a loop per dword, without the packing, ran as long as the busiest
+		// lane of every dword in turn -- measured 6.1 -> 6.9 ms)
+		unsigned b = m_any, od = ex >> 16, on = ex & 0xFFFFu;
+		while (b) {
+			const unsigned j = (unsigned)__ffs((int)b) - 1u; b &= b - 1u;
+			const unsigned kind = ((m_nl >> j) & 1u) * 2u + ((m_comma >> j) & 1u);
+			S.delim[od] = (unsigned short)((FP_LANE * tid + j) | (kind << FP_KIND_SHIFT));
+			if (kind == 2u) S.nl_dord[on++] = (unsigned short)od;
+			++od;
+		}
+	}
+	__syncthreads();
+	const unsigned nl_ahead = S.nl_ahead;
+	if (n_nl == nl_ahead) continue;               // no line ends in the tile
+	const unsigned long long g0 = X.tile_base[tile];
+	// Rounds of 256 lines, three passes each.  (1) A lane a LINE walks the line's entries: every block must show four colons (or
+	// three and the line's end) -- otherwise the line goes to the list -- and is written to S.blk with its five field bounds.
+	// (2) A lane a BLOCK: the two coordinates, the chromosome, the containment filter, the strand -- the expensive part, on every
+	// lane of the wave whatever the lines' block counts are (a lane a line ran this loop twice for every wave that held one
+	// two-block read: a quarter of the lanes busy in the second turn).  (3) A lane a line again: its blocks' outcomes in order
+	// into the merge, then the bucket of the first merged base, key and blocks out.
+	for (unsigned m0 = nl_ahead; m0 < n_nl; m0 += 256u) {
+		if (tid == 0) S.n_blk = 0;
+		__syncthreads();
+		const unsigned m = m0 + tid;
+		// ---- (1)
+		bool live = m < n_nl, odd = false, dropped = false;
+		unsigned long long i = 0;
+		unsigned dS = 0, start = 0, eol = 0, nb = 0, first = 0;
 		const unsigned long long w0 = t0 - MRF_LB;                 // (window byte 0 in the text; wraps below zero for tile 0, whose window bytes < 512 hold nothing)
-		unsigned dS, start;
-		if (m == 0) {
-			if (t0 != 0) { defer(i, w0 + eol, ~0ull); continue; }  // began ahead of the window
-			dS = 0; start = MRF_LB;
-		} else { const unsigned dp = S.nl_dord[m - 1]; dS = dp + 1u; start = (S.delim[dp] & POS) + 1u; }
-		bool odd = false, dropped = false;
-		if (eol > start && text[start] == '#') dropped = true;       // a comment line takes a line number only (count.cpp:288)
-		ReadAcc A;
-		ReadBig B;
-		A.init();
-		LocProbe P;
-		P.chrom = -1; P.bin = 0;
-		unsigned cpos = start, d = dS;
-		while (!dropped) {
-			// the block's four colons
-			unsigned long long e4;
-			__builtin_memcpy(&e4, &S.delim[d], 8);
-			// (or three and the line's end: a block without query fields, whose end field runs to the end of the line -- count.cpp:313-316 with
-			// find() == npos -- and after which nothing follows)
-			const bool to_eol = (e4 & 0xE000600060006000ull) == 0x4000000000000000ull;
-			if ((e4 & 0x6000600060006000ull) != 0ull && !to_eol) { odd = true; break; }
-			const unsigned p1 = (unsigned)e4 & POS, p2 = (unsigned)(e4 >> 16) & POS, p3 = (unsigned)(e4 >> 32) & POS, p4 = (unsigned)(e4 >> 48) & POS;
-			const unsigned l_chr = p1 - cpos, l_str = p2 - p1 - 1u, l_s = p3 - p2 - 1u, l_e = p4 - p3 - 1u;
-			if (l_chr > 7u || l_str > 7u || l_s - 1u > 8u || l_e - 1u > 8u) { odd = true; break; }
-			// the coordinates: the eight bytes that end at the delimiter, and the byte ahead of them
-			unsigned long long ws, we, wc, wt;
-			__builtin_memcpy(&ws, &S.text[FP_PAD + p3 - 8u], 8);
-			__builtin_memcpy(&we, &S.text[FP_PAD + p4 - 8u], 8);
-			__builtin_memcpy(&wc, &S.text[FP_PAD + cpos], 8);
-			__builtin_memcpy(&wt, &S.text[FP_PAD + p1 + 1u], 8);
-			const unsigned s9 = (unsigned)(unsigned char)text[(int)p3 - 9] - (unsigned)'0', e9 = (unsigned)(unsigned char)text[(int)p4 - 9] - (unsigned)'0';
-			unsigned vs, ve;
-			const bool good_s = fp_number8(ws, min(l_s, 8u), vs), good_e = fp_number8(we, min(l_e, 8u), ve);
-			bool good = good_s && good_e;
-			if (l_s == 9u) { good = good && s9 <= 9u; vs += s9 * 100000000u; }
-			if (l_e == 9u) { good = good && e9 <= 9u; ve += e9 * 100000000u; }
-			if (!good) { odd = true; break; }
-			// the next block, if any: behind the first comma after colon 4
-			unsigned dn = d + 4u, kind = 2u;
-			if (!to_eol) while ((kind = S.delim[dn] >> FP_KIND_SHIFT) == 0u) ++dn;
-			// chromosome, containment, strand, merge
-			if (l_chr != 0u) {
-				const unsigned long long mask = l_chr >= 8u ? ~0ull : ((1ull << (8u * l_chr)) - 1ull);
-				const unsigned long long kb = wc & mask;
-				const unsigned long long key = ((unsigned long long)__builtin_bswap32((unsigned)kb) << 32) | (unsigned long long)__builtin_bswap32((unsigned)(kb >> 32)) | (unsigned long long)l_chr;
-				unsigned cid = MRF_NOCHROM;
-				for (unsigned sl = mrf_key_slot(key);; sl = (sl + 1u) & (FP_DICT - 1u)) {
-					const unsigned long long k = S.ckey[sl];
-					if (k == key) { cid = S.cid[sl]; break; }
-					if (k == 0ull) break;
+		if (live) {
+			const unsigned long long g = g0 + (m - nl_ahead);        // the newline's ordinal in the text = the 0-based number of the line it ends
+			if (X.has_header && g == 0) live = false;
+			i = g - X.has_header;
+		}
+		if (live) {
+			const unsigned dE = S.nl_dord[m];
+			eol = S.delim[dE] & POS;
+			if (m == 0) {
+				if (t0 != 0) { defer(i, w0 + eol, ~0ull); live = false; }  // began ahead of the window
+				else { dS = 0; start = MRF_LB; }
+			} else { const unsigned dp = S.nl_dord[m - 1]; dS = dp + 1u; start = (S.delim[dp] & POS) + 1u; }
+		}
+		if (live) {
+			if (eol > start && text[start] == '#') dropped = true;       // a comment line takes a line number only (count.cpp:288)
+			else {
+				// the walk, once to count the blocks ...
+				unsigned d = dS;
+				for (;;) {
+					unsigned long long e4;
+					__builtin_memcpy(&e4, &S.delim[d], 8);
+					// four colons -- or three and the line's end: a block without query fields, whose end field runs to the end of the line
+					// (count.cpp:313-316 with find() == npos) and after which nothing follows
+					const bool to_eol = (e4 & 0xE000600060006000ull) == 0x4000000000000000ull;
+					if ((e4 & 0x6000600060006000ull) != 0ull && !to_eol) { odd = true; break; }
+					++nb;
+					if (to_eol) break;
+					unsigned dn = d + 4u, kind;
+					while ((kind = S.delim[dn] >> FP_KIND_SHIFT) == 0u) ++dn;      // the next block, if any: behind the first comma after colon 4
+					if (kind != 1u) break;
+					d = dn + 1u;
 				}
-				const int s0 = (int)vs - 1, e0 = (int)ve;
-				if (cid < T.n_chrom && route_covered(T, S.chrom[cid], (int)cid, s0, e0, P)) {
-					const unsigned long long tmask = l_str >= 8u ? ~0ull : ((1ull << (8u * l_str)) - 1ull);
-					const unsigned long long tb = wt & tmask;
-					const unsigned long long tkey = ((unsigned long long)__builtin_bswap32((unsigned)tb) << 32) | (unsigned long long)__builtin_bswap32((unsigned)(tb >> 32)) | (unsigned long long)l_str;
-					unsigned sid = 256u;
-					for (unsigned q = 0; q < 256u; ++q) { const unsigned long long cur = S.strand[q]; if (cur == tkey) { sid = q; break; } if (cur == STRAND_EMPTY) break; }
-					if (sid == 256u) sid = mrf_strand_slot(nullptr, G.strand_tab, MrfLdsView{text + (p1 + 1u), l_str}, err);
-					A.add(B, cid, sid, s0, e0);
+				if (!odd) {
+					first = atomicAdd(&S.n_blk, nb);
+					if (first + nb > FP_BCAP) {                     // no room in this round's list: the shared splitter takes the line
+						odd = true;
+						for (unsigned q = first; q < FP_BCAP; ++q) S.blk[q] = make_uint4(0u, 0u, 0u, 3u);      // (its places below the list's end hold nothing)
+					}
+				}
+				if (!odd) {
+					// ... and once to list them
+					unsigned cpos = start, q = first;
+					d = dS;
+					for (;;) {
+						unsigned long long e4;
+						__builtin_memcpy(&e4, &S.delim[d], 8);
+						const bool to_eol = (e4 & 0xE000600060006000ull) == 0x4000000000000000ull;
+						S.blk[q++] = make_uint4(cpos | (((unsigned)e4 & POS) << 16), ((unsigned)(e4 >> 16) & POS) | (((unsigned)(e4 >> 32) & POS) << 16), (unsigned)(e4 >> 48) & POS, 0u);
+						if (to_eol) break;
+						unsigned dn = d + 4u, kind;
+						while ((kind = S.delim[dn] >> FP_KIND_SHIFT) == 0u) ++dn;
+						if (kind != 1u) break;
+						cpos = (S.delim[dn] & POS) + 1u; d = dn + 1u;
+					}
 				}
 			}
-			if (kind != 1u) break;                       // the line's end
-			cpos = (S.delim[dn] & POS) + 1u; d = dn + 1u;
+			if (odd) { defer(i, w0 + start, eol - start); live = false; }
 		}
-		if (odd) { defer(i, w0 + start, eol - start); continue; }
-		if (dropped) { O.key[i] = ROUTE_KEY_DROPPED; continue; }
-		A.finish(B, T, S.chrom, P, O, (unsigned)i);
+		__syncthreads();
+		// ---- (2)
+		const unsigned n_blk = min(S.n_blk, FP_BCAP);          // (lines beyond the list's room listed nothing)
+		for (unsigned q = tid; q < n_blk; q += 256u) {
+			const uint4 bd = S.blk[q];
+			if (bd.w == 3u) continue;
+			const unsigned cpos = bd.x & 0xFFFFu, p1 = bd.x >> 16, p2 = bd.y & 0xFFFFu, p3 = bd.y >> 16, p4 = bd.z;
+			const unsigned l_chr = p1 - cpos, l_str = p2 - p1 - 1u, l_s = p3 - p2 - 1u, l_e = p4 - p3 - 1u;
+			uint4 out = make_uint4(0u, 0u, 0u, 2u);              // .w: 0 kept (.x chromosome | strand << 16, .y / .z the block), 1 passed over, 2 not the usual shape
+			if (!(l_chr > 7u || l_str > 7u || l_s - 1u > 8u || l_e - 1u > 8u)) {
+				// the coordinates: the eight bytes that end at the delimiter, and the byte ahead of them
+				unsigned long long ws, we, wc, wt;
+				__builtin_memcpy(&ws, &S.text[FP_PAD + p3 - 8u], 8);
+				__builtin_memcpy(&we, &S.text[FP_PAD + p4 - 8u], 8);
+				__builtin_memcpy(&wc, &S.text[FP_PAD + cpos], 8);
+				__builtin_memcpy(&wt, &S.text[FP_PAD + p1 + 1u], 8);
+				const unsigned s9 = (unsigned)(unsigned char)text[(int)p3 - 9] - (unsigned)'0', e9 = (unsigned)(unsigned char)text[(int)p4 - 9] - (unsigned)'0';
+				unsigned vs, ve;
+				const bool good_s = fp_number8(ws, min(l_s, 8u), vs), good_e = fp_number8(we, min(l_e, 8u), ve);
+				bool good = good_s && good_e;
+				if (l_s == 9u) { good = good && s9 <= 9u; vs += s9 * 100000000u; }
+				if (l_e == 9u) { good = good && e9 <= 9u; ve += e9 * 100000000u; }
+				if (good) {
+					out.w = 1u;
+					if (l_chr != 0u) {
+						const unsigned long long kb = wc & ((1ull << (8u * l_chr)) - 1ull);
+						const unsigned long long key = ((unsigned long long)__builtin_bswap32((unsigned)kb) << 32) | (unsigned long long)__builtin_bswap32((unsigned)(kb >> 32)) | (unsigned long long)l_chr;
+						unsigned cid = MRF_NOCHROM;
+						for (unsigned sl = mrf_key_slot(key);; sl = (sl + 1u) & (FP_DICT - 1u)) {
+							const unsigned long long k = S.ckey[sl];
+							if (k == key) { cid = S.cid[sl]; break; }
+							if (k == 0ull) break;
+						}
+						const int s0 = (int)vs - 1, e0 = (int)ve;
+						LocProbe P;
+						P.chrom = -1; P.bin = 0;
+						if (cid < T.n_chrom && route_covered(T, S.chrom[cid], (int)cid, s0, e0, P)) {
+							const unsigned long long tb = wt & ((1ull << (8u * l_str)) - 1ull);
+							const unsigned long long tkey = ((unsigned long long)__builtin_bswap32((unsigned)tb) << 32) | (unsigned long long)__builtin_bswap32((unsigned)(tb >> 32)) | (unsigned long long)l_str;
+							unsigned sid = 256u;
+							for (unsigned z = 0; z < FP_STRANDS; ++z) { const unsigned long long cur = S.strand[z]; if (cur == tkey) { sid = z; break; } if (cur == STRAND_EMPTY) break; }
+							if (sid == 256u) sid = mrf_strand_slot(nullptr, G.strand_tab, MrfLdsView{text + (p1 + 1u), l_str}, err);
+							out = make_uint4(cid | (sid << 16), (unsigned)s0, (unsigned)e0, 0u);
+						}
+					}
+				}
+			}
+			S.blk[q] = out;
+		}
+		__syncthreads();
+		// ---- (3)
+		if (live) {
+			if (dropped) O.key[i] = ROUTE_KEY_DROPPED;
+			else {
+				ReadAcc A;
+				ReadBig B;
+				A.init();
+				for (unsigned q = 0; q < nb; ++q) {
+					const uint4 r = S.blk[first + q];
+					if (r.w == 2u) { odd = true; break; }
+					if (r.w == 0u) A.add(B, r.x & 0xFFFFu, r.x >> 16, (int)r.y, (int)r.z);
+				}
+				if (odd) defer(i, w0 + start, eol - start);
+				else {
+					LocProbe P;
+					P.chrom = -1; P.bin = 0;
+					A.finish(B, T, S.chrom, P, O, (unsigned)i);
+				}
+			}
+		}
+	}
 	}
 }
 
