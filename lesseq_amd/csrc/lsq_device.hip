@@ -882,6 +882,9 @@ int lsq_ctx_set_option(lsq_ctx *c, const char *name, double value) LSQ_API_TRY {
 	} else if (n == "em_closed_form") {
 		{ int rc = sync_all(c); if (rc) return rc; }
 		c->opt_em_closed = value != 0;
+	} else if (n == "em_quad_cap") {
+		if (value < 0 || value > 1e6) return fail(LSQ_E_ARG, "em_quad_cap out of range");
+		c->opt_em_quad_cap = (unsigned)value;
 	} else if (n == "em_regroup") {
 		c->opt_em_regroup = value != 0;
 		c->em_order_lane_valid[0] = c->em_order_lane_valid[1] = false;

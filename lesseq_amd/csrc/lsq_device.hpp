@@ -203,6 +203,9 @@ struct lsq_ctx {
 	// "em_closed_form" (default off): two-isoform events with one read file run a few ordinary iterations and finish in the
 	// closed form of their EM map (lsq_em.hip: lsq_em_head_kernel / lsq_em_tail_kernel); the tail's list per step lane
 	bool opt_em_closed = false;
+	// "em_quad_cap" (0: off): the four-lane lean kernel hands events that still run after that many iterations to lsq_em_tail_kernel
+	// (two-isoform events with one read file, where no placement by earlier iteration counts is in use: lsq_em.hip)
+	unsigned opt_em_quad_cap = 0;
 	DevBuf<uint32_t> em_tail_count, em_tail_u32[2];
 	DevBuf<uint8_t> em_tail_flag[2];
 	DevBuf<double> em_tail_f64[2];

@@ -155,6 +155,14 @@ __device__ inline void em_pass_cached(const EmCache &E, const double *th, bool o
 // A wave skips the full routine when every live pair of every lane is inside that range; when it
 // does not, only the pairs outside it take the routine's value, so an event's numbers do not depend
 // on the events it shares a wave with.
+// the list a capped or headed EM leaves for lsq_em_tail_kernel (further down, with the closed form)
+struct EmTail {
+	unsigned *count;               // [0] events appended by the head; [1] tail workgroups done (the last one clears both)
+	unsigned *ev, *iters;
+	unsigned char *flag;
+	double *t0, *t1, *ll;          // theta and log-likelihood after `iters` accepted iterations
+};
+
 template <int SLOTS>
 struct EmPairState { double s[SLOTS], r[SLOTS], lg[SLOTS]; };
 
@@ -237,9 +245,11 @@ __device__ inline void em_pass_lean(const double (&kd)[SLOTS], const double (&gm
 // in registers.  The pass for theta(t+2) starts from z(t+1) as soon as that exists, without waiting
 // for the stop test on ll(t+1): the test (a reciprocal, a compare, a ballot) runs beside the next
 // pass instead of between two passes.  One pass per event is thrown away.
+// cap (0: none): an event still running after that many accepted iterations is not iterated to the end here but appended to T's
+// list with theta, log-likelihood and count as they stand -- lsq_em_tail_kernel finishes it (closed form where it applies).
 template <int SLOTS, int KK, bool FLAT = false, class CacheT = EmCache>
 __device__ inline void em_lean(const EmArgs &A, const CacheT &C, const unsigned e, const unsigned sub, const bool ev_ok, const int K, const unsigned ib,
-                               const double inv_n, const bool any_reads, bool run) {
+                               const double inv_n, const bool any_reads, bool run, const unsigned cap = 0u, const EmTail *T = nullptr) {
 	double kd[SLOTS], gm[SLOTS][KK], t3[KK], z3[KK];
 #pragma unroll
 	for (int t = 0; t < SLOTS; ++t) {
@@ -254,6 +264,7 @@ __device__ inline void em_lean(const EmArgs &A, const CacheT &C, const unsigned 
 	for (int t = 0; t < SLOTS; ++t) { P.s[t] = 1.0; P.r[t] = 1.0; P.lg[t] = 0.0; }
 	unsigned iters = 0;
 	unsigned char flag = 0;
+	bool handed_on = false;
 	double ll = 0;
 	em_pass_lean<SLOTS, KK, FLAT>(kd, gm, t3, any_reads, P, ll, z3);
 	double c3[KK], cll, cz3[KK];           // candidate: theta(t+1), its log-likelihood and numerators
@@ -285,6 +296,7 @@ __device__ inline void em_lean(const EmArgs &A, const CacheT &C, const unsigned 
 		if (go && fabs(crit - 1E-6) < A.band) flag |= 1;
 		if (go && !(crit > 1E-6)) run = false;
 		else if (go && iters >= A.max_iters) { flag |= 2; run = false; }
+		else if (go && cap && iters >= cap) { handed_on = true; run = false; }
 	};
 	{
 		double n3[KK], nll, nz3[KK];
@@ -293,6 +305,13 @@ __device__ inline void em_lean(const EmArgs &A, const CacheT &C, const unsigned 
 			if (!__any(run)) break;
 			turn(n3, nll, nz3, c3, cll, cz3);
 		}
+	}
+	if (handed_on) {
+		if (ev_ok && sub == 0) {
+			const unsigned at = atomicAdd(&T->count[0], 1u);
+			T->ev[at] = e; T->iters[at] = iters; T->flag[at] = flag; T->t0[at] = t3[0]; T->t1[at] = KK > 1 ? t3[KK > 1 ? 1 : 0] : 0.0; T->ll[at] = ll;
+		}
+		return;
 	}
 	if (ev_ok && sub == 0) {
 #pragma unroll
@@ -307,7 +326,7 @@ __device__ inline void em_lean(const EmArgs &A, const CacheT &C, const unsigned 
 // (LESSeq's local events with one read file): only the lean loop, a third of the registers -- the
 // kernel shares the compute units with the next count's streaming kernel (lsq_device.hpp).
 template <bool SMALL>
-__device__ inline void em_quad_body(const EmArgs &A, const unsigned block) {
+__device__ inline void em_quad_body(const EmArgs &A, const unsigned block, const unsigned cap = 0u, const EmTail *T = nullptr) {
 	// The next count's streaming kernel may share the SIMDs (lsq_device.hpp: the result stream); this
 	// kernel is a few dependent chains, that one thousands of independent ones: these waves go first.
 #ifndef LSQ_EM_NO_PRIO
@@ -364,7 +383,7 @@ __device__ inline void em_quad_body(const EmArgs &A, const unsigned block) {
 	bool run = ev_ok && n_total > 0 && K > 1;
 	const bool any_reads = ev_ok && n_total > 0;
 	// every event of the wave fits the registers: a loop with nothing but the lean pass in it
-	if (SMALL) { em_lean<1, 2>(A, C, e, sub, ev_ok, K, ib, inv_n, any_reads, run); return; }
+	if (SMALL) { em_lean<1, 2>(A, C, e, sub, ev_ok, K, ib, inv_n, any_reads, run, cap, T); return; }
 	if (__all(!ev_ok || (cached && K <= 2 && n_pairs <= EM_LANES))) { em_lean<1, 2>(A, C, e, sub, ev_ok, K, ib, inv_n, any_reads, run); return; }
 	if (__all(!ev_ok || cached)) { em_lean<EM_CACHED_PAIRS, EM_CACHED_K>(A, C, e, sub, ev_ok, K, ib, inv_n, any_reads, run); return; }
 	if (cached) em_pass_cached(C, th, any_reads, ll, z);
@@ -454,12 +473,6 @@ __device__ inline void em_flat_body(const EmArgs &A, const unsigned block) {
 // (n1, n2 >= 1, G0, G1 > 0, 0 <= kappa < 1), the ordinary iteration otherwise.  No event waits for the slowest of its wave
 // through hundreds of passes, and nothing is learnt from an earlier solve.
 constexpr unsigned EM_HEAD_PASSES = 6;
-struct EmTail {
-	unsigned *count;               // [0] events appended by the head; [1] tail workgroups done (the last one clears both)
-	unsigned *ev, *iters;
-	unsigned char *flag;
-	double *t0, *t1, *ll;          // theta and log-likelihood after `iters` accepted iterations
-};
 
 template <int FS>
 __device__ inline void em_load_flat(const EmArgs &A, const unsigned e, const bool ev_ok, int &K, unsigned &ib, EmCacheFlat<FS> &C, double &n_total) {
@@ -758,6 +771,9 @@ __global__ void __launch_bounds__(64) lsq_em_lean_kernel(EmArgs A, unsigned n_qu
 // ... and before a placement by iteration counts exists (or with option em_regroup off): four lanes an event throughout,
 // in a kernel of its own (the one-lane form's registers would come on top: 128 against 104 a wave)
 __global__ void __launch_bounds__(64) lsq_em_lean_quad_kernel(EmArgs A) { em_quad_body<true>(A, blockIdx.x); }
+// ... and with a cap on its passes: the few events with long chains (1 % of C3's take 100-160 dependent passes, every event of their
+// waves waiting) go on a list after `cap` accepted iterations, and lsq_em_tail_kernel, launched behind this kernel, finishes them
+__global__ void __launch_bounds__(64) lsq_em_lean_quad_capped_kernel(EmArgs A, EmTail T, unsigned cap) { em_quad_body<true>(A, blockIdx.x, cap, &T); }
 // the other events: more than two isoforms or more than one (method, class) pair per lane
 __global__ void __launch_bounds__(256) lsq_em_kernel(EmArgs A) { em_quad_body<false>(A, blockIdx.x); }
 
@@ -943,7 +959,15 @@ int run_solve(lsq_ctx *c) {
 			const bool flat = regrouped && c->em_small_places >= c->opt_em_flat_min;
 			A.split = c->em_split.p + (flat ? lane : 2);          // (word 2: every place to the four-lane kernel)
 			const unsigned n_quad = (c->em_small_places * EM_LANES + blk - 1) / blk, n_flat = flat ? (c->em_small_places + 63u) / 64u : 0u;
-			if (!n_flat) hipLaunchKernelGGL(lsq_em_lean_quad_kernel, dim3(n_quad), dim3(blk), 0, st, A);
+			if (!n_flat && c->opt_em_quad_cap && E.n_methods == 1) {
+				EmTail T{};
+				T.count = c->em_tail_count.p + 2 * lane;
+				T.ev = c->em_tail_u32[lane].p; T.iters = T.ev + c->em_small_places;
+				T.flag = c->em_tail_flag[lane].p;
+				T.t0 = c->em_tail_f64[lane].p; T.t1 = T.t0 + c->em_small_places; T.ll = T.t1 + c->em_small_places;
+				hipLaunchKernelGGL(lsq_em_lean_quad_capped_kernel, dim3(n_quad), dim3(blk), 0, st, A, T, c->opt_em_quad_cap);
+				hipLaunchKernelGGL(lsq_em_tail_kernel<3>, dim3((c->em_small_places + blk - 1) / blk), dim3(blk), 0, st, A, T);
+			} else if (!n_flat) hipLaunchKernelGGL(lsq_em_lean_quad_kernel, dim3(n_quad), dim3(blk), 0, st, A);
 			else if (E.n_methods == 1) hipLaunchKernelGGL(lsq_em_lean_kernel<3>, dim3(n_quad + n_flat), dim3(blk), 0, st, A, n_quad);
 			else hipLaunchKernelGGL(lsq_em_lean_kernel<4>, dim3(n_quad + n_flat), dim3(blk), 0, st, A, n_quad);
 			HIP_TRY(hipGetLastError());

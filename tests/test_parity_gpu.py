@@ -1429,3 +1429,25 @@ def test_overflow_recount_on_any_number_of_workgroups_and_its_warning(tmp_path):
         assert seen() == before
     L.lib.lsq_set_log_level(2)
     ctx.close()
+
+
+@pytest.mark.parametrize("seed,cap", [(511, 4), (512, 8), (513, 16), (514, 48), (515, 1), (516, 8)])
+def test_em_capped_four_lane_kernel_and_tail_stop_where_the_reference_stops(seed, cap, tmp_path):
+    """option em_quad_cap: the four-lane lean kernel hands events that still run after `cap` accepted iterations to the tail kernel
+    (closed form of the EM map where it applies, ordinary iterations otherwise): iteration count equal to the oracle's for every
+    event, theta and log-likelihood within 1e-6, also over repeated steps (the lane's list is cleared by the tail) and with the
+    placement by earlier iteration counts switched off (the path the cap is for)"""
+    import golden_inputs as gi
+    R = [40, 60, 90, 120][seed % 4]
+    info = gi.write_events_case(str(tmp_path), "ev", seed=seed, n_events=400, n_reads=30000 if seed % 2 else 3000, R=R, n_chrom=2, zipf=(seed % 2 == 0))
+    argv = ["0", "ev", "./", "LH_GENE_TXT", str(tmp_path / "ev.interval"), "UCSC_GENE2ISOFORM", str(tmp_path / "ev.map"), "0", "1000",
+            "MRF_SINGLE", "SHORT_READ" if seed % 3 else "MEDIUM_READ", str(R), str(tmp_path / "ev.mrf"), str(info["total_read_bases"])]
+    rc, otext, exact = ob.run("solve", argv)
+    assert rc == 0
+    plain = gpu_exact(argv)
+    for repeat in (1, 4):
+        got = gpu_exact(argv, options={"em_quad_cap": cap, "em_regroup": 0}, repeat=repeat)
+        compare_exact(got, exact, "capped at %d, seed %d" % (cap, seed))
+        assert max(g["iters"] for g in got) > cap          # some event went past the cap
+        for a, b in zip(got, plain):
+            assert a["iters"] == b["iters"] or (a["flags"] & 4) or (b["flags"] & 4), a["gname"]
