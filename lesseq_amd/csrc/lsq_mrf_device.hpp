@@ -728,7 +728,8 @@ static int pinned_pipeline(lsq_ctx *c, unsigned char *d_dst, const size_t len, F
 	hipStream_t st = c->stream;
 	unsigned char *const *pin = c->pin_buf;
 	int rc_copy = LSQ_OK;
-	const int T = std::max(1, std::min(16, host_threads(0)));
+	int T = std::max(1, std::min(16, host_threads(0)));
+	if (const char *e = getenv("LSQ_COPY_THREADS")) { const int v = atoi(e); if (v > 0 && v <= 64) T = v; }      // developer aid
 	const long n_slices = (long)((len + PIN_SLICE - 1) / PIN_SLICE);
 	std::atomic<long> go{-1}, filled{0};
 	std::atomic<int> io_error{0};
@@ -789,6 +790,8 @@ static int stage_text_file(lsq_ctx *c, const char *path, unsigned long long byte
 	HIP_TRY(hipEventRecord(c->evt0, st));
 	if (pinned && ensure_pinned_buffers(c) != LSQ_OK) pinned = false;
 	if (pinned) {
+		// (tried: the workers copying out of a mapping of the file instead -- 55 GB/s against 40-46, but the mapping's tear-down
+		// costs 70 ms on one thread and more when the workers share it; and 24 / 32 workers on a box's 16 cores: slower)
 		rc = pinned_pipeline(c, d_text.p, (size_t)len, [&](unsigned char *dst, size_t off, size_t n) {
 			size_t a = 0;
 			while (a < n) {
