@@ -790,7 +790,7 @@ static int ingest_device(lsq_ctx *c, int method, Front &F) {
 	const RouteTables T = route_tables(c);
 	// LDS of the partition kernels (a counter per pool and bucket) and of the group kernels (a bucket's image, its junction keys, two counters per group)
 	const size_t part_lds = 8 * (size_t)B;
-	const bool part_in_lds = part_lds <= 128 * 1024;
+	const bool part_in_lds = part_lds <= 128 * 1024 && getenv("LSQ_PART_NO_LDS") == nullptr;       // (the environment switch: the tests run the form for very many buckets on a small input)
 	size_t img_max = 16, jg_max = 0, groups_max = 1;
 	for (unsigned b = 0; b < B; ++b) {
 		const BucketDesc &d = E.buckets[b];
@@ -812,6 +812,7 @@ static int ingest_device(lsq_ctx *c, int method, Front &F) {
 
 	unsigned compact = c->opt_compact_pools ? 1u : 0u;
 	unsigned long long nb_cap = std::max<unsigned long long>(4096, n / 32), nbb_cap = 4 * nb_cap;
+	if (const char *e = getenv("LSQ_NB_LIST")) { const long long v = atoll(e); if (v > 0) { nb_cap = (unsigned long long)v; nbb_cap = 2 * nb_cap; } }      // tests: the list runs over and is sized again
 	unsigned long long tot[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nb_tot[4] = {0, 0, 0, 0}, sums[5] = {0, 0, 0, 0, 0};      // sums: reads of pool 0 / pool 1 partitions, pieces, n-block reads, their blocks
 	for (;;) {
 		if (d_nb_ent.n < nb_cap) { if ((rc = d_nb_ent.alloc((size_t)nb_cap))) return rc; }

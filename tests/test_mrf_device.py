@@ -315,3 +315,59 @@ def test_first_failing_line_through_the_ingest_path(bad, tmp_path):
         ctx.upload_reads_mrf(0, str(p))
     assert eh.value.status == ed.value.status == -4 and str(eh.value) == str(ed.value) and "#301:" in str(ed.value)
     ctx.close()
+
+
+def test_more_chromosomes_than_the_fast_kernel_takes_and_long_names(tmp_path, monkeypatch):
+    """80 chromosomes (the fast kernel's tables hold 64: the whole file goes through the byte-walking kernel), and an annotation whose
+    chromosome names are longer than the seven bytes the fast kernel keys on (every line on them goes to the line list; with a short
+    list the file is routed again by the byte-walking kernel): the tables of the host-parsed path every time"""
+    spec = L.SynthSpec(33, 1200, 150000, 100, 80, L.EVENT_TYPES)
+    L.synth_write(spec, str(tmp_path), "m")
+    ev, ctx = setup(str(tmp_path / "m.interval"), str(tmp_path / "m.map"), 100)
+    want = pools_and_counts(ctx, reads=L.Reads.from_mrf(str(tmp_path / "m.mrf"), ev))
+    assert want[0] > 100000 and int(want[3].sum()) > 50000
+    assert same(want, pools_and_counts(ctx, path=str(tmp_path / "m.mrf")))
+    ctx.close()
+    # long names: chr<N> -> chromosome_number_<N> in all three files
+    spec = L.SynthSpec(34, 600, 80000, 100, 5, L.EVENT_TYPES)
+    L.synth_write(spec, str(tmp_path), "n")
+    import re
+    for f, pat in (("n.interval", r"\tchr(\d+)\t"), ("n.mrf", r"(?m)(?:^|,)chr(\d+):")):
+        text = open(tmp_path / f).read()
+        if f == "n.interval":
+            text = re.sub(pat, lambda m: "\tchromosome_number_%s\t" % m.group(1), text)
+        else:
+            text = re.sub(r"chr(\d+):", lambda m: "chromosome_number_%s:" % m.group(1), text)
+        open(tmp_path / f, "w").write(text)
+    ev, ctx = setup(str(tmp_path / "n.interval"), str(tmp_path / "n.map"), 100)
+    want = pools_and_counts(ctx, reads=L.Reads.from_mrf(str(tmp_path / "n.mrf"), ev))
+    assert want[0] > 50000 and int(want[3].sum()) > 30000
+    assert same(want, pools_and_counts(ctx, path=str(tmp_path / "n.mrf")))          # every line through the list
+    monkeypatch.setenv("LSQ_MRF_LINE_LIST", "1000")
+    assert same(want, pools_and_counts(ctx, path=str(tmp_path / "n.mrf")))          # the list runs over
+    ctx.close()
+
+
+def test_partition_without_lds_counters_and_a_many_block_list_that_runs_over(tmp_path, monkeypatch):
+    """the partition's form for very many buckets (counters in global memory), and a list of many-block reads that is sized again
+    after it ran over, on inputs the other forms have settled: the same tables"""
+    spec = L.SynthSpec(35, 2000, 300000, 100, 4, L.EVENT_TYPES, True)
+    L.synth_write(spec, str(tmp_path), "p")
+    ev, ctx = setup(str(tmp_path / "p.interval"), str(tmp_path / "p.map"), 100)
+    want = pools_and_counts(ctx, path=str(tmp_path / "p.mrf"))
+    monkeypatch.setenv("LSQ_PART_NO_LDS", "1")
+    assert same(want, pools_and_counts(ctx, path=str(tmp_path / "p.mrf")))
+    assert same(want, pools_and_counts(ctx, reads=L.Reads.from_mrf(str(tmp_path / "p.mrf"), ev)))
+    monkeypatch.delenv("LSQ_PART_NO_LDS")
+    ctx.close()
+    # long reads: many-block reads and compact misfits in numbers, the list sized for sixteen of them
+    spec = L.SynthSpec(36, 300, 60000, 1500, 3, L.EVENT_TYPES)
+    L.synth_write(spec, str(tmp_path), "w")
+    iv, mp, mrf, R = str(tmp_path / "w.interval"), str(tmp_path / "w.map"), str(tmp_path / "w.mrf"), 1500
+    ev, ctx = setup(iv, mp, R)
+    ctx.set_option("compact_pools", 1)
+    want = pools_and_counts(ctx, path=mrf)
+    monkeypatch.setenv("LSQ_NB_LIST", "16")
+    assert same(want, pools_and_counts(ctx, path=mrf))
+    assert same(want, pools_and_counts(ctx, reads=L.Reads.from_mrf(mrf, ev)))
+    ctx.close()
