@@ -483,24 +483,30 @@ def run_workload(env, a, wl_name, primary):
         del reads
         # the same reads in coordinate order (what an aligner's sorted output looks like): neighbouring lines fall into the same
         # bucket and the same cell.  The ingest of that file beside the shuffled one's (device time, per pass).
+        # (an auxiliary leg: whatever goes wrong in it is reported under its own key and the job's own reads are put back)
         sdir = os.path.join(tmp, "sorted")
         os.makedirs(sdir, exist_ok=True)
-        t_s = time.perf_counter()
-        L.synth_write(L.SynthSpec(W["seed"], W["n_events"], W["n_reads"], W["R"], W["n_chrom"], types, W.get("zipf", False), sorted_reads=True), sdir, "w", write_mrf=True)
-        e2e["sorted_generate_s"] = time.perf_counter() - t_s
-        stext = ctx.stage_text(os.path.join(sdir, "w.mrf"))
-        ctx.upload_reads_text(0, stext, free=True)
-        sst = ctx.ingest_stages()
-        assert ctx.retained(0) == job_retained, "the sorted file holds other reads than the shuffled one"
-        ctx.count()
-        cs, bs_ = ctx.counts()
-        # (read names are line numbers, so the handful of reads that tie with an event's span start may fall the other way: not compared bit for bit)
-        e2e["ingest_sorted_input"] = {"device_ms": sum(x["ms"] for x in sst), "stages_ms": {x["stage"]: x["ms"] for x in sst},
-                                      "device_ms_shuffled": sum(x["ms"] for x in ingest_stages),
-                                      "valid_assignments": int(cs.sum()), "valid_assignments_shuffled": int(cnt_full.sum())}
-        e2e["ingest_sorted_input"]["sorted_over_shuffled"] = e2e["ingest_sorted_input"]["device_ms"] / max(e2e["ingest_sorted_input"]["device_ms_shuffled"], 1e-9)
-        os.remove(os.path.join(sdir, "w.mrf"))
-        ctx.upload_reads_text(0, ctx.stage_text(mrf), free=True)          # the job's own reads again, for the timed loop
+        try:
+            t_s = time.perf_counter()
+            L.synth_write(L.SynthSpec(W["seed"], W["n_events"], W["n_reads"], W["R"], W["n_chrom"], types, W.get("zipf", False), sorted_reads=True), sdir, "w", write_mrf=True)
+            e2e["sorted_generate_s"] = time.perf_counter() - t_s
+            stext = ctx.stage_text(os.path.join(sdir, "w.mrf"))
+            ctx.upload_reads_text(0, stext, free=True)
+            sst = ctx.ingest_stages()
+            if ctx.retained(0) != job_retained:
+                raise RuntimeError("the sorted file holds other reads than the shuffled one")
+            ctx.count()
+            cs, bs_ = ctx.counts()
+            # (read names are line numbers, so the handful of reads that tie with an event's span start may fall the other way: not compared bit for bit)
+            e2e["ingest_sorted_input"] = {"device_ms": sum(x["ms"] for x in sst), "stages_ms": {x["stage"]: x["ms"] for x in sst},
+                                          "device_ms_shuffled": sum(x["ms"] for x in ingest_stages),
+                                          "valid_assignments": int(cs.sum()), "valid_assignments_shuffled": int(cnt_full.sum())}
+            e2e["ingest_sorted_input"]["sorted_over_shuffled"] = e2e["ingest_sorted_input"]["device_ms"] / max(e2e["ingest_sorted_input"]["device_ms_shuffled"], 1e-9)
+        except Exception as e_:
+            e2e["ingest_sorted_input_error"] = "%s: %s" % (type(e_).__name__, e_)
+        finally:
+            shutil.rmtree(sdir, ignore_errors=True)
+            ctx.upload_reads_text(0, ctx.stage_text(mrf), free=True)          # the job's own reads again, for the timed loop
 
     # ---- the records a step hands over: packed in output order; all-gathered with N > 1
     stride = max(max(ev.record_words(f, c) for f, c in bounds), 1)
@@ -686,49 +692,54 @@ def run_workload(env, a, wl_name, primary):
             fence()
             return ms, float(np.mean(ks))
         saved_gather, in_loop_gather = in_loop_gather, False
-        ctx.set_option("compact_pools", 0)
-        ctx.upload_reads_text(0, ctx.stage_text(mrf), free=True)
-        fmt_w = ctx.pool_format(0)
-        ms_w, k_w = kernel_and_step_ms()
-        assert not fmt_w[0]
-        ev_b = sum(8 * ev.N(i) + 8 * ev.K(i) + 16 + 8 * ((1 << ev.K(i)) - 1) + 8 for i in range(n_ev))
-        wide.update({"wide_ms_per_step": ms_w, "wide_count_fast_kernel_ms": k_w, "wide_resident_bytes": float(fmt_w[1] + ev_b),
-                     "wide_frac": (fmt_w[1] + ev_b) / (k_w * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "wide_note": "this job with option compact_pools = 0: lsq_count_fast_kernel<false, ..> streams (start, end) pairs, 8 bytes a block -- algorithmic bytes = "
-                                  "resident bytes, so wide_frac is that kernel's plain HBM fraction (resident bytes / HIP-event kernel time / 8 TB/s)"})
-        ctx.set_option("compact_pools", 1)
-        # (b)
-        lr = dict(n_events=W["n_events"], n_reads=min(W["n_reads"], 20_000_000), R=1500)
+        ev_keep, blocks_keep = ev, blocks
         ldir = os.path.join(tmp, "long")
-        os.makedirs(ldir, exist_ok=True)
-        lspec = L.SynthSpec(W["seed"] + 77, lr["n_events"], lr["n_reads"], lr["R"], W["n_chrom"], types, W.get("zipf", False))
-        L.synth_write(lspec, ldir, "l", write_mrf=True)
-        lev = L.Events(L.Annotation(os.path.join(ldir, "l.interval"), os.path.join(ldir, "l.map")), ("SHORT_READ",), (lr["R"],))
-        ctx.upload_events(lev)
-        ctx.upload_reads_text(0, ctx.stage_text(os.path.join(ldir, "l.mrf")), free=True)
-        lst = ctx.ingest_stages()
-        fmt_l = ctx.pool_format(0)
-        ev_keep, ev = ev, lev                     # (step() packs with the context's events)
-        stride_l = max(lev.record_words(0, len(lev)), 1)
-        blocks_keep = blocks
-        blocks = [torch.zeros(stride_l, dtype=torch.int64, device=dev) for _ in range(2)]
-        torch.cuda.synchronize()
-        ms_l, k_l = kernel_and_step_ms()
-        lev_b = sum(8 * lev.N(i) + 8 * lev.K(i) + 16 + 8 * ((1 << lev.K(i)) - 1) + 8 for i in range(len(lev)))
-        wide.update({"long_reads_workload": "%d synthetic reads of %d bases over %d mixed events (flank exons %d bases), %d chromosomes" % (lr["n_reads"], lr["R"], lr["n_events"], lr["R"] + 1, W["n_chrom"]),
-                     "long_reads_compact_records_chosen": bool(fmt_l[0]), "long_reads_pool_reads_one_two_many": list(fmt_l[2]),
-                     "long_reads_retained": ctx.retained(0), "long_reads_ms_per_step": ms_l, "long_reads_count_fast_kernel_ms": k_l,
-                     "long_reads_frac": (fmt_l[1] + lev_b) / (k_l * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "long_reads_ingest_device_ms": sum(x["ms"] for x in lst)})
-        ev, blocks = ev_keep, blocks_keep
-        in_loop_gather = saved_gather
-        shutil.rmtree(ldir, ignore_errors=True)
-        # the job's own events and reads again: what follows (tables of the last step, counters) speaks of them
-        ctx.upload_events(ev)
-        ctx.upload_reads_text(0, ctx.stage_text(mrf), free=True)
-        for k in range(2):
-            step(k)
-        fence()
+        try:
+            ctx.set_option("compact_pools", 0)
+            ctx.upload_reads_text(0, ctx.stage_text(mrf), free=True)
+            fmt_w = ctx.pool_format(0)
+            ms_w, k_w = kernel_and_step_ms()
+            assert not fmt_w[0]
+            ev_b = sum(8 * ev.N(i) + 8 * ev.K(i) + 16 + 8 * ((1 << ev.K(i)) - 1) + 8 for i in range(n_ev))
+            wide.update({"wide_ms_per_step": ms_w, "wide_count_fast_kernel_ms": k_w, "wide_resident_bytes": float(fmt_w[1] + ev_b),
+                         "wide_frac": (fmt_w[1] + ev_b) / (k_w * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "wide_note": "this job with option compact_pools = 0: lsq_count_fast_kernel<false, ..> streams (start, end) pairs, 8 bytes a block -- algorithmic bytes = "
+                                      "resident bytes, so wide_frac is that kernel's plain HBM fraction (resident bytes / HIP-event kernel time / 8 TB/s)"})
+            ctx.set_option("compact_pools", 1)
+            # (b)
+            lr = dict(n_events=W["n_events"], n_reads=min(W["n_reads"], 20_000_000), R=1500)
+            os.makedirs(ldir, exist_ok=True)
+            lspec = L.SynthSpec(W["seed"] + 77, lr["n_events"], lr["n_reads"], lr["R"], W["n_chrom"], types, W.get("zipf", False))
+            L.synth_write(lspec, ldir, "l", write_mrf=True)
+            lev = L.Events(L.Annotation(os.path.join(ldir, "l.interval"), os.path.join(ldir, "l.map")), ("SHORT_READ",), (lr["R"],))
+            ctx.upload_events(lev)
+            ctx.upload_reads_text(0, ctx.stage_text(os.path.join(ldir, "l.mrf")), free=True)
+            lst = ctx.ingest_stages()
+            fmt_l = ctx.pool_format(0)
+            ev = lev                     # (step() packs with the context's events)
+            stride_l = max(lev.record_words(0, len(lev)), 1)
+            blocks = [torch.zeros(stride_l, dtype=torch.int64, device=dev) for _ in range(2)]
+            torch.cuda.synchronize()
+            ms_l, k_l = kernel_and_step_ms()
+            lev_b = sum(8 * lev.N(i) + 8 * lev.K(i) + 16 + 8 * ((1 << lev.K(i)) - 1) + 8 for i in range(len(lev)))
+            wide.update({"long_reads_workload": "%d synthetic reads of %d bases over %d mixed events (flank exons %d bases), %d chromosomes" % (lr["n_reads"], lr["R"], lr["n_events"], lr["R"] + 1, W["n_chrom"]),
+                         "long_reads_compact_records_chosen": bool(fmt_l[0]), "long_reads_pool_reads_one_two_many": list(fmt_l[2]),
+                         "long_reads_retained": ctx.retained(0), "long_reads_ms_per_step": ms_l, "long_reads_count_fast_kernel_ms": k_l,
+                         "long_reads_frac": (fmt_l[1] + lev_b) / (k_l * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "long_reads_ingest_device_ms": sum(x["ms"] for x in lst)})
+        except Exception as e_:
+            wide["wide_or_long_reads_error"] = "%s: %s" % (type(e_).__name__, e_)
+        finally:
+            ev, blocks = ev_keep, blocks_keep
+            in_loop_gather = saved_gather
+            shutil.rmtree(ldir, ignore_errors=True)
+            # the job's own options, events and reads again: what follows (tables of the last step, counters) speaks of them
+            ctx.set_option("compact_pools", 1)
+            ctx.upload_events(ev)
+            ctx.upload_reads_text(0, ctx.stage_text(mrf), free=True)
+            for k in range(2):
+                step(k)
+            fence()
     # what the gather costs on its own (N > 1): submitted alone, timed on the host
     gather_ms = None
     if world > 1:
