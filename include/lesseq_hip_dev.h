@@ -52,6 +52,12 @@ int lsq_debug_stream_read_rate(lsq_ctx *c, unsigned long long bytes, double *gb_
  * the boundary").  kind 3 does the same from inside a helper thread of a ThreadGroup (lsq_internal.hpp). */
 int lsq_debug_throw(int kind);
 
+/* Which of the device parse's three kernels the latest MRF text of the context went through (lsq_reads_upload_mrf / _text): tiles the
+ * fast kernel handed to the byte-walking kernel (more delimiters than its LDS tables hold), lines it handed to the shared splitter
+ * (another shape than a read's), and whether the whole file went through the byte-walking kernel (more than 64 chromosomes, or a line
+ * list that ran over).  A file of reads: 0, 0, 0 -- a test holds that, so that a silent fall-back cannot pass as the fast path. */
+int lsq_debug_last_parse_paths(const lsq_ctx *c, unsigned *tiles_handed, unsigned *lines_listed, unsigned *all_slow);
+
 /* HIP_VERSION the library was compiled against and hipRuntimeGetVersion() of the runtime it found in the process (0
  * when that call fails, e.g. without a driver): a binding that loads another runtime first (PyTorch's) can compare. */
 int lsq_debug_hip_versions(int *compiled, int *runtime);

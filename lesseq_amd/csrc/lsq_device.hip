@@ -206,6 +206,14 @@ int lsq_events_upload(lsq_ctx *c, lsq_events *E) LSQ_API_TRY {
 	for (const BucketDesc &bd : E->buckets) if (bd.kind == 2) for (uint32_t q = 0; q < bd.n_events; ++q) host_event[bd.ev_base + q] = true;
 	for (auto &r : c->reads) r.present = false;
 	int rc;
+	const bool timing = getenv("LSQ_CLI_TIMING") != nullptr;
+	auto t_last = std::chrono::steady_clock::now();
+	auto mark = [&](const char *what) {
+		if (!timing) return;
+		const auto t = std::chrono::steady_clock::now();
+		fprintf(stderr, "[timing]     %-32s %.4f s\n", what, std::chrono::duration<double>(t - t_last).count());
+		t_last = t;
+	};
 	if ((rc = c->buckets.upload(E->buckets.data(), E->buckets.size(), c->stream))) return rc;
 	if ((rc = c->images.upload(E->images.data(), E->images.size(), c->stream))) return rc;
 	if ((rc = c->ties.upload(E->ties.data(), E->ties.size(), c->stream))) return rc;
@@ -265,6 +273,7 @@ int lsq_events_upload(lsq_ctx *c, lsq_events *E) LSQ_API_TRY {
 		if ((rc = c->pack_iso.upload(pi.data(), pi.size(), c->stream))) return rc;
 		if ((rc = c->pack_ev.upload(pe.data(), pe.size(), c->stream))) return rc;
 	}
+	mark("events: images, EM order, pack lists");
 	// G = 1/ARS (common/read.h:331-340), device isoform order, per method
 	const size_t n_iso = E->n_iso_total, M = (size_t)E->n_methods;
 	std::vector<double> G(std::max<size_t>(M * n_iso, 1), 0.0);
@@ -293,6 +302,7 @@ int lsq_events_upload(lsq_ctx *c, lsq_events *E) LSQ_API_TRY {
 		HIP_TRY(hipMemsetAsync(c->flags2[l].p, 0, std::max<size_t>(n_ev, 1), c->stream));
 	}
 	select_counter_set(c, 0);
+	mark("events: G, counters, EM outputs");
 	{
 		// ingest tables (lsq_device.hpp: RouteChrom): per chromosome id the covered regions (count/count.cpp:244) as (start, end)
 		// pairs, the spans of the planned events ("clusters") with the bucket each lies in, and the locator grid over both
@@ -377,6 +387,7 @@ int lsq_events_upload(lsq_ctx *c, lsq_events *E) LSQ_API_TRY {
 			if ((rc = c->clu.upload(clu.data(), clu.size(), c->stream))) return rc;
 			HIP_TRY(hipStreamSynchronize(c->stream));          // the host vectors go out of scope
 		}
+		mark("events: loader tables + locator");
 		std::vector<unsigned> bb(E->buckets.size() + 1, 0);
 		for (size_t b = 0; b < E->buckets.size(); ++b) bb[b + 1] = bb[b] + E->buckets[b].n_bins;
 		c->n_fine = bb.back();
@@ -397,6 +408,7 @@ int lsq_events_upload(lsq_ctx *c, lsq_events *E) LSQ_API_TRY {
 	}
 	if ((rc = upload_strand_ranks(c))) return rc;
 	HIP_TRY(hipStreamSynchronize(c->stream));
+	mark("events: group bases, strand ranks");
 	return LSQ_OK;
 } LSQ_API_CATCH
 

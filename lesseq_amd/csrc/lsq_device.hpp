@@ -278,6 +278,9 @@ struct lsq_ctx {
 	std::map<size_t, std::vector<unsigned short>> host_seq;     // host buckets: [device event * M + method] -> classes of its valid reads, index order
 	float count_ms = 0, solve_ms = 0;
 	float mrf_h2d_ms = 0, mrf_parse_ms = 0;
+	// how the latest device parse went (lsq_debug_last_parse_paths): tiles handed to the byte-walking kernel, lines handed to the shared
+	// splitter, and whether the whole file went through the byte-walking kernel
+	unsigned parse_tiles_handed = 0, parse_lines_listed = 0, parse_all_slow = 0;
 	// two pinned 32 MiB host buffers and their "drained" events, made at the first large host-to-device copy (lsq_mrf_device.hpp: pinned_pipeline)
 	unsigned char *pin_buf[2] = {nullptr, nullptr};
 	hipEvent_t pin_ev[2] = {nullptr, nullptr};

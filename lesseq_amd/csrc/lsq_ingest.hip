@@ -1118,6 +1118,7 @@ static int ingest_text(lsq_ctx *c, int method, const char *read_format, lsq_text
 		HIP_TRY(hipMemcpy(counts, d_counts.p, 16, hipMemcpyDeviceToHost));
 		if (counts[2] && !all_slow) { all_slow = true; return LSQ_RETRY; }
 		if (counts[2]) return fail(LSQ_E_INTERNAL, "the device parser's line list ran over");
+		c->parse_tiles_handed = all_slow ? 0u : counts[0]; c->parse_lines_listed = counts[1]; c->parse_all_slow = all_slow ? 1u : 0u;
 		return DD.settle(c, T, has_header, first_line, s);
 	};
 	c->reads[method].named = false;
@@ -1257,6 +1258,15 @@ int lsq_mrf_parse_device(lsq_ctx *c, const char *read_format, const char *path, 
 	*out = R.release();
 	return LSQ_OK;
 } LSQ_API_CATCH
+
+// developer entry (include/lesseq_hip_dev.h): which of the parse's three kernels the latest MRF text went through
+int lsq_debug_last_parse_paths(const lsq_ctx *c, unsigned *tiles_handed, unsigned *lines_listed, unsigned *all_slow) {
+	if (!c) return LSQ_E_ARG;
+	if (tiles_handed) *tiles_handed = c->parse_tiles_handed;
+	if (lines_listed) *lines_listed = c->parse_lines_listed;
+	if (all_slow) *all_slow = c->parse_all_slow;
+	return LSQ_OK;
+}
 
 int lsq_last_mrf_timing(lsq_ctx *c, float *h2d_ms, float *parse_ms) LSQ_API_TRY {
 	if (!c) return fail(LSQ_E_ARG, "null context");

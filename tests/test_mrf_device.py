@@ -178,6 +178,7 @@ def test_two_million_lines_tile_boundaries_and_results(tmp_path, monkeypatch):
     ctx.count(); ctx.solve()
     a, s1 = ctx.counts(), ctx.solution()
     ctx.upload_reads_mrf(0, mrf)
+    assert parse_paths(ctx) == (0, 0, 0)               # a file of reads: every line settled by the fast kernel
     ctx.count(); ctx.solve()
     b, s2 = ctx.counts(), ctx.solution()
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
@@ -194,6 +195,14 @@ def test_two_million_lines_tile_boundaries_and_results(tmp_path, monkeypatch):
 
 # ---- the three ways a line gets parsed on the way into the pools (round 4): the fast kernel's delimiter tables, the line list
 # for lines of another shape than a read's, the byte-walking kernel for tiles (or files) the fast kernel does not take
+
+def parse_paths(ctx):
+    import ctypes as C
+    a, b, c = C.c_uint(), C.c_uint(), C.c_uint()
+    L.lib.lsq_debug_last_parse_paths.argtypes = [C.c_void_p, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
+    assert L.lib.lsq_debug_last_parse_paths(ctx.h, C.byref(a), C.byref(b), C.byref(c)) == 0
+    return a.value, b.value, c.value
+
 
 def pools_and_counts(ctx, path=None, reads=None):
     if reads is not None:
@@ -269,8 +278,11 @@ def test_fast_kernel_line_list_and_byte_walking_kernel_agree_with_the_host_parse
     assert want[0] > 5000 and int(want[3].sum()) > 1000
     fast = pools_and_counts(ctx, path=str(p))
     assert same(want, fast)
+    tiles, listed, slow = parse_paths(ctx)
+    assert slow == 0 and 1000 < listed < 25000          # the odd lines went to the shared splitter, the others did not
     monkeypatch.setenv("LSQ_MRF_LINE_LIST", "50")          # the list runs over: the file goes through the byte-walking kernel
     assert same(want, pools_and_counts(ctx, path=str(p)))
+    assert parse_paths(ctx)[2] == 1
     monkeypatch.delenv("LSQ_MRF_LINE_LIST")
     monkeypatch.setenv("LSQ_MRF_SLOW", "1")                # ... which this asks for outright
     assert same(want, pools_and_counts(ctx, path=str(p)))
@@ -295,6 +307,8 @@ def test_windows_with_more_delimiters_than_the_tables_hold(tmp_path):
     want = pools_and_counts(ctx, reads=L.Reads.from_mrf(str(p), ev))
     assert want[0] > 3000
     assert same(want, pools_and_counts(ctx, path=str(p)))
+    tiles, listed, slow = parse_paths(ctx)
+    assert tiles > 10 and slow == 0                    # the comment lines' tiles went to the byte-walking kernel
     parsed_equal(ev, L.Reads.from_mrf(str(p), ev), ctx.parse_mrf_device(str(p)))
     ctx.close()
 
