@@ -425,6 +425,7 @@ def run_workload(env, a, wl_name, primary):
     t_ingest = time.perf_counter() - t0
     ingest_stages = ctx.ingest_stages()                # device time and minimum bytes of every pass of the loader chain, this ingest
     ingest_h2d_ms = ctx.mrf_timing()["h2d_ms"]
+    ingest_paths = ctx.parse_paths()
     ctx.count()
     ctx.solve()
     cnt_full, bases_full = [x.copy() for x in ctx.counts()]
@@ -936,7 +937,7 @@ def run_workload(env, a, wl_name, primary):
                     "launches; algorithmic_bytes = the pass's input read once + its output written once; traffic = 2 x FETCH_SIZE + WRITE_SIZE of the pass's kernels "
                     "in the same rocprofv3 --pmc child runs that measure the count kernel (null when those did not run)",
             "text_bytes": os.path.getsize(mrf) if os.path.exists(mrf) else None, "lines": W["n_reads"], "h2d_ms": ingest_h2d_ms,
-            "device_ms": ing_ms, "stages": stages,
+            "device_ms": ing_ms, "stages": stages, "parse_paths": ingest_paths,
             "frac_whole_chain": (sum(x["bytes"] for x in ingest_stages) / (ing_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ing_ms > 0 else None,
         }
         out["config"]["one_shot_device_ms"] = ing_ms + float(np.mean(count_ms)) + float(np.mean(solve_ms))

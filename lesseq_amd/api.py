@@ -267,6 +267,15 @@ class Context:
         check(lib.lsq_last_mrf_timing(self.h, C.byref(a), C.byref(b)))
         return {"h2d_ms": a.value, "parse_ms": b.value}
 
+    def parse_paths(self):
+        """(tiles handed to the byte-walking kernel, lines handed to the shared splitter, whole file through the byte-walking kernel)
+        of the latest device parse (lsq_debug_last_parse_paths)"""
+        a, b, c = C.c_uint(), C.c_uint(), C.c_uint()
+        lib.lsq_debug_last_parse_paths.argtypes = [vp, P(C.c_uint), P(C.c_uint), P(C.c_uint)]
+        lib.lsq_debug_last_parse_paths.restype = C.c_int
+        check(lib.lsq_debug_last_parse_paths(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"tiles_to_byte_walking_kernel": a.value, "lines_to_shared_splitter": b.value, "whole_file_byte_walking": bool(c.value)}
+
     def ingest_stages(self):
         """device milliseconds and minimum bytes of every pass of the latest ingest (lsq_last_ingest_stages), in order"""
         n = lib.lsq_ingest_stage_count()
