@@ -2,7 +2,7 @@
 // merge and the bucket / group / pool layout (count/count.cpp:279-364), and the entry points around them.
 //
 // Round 4 form.  The loader is a chain of streaming passes, each of which reads and writes whole cache lines:
-//   newline count   text -> newlines per 8 KiB tile                                   (lsq_mrf_device.hpp)
+//   newline count   text -> newlines per 7 680-byte tile                               (lsq_mrf_device.hpp)
 //   route           text (or parsed blocks from the host) -> per read a key (bucket, pool, strand) and its merged blocks:
 //                   the splitter, the containment filter against the covered regions of the block's own chromosome
 //                   (count/count.cpp:319, interval_list.hpp:396-422), the interval_list merge of the kept blocks (:323,

@@ -1,23 +1,31 @@
 // MRF_SINGLE parsed on the device (included by lsq_ingest.hip; not a public header).
 //
-// The text goes to HBM as it is and is read there twice: once to count the newlines of every 8 KiB tile (16 bytes per
+// The text goes to HBM as it is and is read there twice: once to count the newlines of every 7 680-byte tile (16 bytes per
 // lane, the exact zero-byte test on word ^ 0x0A0A0A0A), once to parse.  A workgroup of the parse owns the lines that END
-// in its tile: it stages the tile and the 512 bytes before it in LDS (coalesced 16-byte loads), finds the newlines
-// there, and one lane per line runs the shared splitter (lsq_mrf_line.hpp -- the code the host parser runs) over LDS
-// bytes.  A line that began more than 512 bytes before the tile is walked in global memory by the same splitter.  The
-// newline ordinal of a line (tile base from a prefix sum over the tile counts + its place in the tile) is its line
-// number: the header and "read-<n>" fall out as in the reference (count/count.cpp:283,286,293-295).
+// in its tile and sees the tile and the 512 bytes before it.  The newline ordinal of a line (tile base from a prefix sum
+// over the tile counts + its place in the tile) is its line number: the header and "read-<n>" fall out as in the
+// reference (count/count.cpp:283,286,293-295).
 //
-// Round 4: the parse feeds the load-time filter directly (lsq_mrf_route_kernel: per line, every block is tested against
-// the covered regions and merged as it is split off; nothing but the routed read leaves the kernel), so no parsed array
-// exists in HBM either.  lsq_mrf_parse_device (tests, tools) still wants those arrays: the same tile walk run twice,
-// counting (lsq_mrf_count_kernel) and writing (lsq_mrf_write_kernel) around two prefix sums.
+// Round 4: the parse IS the routing pass of the loader chain (lsq_ingest.hip): per line, every block goes through the
+// containment filter and the merge as it is split off, and nothing but the routed read leaves the kernel -- no parsed
+// array exists in HBM either.  Three kernels:
+//   lsq_mrf_route_fast_kernel   every tile: delimiter tables from byte-parallel zero-byte tests, lines walk table entries,
+//                               a lane a block does the coordinates (eight-digit sums), the chromosome and strand (64-bit
+//                               keys), the filter; settles every line of a read's usual shape and lists the others
+//   lsq_mrf_route_kernel        the byte-walking form: the tile in LDS, a lane a line runs the SHARED SPLITTER
+//                               (lsq_mrf_line.hpp -- the code the host parser runs) over LDS bytes; takes the tiles the fast
+//                               kernel hands on, or whole files where that one does not apply
+//   lsq_mrf_route_lines_kernel  the listed lines (another shape than a read's; began ahead of their tile's window): a lane
+//                               a line, the shared splitter over the bytes in HBM
+// lsq_mrf_parse_device (tests, tools) still wants the parsed arrays: the byte-walking tile walk run twice, counting
+// (lsq_mrf_count_kernel) and writing (lsq_mrf_write_kernel) around two prefix sums.
 //   - the first line is the header (count.cpp:283); a last line without '\n' is never seen (:285)
 //   - '#' lines and the literal "AlignmentBlocks" consume a line number only (:288)
 //   - a field that fails the cast stops the run: the FIRST such line in file order is reported
-//   - chromosome names resolve against the events' chromosomes (hash table, in LDS when it is small);
-//     strand strings against a 256-slot table seeded with the strands already known, grown with
-//     atomicCAS (strings of at most 7 bytes; longer ones give LSQ_E_UNSUPPORTED -- use lsq_mrf_parse)
+//   - chromosome names resolve against the events' chromosomes (64-bit keys of names up to seven bytes in LDS; a hash table
+//     with byte-wise verification for the byte-walking kernels); strand strings against a 256-slot table seeded with the
+//     strands already known, grown with atomicCAS (strings of at most 7 bytes; longer ones give LSQ_E_UNSUPPORTED -- use
+//     lsq_mrf_parse)
 #pragma once
 
 #ifndef LSQ_MRF_TILE
