@@ -532,8 +532,10 @@ __global__ void __launch_bounds__(256) LSQ_FAST_WAVES_ATTR lsq_mrf_route_fast_ke
 		if (live) {
 			if (eol > start && text[start] == '#') dropped = true;       // a comment line takes a line number only (count.cpp:288)
 			else {
-				// the walk, once to count the blocks ...
-				unsigned d = dS;
+				// the walk: the line's blocks counted, the first two kept in registers (a read has one or two; a line of more is walked once
+				// more to list the rest -- a second walk for every line cost 0.5 ms of the 6.4 on C3)
+				uint4 b0 = make_uint4(0, 0, 0, 0), b1 = b0;
+				unsigned d = dS, cpos = start;
 				for (;;) {
 					unsigned long long e4;
 					__builtin_memcpy(&e4, &S.delim[d], 8);
@@ -541,12 +543,14 @@ __global__ void __launch_bounds__(256) LSQ_FAST_WAVES_ATTR lsq_mrf_route_fast_ke
 					// (count.cpp:313-316 with find() == npos) and after which nothing follows
 					const bool to_eol = (e4 & 0xE000600060006000ull) == 0x4000000000000000ull;
 					if ((e4 & 0x6000600060006000ull) != 0ull && !to_eol) { odd = true; break; }
+					const uint4 bd = make_uint4(cpos | (((unsigned)e4 & POS) << 16), ((unsigned)(e4 >> 16) & POS) | (((unsigned)(e4 >> 32) & POS) << 16), (unsigned)(e4 >> 48) & POS, 0u);
+					if (nb == 0u) b0 = bd; else if (nb == 1u) b1 = bd;
 					++nb;
 					if (to_eol) break;
 					unsigned dn = d + 4u, kind;
 					while ((kind = S.delim[dn] >> FP_KIND_SHIFT) == 0u) ++dn;      // the next block, if any: behind the first comma after colon 4
 					if (kind != 1u) break;
-					d = dn + 1u;
+					cpos = (S.delim[dn] & POS) + 1u; d = dn + 1u;
 				}
 				if (!odd) {
 					first = atomicAdd(&S.n_blk, nb);
@@ -556,19 +560,23 @@ __global__ void __launch_bounds__(256) LSQ_FAST_WAVES_ATTR lsq_mrf_route_fast_ke
 					}
 				}
 				if (!odd) {
-					// ... and once to list them
-					unsigned cpos = start, q = first;
-					d = dS;
-					for (;;) {
-						unsigned long long e4;
-						__builtin_memcpy(&e4, &S.delim[d], 8);
-						const bool to_eol = (e4 & 0xE000600060006000ull) == 0x4000000000000000ull;
-						S.blk[q++] = make_uint4(cpos | (((unsigned)e4 & POS) << 16), ((unsigned)(e4 >> 16) & POS) | (((unsigned)(e4 >> 32) & POS) << 16), (unsigned)(e4 >> 48) & POS, 0u);
-						if (to_eol) break;
-						unsigned dn = d + 4u, kind;
-						while ((kind = S.delim[dn] >> FP_KIND_SHIFT) == 0u) ++dn;
-						if (kind != 1u) break;
-						cpos = (S.delim[dn] & POS) + 1u; d = dn + 1u;
+					S.blk[first] = b0;
+					if (nb > 1u) S.blk[first + 1u] = b1;
+					if (nb > 2u) {
+						unsigned q = first;
+						cpos = start; d = dS;
+						for (;;) {
+							unsigned long long e4;
+							__builtin_memcpy(&e4, &S.delim[d], 8);
+							const bool to_eol = (e4 & 0xE000600060006000ull) == 0x4000000000000000ull;
+							if (q >= first + 2u) S.blk[q] = make_uint4(cpos | (((unsigned)e4 & POS) << 16), ((unsigned)(e4 >> 16) & POS) | (((unsigned)(e4 >> 32) & POS) << 16), (unsigned)(e4 >> 48) & POS, 0u);
+							++q;
+							if (to_eol) break;
+							unsigned dn = d + 4u, kind;
+							while ((kind = S.delim[dn] >> FP_KIND_SHIFT) == 0u) ++dn;
+							if (kind != 1u) break;
+							cpos = (S.delim[dn] & POS) + 1u; d = dn + 1u;
+						}
 					}
 				}
 			}
