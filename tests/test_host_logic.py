@@ -508,3 +508,19 @@ def test_share_plan_of_a_count_launch():
     # a share longer than 2^21 slots is never planned: the weights give way to equal shares
     big = plan(3, (1000.0, 0.0, 0.0, 0.05))
     assert np.diff(big).max() <= max(1 << 21, int(so[-1]) // 3 + 1)
+
+
+def test_sorted_generator_writes_the_same_reads_in_coordinate_order(tmp_path):
+    """lsq_synth_spec.sorted: the stream's reads by chromosome, first base and number; the same lines as the shuffled file"""
+    for zipf in (False, True):
+        a = L.SynthSpec(seed=7, n_events=300, n_reads=150000, read_length=100, n_chrom=4, zipf=zipf, sorted_reads=True)
+        b = L.SynthSpec(seed=7, n_events=300, n_reads=150000, read_length=100, n_chrom=4, zipf=zipf)
+        L.synth_write(a, str(tmp_path), "s")
+        L.synth_write(b, str(tmp_path), "u")
+        sl = open(tmp_path / "s.mrf").read().split("\n")
+        ul = open(tmp_path / "u.mrf").read().split("\n")
+        assert sl[0] == ul[0] == "AlignmentBlocks" and sl[-1] == ul[-1] == ""
+        keys = [(int(l.split(":")[0][3:]), int(l.split(":")[2])) for l in sl[1:-1]]
+        assert keys == sorted(keys) and len(keys) == 150000
+        assert sorted(sl[1:-1]) == sorted(ul[1:-1])
+        assert open(tmp_path / "s.interval").read() == open(tmp_path / "u.interval").read()
