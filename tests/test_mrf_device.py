@@ -385,3 +385,21 @@ def test_partition_without_lds_counters_and_a_many_block_list_that_runs_over(tmp
     assert same(want, pools_and_counts(ctx, path=mrf))
     assert same(want, pools_and_counts(ctx, reads=L.Reads.from_mrf(mrf, ev)))
     ctx.close()
+
+
+def test_ingest_stage_report(tmp_path):
+    """lsq_last_ingest_stages: the loader's seven passes by name, each with device time and the bytes it has to move, for the text path
+    and (without the newline count) for parsed arrays"""
+    spec = L.SynthSpec(41, 800, 400000, 100, 3, L.EVENT_TYPES)
+    L.synth_write(spec, str(tmp_path), "s")
+    ev, ctx = setup(str(tmp_path / "s.interval"), str(tmp_path / "s.map"), 100)
+    ctx.upload_reads_mrf(0, str(tmp_path / "s.mrf"))
+    st = ctx.ingest_stages()
+    assert [s["stage"] for s in st] == ["newline_count", "route", "partition_count", "partition_scatter", "group_classify", "group_offsets", "group_place"]
+    size = os.path.getsize(tmp_path / "s.mrf")
+    assert all(s["ms"] > 0 for s in st) and st[0]["bytes"] >= size and st[1]["bytes"] >= size + 20 * 400000
+    assert sum(s["ms"] for s in st) < 50
+    ctx.upload_reads(0, L.Reads.from_mrf(str(tmp_path / "s.mrf"), ev))
+    st = ctx.ingest_stages()
+    assert st[0]["ms"] == 0 and st[0]["bytes"] == 0 and all(s["ms"] > 0 for s in st[1:])
+    ctx.close()
